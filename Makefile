@@ -1,0 +1,25 @@
+# Builds libcognn_hip.so (the HIP engine + C ABI) for gfx950, in-tree.
+HIPCC ?= /opt/rocm/bin/hipcc
+ARCH ?= gfx950
+CSRC := cognn_amd/csrc
+HOST := cognn_amd/host
+OUT := cognn_amd/libcognn_hip.so
+HIPFLAGS := --offload-arch=$(ARCH) -O3 -fPIC -std=c++17 -Wall -Wno-unused-function -Iinclude -I$(CSRC)
+KERNEL_SRCS := $(CSRC)/capi.hip $(CSRC)/kernels_elementwise.hip $(CSRC)/kernels_gather.hip $(CSRC)/kernels_gemm.hip
+HOST_SRCS := $(wildcard $(HOST)/*.cpp)
+OBJS := $(KERNEL_SRCS:.hip=.o) $(HOST_SRCS:.cpp=.o)
+
+all: $(OUT)
+
+$(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/common.h $(CSRC)/cognn_spec.h include/cognn_hip.h
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(HOST)/%.o: $(HOST)/%.cpp $(wildcard $(HOST)/*.h) $(CSRC)/cognn_spec.h include/cognn_hip.h include/cognn_engine.h
+	$(HIPCC) $(HIPFLAGS) -x hip -c $< -o $@
+
+$(OUT): $(OBJS)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS) -lpthread
+
+clean:
+	rm -f $(OBJS) $(OUT)
+.PHONY: all clean

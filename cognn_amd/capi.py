@@ -1,0 +1,136 @@
+"""ctypes binding of libcognn_hip.so (include/cognn_hip.h, include/cognn_engine.h).
+
+Thin plumbing only: every compute call goes straight to the HIP library.  There is no CPU
+fallback; a missing library or a missing GPU is an error the caller sees.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcognn_hip.so")
+
+NUM_SLOTS = 11
+
+# dealer op ids (cognn_amd/csrc/cognn_spec.h)
+OP_SHARE_FEAT, OP_SHARE_W = 1, 2
+(OP_PS_GEMM, OP_PS_GEMM_TRUNC, OP_PS_SCALE, OP_PS_SCALE_TRUNC, OP_GA_SCALE, OP_GA_SCALE_TRUNC,
+ OP_AP_RELU, OP_AP_SOFTMAX, OP_AP_GEMM, OP_AP_GEMM_TRUNC, OP_AP_GSCALE_TRUNC, OP_AP_LR_TRUNC,
+ OP_WAVG_TRUNC) = range(10, 23)
+(SL_A0, SL_A1, SL_B0, SL_B1, SL_C0, SL_R, SL_R0, SL_RP0, SL_T, SL_T0, SL_RHO) = range(11)
+
+
+class Keys(ctypes.Structure):
+    _fields_ = [("k", ctypes.c_uint64 * NUM_SLOTS)]
+
+
+class CognnError(RuntimeError):
+    pass
+
+
+_P = ctypes.c_void_p
+_I = ctypes.c_int
+_L = ctypes.c_int64
+_U = ctypes.c_uint64
+_KP = ctypes.POINTER(Keys)
+
+_SIGNATURES = {
+    "cognn_abi_version": (_I, []),
+    "cognn_last_error": (ctypes.c_char_p, []),
+    "cognn_ctx_create": (_I, [_I, _P, ctypes.POINTER(_P)]),
+    "cognn_ctx_destroy": (_I, [_P]),
+    "cognn_ctx_sync": (_I, [_P]),
+    "cognn_malloc": (_I, [_P, ctypes.POINTER(_P), ctypes.c_size_t]),
+    "cognn_free": (_I, [_P, _P]),
+    "cognn_memcpy_h2d": (_I, [_P, _P, _P, ctypes.c_size_t]),
+    "cognn_memcpy_d2h": (_I, [_P, _P, _P, ctypes.c_size_t]),
+    "cognn_memcpy_d2d": (_I, [_P, _P, _P, ctypes.c_size_t]),
+    "cognn_memset0": (_I, [_P, _P, ctypes.c_size_t]),
+    "cognn_make_keys": (None, [_U, _U, _U, _U, _KP]),
+    "cognn_fx_encode_f64": (_I, [_P, _P, _P, _P, _L, _L]),
+    "cognn_share_split_u64": (_I, [_P, _P, _U, _P, _P, _L]),
+    "cognn_prng_fill_u64": (_I, [_P, _P, _U, _L]),
+    "cognn_gather_csr_u64": (_I, [_P, _P, _P, _P, _P, _P, _L, _L]),
+    "cognn_scatter_add_rows_u64": (_I, [_P, _P, _P, _P, _L, _L]),
+    "cognn_ring_gemm_u64": (_I, [_P, _P, _P, _P, _L, _L, _L, _I, _I]),
+    "cognn_mask_open_u64": (_I, [_P, _P, _P, _U, _L, _L, _I]),
+    "cognn_add_u64": (_I, [_P, _P, _P, _P, _L]),
+    "cognn_sub_u64": (_I, [_P, _P, _P, _P, _L]),
+    "cognn_dealer_gemm_c1_u64": (_I, [_P, _P, _KP, _L, _L, _L, _I, _P, _P]),
+    "cognn_beaver_gemm_close_u64": (_I, [_P, _P, _P, _P, _P, _KP, _I, _L, _L, _L, _I, _P]),
+    "cognn_trunc_open_u64": (_I, [_P, _P, _P, _U, _KP, _I, _L]),
+    "cognn_trunc_close_u64": (_I, [_P, _P, _P, _P, _KP, _I, _I, _L]),
+    "cognn_rowscale_open_u64": (_I, [_P, _P, _P, _P, _P, _KP, _I, _L, _L]),
+    "cognn_rowscale_close_u64": (_I, [_P, _P, _P, _P, _KP, _KP, _I, _L, _L]),
+    "cognn_relu_open_u64": (_I, [_P, _P, _P, _P, _KP, _I, _L]),
+    "cognn_relu_mul_u64": (_I, [_P, _P, _P, _P, _KP, _I, _L]),
+    "cognn_relu_close_u64": (_I, [_P, _P, _P, _P, _P, _P, _L]),
+    "cognn_mask_select_u64": (_I, [_P, _P, _P, _P, _L]),
+    "cognn_softmax_u64": (_I, [_P, _P, _P, _P, _P, _P, _P, _KP, _I, _L, _L, _L]),
+    "cognn_metrics_q16": (_I, [_P, _P, _P, _P, _L, _L, _L, _L, _P, _P]),
+}
+
+_lib = None
+
+
+def exported_names():
+    return list(_SIGNATURES.keys())
+
+
+def load(path=None):
+    """Load libcognn_hip.so once and declare every entry point of the C ABI."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        raise CognnError("%s not found: build it with `make` (or __graft_entry__.build()); "
+                         "the engine has no CPU fallback" % path)
+    lib = ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    try:
+        from . import engine_api
+        engine_api.declare(lib)
+    except ImportError:
+        pass
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        raise CognnError(load().cognn_last_error().decode())
+
+
+def make_keys(seed, owner, it, op):
+    k = Keys()
+    load().cognn_make_keys(seed, owner, it, op, ctypes.byref(k))
+    return k
+
+
+class Context:
+    """cognn_ctx bound to a HIP stream (by default torch's current stream on `device`)."""
+
+    def __init__(self, device=0, stream=None):
+        lib = load()
+        h = _P()
+        if stream is None:
+            import torch
+            stream = torch.cuda.current_stream(device).cuda_stream
+        check(lib.cognn_ctx_create(device, _P(stream), ctypes.byref(h)))
+        self.lib = lib
+        self.h = h
+        self.device = device
+
+    def sync(self):
+        check(self.lib.cognn_ctx_sync(self.h))
+
+    def close(self):
+        if self.h:
+            self.lib.cognn_ctx_destroy(self.h)
+            self.h = None
+
+    def call(self, name, *args):
+        check(getattr(self.lib, name)(self.h, *args))

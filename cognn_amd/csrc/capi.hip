@@ -1,0 +1,85 @@
+// Context, memory and error plumbing of the C ABI (include/cognn_hip.h).
+#include "common.h"
+#include "../../include/cognn_hip.h"
+#include <string.h>
+
+static thread_local char g_err[1024] = "";
+
+int cognn_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return 1;
+}
+
+extern "C" {
+
+int cognn_abi_version(void) { return COGNN_ABI_VERSION; }
+const char* cognn_last_error(void) { return g_err; }
+
+int cognn_ctx_create(int device, void* stream, cognn_ctx** out) {
+    CG_REQUIRE(out, "cognn_ctx_create: null out");
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return cognn_set_error("cognn_ctx_create: no HIP device available (%s); the engine has no CPU fallback",
+                               e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+    CG_REQUIRE(device >= 0 && device < count, "cognn_ctx_create: device %d out of range (count %d)", device, count);
+    CG_HIP(hipSetDevice(device));
+    cognn_ctx* c = new cognn_ctx();
+    c->device = device;
+    c->own_stream = (stream == nullptr);
+    if (stream) c->stream = (hipStream_t)stream;
+    else CG_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    *out = c;
+    return 0;
+}
+int cognn_ctx_destroy(cognn_ctx* ctx) {
+    if (!ctx) return 0;
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return 0;
+}
+int cognn_ctx_sync(cognn_ctx* ctx) {
+    CG_REQUIRE(ctx, "cognn_ctx_sync: null ctx");
+    CG_HIP(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+int cognn_malloc(cognn_ctx* ctx, void** ptr, size_t bytes) {
+    CG_REQUIRE(ctx && ptr, "cognn_malloc: null argument");
+    CG_HIP(hipSetDevice(ctx->device));
+    CG_HIP(hipMalloc(ptr, bytes ? bytes : 16));
+    return 0;
+}
+int cognn_free(cognn_ctx* ctx, void* ptr) {
+    CG_REQUIRE(ctx, "cognn_free: null ctx");
+    if (ptr) CG_HIP(hipFree(ptr));
+    return 0;
+}
+int cognn_memcpy_h2d(cognn_ctx* ctx, void* dst, const void* src, size_t bytes) {
+    CG_REQUIRE(ctx, "cognn_memcpy_h2d: null ctx");
+    if (bytes) { CG_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream)); CG_HIP(hipStreamSynchronize(ctx->stream)); }
+    return 0;
+}
+int cognn_memcpy_d2h(cognn_ctx* ctx, void* dst, const void* src, size_t bytes) {
+    CG_REQUIRE(ctx, "cognn_memcpy_d2h: null ctx");
+    if (bytes) { CG_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream)); CG_HIP(hipStreamSynchronize(ctx->stream)); }
+    return 0;
+}
+int cognn_memcpy_d2d(cognn_ctx* ctx, void* dst, const void* src, size_t bytes) {
+    CG_REQUIRE(ctx, "cognn_memcpy_d2d: null ctx");
+    if (bytes) CG_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    return 0;
+}
+int cognn_memset0(cognn_ctx* ctx, void* dst, size_t bytes) {
+    CG_REQUIRE(ctx, "cognn_memset0: null ctx");
+    if (bytes) CG_HIP(hipMemsetAsync(dst, 0, bytes, ctx->stream));
+    return 0;
+}
+void cognn_make_keys(uint64_t seed, uint64_t owner, uint64_t iter, uint64_t op, cognn_keys* out) {
+    cognn_opkeys k = cognn_make_opkeys(seed, owner, iter, op);
+    for (int i = 0; i < COGNN_SL_COUNT; ++i) out->k[i] = k.k[i];
+}
+
+}  // extern "C"

@@ -1,0 +1,83 @@
+// Share-arithmetic definitions shared by host and device code of the engine.
+// These stand in for the external CryptoUtil / sci:: primitives that the reference calls but
+// does not contain.  The CPU oracle (oracle/cognn_oracle.py)
+// restates the same definitions independently.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define COGNN_HD __host__ __device__ __forceinline__
+#else
+#define COGNN_HD inline
+#endif
+
+#define COGNN_FX_BITS 16                       /* SCALER_BIT_LENGTH stand-in (gcn.h:191: must be < 31) */
+#define COGNN_FX_ONE (1ull << COGNN_FX_BITS)
+#define COGNN_GAMMA 0x9E3779B97F4A7C15ull
+#define COGNN_TRUNC_OFFSET (1ull << 61)
+#define COGNN_TRUNC_MASK ((1ull << 62) - 1)
+
+/* dealer op ids (one stream family per op instance) */
+enum {
+    COGNN_OP_SHARE_FEAT = 1, COGNN_OP_SHARE_W = 2,
+    COGNN_OP_PS_GEMM = 10, COGNN_OP_PS_GEMM_TRUNC, COGNN_OP_PS_SCALE, COGNN_OP_PS_SCALE_TRUNC,
+    COGNN_OP_GA_SCALE, COGNN_OP_GA_SCALE_TRUNC, COGNN_OP_AP_RELU, COGNN_OP_AP_SOFTMAX,
+    COGNN_OP_AP_GEMM, COGNN_OP_AP_GEMM_TRUNC, COGNN_OP_AP_GSCALE_TRUNC, COGNN_OP_AP_LR_TRUNC,
+    COGNN_OP_WAVG_TRUNC
+};
+/* dealer slots inside one op */
+enum {
+    COGNN_SL_A0 = 0, COGNN_SL_A1, COGNN_SL_B0, COGNN_SL_B1, COGNN_SL_C0,
+    COGNN_SL_R, COGNN_SL_R0, COGNN_SL_RP0, COGNN_SL_T, COGNN_SL_T0, COGNN_SL_RHO, COGNN_SL_COUNT
+};
+#define COGNN_OWNER_WAVG 0xFFFFull
+
+COGNN_HD uint64_t cognn_mix64(uint64_t z) {
+    z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull;
+    z ^= z >> 27; z *= 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return z;
+}
+/* counter PRNG: value idx of stream `key` */
+COGNN_HD uint64_t cognn_prng(uint64_t key, uint64_t idx) {
+    return cognn_mix64(key + (idx + 1) * COGNN_GAMMA);
+}
+COGNN_HD uint64_t cognn_derive(uint64_t key, uint64_t tag) {
+    return cognn_mix64((key ^ cognn_mix64(tag + COGNN_GAMMA)) + COGNN_GAMMA);
+}
+COGNN_HD uint64_t cognn_stream_key(uint64_t seed, uint64_t owner, uint64_t iter, uint64_t op, uint64_t slot) {
+    return cognn_derive(cognn_derive(cognn_derive(cognn_derive(seed, owner), iter), op), slot);
+}
+
+/* all slot keys of one op instance, passed by value to kernels */
+struct cognn_opkeys {
+    uint64_t k[COGNN_SL_COUNT];
+};
+static inline cognn_opkeys cognn_make_opkeys(uint64_t seed, uint64_t owner, uint64_t iter, uint64_t op) {
+    cognn_opkeys r;
+    for (int s = 0; s < COGNN_SL_COUNT; ++s) r.k[s] = cognn_stream_key(seed, owner, iter, op, (uint64_t)s);
+    return r;
+}
+
+/* integer softmax constants: 2^-x on [0,1) in Q30, degree 5 */
+#define COGNN_LOG2E_Q16 94548ll
+#define COGNN_EXP2_C0 1073741765ll
+#define COGNN_EXP2_C1 (-744256846ll)
+#define COGNN_EXP2_C2 257890763ll
+#define COGNN_EXP2_C3 (-59377501ll)
+#define COGNN_EXP2_C4 9890102ll
+#define COGNN_EXP2_C5 (-1017428ll)
+
+/* e = 2^-(d*log2e) in Q30 for d >= 0 in Q16; 0 when d >= 32 */
+COGNN_HD int64_t cognn_exp_neg_q30(int64_t d) {
+    if (d >= (32ll << 16)) return 0;
+    int64_t u = (d * COGNN_LOG2E_Q16) >> 16;
+    int64_t ip = u >> 16, fr = u & 0xFFFF;
+    int64_t acc = COGNN_EXP2_C5;
+    acc = COGNN_EXP2_C4 + ((acc * fr) >> 16);
+    acc = COGNN_EXP2_C3 + ((acc * fr) >> 16);
+    acc = COGNN_EXP2_C2 + ((acc * fr) >> 16);
+    acc = COGNN_EXP2_C1 + ((acc * fr) >> 16);
+    acc = COGNN_EXP2_C0 + ((acc * fr) >> 16);
+    return acc >> ip;
+}

@@ -1,0 +1,35 @@
+// Internal helpers shared by the HIP translation units of libcognn_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "cognn_spec.h"
+
+struct cognn_ctx {
+    int device;
+    hipStream_t stream;
+    bool own_stream;
+};
+
+int cognn_set_error(const char* fmt, ...);
+
+#define CG_HIP(expr)                                                                          \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess)                                                                 \
+            return cognn_set_error("%s:%d: %s failed: %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+    } while (0)
+
+#define CG_REQUIRE(cond, ...)                                  \
+    do {                                                       \
+        if (!(cond)) return cognn_set_error(__VA_ARGS__);      \
+    } while (0)
+
+#define CG_LAUNCH_CHECK() CG_HIP(hipGetLastError())
+
+typedef unsigned long long u64;
+typedef ulonglong2 u64x2;
+
+static inline int cg_div_up(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+static inline bool cg_aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }

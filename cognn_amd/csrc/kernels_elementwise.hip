@@ -1,0 +1,385 @@
+// Element-wise share arithmetic on flat uint64 tensors (HBM-bound; dealer randomness is
+// evaluated in registers from counter-PRNG streams, so it costs no HBM traffic).
+// Stand-ins for the local halves of sci::twoPartyGCN{VectorScale,Relu,MatrixScale,ApplyGradient,
+// CondVectorAddition,ForwardNNPredictionWithoutWeight} (gcn.h:247,476,549,578,676,678) and
+// CryptoUtil::intoShares (gcn.h:70); definitions in DESIGN.md §3.
+#include "common.h"
+#include "../../include/cognn_hip.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+
+__device__ __forceinline__ void ld2(const u64* p, int64_t i, int w, u64 v[2]) {
+    if (w == 2) { u64x2 t = *reinterpret_cast<const u64x2*>(p + i); v[0] = t.x; v[1] = t.y; }
+    else { v[0] = p[i]; v[1] = 0; }
+}
+__device__ __forceinline__ void st2(u64* p, int64_t i, int w, const u64 v[2]) {
+    if (w == 2) { u64x2 t; t.x = v[0]; t.y = v[1]; *reinterpret_cast<u64x2*>(p + i) = t; }
+    else p[i] = v[0];
+}
+
+// dealer streams ------------------------------------------------------------------------------
+__device__ __forceinline__ u64 trunc_r(const cognn_opkeys& k, int p, u64 idx) {
+    u64 r0 = cognn_prng(k.k[COGNN_SL_R0], idx);
+    if (p == 0) return r0;
+    return (cognn_prng(k.k[COGNN_SL_R], idx) & COGNN_TRUNC_MASK) - r0;
+}
+__device__ __forceinline__ u64 trunc_rp(const cognn_opkeys& k, int p, u64 idx) {
+    u64 rp0 = cognn_prng(k.k[COGNN_SL_RP0], idx);
+    if (p == 0) return rp0;
+    return ((cognn_prng(k.k[COGNN_SL_R], idx) & COGNN_TRUNC_MASK) >> COGNN_FX_BITS) - rp0;
+}
+// z_p = p*e*g + e*b_p + a_p*g + c_p for an element-wise Beaver product with masks a (idx) and b (bidx)
+__device__ __forceinline__ u64 beaver_mul(const cognn_opkeys& k, int p, u64 e, u64 g, u64 idx, u64 bidx) {
+    u64 a0 = cognn_prng(k.k[COGNN_SL_A0], idx), b0 = cognn_prng(k.k[COGNN_SL_B0], bidx);
+    u64 c0 = cognn_prng(k.k[COGNN_SL_C0], idx);
+    if (p == 0) return e * b0 + a0 * g + c0;
+    u64 a1 = cognn_prng(k.k[COGNN_SL_A1], idx), b1 = cognn_prng(k.k[COGNN_SL_B1], bidx);
+    u64 c1 = (a0 + a1) * (b0 + b1) - c0;
+    return e * g + e * b1 + a1 * g + c1;
+}
+
+// generic pair launcher: thread t handles flat elements 2t, 2t+1
+template <class F>
+__global__ __launch_bounds__(kThreads) void ew_kernel(int64_t n, F f) {
+    int64_t i = 2 * ((int64_t)blockIdx.x * kThreads + threadIdx.x);
+    if (i + 1 < n) f(i, 2);
+    else if (i < n) f(i, 1);
+}
+template <class F>
+int launch_ew(cognn_ctx* ctx, int64_t n, F f) {
+    if (n <= 0) return 0;
+    int64_t pairs = (n + 1) / 2;
+    dim3 grid((unsigned)((pairs + kThreads - 1) / kThreads));
+    hipLaunchKernelGGL(ew_kernel<F>, grid, dim3(kThreads), 0, ctx->stream, n, f);
+    CG_LAUNCH_CHECK();
+    return 0;
+}
+
+struct PrngFill {
+    u64* out; u64 key;
+    __device__ void operator()(int64_t i, int w) const {
+        u64 v[2] = {cognn_prng(key, (u64)i), cognn_prng(key, (u64)i + 1)};
+        st2(out, i, w, v);
+    }
+};
+struct ShareSplit {
+    const u64* fx; u64 key; u64* s0; u64* s1;
+    __device__ void operator()(int64_t i, int w) const {
+        u64 x[2], a[2], b[2];
+        ld2(fx, i, w, x);
+        for (int j = 0; j < 2; ++j) { b[j] = cognn_prng(key, (u64)(i + j)); a[j] = x[j] - b[j]; }
+        if (s0) st2(s0, i, w, a);
+        if (s1) st2(s1, i, w, b);
+    }
+};
+struct MaskOpen {       // E = X - prng(key, logical idx)
+    u64* E; const u64* X; u64 key; int64_t rows, cols; int transposed;
+    __device__ void operator()(int64_t i, int w) const {
+        u64 x[2], e[2];
+        ld2(X, i, w, x);
+        for (int j = 0; j < 2; ++j) {
+            u64 idx = (u64)(i + j);
+            if (transposed) {              // X stored [cols x rows]; logical element (m,k) = X[k][m]
+                u64 k = idx / (u64)rows, m = idx % (u64)rows;
+                idx = m * (u64)cols + k;
+            }
+            e[j] = x[j] - cognn_prng(key, idx);
+        }
+        st2(E, i, w, e);
+    }
+};
+struct AddSub {
+    u64* out; const u64* a; const u64* b; int sub;
+    __device__ void operator()(int64_t i, int w) const {
+        u64 x[2], y[2], r[2];
+        ld2(a, i, w, x); ld2(b, i, w, y);
+        r[0] = sub ? x[0] - y[0] : x[0] + y[0];
+        r[1] = sub ? x[1] - y[1] : x[1] + y[1];
+        st2(out, i, w, r);
+    }
+};
+struct TruncOpen {
+    u64* c; const u64* x; u64 mul; cognn_opkeys k; int p;
+    __device__ void operator()(int64_t i, int w) const {
+        u64 v[2], r[2];
+        ld2(x, i, w, v);
+        for (int j = 0; j < 2; ++j)
+            r[j] = v[j] * mul + trunc_r(k, p, (u64)(i + j)) + (p == 0 ? COGNN_TRUNC_OFFSET : 0ull);
+        st2(c, i, w, r);
+    }
+};
+struct TruncClose {
+    u64* out; const u64* c0; const u64* c1; cognn_opkeys k; int p; int mode;
+    __device__ void operator()(int64_t i, int w) const {
+        u64 y[2];
+        if (p == 0) {
+            u64 a[2], b[2];
+            ld2(c0, i, w, a); ld2(c1, i, w, b);
+            for (int j = 0; j < 2; ++j)
+                y[j] = ((a[j] + b[j]) >> COGNN_FX_BITS) - (COGNN_TRUNC_OFFSET >> COGNN_FX_BITS) - trunc_rp(k, 0, (u64)(i + j));
+        } else {
+            for (int j = 0; j < 2; ++j) y[j] = 0ull - trunc_rp(k, 1, (u64)(i + j));
+        }
+        if (mode == 1) {
+            u64 o[2];
+            ld2(out, i, w, o);
+            y[0] = o[0] - y[0]; y[1] = o[1] - y[1];
+        }
+        st2(out, i, w, y);
+    }
+};
+struct RowscaleOpenE {   // E = V - a_p
+    u64* E; const u64* V; cognn_opkeys k; int p;
+    __device__ void operator()(int64_t i, int w) const {
+        u64 v[2], e[2];
+        ld2(V, i, w, v);
+        const u64 ka = k.k[p == 0 ? COGNN_SL_A0 : COGNN_SL_A1];
+        e[0] = v[0] - cognn_prng(ka, (u64)i); e[1] = v[1] - cognn_prng(ka, (u64)i + 1);
+        st2(E, i, w, e);
+    }
+};
+struct RowscaleOpenG {   // G[r] = s_p[r] - b_p[r]
+    u64* G; const u64* s; cognn_opkeys k; int p;
+    __device__ void operator()(int64_t i, int w) const {
+        u64 v[2], g[2];
+        ld2(s, i, w, v);
+        const u64 kb = k.k[p == 0 ? COGNN_SL_B0 : COGNN_SL_B1];
+        g[0] = v[0] - cognn_prng(kb, (u64)i); g[1] = v[1] - cognn_prng(kb, (u64)i + 1);
+        st2(G, i, w, g);
+    }
+};
+struct RowscaleClose {   // c_out = beaver(E, G[row]) + trunc mask
+    u64* c; const u64* E; const u64* G; cognn_opkeys k; cognn_opkeys tk; int p; uint32_t F;
+    __device__ void operator()(int64_t i, int w) const {
+        u64 e[2], r[2];
+        ld2(E, i, w, e);
+        for (int j = 0; j < w; ++j) {
+            u64 idx = (u64)(i + j);
+            u64 row = (u64)((uint32_t)idx / F);
+            u64 z = beaver_mul(k, p, e[j], G[row], idx, row);
+            r[j] = z + trunc_r(tk, p, idx) + (p == 0 ? COGNN_TRUNC_OFFSET : 0ull);
+        }
+        st2(c, i, w, r);
+    }
+};
+struct ReluOpen {        // E = z - a_p ; G = t_p - b_p
+    u64* E; u64* G; const u64* z; cognn_opkeys k; int p;
+    __device__ void operator()(int64_t i, int w) const {
+        u64 v[2], e[2], g[2];
+        ld2(z, i, w, v);
+        for (int j = 0; j < 2; ++j) {
+            u64 idx = (u64)(i + j);
+            u64 t0 = cognn_prng(k.k[COGNN_SL_T0], idx);
+            u64 tp = t0;
+            if (p == 1) tp = ((cognn_prng(k.k[COGNN_SL_T], idx) & 0xFFFFFull) | 1ull) - t0;
+            e[j] = v[j] - cognn_prng(k.k[p == 0 ? COGNN_SL_A0 : COGNN_SL_A1], idx);
+            g[j] = tp - cognn_prng(k.k[p == 0 ? COGNN_SL_B0 : COGNN_SL_B1], idx);
+        }
+        st2(E, i, w, e); st2(G, i, w, g);
+    }
+};
+struct ReluMul {
+    u64* wout; const u64* E; const u64* G; cognn_opkeys k; int p;
+    __device__ void operator()(int64_t i, int w) const {
+        u64 e[2], g[2], r[2];
+        ld2(E, i, w, e); ld2(G, i, w, g);
+        for (int j = 0; j < 2; ++j) r[j] = beaver_mul(k, p, e[j], g[j], (u64)(i + j), (u64)(i + j));
+        st2(wout, i, w, r);
+    }
+};
+struct ReluClose {
+    u64* h; uint8_t* mask; const u64* z; const u64* w0; const u64* w1;
+    __device__ void operator()(int64_t i, int w) const {
+        u64 a[2], b[2], v[2], r[2];
+        ld2(w0, i, w, a); ld2(w1, i, w, b); ld2(z, i, w, v);
+        for (int j = 0; j < w; ++j) {
+            bool pos = (long long)(a[j] + b[j]) > 0;
+            r[j] = pos ? v[j] : 0ull;
+            if (mask) mask[i + j] = pos ? 1 : 0;
+        }
+        st2(h, i, w, r);
+    }
+};
+struct MaskSelect {
+    u64* out; const u64* in; const uint8_t* mask;
+    __device__ void operator()(int64_t i, int w) const {
+        u64 v[2], r[2];
+        ld2(in, i, w, v);
+        r[0] = mask[i] ? v[0] : 0ull;
+        r[1] = (w == 2 && mask[i + 1]) ? v[1] : 0ull;
+        st2(out, i, w, r);
+    }
+};
+struct FxEncode {
+    const double* in; const double* rowscale; u64* fx; uint32_t cols;
+    __device__ void operator()(int64_t i, int w) const {
+        u64 r[2] = {0, 0};
+        for (int j = 0; j < w; ++j) {
+            double v = in[i + j];
+            if (rowscale) v *= rowscale[(uint32_t)(i + j) / cols];
+            r[j] = (u64)(long long)llround(v * (double)COGNN_FX_ONE);
+        }
+        st2(fx, i, w, r);
+    }
+};
+
+// one thread per row; L small (<= 64 labels)
+__global__ __launch_bounds__(kThreads) void softmax_kernel(u64* p_out, u64* d_out, u64* pfx_out, const u64* z0, const u64* z1,
+                                                            const int32_t* labels, cognn_opkeys k, int p, int64_t rows, int L,
+                                                            int64_t train_rows) {
+    int64_t r = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (r >= rows) return;
+    const bool keep = r < train_rows;
+    if (p == 1) {
+        for (int j = 0; j < L; ++j) {
+            u64 rho = cognn_prng(k.k[COGNN_SL_RHO], (u64)(r * L + j));
+            if (p_out) p_out[r * L + j] = rho;
+            d_out[r * L + j] = keep ? rho : 0ull;
+        }
+        return;
+    }
+    long long m = (long long)(z0[r * L] + z1[r * L]);
+    for (int j = 1; j < L; ++j) {
+        long long v = (long long)(z0[r * L + j] + z1[r * L + j]);
+        m = v > m ? v : m;
+    }
+    long long S = 0;
+    for (int j = 0; j < L; ++j) S += cognn_exp_neg_q30(m - (long long)(z0[r * L + j] + z1[r * L + j]));
+    const int lab = labels[r];
+    for (int j = 0; j < L; ++j) {
+        long long e = cognn_exp_neg_q30(m - (long long)(z0[r * L + j] + z1[r * L + j]));
+        u64 pf = (u64)(((e << 16) + (S >> 1)) / S);
+        u64 rho = cognn_prng(k.k[COGNN_SL_RHO], (u64)(r * L + j));
+        u64 p0 = pf - rho;
+        if (pfx_out) pfx_out[r * L + j] = pf;
+        if (p_out) p_out[r * L + j] = p0;
+        d_out[r * L + j] = keep ? (p0 - (j == lab ? COGNN_FX_ONE : 0ull)) : 0ull;
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void metrics_kernel(const u64* pfx, const int32_t* labels, const uint8_t* border,
+                                                            int64_t rows, int L, int64_t train_rows, int64_t val_rows,
+                                                            unsigned long long* counts, double* loss) {
+    int64_t r = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (r >= rows) return;
+    int best = 0; u64 bv = pfx[r * L];
+    for (int j = 1; j < L; ++j) { u64 v = pfx[r * L + j]; if (v > bv) { bv = v; best = j; } }
+    const int lab = labels[r];
+    const bool ok = best == lab;
+    const bool b = border ? border[r] != 0 : false;
+    const bool tr = r < train_rows, te = r >= train_rows + val_rows;
+    if (ok) {
+        atomicAdd(&counts[0], 1ull);
+        if (tr) atomicAdd(&counts[1], 1ull);
+        if (tr && b) atomicAdd(&counts[2], 1ull);
+        if (te) atomicAdd(&counts[3], 1ull);
+        if (te && b) atomicAdd(&counts[4], 1ull);
+    }
+    double pl = (double)pfx[r * L + lab] / (double)COGNN_FX_ONE;
+    if (pl == 0.0) pl = 0.001;                         /* gcn.h:613-615 */
+    atomicAdd(loss, -log(pl));
+}
+
+inline cognn_opkeys K(const cognn_keys* k) {
+    cognn_opkeys r;
+    for (int i = 0; i < COGNN_SL_COUNT; ++i) r.k[i] = k->k[i];
+    return r;
+}
+inline bool al(const void* p) { return p == nullptr || cg_aligned16(p); }
+
+}  // namespace
+
+static_assert(COGNN_NUM_SLOTS == COGNN_SL_COUNT, "slot count mismatch between ABI header and spec");
+
+extern "C" {
+
+int cognn_prng_fill_u64(cognn_ctx* ctx, uint64_t* out, uint64_t key, int64_t n) {
+    CG_REQUIRE(ctx && out && al(out), "cognn_prng_fill_u64: bad arguments");
+    return launch_ew(ctx, n, PrngFill{(u64*)out, key});
+}
+int cognn_share_split_u64(cognn_ctx* ctx, const uint64_t* fx, uint64_t key, uint64_t* s0, uint64_t* s1, int64_t n) {
+    CG_REQUIRE(ctx && fx && al(fx) && al(s0) && al(s1), "cognn_share_split_u64: bad arguments");
+    return launch_ew(ctx, n, ShareSplit{(const u64*)fx, key, (u64*)s0, (u64*)s1});
+}
+int cognn_fx_encode_f64(cognn_ctx* ctx, const double* in, const double* rowscale, uint64_t* fx, int64_t rows, int64_t cols) {
+    CG_REQUIRE(ctx && in && fx && al(fx), "cognn_fx_encode_f64: bad arguments");
+    CG_REQUIRE(rows * cols < (1ll << 32), "cognn_fx_encode_f64: tensor too large");
+    return launch_ew(ctx, rows * cols, FxEncode{in, rowscale, (u64*)fx, (uint32_t)cols});
+}
+int cognn_mask_open_u64(cognn_ctx* ctx, uint64_t* E, const uint64_t* X, uint64_t key, int64_t rows, int64_t cols, int transposed) {
+    CG_REQUIRE(ctx && E && X && al(E) && al(X), "cognn_mask_open_u64: bad arguments");
+    return launch_ew(ctx, rows * cols, MaskOpen{(u64*)E, (const u64*)X, key, rows, cols, transposed});
+}
+int cognn_add_u64(cognn_ctx* ctx, uint64_t* out, const uint64_t* a, const uint64_t* b, int64_t n) {
+    CG_REQUIRE(ctx && out && a && b && al(out) && al(a) && al(b), "cognn_add_u64: bad arguments");
+    return launch_ew(ctx, n, AddSub{(u64*)out, (const u64*)a, (const u64*)b, 0});
+}
+int cognn_sub_u64(cognn_ctx* ctx, uint64_t* out, const uint64_t* a, const uint64_t* b, int64_t n) {
+    CG_REQUIRE(ctx && out && a && b && al(out) && al(a) && al(b), "cognn_sub_u64: bad arguments");
+    return launch_ew(ctx, n, AddSub{(u64*)out, (const u64*)a, (const u64*)b, 1});
+}
+int cognn_trunc_open_u64(cognn_ctx* ctx, uint64_t* c, const uint64_t* x, uint64_t mul, const cognn_keys* keys, int p, int64_t n) {
+    CG_REQUIRE(ctx && c && x && keys && (p == 0 || p == 1) && al(c) && al(x), "cognn_trunc_open_u64: bad arguments");
+    return launch_ew(ctx, n, TruncOpen{(u64*)c, (const u64*)x, mul, K(keys), p});
+}
+int cognn_trunc_close_u64(cognn_ctx* ctx, uint64_t* out, const uint64_t* c0, const uint64_t* c1, const cognn_keys* keys,
+                          int p, int mode, int64_t n) {
+    CG_REQUIRE(ctx && out && keys && (p == 0 || p == 1) && al(out) && al(c0) && al(c1), "cognn_trunc_close_u64: bad arguments");
+    CG_REQUIRE(p == 1 || (c0 && c1), "cognn_trunc_close_u64: p=0 needs both opened values");
+    return launch_ew(ctx, n, TruncClose{(u64*)out, (const u64*)c0, (const u64*)c1, K(keys), p, mode});
+}
+int cognn_rowscale_open_u64(cognn_ctx* ctx, uint64_t* E, uint64_t* G, const uint64_t* V, const uint64_t* s,
+                            const cognn_keys* keys, int p, int64_t rows, int64_t F) {
+    CG_REQUIRE(ctx && E && G && V && s && keys && al(E) && al(G) && al(V) && al(s), "cognn_rowscale_open_u64: bad arguments");
+    int rc = launch_ew(ctx, rows * F, RowscaleOpenE{(u64*)E, (const u64*)V, K(keys), p});
+    if (rc) return rc;
+    return launch_ew(ctx, rows, RowscaleOpenG{(u64*)G, (const u64*)s, K(keys), p});
+}
+int cognn_rowscale_close_u64(cognn_ctx* ctx, uint64_t* c_out, const uint64_t* E, const uint64_t* G,
+                             const cognn_keys* keys, const cognn_keys* tkeys, int p, int64_t rows, int64_t F) {
+    CG_REQUIRE(ctx && c_out && E && G && keys && tkeys && al(c_out) && al(E), "cognn_rowscale_close_u64: bad arguments");
+    CG_REQUIRE(rows * F < (1ll << 32), "cognn_rowscale_close_u64: tensor too large");
+    return launch_ew(ctx, rows * F, RowscaleClose{(u64*)c_out, (const u64*)E, (const u64*)G, K(keys), K(tkeys), p, (uint32_t)F});
+}
+int cognn_relu_open_u64(cognn_ctx* ctx, uint64_t* E, uint64_t* G, const uint64_t* z, const cognn_keys* keys, int p, int64_t n) {
+    CG_REQUIRE(ctx && E && G && z && keys && al(E) && al(G) && al(z), "cognn_relu_open_u64: bad arguments");
+    return launch_ew(ctx, n, ReluOpen{(u64*)E, (u64*)G, (const u64*)z, K(keys), p});
+}
+int cognn_relu_mul_u64(cognn_ctx* ctx, uint64_t* w, const uint64_t* E, const uint64_t* G, const cognn_keys* keys, int p, int64_t n) {
+    CG_REQUIRE(ctx && w && E && G && keys && al(w) && al(E) && al(G), "cognn_relu_mul_u64: bad arguments");
+    return launch_ew(ctx, n, ReluMul{(u64*)w, (const u64*)E, (const u64*)G, K(keys), p});
+}
+int cognn_relu_close_u64(cognn_ctx* ctx, uint64_t* h, uint8_t* mask, const uint64_t* z, const uint64_t* w0, const uint64_t* w1, int64_t n) {
+    CG_REQUIRE(ctx && h && z && w0 && w1 && al(h) && al(z) && al(w0) && al(w1), "cognn_relu_close_u64: bad arguments");
+    return launch_ew(ctx, n, ReluClose{(u64*)h, mask, (const u64*)z, (const u64*)w0, (const u64*)w1});
+}
+int cognn_mask_select_u64(cognn_ctx* ctx, uint64_t* out, const uint64_t* in, const uint8_t* mask, int64_t n) {
+    CG_REQUIRE(ctx && out && in && mask && al(out) && al(in), "cognn_mask_select_u64: bad arguments");
+    return launch_ew(ctx, n, MaskSelect{(u64*)out, (const u64*)in, mask});
+}
+int cognn_softmax_u64(cognn_ctx* ctx, uint64_t* p_out, uint64_t* d_out, uint64_t* pfx_out, const uint64_t* z0, const uint64_t* z1,
+                      const int32_t* labels, const cognn_keys* keys, int p, int64_t rows, int64_t L, int64_t train_rows) {
+    CG_REQUIRE(ctx && d_out && keys && (p == 0 || p == 1), "cognn_softmax_u64: bad arguments");
+    CG_REQUIRE(p == 1 || (z0 && z1 && labels), "cognn_softmax_u64: owner side needs z0, z1, labels");
+    CG_REQUIRE(L > 0 && L <= 4096, "cognn_softmax_u64: unsupported label count %lld", (long long)L);
+    if (rows <= 0) return 0;
+    hipLaunchKernelGGL(softmax_kernel, dim3(cg_div_up(rows, kThreads)), dim3(kThreads), 0, ctx->stream, (u64*)p_out, (u64*)d_out,
+                       (u64*)pfx_out, (const u64*)z0, (const u64*)z1, labels, K(keys), p, rows, (int)L, train_rows);
+    CG_LAUNCH_CHECK();
+    return 0;
+}
+int cognn_metrics_q16(cognn_ctx* ctx, const uint64_t* pfx, const int32_t* labels, const uint8_t* border,
+                      int64_t rows, int64_t L, int64_t train_rows, int64_t val_rows, int64_t* counts6, double* loss) {
+    CG_REQUIRE(ctx && pfx && labels && counts6 && loss, "cognn_metrics_q16: bad arguments");
+    CG_HIP(hipMemsetAsync(counts6, 0, 6 * sizeof(int64_t), ctx->stream));
+    CG_HIP(hipMemsetAsync(loss, 0, sizeof(double), ctx->stream));
+    if (rows <= 0) return 0;
+    hipLaunchKernelGGL(metrics_kernel, dim3(cg_div_up(rows, kThreads)), dim3(kThreads), 0, ctx->stream, (const u64*)pfx, labels,
+                       border, rows, (int)L, train_rows, val_rows, (unsigned long long*)counts6, loss);
+    CG_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"

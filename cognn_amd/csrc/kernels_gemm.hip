@@ -1,0 +1,307 @@
+// Ring GEMM on uint64 shares (mod 2^64): the local arithmetic of sci::twoPartyGCNMatMul
+// (optimize-gcn/gcn.h:233,665,671,710) under Beaver triples.
+//
+// Fast path (NN, tall-skinny A): v_mfma_i32_32x32x32_i8 on a signed 8-bit limb decomposition.
+//   x = sum_i d_i 2^(8i) (mod 2^64), d_i in [-128,127]:  d = ((x + 0x80..80) ^ 0x80..80) bytes.
+//   C = sum_{s=0..7} 2^(8s) P_s,  P_s = sum_{i+j=s} A_i . B_j   (36 limb-pair products, int32
+//   accumulators, products with i+j > 7 vanish mod 2^64).
+// A workgroup of 8 waves owns 128 (BN=64) or 256 (BN=32) rows; B's limb planes live in LDS for
+// the whole kernel, A tiles are streamed HBM -> registers -> (limb split) -> LDS -> MFMA with a
+// two-stage LDS ring and one barrier per 32-deep K step; the next tile's global loads are issued
+// before the current tile's MFMAs.
+// Generic path: a split-K VALU kernel for every other shape (transposed A, tiny M, huge K).
+#include "common.h"
+#include <algorithm>
+#include "../../include/cognn_hip.h"
+
+namespace {
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+
+// ------------------------------------------------------------------------------------------
+// generic split-K kernel: C (+)= op(A) . B
+// ------------------------------------------------------------------------------------------
+template <bool TA>
+__global__ __launch_bounds__(256) void ring_gemm_simple_kernel(u64* C, const u64* __restrict__ A, const u64* __restrict__ B,
+                                                                int M, int N, int K, int kchunk, int use_atomic) {
+    const int n = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int m = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (n >= N || m >= M) return;
+    const int k0 = blockIdx.z * kchunk;
+    const int k1 = min(K, k0 + kchunk);
+    u64 acc = 0;
+    for (int k = k0; k < k1; ++k) {
+        const u64 a = TA ? A[(size_t)k * M + m] : A[(size_t)m * K + k];
+        acc += a * B[(size_t)k * N + n];
+    }
+    if (use_atomic) atomicAdd((unsigned long long*)&C[(size_t)m * N + n], acc);
+    else C[(size_t)m * N + n] += acc;
+}
+
+// ------------------------------------------------------------------------------------------
+// MFMA i8 limb kernel (NN)
+// ------------------------------------------------------------------------------------------
+constexpr int kWavesM = 4;                  // waves along M per workgroup -> 128 rows per block
+constexpr int kKStep = 32;
+constexpr u64 kBias = 0x8080808080808080ull;
+
+__device__ __forceinline__ void split4(const u64 v[4], uint32_t plane[8]) {
+    // signed limb digits of four values -> plane[i] = bytes (d_i(v0), d_i(v1), d_i(v2), d_i(v3))
+    uint32_t lo[4], hi[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const u64 d = (v[j] + kBias) ^ kBias;
+        lo[j] = (uint32_t)d; hi[j] = (uint32_t)(d >> 32);
+    }
+    // v_perm_b32: selector 0-3 picks bytes of the 2nd operand, 4-7 bytes of the 1st
+    uint32_t a = __builtin_amdgcn_perm(lo[1], lo[0], 0x05010400u), b = __builtin_amdgcn_perm(lo[1], lo[0], 0x07030602u);
+    uint32_t c = __builtin_amdgcn_perm(lo[3], lo[2], 0x05010400u), d = __builtin_amdgcn_perm(lo[3], lo[2], 0x07030602u);
+    plane[0] = __builtin_amdgcn_perm(c, a, 0x05040100u); plane[1] = __builtin_amdgcn_perm(c, a, 0x07060302u);
+    plane[2] = __builtin_amdgcn_perm(d, b, 0x05040100u); plane[3] = __builtin_amdgcn_perm(d, b, 0x07060302u);
+    a = __builtin_amdgcn_perm(hi[1], hi[0], 0x05010400u); b = __builtin_amdgcn_perm(hi[1], hi[0], 0x07030602u);
+    c = __builtin_amdgcn_perm(hi[3], hi[2], 0x05010400u); d = __builtin_amdgcn_perm(hi[3], hi[2], 0x07030602u);
+    plane[4] = __builtin_amdgcn_perm(c, a, 0x05040100u); plane[5] = __builtin_amdgcn_perm(c, a, 0x07060302u);
+    plane[6] = __builtin_amdgcn_perm(d, b, 0x05040100u); plane[7] = __builtin_amdgcn_perm(d, b, 0x07060302u);
+}
+
+// BN: output columns per workgroup (32 or 64). Waves are arranged kWavesM x (BN/32).
+template <int BN>
+__global__ __launch_bounds__(kWavesM * (BN / 32) * 64) void ring_gemm_mfma_kernel(u64* C, const u64* __restrict__ A,
+                                                                       const u64* __restrict__ B, int M, int N, int K,
+                                                                       int accumulate) {
+    constexpr int WN = BN / 32;                 // waves along N
+    constexpr int WM = kWavesM;                 // waves along M
+    constexpr int BM = WM * 32;                 // rows per workgroup block
+    constexpr int kGemmThreads = WM * WN * 64;
+    constexpr int kAStage = 8 * 2 * BM * 16;    // bytes: [plane][khalf][row][16]
+    constexpr int kTasks = BM * 8 / kGemmThreads;   // (row, 4-k quad) tasks per thread per K step
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int KP = ((K + kKStep - 1) / kKStep) * kKStep;   // K padded to the step
+    const int KS = KP + 16;                                // B plane row stride (bank spread)
+    unsigned char* sB = smem;                              // [8][BN][KS]
+    unsigned char* sA = smem + 8 * BN * KS;                // 2 stages
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int n0 = blockIdx.y * BN;
+
+    // ---- B limb planes -> LDS (once) ----------------------------------------------------------
+    for (int t = tid; t < (KP / 4) * BN; t += kGemmThreads) {
+        const int c = t % BN, kq = t / BN;
+        u64 v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = kq * 4 + j;
+            v[j] = (k < K && n0 + c < N) ? B[(size_t)k * N + n0 + c] : 0ull;
+        }
+        uint32_t pl[8];
+        split4(v, pl);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) *reinterpret_cast<uint32_t*>(sB + (size_t)i * BN * KS + c * KS + kq * 4) = pl[i];
+    }
+
+    const int nkt = KP / kKStep;
+    const int nmb = (M + BM - 1) / BM;
+    // flattened (m-block, k-step) iteration space of this workgroup
+    const int my_blocks = (nmb - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int total = my_blocks * nkt;
+
+    u64 nxt[kTasks][4];
+    auto issue_load = [&](int it) {
+        const int mb = blockIdx.x + (it / nkt) * gridDim.x, kt = it % nkt;
+#pragma unroll
+        for (int q = 0; q < kTasks; ++q) {
+            const int task = tid + q * kGemmThreads;
+            const int row = task >> 3, kq = task & 7;
+            const int m = mb * BM + row, k = kt * kKStep + kq * 4;
+            if (m < M && k + 3 < K) {
+                const u64x2* p = reinterpret_cast<const u64x2*>(A + (size_t)m * K + k);
+                if ((K & 1) == 0) { u64x2 t0 = p[0], t1 = p[1]; nxt[q][0] = t0.x; nxt[q][1] = t0.y; nxt[q][2] = t1.x; nxt[q][3] = t1.y; }
+                else { const u64* s = A + (size_t)m * K + k; nxt[q][0] = s[0]; nxt[q][1] = s[1]; nxt[q][2] = s[2]; nxt[q][3] = s[3]; }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) nxt[q][j] = (m < M && k + j < K) ? A[(size_t)m * K + k + j] : 0ull;
+            }
+        }
+    };
+    auto write_stage = [&](int stage) {
+        unsigned char* dst = sA + stage * kAStage;
+#pragma unroll
+        for (int q = 0; q < kTasks; ++q) {
+            const int task = tid + q * kGemmThreads;
+            const int row = task >> 3, kq = task & 7;
+            uint32_t pl[8];
+            split4(nxt[q], pl);
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                *reinterpret_cast<uint32_t*>(dst + i * (2 * BM * 16) + (kq >> 2) * (BM * 16) + row * 16 + (kq & 3) * 4) = pl[i];
+        }
+    };
+
+    v16i acc[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[s][r] = 0;
+
+    if (total > 0) issue_load(0);
+    for (int it = 0; it < total; ++it) {
+        const int stage = it & 1;
+        const int kt = it % nkt;
+        write_stage(stage);
+        if (it + 1 < total) issue_load(it + 1);
+        __syncthreads();
+
+        v4i af[8], bf[8];
+        const unsigned char* pa = sA + stage * kAStage + (lane >> 5) * (BM * 16) + (wm * 32 + (lane & 31)) * 16;
+        const unsigned char* pb = sB + (size_t)(wn * 32 + (lane & 31)) * KS + kt * kKStep + (lane >> 5) * 16;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            af[i] = *reinterpret_cast<const v4i*>(pa + i * (2 * BM * 16));
+            bf[i] = *reinterpret_cast<const v4i*>(pb + (size_t)i * BN * KS);
+        }
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+#pragma unroll
+            for (int i = 0; i <= s; ++i) acc[s] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[i], bf[s - i], acc[s], 0, 0, 0);
+
+        if (kt == nkt - 1) {
+            // ---- epilogue of this m-block: recombine limb groups, write C ------------------------
+            const int mb = blockIdx.x + (it / nkt) * gridDim.x;
+            const int col = n0 + wn * 32 + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = mb * BM + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const uint32_t hi = (uint32_t)acc[4][r] + ((uint32_t)acc[5][r] << 8) + ((uint32_t)acc[6][r] << 16) + ((uint32_t)acc[7][r] << 24);
+                u64 v = (u64)(long long)acc[0][r] + ((u64)(long long)acc[1][r] << 8) + ((u64)(long long)acc[2][r] << 16) +
+                        ((u64)(long long)acc[3][r] << 24) + ((u64)hi << 32);
+                if (row < M && col < N) {
+                    u64* dst = C + (size_t)row * N + col;
+                    if (accumulate) v += *dst;
+                    *dst = v;
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < 8; ++s)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[s][r] = 0;
+        }
+    }
+}
+
+// element-wise helpers used by the Beaver composites -------------------------------------------
+__global__ __launch_bounds__(256) void prng_fill2_kernel(u64* out, u64 k0, u64 k1, int64_t rows, int64_t cols, int transposed,
+                                                          int two, const u64* addend) {
+    // out (storage layout) = prng(k0, lidx) [+ prng(k1, lidx)] [+ addend]; transposed: storage [cols x rows]
+    const int64_t n = rows * cols;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        u64 idx = (u64)i;
+        if (transposed) { const u64 k = idx / (u64)rows, m = idx % (u64)rows; idx = m * (u64)cols + k; }
+        u64 v = cognn_prng(k0, idx);
+        if (two) v += cognn_prng(k1, idx);
+        if (addend) v += addend[i];
+        out[i] = v;
+    }
+}
+__global__ __launch_bounds__(256) void sub_prng_kernel(u64* out, u64 key, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) out[i] -= cognn_prng(key, (u64)i);
+}
+
+int fill(cognn_ctx* ctx, u64* out, u64 k0, u64 k1, int64_t rows, int64_t cols, int transposed, int two, const u64* addend) {
+    const int64_t n = rows * cols;
+    if (n <= 0) return 0;
+    dim3 grid((unsigned)std::min<int64_t>((n + 255) / 256, 256 * 32));
+    hipLaunchKernelGGL(prng_fill2_kernel, grid, dim3(256), 0, ctx->stream, out, k0, k1, rows, cols, transposed, two, addend);
+    CG_LAUNCH_CHECK();
+    return 0;
+}
+
+int gemm_dispatch(cognn_ctx* ctx, u64* C, const u64* A, const u64* B, int64_t M, int64_t N, int64_t K, int transA, int accumulate) {
+    if (M <= 0 || N <= 0) return 0;
+    if (K <= 0) {
+        if (!accumulate) CG_HIP(hipMemsetAsync(C, 0, (size_t)M * N * 8, ctx->stream));
+        return 0;
+    }
+    const int64_t KP = (K + kKStep - 1) / kKStep * kKStep;
+    const bool mfma_ok = !transA && M >= 256 && K <= 8192;
+    if (mfma_ok) {
+        const int BN = N <= 32 ? 32 : 64;
+        const int BM = kWavesM * 32;
+        const int kGemmThreads = kWavesM * (BN / 32) * 64;
+        const size_t lds = (size_t)8 * BN * (KP + 16) + 2 * (size_t)(8 * 2 * BM * 16);
+        if (lds <= 160 * 1024) {
+            const int nmb = (int)((M + BM - 1) / BM);
+            dim3 grid((unsigned)std::min(nmb, 256), (unsigned)((N + BN - 1) / BN));
+            if (BN == 32) {
+                CG_HIP(hipFuncSetAttribute((const void*)ring_gemm_mfma_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                hipLaunchKernelGGL(ring_gemm_mfma_kernel<32>, grid, dim3(kGemmThreads), lds, ctx->stream, C, A, B, (int)M, (int)N, (int)K, accumulate);
+            } else {
+                CG_HIP(hipFuncSetAttribute((const void*)ring_gemm_mfma_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                hipLaunchKernelGGL(ring_gemm_mfma_kernel<64>, grid, dim3(kGemmThreads), lds, ctx->stream, C, A, B, (int)M, (int)N, (int)K, accumulate);
+            }
+            CG_LAUNCH_CHECK();
+            return 0;
+        }
+    }
+    // generic path
+    int kchunk = (int)K, splits = 1;
+    const int64_t out_threads = M * N;
+    if (out_threads < 256 * 256 * 4 && K > 2048) {
+        kchunk = 1024;
+        splits = (int)((K + kchunk - 1) / kchunk);
+    }
+    if (!accumulate) CG_HIP(hipMemsetAsync(C, 0, (size_t)M * N * 8, ctx->stream));
+    dim3 grid((unsigned)((N + 63) / 64), (unsigned)((M + 3) / 4), (unsigned)splits);
+    CG_REQUIRE(grid.y <= 65535 && splits <= 65535, "ring_gemm: shape too large for generic path");
+    if (transA) hipLaunchKernelGGL(ring_gemm_simple_kernel<true>, grid, dim3(256), 0, ctx->stream, C, A, B, (int)M, (int)N, (int)K, kchunk, splits > 1);
+    else hipLaunchKernelGGL(ring_gemm_simple_kernel<false>, grid, dim3(256), 0, ctx->stream, C, A, B, (int)M, (int)N, (int)K, kchunk, splits > 1);
+    CG_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int cognn_ring_gemm_u64(cognn_ctx* ctx, uint64_t* C, const uint64_t* A, const uint64_t* B,
+                        int64_t M, int64_t N, int64_t K, int transA, int accumulate) {
+    CG_REQUIRE(ctx && C && A && B, "cognn_ring_gemm_u64: null argument");
+    CG_REQUIRE(M >= 0 && N >= 0 && K >= 0 && M < (1ll << 31) && N < (1ll << 31) && K < (1ll << 31), "cognn_ring_gemm_u64: bad shape");
+    CG_REQUIRE(cg_aligned16(A) && cg_aligned16(B) && cg_aligned16(C), "cognn_ring_gemm_u64: operands must be 16-byte aligned");
+    return gemm_dispatch(ctx, (u64*)C, (const u64*)A, (const u64*)B, M, N, K, transA, accumulate);
+}
+
+int cognn_dealer_gemm_c1_u64(cognn_ctx* ctx, uint64_t* C1, const cognn_keys* keys, int64_t M, int64_t N, int64_t K,
+                             int transA, uint64_t* scratchA, uint64_t* scratchB) {
+    CG_REQUIRE(ctx && C1 && keys && scratchA && scratchB, "cognn_dealer_gemm_c1_u64: null argument");
+    int rc;
+    if ((rc = fill(ctx, (u64*)scratchA, keys->k[COGNN_SL_A0], keys->k[COGNN_SL_A1], M, K, transA, 1, nullptr))) return rc;
+    if ((rc = fill(ctx, (u64*)scratchB, keys->k[COGNN_SL_B0], keys->k[COGNN_SL_B1], K, N, 0, 1, nullptr))) return rc;
+    if ((rc = gemm_dispatch(ctx, (u64*)C1, (const u64*)scratchA, (const u64*)scratchB, M, N, K, transA, 0))) return rc;
+    const int64_t n = M * N;
+    if (n > 0) {
+        hipLaunchKernelGGL(sub_prng_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 8192)), dim3(256), 0, ctx->stream, (u64*)C1,
+                           keys->k[COGNN_SL_C0], n);
+        CG_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+int cognn_beaver_gemm_close_u64(cognn_ctx* ctx, uint64_t* Z, const uint64_t* E, const uint64_t* F, const uint64_t* c1,
+                                const cognn_keys* keys, int p, int64_t M, int64_t N, int64_t K, int transA, uint64_t* scratch) {
+    CG_REQUIRE(ctx && Z && E && F && keys && scratch && (p == 0 || p == 1), "cognn_beaver_gemm_close_u64: bad arguments");
+    CG_REQUIRE(p == 0 || c1, "cognn_beaver_gemm_close_u64: p=1 needs the dealer share c1");
+    u64* Ap = (u64*)scratch;
+    u64* Bp = Ap + (size_t)M * K;
+    int rc;
+    // A_p (storage layout of E), B_p (+F for p==1), Z <- C_p
+    if ((rc = fill(ctx, Ap, keys->k[p == 0 ? COGNN_SL_A0 : COGNN_SL_A1], 0, M, K, transA, 0, nullptr))) return rc;
+    if ((rc = fill(ctx, Bp, keys->k[p == 0 ? COGNN_SL_B0 : COGNN_SL_B1], 0, K, N, 0, 0, p == 1 ? (const u64*)F : nullptr))) return rc;
+    if (p == 0) { if ((rc = fill(ctx, (u64*)Z, keys->k[COGNN_SL_C0], 0, M, N, 0, 0, nullptr))) return rc; }
+    else CG_HIP(hipMemcpyAsync(Z, c1, (size_t)M * N * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    if ((rc = gemm_dispatch(ctx, (u64*)Z, (const u64*)E, Bp, M, N, K, transA, 1))) return rc;
+    return gemm_dispatch(ctx, (u64*)Z, Ap, (const u64*)F, M, N, K, transA, 1);
+}
+
+}  // extern "C"

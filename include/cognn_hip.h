@@ -1,0 +1,122 @@
+/* cognn_hip.h — C ABI of the MI355X-native secret-shared GCN engine (libcognn_hip.so).
+ *
+ * This is the drop-in boundary for CoGNN's hot path.  The reference has no
+ * FFI: its GAS callbacks (algo_kernels/vertex_centric/optimize-gcn/gcn.h) call free functions
+ * of external libraries (sci::*, *_oblivious_mapper_online, prefix_network_aggregate,
+ * CryptoUtil::*) on nested std::vector<uint64_t>.  Every entry point below names the reference
+ * call site(s) it replaces.  Conventions:
+ *   - all tensors are flat row-major uint64 additive shares mod 2^64 in DEVICE memory
+ *     (ShareVecVec, include/task/task.h:237-272, flattened), caller-owned;
+ *   - every call is asynchronous on the context's HIP stream and returns 0 on success,
+ *     non-zero on error (cognn_last_error() has the text); nothing calls exit() — the
+ *     reference's printf+exit(-1) sites (ss_...h:386,794,869,1116) become error returns;
+ *   - `p` is the share index of the calling side: 0 = owner/client (sci::ALICE),
+ *     1 = co-party/server (sci::BOB)  (ss_...h:743,993; gcn.h:532-533);
+ *   - dealer randomness is addressed by (seed, owner, iter, op) -> cognn_opkeys, see
+ *     cognn_amd/csrc/cognn_spec.h; "open" steps produce the value a party sends to its peer,
+ *     "close" steps consume both parties' opened values.
+ */
+#ifndef COGNN_HIP_H_
+#define COGNN_HIP_H_
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define COGNN_ABI_VERSION 1
+#define COGNN_NUM_SLOTS 11
+
+typedef struct cognn_ctx cognn_ctx;
+typedef struct { uint64_t k[COGNN_NUM_SLOTS]; } cognn_keys;   /* == cognn_opkeys */
+
+/* ---- context / memory ------------------------------------------------------------------ */
+int cognn_abi_version(void);
+const char* cognn_last_error(void);
+/* stream: a hipStream_t owned by the caller (e.g. torch's current stream) or NULL for a private one */
+int cognn_ctx_create(int device, void* stream, cognn_ctx** out);
+int cognn_ctx_destroy(cognn_ctx* ctx);
+int cognn_ctx_sync(cognn_ctx* ctx);
+int cognn_malloc(cognn_ctx* ctx, void** ptr, size_t bytes);
+int cognn_free(cognn_ctx* ctx, void* ptr);
+int cognn_memcpy_h2d(cognn_ctx* ctx, void* dst, const void* src, size_t bytes);
+int cognn_memcpy_d2h(cognn_ctx* ctx, void* dst, const void* src, size_t bytes);
+int cognn_memcpy_d2d(cognn_ctx* ctx, void* dst, const void* src, size_t bytes);
+int cognn_memset0(cognn_ctx* ctx, void* dst, size_t bytes);
+/* derive the slot keys of one dealer op instance (host-side helper) */
+void cognn_make_keys(uint64_t seed, uint64_t owner, uint64_t iter, uint64_t op, cognn_keys* out);
+
+/* ---- codec / sharing: CryptoUtil::intoShares, encodeDoubleAsFixedPoint (gcn.h:64-99,220) -- */
+/* fx[i] = llround(in[i] * rowscale[i / cols] * 2^16); rowscale may be NULL */
+int cognn_fx_encode_f64(cognn_ctx*, const double* in, const double* rowscale, uint64_t* fx, int64_t rows, int64_t cols);
+/* s1[i] = prng(key, i); s0[i] = fx[i] - s1[i]  (either output may be NULL) */
+int cognn_share_split_u64(cognn_ctx*, const uint64_t* fx, uint64_t key, uint64_t* s0, uint64_t* s1, int64_t n);
+int cognn_prng_fill_u64(cognn_ctx*, uint64_t* out, uint64_t key, int64_t n);
+
+/* ---- Gather: OEP + ScatterComp + prefix_network_aggregate + OEP + CondVectorAddition fused
+ *      (ss_...h:752-763,815-827,847-854,866-880; gcn.h:257-342,454-463) -------------------- */
+/* out[r,:] = (base ? base[r,:] : 0) + sum_{e in [rowptr[r],rowptr[r+1])} table[col[e],:]
+ * CSR values are implicitly 1; rows with no entries are the reference's masked (dummy) rows. */
+int cognn_gather_csr_u64(cognn_ctx*, uint64_t* out, const uint64_t* base, const uint64_t* table,
+                         const uint32_t* rowptr, const uint32_t* col, int64_t n_rows, int64_t F);
+/* v[row_index[q],:] += partial[q,:]  (row_index entries distinct): receive side of the mirror
+ * vertex update exchange (ss_...h:847-854 with allow-missing, then gcn.h:456). */
+int cognn_scatter_add_rows_u64(cognn_ctx*, uint64_t* v, const uint64_t* partial, const uint32_t* row_index,
+                               int64_t n_partial, int64_t F);
+
+/* ---- ring GEMM on shares: the local part of sci::twoPartyGCNMatMul (gcn.h:233,665,671,710) - */
+/* C[MxN] = (accumulate ? C : 0) + op(A)[MxK] . B[KxN]  mod 2^64.  transA: A is stored [KxM]. */
+int cognn_ring_gemm_u64(cognn_ctx*, uint64_t* C, const uint64_t* A, const uint64_t* B,
+                        int64_t M, int64_t N, int64_t K, int transA, int accumulate);
+/* Beaver reveal share: E_p = X_p - prng(key, logical idx). transposed: X is stored [cols x rows]
+ * while the logical (masked) matrix is its transpose [rows x cols]. */
+int cognn_mask_open_u64(cognn_ctx*, uint64_t* E, const uint64_t* X, uint64_t key, int64_t rows, int64_t cols, int transposed);
+int cognn_add_u64(cognn_ctx*, uint64_t* out, const uint64_t* a, const uint64_t* b, int64_t n);
+int cognn_sub_u64(cognn_ctx*, uint64_t* out, const uint64_t* a, const uint64_t* b, int64_t n);
+/* dealer (offline): C1 = (A0+A1).(B0+B1) - C0 with all five streams evaluated from keys */
+int cognn_dealer_gemm_c1_u64(cognn_ctx*, uint64_t* C1, const cognn_keys* keys, int64_t M, int64_t N, int64_t K, int transA,
+                             uint64_t* scratchA /*MxK*/, uint64_t* scratchB /*KxN*/);
+/* Z_p = p*E.F + E.B_p + A_p.F + C_p.  E [MxK] and F [KxN] are the opened values; A_p/B_p/C_0 come
+ * from keys, C_1 from `c1` (p==1).  transA: E is stored [KxM] (as produced by cognn_mask_open_u64 with
+ * transposed=1).  scratch: MxK + KxN u64. */
+int cognn_beaver_gemm_close_u64(cognn_ctx*, uint64_t* Z, const uint64_t* E, const uint64_t* F, const uint64_t* c1,
+                                const cognn_keys* keys, int p, int64_t M, int64_t N, int64_t K, int transA, uint64_t* scratch);
+
+/* ---- truncation by 2^16 (implicit in every sci:: fixed-point op) ------------------------- */
+/* c_p = mul * x_p + r_p (+2^61 if p==0) */
+int cognn_trunc_open_u64(cognn_ctx*, uint64_t* c, const uint64_t* x, uint64_t mul, const cognn_keys* keys, int p, int64_t n);
+/* y_p = p==0 ? ((c0+c1)>>16) - 2^45 - rp0 : -rp1.  mode 0: out = y; mode 1: out = out - y
+ * (twoPartyGCNApplyGradient, gcn.h:678,730). */
+int cognn_trunc_close_u64(cognn_ctx*, uint64_t* out, const uint64_t* c0, const uint64_t* c1, const cognn_keys* keys,
+                          int p, int mode, int64_t n);
+
+/* ---- sci::twoPartyGCNVectorScale (gcn.h:247,476): row scale by an additively shared vector - */
+int cognn_rowscale_open_u64(cognn_ctx*, uint64_t* E, uint64_t* G, const uint64_t* V, const uint64_t* s,
+                            const cognn_keys* keys, int p, int64_t rows, int64_t F);
+/* z_p = p*E*G + E*b_p + a_p*G + c_p, immediately followed by trunc_open with tkeys:
+ * c_out = z_p + r_p (+2^61).  E [rows x F], G [rows] are the opened sums. */
+int cognn_rowscale_close_u64(cognn_ctx*, uint64_t* c_out, const uint64_t* E, const uint64_t* G,
+                             const cognn_keys* keys, const cognn_keys* tkeys, int p, int64_t rows, int64_t F);
+
+/* ---- sci::twoPartyGCNRelu / twoPartyGCNBackwardNNWithoutAH (gcn.h:549,705) ---------------- */
+int cognn_relu_open_u64(cognn_ctx*, uint64_t* E, uint64_t* G, const uint64_t* z, const cognn_keys* keys, int p, int64_t n);
+int cognn_relu_mul_u64(cognn_ctx*, uint64_t* w, const uint64_t* E, const uint64_t* G, const cognn_keys* keys, int p, int64_t n);
+/* h_p = (int64)(w0+w1) > 0 ? z_p : 0; mask (1 byte/element, public) may be NULL */
+int cognn_relu_close_u64(cognn_ctx*, uint64_t* h, uint8_t* mask, const uint64_t* z, const uint64_t* w0, const uint64_t* w1, int64_t n);
+int cognn_mask_select_u64(cognn_ctx*, uint64_t* out, const uint64_t* in, const uint8_t* mask, int64_t n);
+
+/* ---- twoPartyGCNForwardNNPredictionWithoutWeight + getPlainShareVecVec (gcn.h:578-604) ---- */
+/* owner side (p=0): z=z0+z1 -> integer softmax pfx (Q16) ; p0 = pfx - rho ; d0 = p0 - onehot(label),
+ * rows >= train_rows zeroed.  co side (p=1): pass z1=NULL,labels=NULL: p = rho, d = rho (zeroed rows). */
+int cognn_softmax_u64(cognn_ctx*, uint64_t* p_out, uint64_t* d_out, uint64_t* pfx_out, const uint64_t* z0, const uint64_t* z1,
+                      const int32_t* labels, const cognn_keys* keys, int p, int64_t rows, int64_t L, int64_t train_rows);
+/* sci::cross_entropy_loss / accuracy (gcn.h:620-632) on the revealed Q16 probabilities.
+ * out[0..5] (int64 counts: correct full/train/border-train/test/border-test, n) + loss (double). */
+int cognn_metrics_q16(cognn_ctx*, const uint64_t* pfx, const int32_t* labels, const uint8_t* border,
+                      int64_t rows, int64_t L, int64_t train_rows, int64_t val_rows, int64_t* counts6, double* loss);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* COGNN_HIP_H_ */

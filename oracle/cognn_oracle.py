@@ -90,7 +90,9 @@ def prng_shape(key, shape):
 def fx_encode(x):
     """CryptoUtil::encodeDoubleAsFixedPoint stand-in (gcn.h:220): llround(x*2^f), two's complement."""
     a = np.asarray(x, dtype=np.float64) * FX_ONE
-    r = np.where(a >= 0, np.floor(a + 0.5), np.ceil(a - 0.5))     # llround: half away from zero
+    t = np.trunc(a)
+    frac = a - t                                                  # exact
+    r = t + (frac >= 0.5).astype(np.float64) - (frac <= -0.5).astype(np.float64)   # llround
     return r.astype(np.int64).astype(U64)
 
 
@@ -103,10 +105,18 @@ def fx_decode(v):
     return np.asarray(v, dtype=U64).astype(np.int64).astype(np.float64) / FX_ONE
 
 
+def pow_neg_half(deg_plus_one):
+    """libm pow(x, -0.5) element by element (numpy's vectorised pow may differ from libm by an ulp)."""
+    x = np.asarray(deg_plus_one, dtype=np.float64)
+    uniq, inv = np.unique(x, return_inverse=True)
+    vals = np.array([math.pow(float(u), -0.5) for u in uniq], dtype=np.float64)
+    return vals[inv].reshape(x.shape)
+
+
 def normalizer(deg):
     """gcn.h:219-221 / 471-474 / 536-539: deg==0 ? 0 : fx(pow(deg+1,-0.5))."""
     deg = np.asarray(deg, dtype=np.float64)
-    return np.where(deg == 0, U64(0), fx_encode(np.power(deg + 1.0, -0.5)))
+    return np.where(deg == 0, U64(0), fx_encode(pow_neg_half(deg + 1.0)))
 
 
 # ----------------------------------------------------------------------------------------
@@ -455,7 +465,7 @@ class OracleEngine:
             n = len(vids)
             feat = np.asarray(features)[vids].astype(np.float64)
             tdeg = np.array([gs.true_in_deg[v] for v in vids], dtype=np.float64)
-            feat = feat * np.power(tdeg + 1.0, -0.5)[:, None]          # normalizeFeatureVec, gcn.h:819-835
+            feat = feat * pow_neg_half(tdeg + 1.0)[:, None]          # normalizeFeatureVec, gcn.h:819-835
             gs.labels = np.asarray(labels)[vids].astype(np.int64)
             gs.plainFeat = feat
             fx = fx_encode(feat)

@@ -1,0 +1,341 @@
+"""Parity of every C-ABI arithmetic entry point against the CPU oracle (bit-exact; integer ring).
+The oracle is "parity unpinned" w.r.t. the reference (no golden vectors exist)."""
+import ctypes
+import numpy as np
+import pytest
+
+import cognn_oracle as co
+from gpu_util import dev, dev_empty, host, ptr, rand_u64, U64
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    from cognn_amd import capi
+    c = capi.Context(0)
+    yield c
+    c.close()
+
+
+def keys_of(seed, owner, it, op):
+    from cognn_amd import capi
+    return capi.make_keys(seed, owner, it, op), (lambda slot: co.stream_key(seed, owner, it, op, slot))
+
+
+def test_prng_and_share_split(ctx):
+    n = 100003
+    key = co.stream_key(7, 1, 2, 3, 4)
+    out = dev_empty(n)
+    ctx.call("cognn_prng_fill_u64", ptr(out), ctypes.c_uint64(key), n)
+    assert np.array_equal(host(out), co.prng(key, n))
+    rng = np.random.default_rng(0)
+    fx = rand_u64(rng, n)
+    s0, s1 = dev_empty(n), dev_empty(n)
+    ctx.call("cognn_share_split_u64", ptr(dev(fx)), ctypes.c_uint64(key), ptr(s0), ptr(s1), n)
+    with np.errstate(over="ignore"):
+        assert np.array_equal(host(s1), co.prng(key, n))
+        assert np.array_equal(host(s0) + host(s1), fx)
+
+
+def test_fx_encode(ctx):
+    rng = np.random.default_rng(1)
+    rows, cols = 301, 17
+    x = rng.normal(size=(rows, cols)) * 3
+    x[0, 0] = 0.5 / 65536; x[0, 1] = -0.5 / 65536; x[0, 2] = 1.5 / 65536
+    sc = rng.random(rows) + 0.1
+    out = dev_empty((rows, cols))
+    ctx.call("cognn_fx_encode_f64", ptr(dev(x)), ptr(dev(sc)), ptr(out), rows, cols)
+    assert np.array_equal(host(out), co.fx_encode(x * sc[:, None]))
+    ctx.call("cognn_fx_encode_f64", ptr(dev(x)), None, ptr(out), rows, cols)
+    assert np.array_equal(host(out), co.fx_encode(x))
+
+
+def _random_csr(rng, n_rows, n_table, avg_deg, empty_frac=0.1):
+    deg = rng.poisson(avg_deg, size=n_rows)
+    deg[rng.random(n_rows) < empty_frac] = 0
+    rowptr = np.zeros(n_rows + 1, dtype=np.uint32)
+    rowptr[1:] = np.cumsum(deg)
+    col = rng.integers(0, n_table, size=int(rowptr[-1]), dtype=np.uint32)
+    return rowptr, col
+
+
+def _csr_ref(base, table, rowptr, col):
+    out = np.zeros((len(rowptr) - 1, table.shape[1]), dtype=U64) if base is None else base.copy()
+    with np.errstate(over="ignore"):
+        for r in range(len(rowptr) - 1):
+            for e in range(rowptr[r], rowptr[r + 1]):
+                out[r] += table[col[e]]
+    return out
+
+
+@pytest.mark.parametrize("F", [64, 16, 7, 1, 2, 130, 6])
+@pytest.mark.parametrize("with_base", [True, False])
+def test_gather_csr(ctx, F, with_base):
+    rng = np.random.default_rng(F * 2 + with_base)
+    n_rows, n_table = 777, 1500
+    rowptr, col = _random_csr(rng, n_rows, n_table, 9)
+    table = rand_u64(rng, (n_table, F))
+    base = rand_u64(rng, (n_rows, F)) if with_base else None
+    out = dev_empty((n_rows, F))
+    ctx.call("cognn_gather_csr_u64", ptr(out), ptr(dev(base)) if with_base else None, ptr(dev(table)),
+             ptr(dev(rowptr.view(np.int32))), ptr(dev(col.view(np.int32))), n_rows, F)
+    assert np.array_equal(host(out), _csr_ref(base, table, rowptr, col))
+
+
+def test_gather_csr_heavy_rows_and_empty(ctx):
+    """Tiles whose edge count exceeds the LDS staging capacity, plus zero-row and all-empty inputs."""
+    rng = np.random.default_rng(5)
+    n_rows, n_table, F = 130, 400, 16
+    deg = np.full(n_rows, 3); deg[7] = 5000; deg[64] = 4000
+    rowptr = np.zeros(n_rows + 1, dtype=np.uint32); rowptr[1:] = np.cumsum(deg)
+    col = rng.integers(0, n_table, size=int(rowptr[-1]), dtype=np.uint32)
+    table = rand_u64(rng, (n_table, F))
+    out = dev_empty((n_rows, F))
+    ctx.call("cognn_gather_csr_u64", ptr(out), None, ptr(dev(table)), ptr(dev(rowptr.view(np.int32))),
+             ptr(dev(col.view(np.int32))), n_rows, F)
+    assert np.array_equal(host(out), _csr_ref(None, table, rowptr, col))
+    ctx.call("cognn_gather_csr_u64", ptr(out), None, ptr(dev(table)), ptr(dev(rowptr.view(np.int32))),
+             ptr(dev(col.view(np.int32))), 0, F)
+    rp0 = np.zeros(n_rows + 1, dtype=np.uint32)
+    base = rand_u64(rng, (n_rows, F))
+    ctx.call("cognn_gather_csr_u64", ptr(out), ptr(dev(base)), ptr(dev(table)), ptr(dev(rp0.view(np.int32))),
+             ptr(dev(col.view(np.int32))), n_rows, F)
+    assert np.array_equal(host(out), base)
+
+
+def test_gather_matches_unfused_reference_chain(ctx):
+    """Fused CSR gather == OEP -> copy -> prefix_network_aggregate -> OEP -> cond-add of the oracle."""
+    rng = np.random.default_rng(11)
+    n, F = 50, 8
+    pos = np.arange(100, 100 + n)                       # localVertexPos
+    srcs, dsts, dummy = [], [], []
+    for v in pos:
+        d = rng.integers(0, 5)
+        if d == 0:
+            srcs.append(v); dsts.append(v); dummy.append(True)
+        else:
+            s = rng.choice(pos, size=d)
+            srcs.extend(s); dsts.extend([v] * d); dummy.append(False)
+    x = rand_u64(rng, (n, F))
+    upd = co.oep(pos, srcs, x)
+    ext = co.oep(dsts, pos, co.prefix_network_aggregate(dsts, upd))
+    with np.errstate(over="ignore"):
+        want = x + np.where(~np.array(dummy)[:, None], ext, U64(0))
+    rowptr = [0]; col = []
+    i = 0
+    for r, v in enumerate(pos):
+        cnt = 0
+        while i < len(dsts) and dsts[i] == v:
+            if not dummy[r]:
+                col.append(srcs[i] - 100); cnt += 1
+            i += 1
+        rowptr.append(rowptr[-1] + cnt)
+    rowptr = np.array(rowptr, dtype=np.uint32); col = np.array(col, dtype=np.uint32)
+    xd = dev(x); out = dev_empty((n, F))
+    ctx.call("cognn_gather_csr_u64", ptr(out), ptr(xd), ptr(xd), ptr(dev(rowptr.view(np.int32))),
+             ptr(dev(col.view(np.int32))), n, F)
+    assert np.array_equal(host(out), want)
+
+
+@pytest.mark.parametrize("F", [64, 16, 7])
+def test_scatter_add_rows(ctx, F):
+    rng = np.random.default_rng(F)
+    n, q = 500, 211
+    v = rand_u64(rng, (n, F)); part = rand_u64(rng, (q, F))
+    idx = rng.permutation(n)[:q].astype(np.uint32)
+    vd = dev(v)
+    ctx.call("cognn_scatter_add_rows_u64", ptr(vd), ptr(dev(part)), ptr(dev(idx.view(np.int32))), q, F)
+    want = v.copy()
+    with np.errstate(over="ignore"):
+        want[idx] += part
+    assert np.array_equal(host(vd), want)
+
+
+GEMM_SHAPES = [
+    # M, N, K, transA
+    (300, 64, 128, 0), (1000, 16, 64, 0), (257, 7, 33, 0), (4096, 64, 128, 0), (513, 48, 96, 0),
+    (700, 128, 64, 0), (16, 7, 5000, 1), (128, 64, 3000, 1), (5, 3, 2, 0), (260, 16, 16, 0),
+]
+
+
+@pytest.mark.parametrize("M,N,K,transA", GEMM_SHAPES)
+def test_ring_gemm(ctx, M, N, K, transA):
+    rng = np.random.default_rng(M + N + K)
+    A = rand_u64(rng, (M, K)); B = rand_u64(rng, (K, N)); C0 = rand_u64(rng, (M, N))
+    Ad = dev(A.T.copy() if transA else A); Bd = dev(B); Cd = dev(C0)
+    ctx.call("cognn_ring_gemm_u64", ptr(Cd), ptr(Ad), ptr(Bd), M, N, K, transA, 0)
+    want = co.ring_matmul(A, B)
+    assert np.array_equal(host(Cd), want)
+    Cd = dev(C0)
+    ctx.call("cognn_ring_gemm_u64", ptr(Cd), ptr(Ad), ptr(Bd), M, N, K, transA, 1)
+    with np.errstate(over="ignore"):
+        assert np.array_equal(host(Cd), want + C0)
+
+
+def test_ring_gemm_limb_edge_values(ctx):
+    """Operands made of 0x80 / 0x7f / 0xff bytes exercise the signed-limb carry chain."""
+    M, N, K = 256, 64, 64
+    vals = np.array([0x8080808080808080, 0x7F7F7F7F7F7F7F7F, 0xFFFFFFFFFFFFFFFF, 0x0000000000000080,
+                     0x8000000000000000, 0x00FF00FF00FF00FF, 1, 0], dtype=U64)
+    rng = np.random.default_rng(3)
+    A = vals[rng.integers(0, len(vals), size=(M, K))]
+    B = vals[rng.integers(0, len(vals), size=(K, N))]
+    Cd = dev_empty((M, N))
+    ctx.call("cognn_ring_gemm_u64", ptr(Cd), ptr(dev(A)), ptr(dev(B)), M, N, K, 0, 0)
+    assert np.array_equal(host(Cd), co.ring_matmul(A, B))
+
+
+def test_trunc_pair(ctx):
+    rng = np.random.default_rng(2)
+    n = 4099
+    x = (rng.normal(size=n) * 2 ** 36).astype(np.int64).astype(U64)       # Q32-ish magnitudes
+    x0 = rand_u64(rng, n)
+    with np.errstate(over="ignore"):
+        x1 = x - x0
+    k, kf = keys_of(9, 3, 5, co.OP_PS_GEMM_TRUNC)
+    c0, c1, o0, o1 = (dev_empty(n) for _ in range(4))
+    ctx.call("cognn_trunc_open_u64", ptr(c0), ptr(dev(x0)), ctypes.c_uint64(1), ctypes.byref(k), 0, n)
+    ctx.call("cognn_trunc_open_u64", ptr(c1), ptr(dev(x1)), ctypes.c_uint64(1), ctypes.byref(k), 1, n)
+    ctx.call("cognn_trunc_close_u64", ptr(o0), ptr(c0), ptr(c1), ctypes.byref(k), 0, 0, n)
+    ctx.call("cognn_trunc_close_u64", ptr(o1), None, None, ctypes.byref(k), 1, 0, n)
+    w0, w1 = co.trunc_pair(x0, x1, kf)
+    assert np.array_equal(host(o0), w0) and np.array_equal(host(o1), w1)
+    with np.errstate(over="ignore"):
+        rec = (host(o0) + host(o1)).astype(np.int64)
+    exact = x.astype(np.int64) >> 16
+    assert np.all((rec - exact >= 0) & (rec - exact <= 1))               # floor or floor+1
+    # mode 1 (apply gradient): out -= y, with a public multiplier
+    W = rand_u64(rng, n); Wd0 = dev(W); Wd1 = dev(W)
+    mul = 32768
+    ctx.call("cognn_trunc_open_u64", ptr(c0), ptr(dev(x0)), ctypes.c_uint64(mul), ctypes.byref(k), 0, n)
+    ctx.call("cognn_trunc_open_u64", ptr(c1), ptr(dev(x1)), ctypes.c_uint64(mul), ctypes.byref(k), 1, n)
+    ctx.call("cognn_trunc_close_u64", ptr(Wd0), ptr(c0), ptr(c1), ctypes.byref(k), 0, 1, n)
+    ctx.call("cognn_trunc_close_u64", ptr(Wd1), None, None, ctypes.byref(k), 1, 1, n)
+    u0, u1 = co.const_scale_trunc_pair(x0, x1, mul, kf)
+    with np.errstate(over="ignore"):
+        assert np.array_equal(host(Wd0), W - u0) and np.array_equal(host(Wd1), W - u1)
+
+
+@pytest.mark.parametrize("F", [64, 7])
+def test_rowscale_trunc_pair(ctx, F):
+    rng = np.random.default_rng(F)
+    rows = 333
+    v = co.fx_encode(rng.normal(size=(rows, F)) * 4)
+    v0 = rand_u64(rng, (rows, F))
+    with np.errstate(over="ignore"):
+        v1 = v - v0
+    s0 = co.normalizer(rng.integers(0, 30, size=rows)); s1 = np.zeros(rows, dtype=U64)
+    k, kf = keys_of(1, 2, 3, co.OP_GA_SCALE)
+    tk, tkf = keys_of(1, 2, 3, co.OP_GA_SCALE_TRUNC)
+    E = [dev_empty((rows, F)) for _ in range(2)]; G = [dev_empty(rows) for _ in range(2)]
+    for p, (vp, sp) in enumerate(((v0, s0), (v1, s1))):
+        ctx.call("cognn_rowscale_open_u64", ptr(E[p]), ptr(G[p]), ptr(dev(vp)), ptr(dev(sp)), ctypes.byref(k), p, rows, F)
+    Es, Gs = dev_empty((rows, F)), dev_empty(rows)
+    ctx.call("cognn_add_u64", ptr(Es), ptr(E[0]), ptr(E[1]), rows * F)
+    ctx.call("cognn_add_u64", ptr(Gs), ptr(G[0]), ptr(G[1]), rows)
+    c = [dev_empty((rows, F)) for _ in range(2)]
+    for p in range(2):
+        ctx.call("cognn_rowscale_close_u64", ptr(c[p]), ptr(Es), ptr(Gs), ctypes.byref(k), ctypes.byref(tk), p, rows, F)
+    o = [dev_empty((rows, F)) for _ in range(2)]
+    ctx.call("cognn_trunc_close_u64", ptr(o[0]), ptr(c[0]), ptr(c[1]), ctypes.byref(tk), 0, 0, rows * F)
+    ctx.call("cognn_trunc_close_u64", ptr(o[1]), None, None, ctypes.byref(tk), 1, 0, rows * F)
+    z0, z1 = co.beaver_rowscale_pair(v0, v1, s0, s1, kf)
+    w0, w1 = co.trunc_pair(z0, z1, tkf)
+    assert np.array_equal(host(o[0]), w0) and np.array_equal(host(o[1]), w1)
+
+
+def test_relu_pair(ctx):
+    rng = np.random.default_rng(8)
+    n = 5001
+    z = co.fx_encode(rng.normal(size=n) * 10); z[:5] = 0
+    z0 = rand_u64(rng, n)
+    with np.errstate(over="ignore"):
+        z1 = z - z0
+    k, kf = keys_of(4, 0, 6, co.OP_AP_RELU)
+    E = [dev_empty(n) for _ in range(2)]; G = [dev_empty(n) for _ in range(2)]
+    zd = [dev(z0), dev(z1)]
+    for p in range(2):
+        ctx.call("cognn_relu_open_u64", ptr(E[p]), ptr(G[p]), ptr(zd[p]), ctypes.byref(k), p, n)
+    Es, Gs = dev_empty(n), dev_empty(n)
+    ctx.call("cognn_add_u64", ptr(Es), ptr(E[0]), ptr(E[1]), n)
+    ctx.call("cognn_add_u64", ptr(Gs), ptr(G[0]), ptr(G[1]), n)
+    w = [dev_empty(n) for _ in range(2)]
+    for p in range(2):
+        ctx.call("cognn_relu_mul_u64", ptr(w[p]), ptr(Es), ptr(Gs), ctypes.byref(k), p, n)
+    h = [dev_empty(n) for _ in range(2)]; mask = dev_empty(n, "u8")
+    for p in range(2):
+        ctx.call("cognn_relu_close_u64", ptr(h[p]), ptr(mask) if p == 0 else None, ptr(zd[p]), ptr(w[0]), ptr(w[1]), n)
+    h0, h1, pos = co.relu_pair(z0, z1, kf)
+    assert np.array_equal(host(h[0]), h0) and np.array_equal(host(h[1]), h1)
+    assert np.array_equal(host(mask, np.uint8).astype(bool), pos)
+    assert np.array_equal(pos, z.astype(np.int64) > 0)
+    sel = dev_empty(n)
+    ctx.call("cognn_mask_select_u64", ptr(sel), ptr(zd[0]), ptr(mask), n)
+    assert np.array_equal(host(sel), np.where(pos, z0, U64(0)))
+
+
+@pytest.mark.parametrize("L", [7, 16, 3])
+def test_softmax_pair_and_metrics(ctx, L):
+    rng = np.random.default_rng(L)
+    rows, train = 400, 80
+    z = co.fx_encode(rng.normal(size=(rows, L)) * 3)
+    z[0] = co.fx_encode(np.array([40.0] + [-40.0] * (L - 1)))            # saturating row
+    z0 = rand_u64(rng, (rows, L))
+    with np.errstate(over="ignore"):
+        z1 = z - z0
+    labels = rng.integers(0, L, size=rows).astype(np.int32)
+    k, kf = keys_of(5, 1, 1, co.OP_AP_SOFTMAX)
+    p = [dev_empty((rows, L)) for _ in range(2)]; d = [dev_empty((rows, L)) for _ in range(2)]; pfx = dev_empty((rows, L))
+    ctx.call("cognn_softmax_u64", ptr(p[0]), ptr(d[0]), ptr(pfx), ptr(dev(z0)), ptr(dev(z1)), ptr(dev(labels)),
+             ctypes.byref(k), 0, rows, L, train)
+    ctx.call("cognn_softmax_u64", ptr(p[1]), ptr(d[1]), None, None, None, None, ctypes.byref(k), 1, rows, L, train)
+    p0, p1, d0, d1, plainP = co.softmax_pair(z0, z1, labels, train, kf)
+    assert np.array_equal(host(p[0]), p0) and np.array_equal(host(p[1]), p1)
+    assert np.array_equal(host(d[0]), d0) and np.array_equal(host(d[1]), d1)
+    assert np.array_equal(host(pfx).astype(np.float64) / 65536, plainP)
+    # integer softmax tracks the float softmax
+    zf = co.fx_decode(z); e = np.exp(zf - zf.max(1, keepdims=True)); pf = e / e.sum(1, keepdims=True)
+    assert np.abs(plainP - pf).max() < 1e-4
+    border = (rng.random(rows) < 0.3).astype(np.uint8)
+    val = 80
+    counts = dev_empty(6); loss = dev_empty(1, "f64")
+    ctx.call("cognn_metrics_q16", ptr(pfx), ptr(dev(labels)), ptr(dev(border)), rows, L, train, val, ptr(counts), ptr(loss))
+    pp = np.where(plainP == 0, 0.001, plainP)
+    ok = pp.argmax(1) == labels
+    idx = np.arange(rows); tr = idx < train; te = idx >= train + val; b = border.astype(bool)
+    cnt = host(counts, np.int64)
+    assert list(cnt[:5]) == [ok.sum(), (ok & tr).sum(), (ok & tr & b).sum(), (ok & te).sum(), (ok & te & b).sum()]
+    want_loss = -np.log(pp[idx, labels]).sum()
+    assert abs(float(host(loss, np.float64)[0]) - want_loss) < 1e-9 * max(1.0, abs(want_loss))   # fp tolerance: atomics order
+
+
+@pytest.mark.parametrize("M,N,K,transA", [(300, 64, 128, 0), (270, 7, 16, 0), (16, 7, 300, 1), (1433, 16, 270, 1)])
+def test_beaver_gemm_pair(ctx, M, N, K, transA):
+    """Full Beaver product: mask-open, exchange, dealer C1, close; vs oracle twoPartyGCNMatMul stand-in."""
+    rng = np.random.default_rng(M * 3 + N)
+    X = rand_u64(rng, (M, K)); W = rand_u64(rng, (K, N))
+    X0 = rand_u64(rng, (M, K)); W0 = rand_u64(rng, (K, N))
+    with np.errstate(over="ignore"):
+        X1 = X - X0; W1 = W - W0
+    k, kf = keys_of(11, 2, 4, co.OP_PS_GEMM)
+    stor = (lambda a: a.T.copy()) if transA else (lambda a: a)
+    E = [dev_empty(stor(X0).shape) for _ in range(2)]; Fm = [dev_empty((K, N)) for _ in range(2)]
+    for p, (xp, wp) in enumerate(((X0, W0), (X1, W1))):
+        ctx.call("cognn_mask_open_u64", ptr(E[p]), ptr(dev(stor(xp))), ctypes.c_uint64(kf(co.SL_A0 + p)), M, K, transA)
+        ctx.call("cognn_mask_open_u64", ptr(Fm[p]), ptr(dev(wp)), ctypes.c_uint64(kf(co.SL_B0 + p)), K, N, 0)
+    Es, Fs = dev_empty(stor(X0).shape), dev_empty((K, N))
+    ctx.call("cognn_add_u64", ptr(Es), ptr(E[0]), ptr(E[1]), M * K)
+    ctx.call("cognn_add_u64", ptr(Fs), ptr(Fm[0]), ptr(Fm[1]), K * N)
+    c1 = dev_empty((M, N)); sa = dev_empty(M * K + K * N)
+    ctx.call("cognn_dealer_gemm_c1_u64", ptr(c1), ctypes.byref(k), M, N, K, transA, ptr(sa), ctypes.c_void_p(sa.data_ptr() + 8 * M * K))
+    Z = [dev_empty((M, N)) for _ in range(2)]
+    for p in range(2):
+        ctx.call("cognn_beaver_gemm_close_u64", ptr(Z[p]), ptr(Es), ptr(Fs), ptr(c1) if p == 1 else None, ctypes.byref(k), p,
+                 M, N, K, transA, ptr(sa))
+    z0, z1 = co.beaver_gemm_pair(X0, X1, W0, W1, kf)
+    assert np.array_equal(host(Z[0]), z0) and np.array_equal(host(Z[1]), z1)
+    with np.errstate(over="ignore"):
+        assert np.array_equal(host(Z[0]) + host(Z[1]), co.ring_matmul(X, W))
