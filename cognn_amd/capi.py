@@ -37,6 +37,7 @@ _SIGNATURES = {
     "cognn_abi_version": (_I, []),
     "cognn_last_error": (ctypes.c_char_p, []),
     "cognn_ctx_create": (_I, [_I, _P, ctypes.POINTER(_P)]),
+    "cognn_ctx_create_private": (_I, [_I, ctypes.POINTER(_P)]),
     "cognn_ctx_destroy": (_I, [_P]),
     "cognn_ctx_sync": (_I, [_P]),
     "cognn_malloc": (_I, [_P, ctypes.POINTER(_P), ctypes.c_size_t]),

@@ -29,10 +29,16 @@ int cognn_ctx_create(int device, void* stream, cognn_ctx** out) {
     CG_HIP(hipSetDevice(device));
     cognn_ctx* c = new cognn_ctx();
     c->device = device;
-    c->own_stream = (stream == nullptr);
-    if (stream) c->stream = (hipStream_t)stream;
-    else CG_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    c->own_stream = false;
+    c->stream = (hipStream_t)stream;          /* NULL = the device's default (null) stream */
     *out = c;
+    return 0;
+}
+int cognn_ctx_create_private(int device, cognn_ctx** out) {
+    int rc = cognn_ctx_create(device, nullptr, out);
+    if (rc) return rc;
+    CG_HIP(hipStreamCreateWithFlags(&(*out)->stream, hipStreamNonBlocking));
+    (*out)->own_stream = true;
     return 0;
 }
 int cognn_ctx_destroy(cognn_ctx* ctx) {

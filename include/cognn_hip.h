@@ -34,8 +34,10 @@ typedef struct { uint64_t k[COGNN_NUM_SLOTS]; } cognn_keys;   /* == cognn_opkeys
 /* ---- context / memory ------------------------------------------------------------------ */
 int cognn_abi_version(void);
 const char* cognn_last_error(void);
-/* stream: a hipStream_t owned by the caller (e.g. torch's current stream) or NULL for a private one */
+/* stream: a hipStream_t owned by the caller (e.g. torch's current stream); NULL = the default stream */
 int cognn_ctx_create(int device, void* stream, cognn_ctx** out);
+/* same, on a private non-blocking stream owned by the context */
+int cognn_ctx_create_private(int device, cognn_ctx** out);
 int cognn_ctx_destroy(cognn_ctx* ctx);
 int cognn_ctx_sync(cognn_ctx* ctx);
 int cognn_malloc(cognn_ctx* ctx, void** ptr, size_t bytes);

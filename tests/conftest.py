@@ -2,6 +2,7 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 for p in (ROOT, os.path.join(ROOT, "oracle")):
     if p not in sys.path:
         sys.path.insert(0, p)
@@ -9,3 +10,16 @@ for p in (ROOT, os.path.join(ROOT, "oracle")):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: test needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+import pytest
+
+
+@pytest.fixture(autouse=True)
+def _release_device_tensors():
+    yield
+    try:
+        import gpu_util
+        gpu_util.release()
+    except ImportError:
+        pass

@@ -3,6 +3,11 @@ import ctypes
 import numpy as np
 
 U64 = np.uint64
+_KEEP = []      # device tensors stay alive until the next test starts (pointers are passed raw)
+
+
+def release():
+    del _KEEP[:]
 
 
 def dev(arr):
@@ -10,13 +15,17 @@ def dev(arr):
     a = np.ascontiguousarray(arr)
     if a.dtype == np.uint64:
         a = a.view(np.int64)
-    return torch.from_numpy(a).cuda()
+    t = torch.from_numpy(a).cuda()
+    _KEEP.append(t)
+    return t
 
 
 def dev_empty(shape, dtype="u64"):
     import torch
     td = {"u64": torch.int64, "u8": torch.uint8, "i32": torch.int32, "f64": torch.float64, "u32": torch.int32}[dtype]
-    return torch.zeros(shape, dtype=td, device="cuda")
+    t = torch.zeros(shape, dtype=td, device="cuda")
+    _KEEP.append(t)
+    return t
 
 
 def host(t, dtype=U64):
