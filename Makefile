@@ -4,6 +4,8 @@ ARCH ?= gfx950
 CSRC := cognn_amd/csrc
 HOST := cognn_amd/host
 OUT := cognn_amd/libcognn_hip.so
+HOSTCXX ?= g++
+HOSTFLAGS := -O2 -fPIC -std=c++17 -Wall -Wno-unused-function -Iinclude -I$(CSRC)
 HIPFLAGS := --offload-arch=$(ARCH) -O3 -fPIC -std=c++17 -Wall -Wno-unused-function -Iinclude -I$(CSRC)
 KERNEL_SRCS := $(CSRC)/capi.hip $(CSRC)/kernels_elementwise.hip $(CSRC)/kernels_gather.hip $(CSRC)/kernels_gemm.hip
 HOST_SRCS := $(wildcard $(HOST)/*.cpp)
@@ -15,7 +17,7 @@ $(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/common.h $(CSRC)/cognn_spec.h include/cognn_h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
 $(HOST)/%.o: $(HOST)/%.cpp $(wildcard $(HOST)/*.h) $(CSRC)/cognn_spec.h include/cognn_hip.h include/cognn_engine.h
-	$(HIPCC) $(HIPFLAGS) -x hip -c $< -o $@
+	$(HOSTCXX) $(HOSTFLAGS) -c $< -o $@
 
 $(OUT): $(OBJS)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS) -lpthread

@@ -68,6 +68,11 @@ _SIGNATURES = {
     "cognn_mask_select_u64": (_I, [_P, _P, _P, _P, _L]),
     "cognn_softmax_u64": (_I, [_P, _P, _P, _P, _P, _P, _P, _KP, _I, _L, _L, _L]),
     "cognn_metrics_q16": (_I, [_P, _P, _P, _P, _L, _L, _L, _L, _P, _P]),
+    "cognn_transpose_u64": (_I, [_P, _P, _P, _L, _L]),
+    "cognn_timer_begin": (_I, [_P, _I]),
+    "cognn_timer_end": (_I, [_P, _I]),
+    "cognn_timer_read": (_I, [_P, _I, ctypes.POINTER(_L), ctypes.POINTER(ctypes.c_double)]),
+    "cognn_timer_reset": (_I, [_P]),
 }
 
 _lib = None

@@ -43,6 +43,7 @@ int cognn_ctx_create_private(int device, cognn_ctx** out) {
 }
 int cognn_ctx_destroy(cognn_ctx* ctx) {
     if (!ctx) return 0;
+    (void)cognn_timer_reset(ctx);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return 0;
@@ -81,6 +82,47 @@ int cognn_memcpy_d2d(cognn_ctx* ctx, void* dst, const void* src, size_t bytes) {
 int cognn_memset0(cognn_ctx* ctx, void* dst, size_t bytes) {
     CG_REQUIRE(ctx, "cognn_memset0: null ctx");
     if (bytes) CG_HIP(hipMemsetAsync(dst, 0, bytes, ctx->stream));
+    return 0;
+}
+int cognn_timer_begin(cognn_ctx* ctx, int kind) {
+    CG_REQUIRE(ctx && kind >= 0 && kind < 8, "cognn_timer_begin: bad arguments");
+    hipEvent_t ev;
+    CG_HIP(hipEventCreate(&ev));
+    CG_HIP(hipEventRecord(ev, ctx->stream));
+    ctx->open_begin[kind].push_back(ev);
+    return 0;
+}
+int cognn_timer_end(cognn_ctx* ctx, int kind) {
+    CG_REQUIRE(ctx && kind >= 0 && kind < 8 && !ctx->open_begin[kind].empty(), "cognn_timer_end: no open timer");
+    hipEvent_t ev;
+    CG_HIP(hipEventCreate(&ev));
+    CG_HIP(hipEventRecord(ev, ctx->stream));
+    cognn_timer_pair pr{ctx->open_begin[kind].back(), ev};
+    ctx->open_begin[kind].pop_back();
+    ctx->timers[kind].push_back(pr);
+    return 0;
+}
+int cognn_timer_read(cognn_ctx* ctx, int kind, int64_t* launches, double* total_ms) {
+    CG_REQUIRE(ctx && kind >= 0 && kind < 8 && launches && total_ms, "cognn_timer_read: bad arguments");
+    CG_HIP(hipStreamSynchronize(ctx->stream));
+    double tot = 0;
+    for (auto& pr : ctx->timers[kind]) {
+        float ms = 0;
+        CG_HIP(hipEventElapsedTime(&ms, pr.b, pr.e));
+        tot += ms;
+    }
+    *launches = (int64_t)ctx->timers[kind].size();
+    *total_ms = tot;
+    return 0;
+}
+int cognn_timer_reset(cognn_ctx* ctx) {
+    CG_REQUIRE(ctx, "cognn_timer_reset: null ctx");
+    for (int k = 0; k < 8; ++k) {
+        for (auto& pr : ctx->timers[k]) { (void)hipEventDestroy(pr.b); (void)hipEventDestroy(pr.e); }
+        ctx->timers[k].clear();
+        for (auto& ev : ctx->open_begin[k]) (void)hipEventDestroy(ev);
+        ctx->open_begin[k].clear();
+    }
     return 0;
 }
 void cognn_make_keys(uint64_t seed, uint64_t owner, uint64_t iter, uint64_t op, cognn_keys* out) {

@@ -6,10 +6,14 @@
 #include <stdio.h>
 #include "cognn_spec.h"
 
+#include <vector>
+struct cognn_timer_pair { hipEvent_t b, e; };
 struct cognn_ctx {
     int device;
     hipStream_t stream;
     bool own_stream;
+    std::vector<cognn_timer_pair> timers[8];   // per kind
+    std::vector<hipEvent_t> open_begin[8];
 };
 
 int cognn_set_error(const char* fmt, ...);

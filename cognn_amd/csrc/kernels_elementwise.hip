@@ -282,6 +282,13 @@ __global__ __launch_bounds__(kThreads) void metrics_kernel(const u64* pfx, const
     atomicAdd(loss, -log(pl));
 }
 
+__global__ __launch_bounds__(kThreads) void transpose_kernel(u64* out, const u64* in, int64_t rows, int64_t cols) {
+    const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (i >= rows * cols) return;
+    const int64_t r = i / cols, c = i % cols;
+    out[c * rows + r] = in[i];
+}
+
 inline cognn_opkeys K(const cognn_keys* k) {
     cognn_opkeys r;
     for (int i = 0; i < COGNN_SL_COUNT; ++i) r.k[i] = k->k[i];
@@ -378,6 +385,15 @@ int cognn_metrics_q16(cognn_ctx* ctx, const uint64_t* pfx, const int32_t* labels
     if (rows <= 0) return 0;
     hipLaunchKernelGGL(metrics_kernel, dim3(cg_div_up(rows, kThreads)), dim3(kThreads), 0, ctx->stream, (const u64*)pfx, labels,
                        border, rows, (int)L, train_rows, val_rows, (unsigned long long*)counts6, loss);
+    CG_LAUNCH_CHECK();
+    return 0;
+}
+
+int cognn_transpose_u64(cognn_ctx* ctx, uint64_t* out, const uint64_t* in, int64_t rows, int64_t cols) {
+    CG_REQUIRE(ctx && out && in && out != in, "cognn_transpose_u64: bad arguments");
+    if (rows * cols <= 0) return 0;
+    hipLaunchKernelGGL(transpose_kernel, dim3(cg_div_up(rows * cols, kThreads)), dim3(kThreads), 0, ctx->stream, (u64*)out,
+                       (const u64*)in, rows, cols);
     CG_LAUNCH_CHECK();
     return 0;
 }

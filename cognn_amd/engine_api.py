@@ -2,11 +2,45 @@
 import ctypes
 
 _P = ctypes.c_void_p
-_I = ctypes.c_int
+_I = ctypes.c_int32
 _L = ctypes.c_int64
 _U = ctypes.c_uint64
+_D = ctypes.c_double
 
-_SIGNATURES = {}
+
+class EngineConfig(ctypes.Structure):
+    _fields_ = [("num_parties", _I), ("rank", _I), ("world", _I), ("variant", _I),
+                ("num_layers", _I), ("num_labels", _I), ("input_dim", _I), ("hidden_dim", _I),
+                ("learning_rate", _D), ("train_ratio", _D), ("val_ratio", _D), ("test_ratio", _D),
+                ("seed", _U), ("device", _I), ("stream", _P), ("undirected", _I), ("verbose", _I)]
+
+
+class Xfer(ctypes.Structure):
+    _fields_ = [("peer", _I), ("is_send", _I), ("ptr", _P), ("bytes", _L)]
+
+
+EXCHANGE_FN = ctypes.CFUNCTYPE(ctypes.c_int, _P, ctypes.POINTER(Xfer), _I)
+
+_SIGNATURES = {
+    "cognn_engine_last_error": (ctypes.c_char_p, []),
+    "cognn_engine_create": (ctypes.c_int, [ctypes.POINTER(EngineConfig), _L, _L, _P, _P, _P, ctypes.POINTER(_P)]),
+    "cognn_engine_destroy": (ctypes.c_int, [_P]),
+    "cognn_engine_set_exchange": (ctypes.c_int, [_P, EXCHANGE_FN, _P]),
+    "cognn_engine_party_rows": (ctypes.c_int, [_P, _I, ctypes.POINTER(_L)]),
+    "cognn_engine_party_vids": (ctypes.c_int, [_P, _I, _P]),
+    "cognn_engine_party_degrees": (ctypes.c_int, [_P, _I, _P, _P, _P]),
+    "cognn_engine_set_party_data": (ctypes.c_int, [_P, _I, _P, _P]),
+    "cognn_engine_set_weights": (ctypes.c_int, [_P, _P, _P]),
+    "cognn_engine_start": (ctypes.c_int, [_P]),
+    "cognn_engine_offline": (ctypes.c_int, [_P, _L, _L]),
+    "cognn_engine_run": (ctypes.c_int, [_P, _L, _L]),
+    "cognn_engine_get_shares": (ctypes.c_int, [_P, _I, _I, _P, ctypes.POINTER(_L), ctypes.POINTER(_L)]),
+    "cognn_engine_get_weight": (ctypes.c_int, [_P, _I, _I, _I, _P]),
+    "cognn_engine_get_metrics": (ctypes.c_int, [_P, _I, _P]),
+    "cognn_engine_enable_timing": (ctypes.c_int, [_P, _I]),
+    "cognn_engine_get_timing": (ctypes.c_int, [_P, _I, ctypes.POINTER(_L), ctypes.POINTER(_D), ctypes.POINTER(_D)]),
+    "cognn_engine_get_workload": (ctypes.c_int, [_P, _P]),
+}
 
 
 def exported_names():

@@ -1,0 +1,969 @@
+// Host engine: the MI355X-first counterpart of SSEdgeCentricAlgoKernel (include/
+// ss_vertex_centric_algo_kernel.h:168-277, 680-910, 912-1189) running the optimize-gcn callbacks
+// (algo_kernels/vertex_centric/optimize-gcn/gcn.h:198-811) for every party hosted on this rank.
+//
+// Differences from the reference's structure (results on shares are those of oracle/cognn_oracle.py):
+//  * no thread-per-peer: one HIP stream, kernels batched over all hosted parties;
+//  * a "Side" is one share-holder role for one owner's vertices: p=0 the owner (client, sci::ALICE),
+//    p=1 the co-party (owner+1)%k (server, sci::BOB).  Every two-party op is open -> exchange -> close;
+//    when both sides live on this rank the exchange is a pointer hand-off;
+//  * Scatter/PreMerge/Gather are two CSR launches per round over a rank-wide share table
+//    (partials for remote destinations, then the aggregate of every hosted row), see DESIGN.md §4.
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <map>
+#include <stdexcept>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "../../include/cognn_engine.h"
+#include "../csrc/cognn_spec.h"
+#include "backend.h"
+#include "graph.h"
+
+typedef uint64_t u64;
+
+namespace {
+
+thread_local std::string g_engine_error;
+
+struct EngineError : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+
+enum { T_AGG = 0, T_PART = 1, T_GEMM = 2 };
+
+struct Side {
+    int owner = 0, p = 0, n = 0;
+    int peer_rank = 0;
+    Side* peer = nullptr;          // non-null when the other share-holder is hosted on this rank
+    u64* feat = nullptr;           // [n x in] input-feature share (localVertexSvvBackup / remoteVertexSvvsBackup)
+    u64* W[2] = {nullptr, nullptr};
+    u64* WT = nullptr;             // transposed W1 scratch [lab x hid]
+    u64* h1 = nullptr;             // h_t of layer 1 [n x hid]   (vertexInterData["h_t"], gcn.h:230-231)
+    u64* g = nullptr;              // vertexInterData["g"] [n x hid]
+    uint8_t* relu_mask = nullptr;  // public sign of z[0] (revealed by the masked-sign ReLU)
+    u64* cur = nullptr;            // current vertex tensor share [n x curF]
+    int curF = 0;
+    u64* buf[2] = {nullptr, nullptr};
+    u64* ob[2] = {nullptr, nullptr};
+    u64* ib_store[2] = {nullptr, nullptr};
+    u64* ib[2] = {nullptr, nullptr};
+    u64* sum[2] = {nullptr, nullptr};
+    u64* scratch = nullptr;
+    u64* zbuf = nullptr;           // untruncated GEMM output
+    u64* small[3] = {nullptr, nullptr, nullptr};   // [in x hid]-sized temporaries for the weight chain
+    u64* svec = nullptr;           // normaliser share [n]
+    int32_t* labels = nullptr;
+    uint8_t* border = nullptr;
+    u64* pfx = nullptr;            // revealed Q16 probabilities (owner only)
+    int64_t* counts = nullptr;
+    double* loss = nullptr;
+    bool has_metrics = false;
+    std::map<std::pair<int64_t, int>, u64*> c1;   // dealer product shares, (iter, op) -> [M x N]
+};
+
+}  // namespace
+
+struct cognn_engine {
+    cognn_engine_config cfg;
+    const cognn_backend* be = nullptr;
+    cognn_ctx* ctx = nullptr;
+    cognn::PartitionedGraph G;
+    int k = 0, world = 1, rank = 0, m = 1;
+    std::vector<int> hosted, cohosted;
+    std::vector<Side> sides;
+    std::vector<void*> allocs;
+    cognn_exchange_fn xfn = nullptr;
+    void* xuser = nullptr;
+    bool started = false, timing = false;
+    // share table of the current message-passing round
+    int64_t tableRows = 0, aggRows = 0, inboxRows = 0, inboxLocalOff = 0, partRows = 0;
+    int Fmp = 0;
+    std::vector<int64_t> A_off, B_off;
+    u64* table = nullptr;
+    u64* aggOut = nullptr;
+    uint32_t *agg_rowptr = nullptr, *agg_col = nullptr, *part_rowptr = nullptr, *part_col = nullptr;
+    int64_t aggEdges = 0, partEdges = 0;
+    struct Seg { int src_party, dst_owner; int64_t rows, inbox_off, out_off; int src_rank, dst_rank; };
+    std::vector<Seg> segs;         // partial-sum segments this rank sends or receives
+    std::vector<std::vector<double>> hostFeat;
+    std::vector<std::vector<int32_t>> hostLabels;
+    std::vector<double> w0, w1;
+    double algo[3] = {0, 0, 0};
+
+    int in() const { return cfg.input_dim; }
+    int hid() const { return cfg.hidden_dim; }
+    int lab() const { return cfg.num_labels; }
+    int rank_of(int party) const { return party / m; }
+    int co(int owner) const { return (owner + 1) % k; }
+    Side* side(int owner, int p) {
+        for (auto& s : sides) if (s.owner == owner && s.p == p) return &s;
+        return nullptr;
+    }
+};
+
+namespace {
+
+#define BE(call)                                                                   \
+    do {                                                                           \
+        if ((E->be->call) != 0) throw EngineError(std::string(E->be->cognn_last_error())); \
+    } while (0)
+
+template <class T>
+T* dalloc(cognn_engine* E, size_t count) {
+    void* p = nullptr;
+    BE(cognn_malloc(E->ctx, &p, std::max<size_t>(count, 2) * sizeof(T)));
+    E->allocs.push_back(p);
+    return (T*)p;
+}
+template <class T>
+T* upload(cognn_engine* E, const std::vector<T>& v) {
+    T* d = dalloc<T>(E, v.size());
+    if (!v.empty()) BE(cognn_memcpy_h2d(E->ctx, d, v.data(), v.size() * sizeof(T)));
+    return d;
+}
+
+cognn_keys keys(cognn_engine* E, u64 owner, int64_t it, int op) {
+    cognn_keys k;
+    cognn_opkeys o = cognn_make_opkeys(E->cfg.seed, owner, (u64)it, (u64)op);
+    for (int i = 0; i < COGNN_SL_COUNT; ++i) k.k[i] = o.k[i];
+    return k;
+}
+
+u64 fx_llround(double x) { return (u64)(long long)llround(x * (double)COGNN_FX_ONE); }
+u64 fx_trunc(double x) { return (u64)(x * (double)COGNN_FX_ONE); }   // static_cast as in gcn.h:676,678,764
+
+// ---------------------------------------------------------------------------------------------
+// exchange
+// ---------------------------------------------------------------------------------------------
+struct XList {
+    std::vector<cognn_xfer> v;
+    void send(int peer, void* p, int64_t bytes) { if (bytes > 0) v.push_back(cognn_xfer{peer, 1, p, bytes}); }
+    void recv(int peer, void* p, int64_t bytes) { if (bytes > 0) v.push_back(cognn_xfer{peer, 0, p, bytes}); }
+};
+void run_exchange(cognn_engine* E, XList& xl) {
+    if (xl.v.empty()) return;
+    if (!E->xfn) throw EngineError("engine: world > 1 needs an exchange function (cognn_engine_set_exchange)");
+    if (E->xfn(E->xuser, xl.v.data(), (int32_t)xl.v.size()) != 0) throw EngineError("engine: exchange function failed");
+}
+// pairwise swap of outbox j (elems u64 each) between the two sides of every owner
+void exchange_ob(cognn_engine* E, int j, const std::vector<int64_t>& elems) {
+    XList xl;
+    for (size_t i = 0; i < E->sides.size(); ++i) {
+        Side& s = E->sides[i];
+        if (s.peer) continue;
+        xl.send(s.peer_rank, s.ob[j], elems[i] * 8);
+        xl.recv(s.peer_rank, s.ib[j], elems[i] * 8);
+    }
+    run_exchange(E, xl);
+}
+std::vector<int64_t> per_side(cognn_engine* E, int64_t (*f)(cognn_engine*, Side&)) {
+    std::vector<int64_t> r;
+    for (auto& s : E->sides) r.push_back(f(E, s));
+    return r;
+}
+
+// ---------------------------------------------------------------------------------------------
+// two-party stages (all hosted sides advance together)
+// ---------------------------------------------------------------------------------------------
+struct GemmSpec {            // logical Z[MxN] = X[MxK] . Wm[KxN]
+    int64_t M, N, K;
+    int transA;
+    int op, top;             // dealer op ids for the product and its truncation
+};
+
+// truncation of every side's `x` (elems) scaled by `mul`; result written/applied to dst(side)
+template <class DstFn>
+void trunc_stage(cognn_engine* E, int64_t it, int op, u64 mul, const std::vector<u64*>& x, const std::vector<int64_t>& elems,
+                 DstFn dst, int mode, u64 owner_override = ~0ull) {
+    for (size_t i = 0; i < E->sides.size(); ++i) {
+        Side& s = E->sides[i];
+        cognn_keys k = keys(E, owner_override == ~0ull ? (u64)s.owner : owner_override, it, op);
+        BE(cognn_trunc_open_u64(E->ctx, s.ob[0], x[i], mul, &k, s.p, elems[i]));
+    }
+    exchange_ob(E, 0, elems);
+    for (size_t i = 0; i < E->sides.size(); ++i) {
+        Side& s = E->sides[i];
+        cognn_keys k = keys(E, owner_override == ~0ull ? (u64)s.owner : owner_override, it, op);
+        BE(cognn_trunc_close_u64(E->ctx, dst(s), s.p == 0 ? s.ob[0] : nullptr, s.p == 0 ? s.ib[0] : nullptr, &k, s.p, mode, elems[i]));
+    }
+}
+
+// Beaver GEMM for every side: X(side), Wm(side) -> truncated product written to dst(side)
+template <class XFn, class WFn, class SpecFn, class DstFn>
+void gemm_stage(cognn_engine* E, int64_t it, XFn X, WFn Wm, SpecFn spec, DstFn dst) {
+    std::vector<int64_t> e0, e1, eo;
+    for (auto& s : E->sides) {
+        GemmSpec g = spec(s);
+        cognn_keys k = keys(E, s.owner, it, g.op);
+        BE(cognn_mask_open_u64(E->ctx, s.ob[0], X(s), k.k[s.p == 0 ? COGNN_SL_A0 : COGNN_SL_A1], g.M, g.K, g.transA));
+        BE(cognn_mask_open_u64(E->ctx, s.ob[1], Wm(s), k.k[s.p == 0 ? COGNN_SL_B0 : COGNN_SL_B1], g.K, g.N, 0));
+        e0.push_back(g.M * g.K); e1.push_back(g.K * g.N); eo.push_back(g.M * g.N);
+    }
+    exchange_ob(E, 0, e0);
+    exchange_ob(E, 1, e1);
+    for (size_t i = 0; i < E->sides.size(); ++i) {
+        Side& s = E->sides[i];
+        BE(cognn_add_u64(E->ctx, s.sum[0], s.ob[0], s.ib[0], e0[i]));
+        BE(cognn_add_u64(E->ctx, s.sum[1], s.ob[1], s.ib[1], e1[i]));
+    }
+    std::vector<u64*> z;
+    for (size_t i = 0; i < E->sides.size(); ++i) {
+        Side& s = E->sides[i];
+        GemmSpec g = spec(s);
+        cognn_keys k = keys(E, s.owner, it, g.op);
+        const u64* c1 = nullptr;
+        if (s.p == 1) {
+            auto f = s.c1.find({it, g.op});
+            if (f == s.c1.end()) {                       // dealer product share not precomputed: do it now
+                u64* c = dalloc<u64>(E, (size_t)eo[i]);
+                BE(cognn_dealer_gemm_c1_u64(E->ctx, c, &k, g.M, g.N, g.K, g.transA, s.scratch, s.scratch + g.M * g.K));
+                f = s.c1.emplace(std::make_pair(it, g.op), c).first;
+            }
+            c1 = f->second;
+        }
+        if (E->timing) BE(cognn_timer_begin(E->ctx, T_GEMM));
+        BE(cognn_beaver_gemm_close_u64(E->ctx, s.zbuf, s.sum[0], s.sum[1], c1, &k, s.p, g.M, g.N, g.K, g.transA, s.scratch));
+        if (E->timing) { BE(cognn_timer_end(E->ctx, T_GEMM)); E->algo[T_GEMM] += 2.0 * 36 * 2 * (double)g.M * g.K * g.N; }
+        z.push_back(s.zbuf);
+    }
+    // all GEMMs of one stage share the truncation op id
+    GemmSpec g0 = spec(E->sides[0]);
+    trunc_stage(E, it, g0.top, 1, z, eo, dst, 0);
+}
+
+// row scale by the (owner-known) normaliser followed by truncation; x(side) [n x F] -> dst(side)
+template <class XFn, class DstFn>
+void rowscale_stage(cognn_engine* E, int64_t it, int op, int top, int F, XFn X, DstFn dst) {
+    std::vector<int64_t> eF, e1;
+    for (auto& s : E->sides) {
+        cognn_keys k = keys(E, s.owner, it, op);
+        BE(cognn_rowscale_open_u64(E->ctx, s.ob[0], s.ob[1], X(s), s.svec, &k, s.p, s.n, F));
+        eF.push_back((int64_t)s.n * F); e1.push_back(s.n);
+    }
+    exchange_ob(E, 0, eF);
+    exchange_ob(E, 1, e1);
+    for (size_t i = 0; i < E->sides.size(); ++i) {
+        Side& s = E->sides[i];
+        BE(cognn_add_u64(E->ctx, s.sum[0], s.ob[0], s.ib[0], eF[i]));
+        BE(cognn_add_u64(E->ctx, s.sum[1], s.ob[1], s.ib[1], e1[i]));
+    }
+    for (auto& s : E->sides) {
+        cognn_keys k = keys(E, s.owner, it, op), tk = keys(E, s.owner, it, top);
+        BE(cognn_rowscale_close_u64(E->ctx, s.ob[0], s.sum[0], s.sum[1], &k, &tk, s.p, s.n, F));
+    }
+    exchange_ob(E, 0, eF);
+    for (size_t i = 0; i < E->sides.size(); ++i) {
+        Side& s = E->sides[i];
+        cognn_keys tk = keys(E, s.owner, it, top);
+        BE(cognn_trunc_close_u64(E->ctx, dst(s), s.p == 0 ? s.ob[0] : nullptr, s.p == 0 ? s.ib[0] : nullptr, &tk, s.p, 0, eF[i]));
+    }
+}
+
+void relu_stage(cognn_engine* E, int64_t it) {
+    const int F = E->hid();
+    std::vector<int64_t> eF;
+    for (auto& s : E->sides) {
+        cognn_keys k = keys(E, s.owner, it, COGNN_OP_AP_RELU);
+        BE(cognn_relu_open_u64(E->ctx, s.ob[0], s.ob[1], s.cur, &k, s.p, (int64_t)s.n * F));
+        eF.push_back((int64_t)s.n * F);
+    }
+    exchange_ob(E, 0, eF);
+    exchange_ob(E, 1, eF);
+    for (size_t i = 0; i < E->sides.size(); ++i) {
+        Side& s = E->sides[i];
+        BE(cognn_add_u64(E->ctx, s.sum[0], s.ob[0], s.ib[0], eF[i]));
+        BE(cognn_add_u64(E->ctx, s.sum[1], s.ob[1], s.ib[1], eF[i]));
+    }
+    for (size_t i = 0; i < E->sides.size(); ++i) {
+        Side& s = E->sides[i];
+        cognn_keys k = keys(E, s.owner, it, COGNN_OP_AP_RELU);
+        BE(cognn_relu_mul_u64(E->ctx, s.ob[0], s.sum[0], s.sum[1], &k, s.p, eF[i]));
+    }
+    exchange_ob(E, 0, eF);
+    for (size_t i = 0; i < E->sides.size(); ++i) {
+        Side& s = E->sides[i];
+        u64* dstb = (s.cur == s.buf[1]) ? s.buf[0] : s.buf[1];
+        BE(cognn_relu_close_u64(E->ctx, dstb, s.relu_mask, s.cur, s.ob[0], s.ib[0], eF[i]));
+        s.cur = dstb;
+    }
+}
+
+void softmax_stage(cognn_engine* E, int64_t it) {
+    const int L = E->lab();
+    XList xl;                                            // the co-party reveals its share of z to the owner
+    for (auto& s : E->sides) {
+        if (s.peer) continue;
+        if (s.p == 1) xl.send(s.peer_rank, s.cur, (int64_t)s.n * L * 8);
+        else xl.recv(s.peer_rank, s.ib[0], (int64_t)s.n * L * 8);
+    }
+    run_exchange(E, xl);
+    for (auto& s : E->sides) {
+        cognn_keys k = keys(E, s.owner, it, COGNN_OP_AP_SOFTMAX);
+        const int64_t train = (int64_t)((double)s.n * E->cfg.train_ratio);      // gcn.h:560
+        const int64_t val = (int64_t)((double)s.n * E->cfg.val_ratio);
+        u64* dstb = (s.cur == s.buf[1]) ? s.buf[0] : s.buf[1];
+        if (s.p == 0) {
+            const u64* z1 = s.peer ? s.peer->cur : s.ib[0];
+            BE(cognn_softmax_u64(E->ctx, nullptr, dstb, s.pfx, s.cur, z1, s.labels, &k, 0, s.n, L, train));
+            BE(cognn_metrics_q16(E->ctx, s.pfx, s.labels, s.border, s.n, L, train, val, s.counts, s.loss));
+            s.has_metrics = true;
+        } else {
+            BE(cognn_softmax_u64(E->ctx, nullptr, dstb, nullptr, nullptr, nullptr, nullptr, &k, 1, s.n, L, train));
+        }
+    }
+    for (auto& s : E->sides) s.cur = (s.cur == s.buf[1]) ? s.buf[0] : s.buf[1];   // after every owner has read its peer's z
+}
+
+// ---------------------------------------------------------------------------------------------
+// message passing: Scatter + PreMerge + Gather fused into two CSR launches over the share table
+// ---------------------------------------------------------------------------------------------
+u64* table_seg(cognn_engine* E, Side& s, int F) {
+    const int64_t off = s.p == 0 ? E->A_off[s.owner] : E->B_off[s.owner];
+    return E->table + off * F;
+}
+
+void message_passing(cognn_engine* E, int F) {
+    // replicate the co-party's fresh share of every owner to the other ranks (ss_...h:997-1002 / :982)
+    if (E->world > 1) {
+        XList xl;
+        for (int o = 0; o < E->k; ++o) {
+            const int rc = E->rank_of(E->co(o));
+            const int64_t bytes = (int64_t)E->G.party[o].localVertexPos.size() * F * 8;
+            u64* seg = E->table + E->B_off[o] * F;
+            if (rc == E->rank) {
+                for (int r = 0; r < E->world; ++r) {
+                    if (r == E->rank) continue;
+                    if (E->m == 1 && r == E->rank_of(o)) continue;   // that rank hosts only the owner itself
+                    xl.send(r, seg, bytes);
+                }
+            } else if (!(E->m == 1 && E->rank == E->rank_of(o))) {
+                xl.recv(rc, seg, bytes);
+            }
+        }
+        run_exchange(E, xl);
+    }
+    // partial sums of every hosted party for its remote destinations (ss_...h:827-835, 1063-1067)
+    if (E->partRows > 0) {
+        if (E->timing) BE(cognn_timer_begin(E->ctx, T_PART));
+        BE(cognn_gather_csr_u64(E->ctx, E->table + E->inboxLocalOff * F, nullptr, E->table, E->part_rowptr, E->part_col, E->partRows, F));
+        if (E->timing) {
+            BE(cognn_timer_end(E->ctx, T_PART));
+            E->algo[T_PART] += 8.0 * F * ((double)E->partEdges + E->partRows) + 4.0 * E->partEdges + 4.0 * (E->partRows + 1);
+        }
+    }
+    if (E->world > 1) {
+        XList xl;
+        for (auto& sg : E->segs) {
+            if (sg.src_rank == E->rank && sg.dst_rank != E->rank) xl.send(sg.dst_rank, E->table + sg.out_off * F, sg.rows * F * 8);
+            if (sg.dst_rank == E->rank && sg.src_rank != E->rank) xl.recv(sg.src_rank, E->table + sg.inbox_off * F, sg.rows * F * 8);
+        }
+        run_exchange(E, xl);
+    }
+    // aggregate: out = self + local in-edges + replica in-edges (owner rows) / + received partials (co rows)
+    if (E->timing) BE(cognn_timer_begin(E->ctx, T_AGG));
+    BE(cognn_gather_csr_u64(E->ctx, E->aggOut, E->table, E->table, E->agg_rowptr, E->agg_col, E->aggRows, F));
+    if (E->timing) {
+        BE(cognn_timer_end(E->ctx, T_AGG));
+        E->algo[T_AGG] += 8.0 * F * ((double)E->aggEdges + 2.0 * E->aggRows) + 4.0 * E->aggEdges + 4.0 * (E->aggRows + 1);
+    }
+    for (auto& s : E->sides) {
+        const int64_t off = s.p == 0 ? E->A_off[s.owner] : E->B_off[s.owner];
+        s.cur = E->aggOut + off * F;
+        s.curF = F;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight averaging (gcn.h:747-802)
+// ---------------------------------------------------------------------------------------------
+void weight_average(cognn_engine* E, int64_t it, int layer) {
+    if (E->world > 1) throw EngineError("engine: weight averaging across ranks is not implemented yet (training needs world == 1)");
+    const int k = E->k;
+    const int64_t elems = layer == 0 ? (int64_t)E->in() * E->hid() : (int64_t)E->hid() * E->lab();
+    Side* h0 = E->side(0, 0);      // party 0 accumulates here, party 1 in side(1,0)
+    Side* h1 = E->side(1, 0);
+    u64* sum0 = h0->small[0];
+    u64* sum1 = h1->small[0];
+    BE(cognn_memcpy_d2d(E->ctx, sum0, h0->W[layer], elems * 8));
+    for (int o = 1; o < k; ++o) BE(cognn_add_u64(E->ctx, sum0, sum0, E->side(o, 1)->W[layer], elems));
+    BE(cognn_memcpy_d2d(E->ctx, sum1, h1->W[layer], elems * 8));
+    for (int o = 2; o < k; ++o) BE(cognn_add_u64(E->ctx, sum1, sum1, E->side(o, 0)->W[layer], elems));
+    BE(cognn_add_u64(E->ctx, sum1, sum1, E->side(0, 1)->W[layer], elems));
+    if (E->cfg.variant == COGNN_VARIANT_OPTIMIZE_GCN) {   // gcn.h:763-764; absent in the inference variant
+        cognn_keys tk = keys(E, COGNN_OWNER_WAVG, it, COGNN_OP_WAVG_TRUNC);
+        const u64 ws = fx_trunc(1.0 / k);
+        u64* c0 = h0->small[1];
+        u64* c1 = h1->small[1];
+        BE(cognn_trunc_open_u64(E->ctx, c0, sum0, ws, &tk, 0, elems));
+        BE(cognn_trunc_open_u64(E->ctx, c1, sum1, ws, &tk, 1, elems));
+        BE(cognn_trunc_close_u64(E->ctx, sum0, c0, c1, &tk, 0, 0, elems));
+        BE(cognn_trunc_close_u64(E->ctx, sum1, nullptr, nullptr, &tk, 1, 0, elems));
+    }
+    for (int o = 0; o < k; ++o) {                          // gcn.h:765-778
+        BE(cognn_memcpy_d2d(E->ctx, E->side(o, 0)->W[layer], o == 0 ? sum0 : sum1, elems * 8));
+        BE(cognn_memcpy_d2d(E->ctx, E->side(o, 1)->W[layer], o == 0 ? sum1 : sum0, elems * 8));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// schedule (Appendix A of SURVEY.md; gcn.h:893-948)
+// ---------------------------------------------------------------------------------------------
+struct IterInfo {
+    int e, f, ep, layer;
+    bool fwd, apply_only;
+};
+IterInfo iter_info(cognn_engine* E, int64_t it) {
+    IterInfo r;
+    r.f = E->cfg.num_layers;
+    r.ep = 3 * E->cfg.num_layers;
+    r.e = (int)(it % r.ep);
+    r.fwd = r.e < r.f;
+    r.layer = r.fwd ? r.e : r.f - 1 - ((r.e - r.f) / 2);
+    r.apply_only = (r.e != 0 && r.e % r.f == 0);          // ss_...h:709, 941
+    return r;
+}
+int mp_width(cognn_engine* E, int e) {                    // getPlainNumPerOperand(iter), gcn.h:898-927
+    switch (e) { case 0: return E->hid(); case 1: case 2: case 3: return E->lab(); default: return E->hid(); }
+}
+
+GemmSpec prescatter_spec(cognn_engine* E, Side& s, int layer) {
+    return GemmSpec{s.n, layer == 0 ? E->hid() : E->lab(), layer == 0 ? E->in() : E->hid(), 0, COGNN_OP_PS_GEMM, COGNN_OP_PS_GEMM_TRUNC};
+}
+
+void weight_update_chain(cognn_engine* E, int64_t it, int layer) {
+    // d (in side.small[0]) -> *1/trainSetSize -> W -= lr*d   (gcn.h:673-678, 720-730)
+    const int64_t elems = layer == 0 ? (int64_t)E->in() * E->hid() : (int64_t)E->hid() * E->lab();
+    std::vector<u64*> d, d2;
+    std::vector<int64_t> el;
+    for (auto& s : E->sides) { d.push_back(s.small[0]); d2.push_back(s.small[1]); el.push_back(elems); }
+    // gradient scale: per-owner constant, so the stage runs per side with its own multiplier
+    for (size_t i = 0; i < E->sides.size(); ++i) {
+        Side& s = E->sides[i];
+        const int64_t train = (int64_t)((double)s.n * E->cfg.train_ratio);
+        const u64 gs = train > 0 ? fx_trunc(1.0 / (double)train) : 0;
+        cognn_keys k = keys(E, s.owner, it, COGNN_OP_AP_GSCALE_TRUNC);
+        BE(cognn_trunc_open_u64(E->ctx, s.ob[0], d[i], gs, &k, s.p, elems));
+    }
+    exchange_ob(E, 0, el);
+    for (size_t i = 0; i < E->sides.size(); ++i) {
+        Side& s = E->sides[i];
+        cognn_keys k = keys(E, s.owner, it, COGNN_OP_AP_GSCALE_TRUNC);
+        BE(cognn_trunc_close_u64(E->ctx, d2[i], s.p == 0 ? s.ob[0] : nullptr, s.p == 0 ? s.ib[0] : nullptr, &k, s.p, 0, elems));
+    }
+    const u64 lr = fx_trunc(E->cfg.learning_rate);
+    trunc_stage(E, it, COGNN_OP_AP_LR_TRUNC, lr, d2, el, [&](Side& s) { return s.W[layer]; }, 1);
+    if (E->cfg.variant == COGNN_VARIANT_OPTIMIZE_GCN_INFERENCE) {   // optimize-gcn-inference/gcn.h:680-681,732-733
+        std::vector<u64*> w;
+        for (auto& s : E->sides) w.push_back(s.W[layer]);
+        trunc_stage(E, it, COGNN_OP_WAVG_TRUNC, fx_trunc(1.0 / E->k), w, el, [&](Side& s) { return s.W[layer]; }, 0);
+    }
+}
+
+void run_iteration(cognn_engine* E, int64_t it) {
+    const IterInfo I = iter_info(E, it);
+    if (I.e == 0) {                                        // ss_...h:695, 938: back to the input features
+        for (auto& s : E->sides) { s.cur = s.feat; s.curF = E->in(); }
+    }
+    if (!I.apply_only) {
+        const int F = mp_width(E, I.e);
+        // ---- PreScatterComp (gcn.h:198-255) ----
+        if (I.fwd) {
+            if (I.layer == 1)
+                for (auto& s : E->sides) BE(cognn_memcpy_d2d(E->ctx, s.h1, s.cur, (size_t)s.n * E->hid() * 8));   // h_t[1]
+            const bool scale_follows = I.e != 0;
+            gemm_stage(E, it, [&](Side& s) { return s.cur; }, [&](Side& s) { return s.W[I.layer]; },
+                       [&](Side& s) { return prescatter_spec(E, s, I.layer); },
+                       [&](Side& s) { return scale_follows ? s.buf[1] : table_seg(E, s, F); });
+            if (scale_follows)
+                rowscale_stage(E, it, COGNN_OP_PS_SCALE, COGNN_OP_PS_SCALE_TRUNC, F, [&](Side& s) { return s.buf[1]; },
+                               [&](Side& s) { return table_seg(E, s, F); });
+        } else {
+            rowscale_stage(E, it, COGNN_OP_PS_SCALE, COGNN_OP_PS_SCALE_TRUNC, F, [&](Side& s) { return s.cur; },
+                           [&](Side& s) { return table_seg(E, s, F); });
+        }
+        // ---- Scatter / PreMerge / Gather ----
+        message_passing(E, F);
+        if ((it + 1) % I.ep != 0) {                        // gcn.h:470
+            rowscale_stage(E, it, COGNN_OP_GA_SCALE, COGNN_OP_GA_SCALE_TRUNC, F, [&](Side& s) { return s.cur; },
+                           [&](Side& s) { return s.buf[1]; });
+            for (auto& s : E->sides) s.cur = s.buf[1];
+        }
+    }
+    // ---- ApplyComp (gcn.h:515-811) ----
+    if (I.fwd) {
+        if (I.e != I.f - 1) relu_stage(E, it);
+        else softmax_stage(E, it);
+        for (auto& s : E->sides) s.curF = (I.e != I.f - 1) ? E->hid() : E->lab();
+        return;
+    }
+    const bool first_of_two = ((I.e - I.f) % 2 == 0);
+    if (first_of_two) {
+        if (I.layer == I.f - 1) {                          // g = (p-y) . W1^T, out = in  (gcn.h:664-669)
+            for (auto& s : E->sides) BE(cognn_transpose_u64(E->ctx, s.WT, s.W[1], E->hid(), E->lab()));
+            gemm_stage(E, it, [&](Side& s) { return s.cur; }, [&](Side& s) { return s.WT; },
+                       [&](Side& s) { return GemmSpec{s.n, E->hid(), E->lab(), 0, COGNN_OP_AP_GEMM, COGNN_OP_AP_GEMM_TRUNC}; },
+                       [&](Side& s) { return s.g; });
+        } else {                                           // out = in * 1[z>0]  (gcn.h:702-708; g' skipped for layer 0)
+            for (auto& s : E->sides) {
+                u64* dstb = (s.cur == s.buf[1]) ? s.buf[0] : s.buf[1];
+                BE(cognn_mask_select_u64(E->ctx, dstb, s.cur, s.relu_mask, (int64_t)s.n * E->hid()));
+                s.cur = dstb;
+            }
+        }
+        return;
+    }
+    // d = h_t^T . in ; scale ; W -= lr d ; out = g  (gcn.h:671-684, 710-736)
+    const int Min = I.layer == 0 ? E->in() : E->hid();
+    const int Nout = I.layer == 0 ? E->hid() : E->lab();
+    gemm_stage(E, it, [&](Side& s) { return I.layer == 0 ? s.feat : s.h1; }, [&](Side& s) { return s.cur; },
+               [&](Side& s) { return GemmSpec{Min, Nout, s.n, 1, COGNN_OP_AP_GEMM, COGNN_OP_AP_GEMM_TRUNC}; },
+               [&](Side& s) { return s.small[0]; });
+    weight_update_chain(E, it, I.layer);
+    for (auto& s : E->sides) {
+        if (I.layer == I.f - 1) { s.cur = s.g; s.curF = E->hid(); }
+        else { s.curF = 0; }                               // vertexInterData["g"] is empty for the first layer
+    }
+    weight_average(E, it, I.layer);
+}
+
+// dealer phase: product shares of every Beaver GEMM in [it0,it1)
+void run_offline(cognn_engine* E, int64_t it0, int64_t it1) {
+    for (int64_t it = it0; it < it1; ++it) {
+        const IterInfo I = iter_info(E, it);
+        for (auto& s : E->sides) {
+            if (s.p != 1) continue;
+            GemmSpec g;
+            bool have = false;
+            if (!I.apply_only && I.fwd) { g = prescatter_spec(E, s, I.layer); have = true; }
+            else if (!I.fwd && (I.e - I.f) % 2 == 0 && I.layer == I.f - 1) {
+                g = GemmSpec{s.n, E->hid(), E->lab(), 0, COGNN_OP_AP_GEMM, COGNN_OP_AP_GEMM_TRUNC}; have = true;
+            } else if (!I.fwd && (I.e - I.f) % 2 == 1) {
+                g = GemmSpec{I.layer == 0 ? E->in() : E->hid(), I.layer == 0 ? E->hid() : E->lab(), s.n, 1, COGNN_OP_AP_GEMM, COGNN_OP_AP_GEMM_TRUNC};
+                have = true;
+            }
+            if (!have || s.c1.count({it, g.op})) continue;
+            cognn_keys k = keys(E, s.owner, it, g.op);
+            u64* c = dalloc<u64>(E, (size_t)(g.M * g.N));
+            BE(cognn_dealer_gemm_c1_u64(E->ctx, c, &k, g.M, g.N, g.K, g.transA, s.scratch, s.scratch + g.M * g.K));
+            s.c1[{it, g.op}] = c;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// setup
+// ---------------------------------------------------------------------------------------------
+void build_layout(cognn_engine* E) {
+    const int k = E->k;
+    auto& G = E->G;
+    auto nrows = [&](int p) { return (int64_t)G.party[p].localVertexPos.size(); };
+    E->hosted.clear(); E->cohosted.clear();
+    for (int p = 0; p < k; ++p) if (E->rank_of(p) == E->rank) E->hosted.push_back(p);
+    for (int p : E->hosted) E->cohosted.push_back((p + k - 1) % k);
+    // sides in canonical (owner, p) order
+    E->sides.clear();
+    for (int o = 0; o < k; ++o) {
+        for (int p = 0; p < 2; ++p) {
+            const int holder = p == 0 ? o : E->co(o);
+            if (E->rank_of(holder) != E->rank) continue;
+            Side s;
+            s.owner = o; s.p = p; s.n = (int)nrows(o);
+            s.peer_rank = E->rank_of(p == 0 ? E->co(o) : o);
+            E->sides.push_back(s);
+        }
+    }
+    for (auto& s : E->sides) s.peer = (s.peer_rank == E->rank) ? E->side(s.owner, 1 - s.p) : nullptr;
+    // table rows: [A of hosted][B of co-hosted owners][B replicas of the others][inbox remote][inbox local][outbox]
+    E->A_off.assign(k, -1); E->B_off.assign(k, -1);
+    // every segment starts on an even row so that its byte offset is 16-byte aligned for any row width
+    int64_t off = 0;
+    auto even = [&]() { off = (off + 1) & ~(int64_t)1; };
+    for (int p : E->hosted) { even(); E->A_off[p] = off; off += nrows(p); }
+    for (int o : E->cohosted) { even(); E->B_off[o] = off; off += nrows(o); }
+    even();
+    E->aggRows = off;
+    for (int o = 0; o < k; ++o) if (E->B_off[o] < 0) { even(); E->B_off[o] = off; off += nrows(o); }
+    // partial-sum segments: (Q -> g) goes from rank(Q) to rank(co(g)); receiver-side order: source rank, then g, then Q
+    E->segs.clear();
+    const int64_t inbox0 = off;
+    auto seg_rows = [&](int Q, int g) { return (int64_t)G.party[Q].out[g].rows_vid.size(); };
+    std::vector<int> src_order;
+    for (int r = 0; r < E->world; ++r) if (r != E->rank) src_order.push_back(r);
+    src_order.push_back(E->rank);                          // own-rank segments last, adjacent to the outbox
+    for (int sr : src_order) {
+        if (sr == E->rank) { even(); E->inboxLocalOff = off; }
+        for (int g : E->cohosted)
+            for (int Q = 0; Q < k; ++Q) {
+                if (Q == g || E->rank_of(Q) != sr) continue;
+                cognn_engine::Seg sg{Q, g, seg_rows(Q, g), off, -1, sr, E->rank};
+                if (sr == E->rank) sg.out_off = off;
+                E->segs.push_back(sg);
+                off += sg.rows;
+            }
+    }
+    E->inboxRows = off - inbox0;
+    // outbox: segments of hosted parties for owners co-hosted elsewhere, grouped by destination rank in the
+    // receiver's order (g of that rank's cohosted list, then Q)
+    for (int dr = 0; dr < E->world; ++dr) {
+        if (dr == E->rank) continue;
+        for (int P = dr * E->m; P < (dr + 1) * E->m; ++P) {
+            const int g = (P + k - 1) % k;                 // owner whose co-party P lives on rank dr
+            for (int Q : E->hosted) {
+                if (Q == g) continue;
+                cognn_engine::Seg sg{Q, g, seg_rows(Q, g), -1, off, E->rank, dr};
+                E->segs.push_back(sg);
+                off += sg.rows;
+            }
+        }
+    }
+    E->tableRows = off;
+    E->partRows = off - E->inboxLocalOff;
+}
+
+void build_csrs(cognn_engine* E) {
+    auto& G = E->G;
+    const int k = E->k;
+    // ---- partial launch: rows = segments produced on this rank, in table order from inboxLocalOff ----
+    std::vector<uint32_t> prp{0}, pcol;
+    std::vector<const cognn_engine::Seg*> produced;
+    for (auto& sg : E->segs) if (sg.src_rank == E->rank) produced.push_back(&sg);
+    std::sort(produced.begin(), produced.end(), [](const cognn_engine::Seg* a, const cognn_engine::Seg* b) { return a->out_off < b->out_off; });
+    int64_t expect = E->inboxLocalOff;
+    for (auto* sg : produced) {
+        if (sg->out_off != expect) throw EngineError("engine: partial segment layout is not contiguous");
+        const cognn::EdgeBlock& blk = G.party[sg->src_party].out[sg->dst_owner];
+        const int64_t abase = E->A_off[sg->src_party];
+        for (size_t r = 0; r + 1 < blk.rowptr.size(); ++r) {
+            for (uint32_t q = blk.rowptr[r]; q < blk.rowptr[r + 1]; ++q) pcol.push_back((uint32_t)(abase + blk.col[q]));
+            prp.push_back((uint32_t)pcol.size());
+        }
+        expect += sg->rows;
+    }
+    E->partEdges = (int64_t)pcol.size();
+    // ---- aggregate launch: rows = A rows of hosted parties then B rows of co-hosted owners ----
+    std::vector<std::vector<uint32_t>> lists((size_t)E->aggRows);
+    for (int P : E->hosted) {
+        const int64_t rbase = E->A_off[P];
+        const cognn::EdgeBlock& self = G.party[P].out[P];
+        for (size_t r = 0; r + 1 < self.rowptr.size(); ++r)
+            for (uint32_t q = self.rowptr[r]; q < self.rowptr[r + 1]; ++q) lists[rbase + r].push_back((uint32_t)(rbase + self.col[q]));
+        for (int Q = 0; Q < k; ++Q) {                      // in-edges from party Q, evaluated on the replica of Q's co-share
+            if (Q == P) continue;
+            const cognn::EdgeBlock& blk = G.party[Q].out[P];
+            for (size_t r = 0; r + 1 < blk.rowptr.size(); ++r) {
+                const uint32_t lr = G.row_of_vid[blk.rows_vid[r]];
+                for (uint32_t q = blk.rowptr[r]; q < blk.rowptr[r + 1]; ++q) lists[rbase + lr].push_back((uint32_t)(E->B_off[Q] + blk.col[q]));
+            }
+        }
+    }
+    for (int o : E->cohosted) {
+        const int64_t rbase = E->B_off[o];
+        const cognn::EdgeBlock& self = G.party[o].out[o];
+        for (size_t r = 0; r + 1 < self.rowptr.size(); ++r)
+            for (uint32_t q = self.rowptr[r]; q < self.rowptr[r + 1]; ++q) lists[rbase + r].push_back((uint32_t)(rbase + self.col[q]));
+    }
+    for (auto& sg : E->segs) {                              // received partial rows
+        if (sg.dst_rank != E->rank) continue;
+        const cognn::EdgeBlock& blk = G.party[sg.src_party].out[sg.dst_owner];
+        const int64_t rbase = E->B_off[sg.dst_owner];
+        for (size_t r = 0; r < blk.rows_vid.size(); ++r) lists[rbase + G.row_of_vid[blk.rows_vid[r]]].push_back((uint32_t)(sg.inbox_off + r));
+    }
+    std::vector<uint32_t> arp{0}, acol;
+    for (auto& l : lists) { acol.insert(acol.end(), l.begin(), l.end()); arp.push_back((uint32_t)acol.size()); }
+    E->aggEdges = (int64_t)acol.size();
+    E->agg_rowptr = upload(E, arp); E->agg_col = upload(E, acol);
+    E->part_rowptr = upload(E, prp); E->part_col = upload(E, pcol);
+}
+
+void alloc_sides(cognn_engine* E) {
+    const int in = E->in(), hid = E->hid(), lab = E->lab();
+    const int fm = std::max(hid, lab);
+    E->Fmp = fm;
+    E->table = dalloc<u64>(E, (size_t)E->tableRows * fm);
+    E->aggOut = dalloc<u64>(E, (size_t)E->aggRows * fm);
+    for (auto& s : E->sides) {
+        const size_t n = (size_t)s.n;
+        const size_t big = std::max<size_t>({n * (size_t)in, (size_t)in * hid, n * (size_t)fm, (size_t)hid * lab});
+        s.feat = dalloc<u64>(E, n * in);
+        s.W[0] = dalloc<u64>(E, (size_t)in * hid);
+        s.W[1] = dalloc<u64>(E, (size_t)hid * lab);
+        s.WT = dalloc<u64>(E, (size_t)hid * lab);
+        s.h1 = dalloc<u64>(E, n * hid);
+        s.g = dalloc<u64>(E, n * hid);
+        s.relu_mask = dalloc<uint8_t>(E, n * hid);
+        for (int j = 0; j < 2; ++j) {
+            s.buf[j] = dalloc<u64>(E, n * fm);
+            s.ob[j] = dalloc<u64>(E, big);
+            s.sum[j] = dalloc<u64>(E, big);
+        }
+        for (int j = 0; j < 3; ++j) s.small[j] = dalloc<u64>(E, (size_t)in * hid + (size_t)hid * lab);
+        s.scratch = dalloc<u64>(E, big + std::max<size_t>({(size_t)in * hid, n * (size_t)fm, (size_t)hid * lab}));
+        s.zbuf = dalloc<u64>(E, std::max<size_t>({(size_t)in * hid, n * (size_t)fm, (size_t)hid * lab}));
+        s.svec = dalloc<u64>(E, n);
+        if (s.p == 0) {
+            s.labels = dalloc<int32_t>(E, n);
+            s.border = dalloc<uint8_t>(E, n);
+            s.pfx = dalloc<u64>(E, n * lab);
+            s.counts = dalloc<int64_t>(E, 6);
+            s.loss = dalloc<double>(E, 1);
+        }
+    }
+    for (auto& s : E->sides) {
+        const size_t n = (size_t)s.n;
+        const size_t big = std::max<size_t>({n * (size_t)in, (size_t)in * hid, n * (size_t)fm, (size_t)hid * lab});
+        for (int j = 0; j < 2; ++j) {
+            if (s.peer) s.ib[j] = s.peer->ob[j];           // in-device exchange: read the peer's outbox directly
+            else { s.ib_store[j] = dalloc<u64>(E, big); s.ib[j] = s.ib_store[j]; }
+        }
+    }
+}
+
+std::vector<double> glorot(int d0, int d1) {               // gcn.h:838-852, libc rand() re-seeded per matrix
+    std::vector<double> w((size_t)d0 * d1);
+    std::srand(42);
+    const double limit = std::sqrt(6.0 / (d0 + d1));
+    for (int i = 0; i < d0; ++i)
+        for (int j = 0; j < d1; ++j) w[(size_t)i * d1 + j] = (double)std::rand() / RAND_MAX * 2 * limit - limit;
+    return w;
+}
+
+void start(cognn_engine* E) {
+    const int in = E->in(), hid = E->hid(), lab = E->lab();
+    if (E->w0.empty()) { E->w0 = glorot(in, hid); E->w1 = glorot(hid, lab); }
+    std::vector<u64> wfx[2];
+    for (double v : E->w0) wfx[0].push_back(fx_llround(v));
+    for (double v : E->w1) wfx[1].push_back(fx_llround(v));
+    u64* dW[2] = {upload(E, wfx[0]), upload(E, wfx[1])};
+    for (auto& s : E->sides) {
+        const cognn::PartyGraph& pg = E->G.party[s.owner];
+        const size_t n = (size_t)s.n;
+        const u64 fkey = cognn_stream_key(E->cfg.seed, (u64)s.owner, 0, COGNN_OP_SHARE_FEAT, 0);
+        if (s.p == 0) {
+            const int slot = (int)(std::find(E->hosted.begin(), E->hosted.end(), s.owner) - E->hosted.begin());
+            if (E->hostFeat[slot].size() != n * in) throw EngineError("engine: features of party " + std::to_string(s.owner) + " were not set");
+            std::vector<double> rs(n);
+            for (size_t r = 0; r < n; ++r) rs[r] = std::pow((double)pg.trueInDeg[r] + 1.0, -0.5);   // normalizeFeatureVec, gcn.h:819-835
+            double* dF = upload(E, E->hostFeat[slot]);
+            double* dR = upload(E, rs);
+            BE(cognn_fx_encode_f64(E->ctx, dF, dR, s.ob[0], (int64_t)n, in));
+            BE(cognn_share_split_u64(E->ctx, s.ob[0], fkey, s.feat, nullptr, (int64_t)n * in));    // CryptoUtil::intoShares, gcn.h:64-75
+            std::vector<u64> sv(n);
+            for (size_t r = 0; r < n; ++r) sv[r] = pg.inDeg[r] == 0 ? 0 : fx_llround(std::pow((double)pg.inDeg[r] + 1.0, -0.5));   // gcn.h:219-221
+            BE(cognn_memcpy_h2d(E->ctx, s.svec, sv.data(), n * 8));
+            BE(cognn_memcpy_h2d(E->ctx, s.labels, E->hostLabels[slot].data(), n * 4));
+            BE(cognn_memcpy_h2d(E->ctx, s.border, pg.isBorder.data(), n));
+        } else {
+            BE(cognn_prng_fill_u64(E->ctx, s.feat, fkey, (int64_t)n * in));   // the co-party's share is the mask itself
+            BE(cognn_memset0(E->ctx, s.svec, n * 8));                          // server passes zero degrees (ss_...h:985-989)
+        }
+        for (int l = 0; l < 2; ++l) {                      // intoShareTensor, gcn.h:85-99,880-882; ring hand-off ss_...h:231-232
+            const u64 wkey = cognn_stream_key(E->cfg.seed, (u64)s.owner, 0, COGNN_OP_SHARE_W, (u64)l);
+            const int64_t elems = l == 0 ? (int64_t)in * hid : (int64_t)hid * lab;
+            BE(cognn_share_split_u64(E->ctx, dW[l], wkey, s.p == 0 ? s.W[l] : nullptr, s.p == 1 ? s.W[l] : nullptr, elems));
+        }
+        s.cur = s.feat; s.curF = in;
+    }
+    BE(cognn_ctx_sync(E->ctx));
+    E->started = true;
+}
+
+int guard(const std::function<void()>& f) {
+    try {
+        f();
+        return 0;
+    } catch (const std::exception& ex) {
+        g_engine_error = ex.what();
+        return 1;
+    }
+}
+}  // namespace
+
+extern "C" {
+
+const char* cognn_engine_last_error(void) { return g_engine_error.c_str(); }
+
+int cognn_engine_create(const cognn_engine_config* cfg, int64_t V, int64_t Ecount, const int64_t* src, const int64_t* dst,
+                        const int32_t* part, cognn_engine** out) {
+    return guard([&] {
+        if (!cfg || !out || !part || (Ecount > 0 && (!src || !dst))) throw EngineError("cognn_engine_create: null argument");
+        if (cfg->num_parties < 2) throw EngineError("cognn_engine_create: need at least 2 parties");
+        if (cfg->world < 1 || cfg->num_parties % cfg->world != 0 || cfg->rank < 0 || cfg->rank >= cfg->world)
+            throw EngineError("cognn_engine_create: the number of parties must be a multiple of the number of ranks");
+        if (cfg->num_layers != 2) throw EngineError("cognn_engine_create: num_layers must be 2 (as in every reference config)");
+        cognn_engine* E = new cognn_engine();
+        E->cfg = *cfg;
+        E->be = cognn_default_backend();
+        E->k = cfg->num_parties; E->world = cfg->world; E->rank = cfg->rank; E->m = E->k / E->world;
+        if (E->be->cognn_ctx_create(cfg->device, cfg->stream, &E->ctx) != 0) {
+            std::string msg = E->be->cognn_last_error();
+            delete E;
+            throw EngineError(msg);
+        }
+        try {
+            E->G = cognn::build_partitioned_graph(E->k, V, Ecount, src, dst, part, cfg->undirected != 0);
+            build_layout(E);
+            build_csrs(E);
+            alloc_sides(E);
+            E->hostFeat.resize(E->hosted.size());
+            E->hostLabels.resize(E->hosted.size());
+        } catch (...) {
+            cognn_engine_destroy(E);
+            throw;
+        }
+        *out = E;
+    });
+}
+
+int cognn_engine_destroy(cognn_engine* E) {
+    if (!E) return 0;
+    if (E->ctx) {
+        for (void* p : E->allocs) E->be->cognn_free(E->ctx, p);
+        E->be->cognn_ctx_destroy(E->ctx);
+    }
+    delete E;
+    return 0;
+}
+
+int cognn_engine_set_exchange(cognn_engine* E, cognn_exchange_fn fn, void* user) {
+    return guard([&] { if (!E) throw EngineError("null engine"); E->xfn = fn; E->xuser = user; });
+}
+
+int cognn_engine_party_rows(cognn_engine* E, int32_t party, int64_t* rows) {
+    return guard([&] {
+        if (!E || party < 0 || party >= E->k || !rows) throw EngineError("cognn_engine_party_rows: bad arguments");
+        *rows = (int64_t)E->G.party[party].localVertexPos.size();
+    });
+}
+int cognn_engine_party_vids(cognn_engine* E, int32_t party, int64_t* vids) {
+    return guard([&] {
+        if (!E || party < 0 || party >= E->k || !vids) throw EngineError("cognn_engine_party_vids: bad arguments");
+        const auto& v = E->G.party[party].localVertexPos;
+        for (size_t i = 0; i < v.size(); ++i) vids[i] = (int64_t)v[i];
+    });
+}
+int cognn_engine_party_degrees(cognn_engine* E, int32_t party, int64_t* tdeg, int64_t* ideg, uint8_t* border) {
+    return guard([&] {
+        if (!E || party < 0 || party >= E->k) throw EngineError("cognn_engine_party_degrees: bad arguments");
+        const auto& pg = E->G.party[party];
+        for (size_t i = 0; i < pg.localVertexPos.size(); ++i) {
+            if (tdeg) tdeg[i] = pg.trueInDeg[i];
+            if (ideg) ideg[i] = pg.inDeg[i];
+            if (border) border[i] = pg.isBorder[i];
+        }
+    });
+}
+int cognn_engine_set_party_data(cognn_engine* E, int32_t party, const double* features, const int32_t* labels) {
+    return guard([&] {
+        if (!E || !features || !labels) throw EngineError("cognn_engine_set_party_data: null argument");
+        auto it = std::find(E->hosted.begin(), E->hosted.end(), party);
+        if (it == E->hosted.end()) throw EngineError("cognn_engine_set_party_data: party " + std::to_string(party) + " is not hosted on this rank");
+        const size_t slot = (size_t)(it - E->hosted.begin());
+        const size_t n = E->G.party[party].localVertexPos.size();
+        E->hostFeat[slot].assign(features, features + n * (size_t)E->in());
+        E->hostLabels[slot].assign(labels, labels + n);
+        for (size_t i = 0; i < n; ++i)
+            if (labels[i] < 0 || labels[i] >= E->lab()) throw EngineError("cognn_engine_set_party_data: label out of range");
+    });
+}
+int cognn_engine_set_weights(cognn_engine* E, const double* w0, const double* w1) {
+    return guard([&] {
+        if (!E || !w0 || !w1) throw EngineError("cognn_engine_set_weights: null argument");
+        E->w0.assign(w0, w0 + (size_t)E->in() * E->hid());
+        E->w1.assign(w1, w1 + (size_t)E->hid() * E->lab());
+    });
+}
+int cognn_engine_start(cognn_engine* E) {
+    return guard([&] { if (!E) throw EngineError("null engine"); start(E); });
+}
+int cognn_engine_offline(cognn_engine* E, int64_t it0, int64_t it1) {
+    return guard([&] {
+        if (!E || !E->started) throw EngineError("cognn_engine_offline: engine not started");
+        run_offline(E, it0, it1);
+    });
+}
+int cognn_engine_run(cognn_engine* E, int64_t it0, int64_t it1) {
+    return guard([&] {
+        if (!E || !E->started) throw EngineError("cognn_engine_run: engine not started");
+        for (int64_t it = it0; it < it1; ++it) {
+            auto t0 = std::chrono::high_resolution_clock::now();
+            run_iteration(E, it);
+            if (E->cfg.verbose) {
+                BE(cognn_ctx_sync(E->ctx));
+                const double sec = std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - t0).count();
+                printf("tid-> %d, iteration-> %lld\n::iteration took %lf seconds\n", E->hosted.empty() ? -1 : E->hosted[0], (long long)it, sec);
+            }
+        }
+    });
+}
+int cognn_engine_get_shares(cognn_engine* E, int32_t owner, int32_t sd, uint64_t* host_out, int64_t* rows, int64_t* cols) {
+    return guard([&] {
+        Side* s = E ? E->side(owner, sd) : nullptr;
+        if (!s) throw EngineError("cognn_engine_get_shares: that share is not held on this rank");
+        if (rows) *rows = s->n;
+        if (cols) *cols = s->curF;
+        if (host_out && s->curF > 0) BE(cognn_memcpy_d2h(E->ctx, host_out, s->cur, (size_t)s->n * s->curF * 8));
+    });
+}
+int cognn_engine_get_weight(cognn_engine* E, int32_t owner, int32_t sd, int32_t layer, uint64_t* host_out) {
+    return guard([&] {
+        Side* s = E ? E->side(owner, sd) : nullptr;
+        if (!s || layer < 0 || layer > 1 || !host_out) throw EngineError("cognn_engine_get_weight: bad arguments");
+        const size_t elems = layer == 0 ? (size_t)E->in() * E->hid() : (size_t)E->hid() * E->lab();
+        BE(cognn_memcpy_d2h(E->ctx, host_out, s->W[layer], elems * 8));
+    });
+}
+int cognn_engine_get_metrics(cognn_engine* E, int32_t party, double* out8) {
+    return guard([&] {
+        Side* s = E ? E->side(party, 0) : nullptr;
+        if (!s || !out8 || !s->has_metrics) throw EngineError("cognn_engine_get_metrics: no prediction layer has run for that party here");
+        int64_t c[6]; double loss;
+        BE(cognn_memcpy_d2h(E->ctx, c, s->counts, sizeof(c)));
+        BE(cognn_memcpy_d2h(E->ctx, &loss, s->loss, sizeof(loss)));
+        const auto& pg = E->G.party[party];
+        const int64_t n = s->n;
+        const int64_t train = (int64_t)((double)n * E->cfg.train_ratio), val = (int64_t)((double)n * E->cfg.val_ratio);
+        int64_t nb = 0, nbt = 0, nbe = 0;
+        for (int64_t r = 0; r < n; ++r) {
+            if (!pg.isBorder[r]) continue;
+            nb++;
+            if (r < train) nbt++;
+            if (r >= train + val) nbe++;
+        }
+        auto ratio = [](int64_t a, int64_t b) { return b > 0 ? (double)a / (double)b : 0.0; };
+        out8[0] = ratio(c[0], n); out8[1] = ratio(c[1], train); out8[2] = ratio(c[2], nbt);
+        out8[3] = ratio(c[3], n - train - val); out8[4] = ratio(c[4], nbe);
+        out8[5] = n > 0 ? loss / (double)n : 0.0; out8[6] = (double)n; out8[7] = (double)nb;
+    });
+}
+int cognn_engine_enable_timing(cognn_engine* E, int32_t on) {
+    return guard([&] {
+        if (!E) throw EngineError("null engine");
+        E->timing = on != 0;
+        BE(cognn_timer_reset(E->ctx));
+        E->algo[0] = E->algo[1] = E->algo[2] = 0;
+    });
+}
+int cognn_engine_get_timing(cognn_engine* E, int32_t kind, int64_t* launches, double* total_ms, double* algo) {
+    return guard([&] {
+        if (!E || kind < 0 || kind > 2) throw EngineError("cognn_engine_get_timing: bad arguments");
+        BE(cognn_timer_read(E->ctx, kind, launches, total_ms));
+        if (algo) *algo = E->algo[kind];
+    });
+}
+int cognn_engine_get_workload(cognn_engine* E, int64_t* out6) {
+    return guard([&] {
+        if (!E || !out6) throw EngineError("cognn_engine_get_workload: bad arguments");
+        out6[0] = E->aggEdges; out6[1] = E->aggRows; out6[2] = E->partEdges; out6[3] = E->partRows;
+        out6[4] = E->G.num_edges; out6[5] = E->tableRows;
+    });
+}
+
+}  // extern "C"

@@ -1,0 +1,87 @@
+/* cognn_engine.h — C ABI of the C++ GAS engine inside libcognn_hip.so.
+ *
+ * The engine is the MI355X-native counterpart of SSEdgeCentricAlgoKernel::operator()
+ * (include/ss_vertex_centric_algo_kernel.h:168-277) driving the optimize-gcn callbacks
+ * (algo_kernels/vertex_centric/optimize-gcn/gcn.h): preprocessing -> share distribution ->
+ * per-iteration PreScatter / Scatter+PreMerge+Gather (fused CSR) / Apply.  One engine instance
+ * runs every party hosted on this process' GPU ("rank"); parties are mapped to ranks in
+ * contiguous blocks (party P lives on rank P / (k/world)), so with world == 1 all k parties are
+ * co-located and every exchange is an in-device hand-off.  With world > 1 the engine calls the
+ * host-supplied exchange function for the share-exchange / Beaver-reveal rounds that the reference
+ * carries over TCP (comm_sync.h:245-277, TaskComm); the Python host implements it with
+ * torch.distributed (RCCL) p2p groups.
+ */
+#ifndef COGNN_ENGINE_H_
+#define COGNN_ENGINE_H_
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct cognn_engine cognn_engine;
+
+enum { COGNN_VARIANT_OPTIMIZE_GCN = 0, COGNN_VARIANT_OPTIMIZE_GCN_INFERENCE = 1 };
+
+/* GNNParam (include/task/task.h:78-170) + harness flags (include/harness.h:123) */
+typedef struct {
+    int32_t num_parties;     /* -t / -g */
+    int32_t rank, world;     /* this process and the number of processes (GPUs) */
+    int32_t variant;         /* gcn-optimize or gcn-inference-optimize */
+    int32_t num_layers, num_labels, input_dim, hidden_dim;
+    double learning_rate, train_ratio, val_ratio, test_ratio;
+    uint64_t seed;           /* dealer / sharing seed (stands in for the -s setting string) */
+    int32_t device;
+    void* stream;            /* hipStream_t (NULL = default stream) */
+    int32_t undirected;      /* -u */
+    int32_t verbose;         /* print the reference's "::tag took X seconds" lines */
+} cognn_engine_config;
+
+/* one logical message of an exchange round; buffers are device pointers on this rank */
+typedef struct {
+    int32_t peer;            /* rank */
+    int32_t is_send;
+    void* ptr;
+    int64_t bytes;
+} cognn_xfer;
+/* must perform all transfers of the list as one p2p group, ordered after previously enqueued work of
+ * the engine's stream and complete (stream-ordered) before returning control for later kernels */
+typedef int (*cognn_exchange_fn)(void* user, const cognn_xfer* xfers, int32_t n);
+
+const char* cognn_engine_last_error(void);
+int cognn_engine_create(const cognn_engine_config* cfg, int64_t num_vertices, int64_t num_edges,
+                        const int64_t* src, const int64_t* dst, const int32_t* part, cognn_engine** out);
+int cognn_engine_destroy(cognn_engine* e);
+int cognn_engine_set_exchange(cognn_engine* e, cognn_exchange_fn fn, void* user);
+/* rows (local vertices) of a party and their vids in row order (localVertexPos, ss_...h:474) */
+int cognn_engine_party_rows(cognn_engine* e, int32_t party, int64_t* rows);
+int cognn_engine_party_vids(cognn_engine* e, int32_t party, int64_t* vids);
+int cognn_engine_party_degrees(cognn_engine* e, int32_t party, int64_t* true_in_deg, int64_t* inflated_in_deg, uint8_t* is_border);
+/* raw features / labels of a hosted party in row order (harness.cpp:21-48 loadVertexData) */
+int cognn_engine_set_party_data(cognn_engine* e, int32_t party, const double* features, const int32_t* labels);
+/* optional: replace the srand(42) Glorot initialisation (gcn.h:838-852); w0 [in x hid], w1 [hid x lab] */
+int cognn_engine_set_weights(cognn_engine* e, const double* w0, const double* w1);
+/* onAlgoKernelStart + share distribution (gcn.h:854-887, ss_...h:205-232) */
+int cognn_engine_start(cognn_engine* e);
+/* dealer ("offline") phase for iterations [begin,end): Beaver-triple product shares of every GEMM */
+int cognn_engine_offline(cognn_engine* e, int64_t iter_begin, int64_t iter_end);
+/* GAS iterations [begin,end) (ss_...h:239-248) */
+int cognn_engine_run(cognn_engine* e, int64_t iter_begin, int64_t iter_end);
+/* current vertex tensor share of `owner` held by side 0 (owner) / 1 (co-party); host_out may be NULL to query shape */
+int cognn_engine_get_shares(cognn_engine* e, int32_t owner, int32_t side, uint64_t* host_out, int64_t* rows, int64_t* cols);
+int cognn_engine_get_weight(cognn_engine* e, int32_t owner, int32_t side, int32_t layer, uint64_t* host_out);
+/* metrics of the last prediction layer of a hosted party: out[0..4] = accuracies (full, train, border-train,
+ * test, border-test), out[5] = cross-entropy loss, out[6] = #vertices, out[7] = #border (gcn.h:620-632) */
+int cognn_engine_get_metrics(cognn_engine* e, int32_t party, double* out8);
+/* kernel timing (HIP events on the engine's stream). kind: 0 gather-aggregate, 1 gather-partials, 2 gemm */
+int cognn_engine_enable_timing(cognn_engine* e, int32_t on);
+int cognn_engine_get_timing(cognn_engine* e, int32_t kind, int64_t* launches, double* total_ms, double* algo_bytes_or_ops);
+/* static workload numbers: per message-passing round at width F=1 (multiply by F):
+ * out[0] edge-rows gathered by aggregate launch, out[1] rows written by it, out[2] edge-rows of the partial launch,
+ * out[3] rows written by it, out[4] total directed edges, out[5] table rows */
+int cognn_engine_get_workload(cognn_engine* e, int64_t* out6);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* COGNN_ENGINE_H_ */

@@ -118,6 +118,16 @@ int cognn_softmax_u64(cognn_ctx*, uint64_t* p_out, uint64_t* d_out, uint64_t* pf
 int cognn_metrics_q16(cognn_ctx*, const uint64_t* pfx, const int32_t* labels, const uint8_t* border,
                       int64_t rows, int64_t L, int64_t train_rows, int64_t val_rows, int64_t* counts6, double* loss);
 
+/* out[c,r] = in[r,c] for a small [rows x cols] matrix (transpose(), include/task/task.h:243; gcn.h:648) */
+int cognn_transpose_u64(cognn_ctx*, uint64_t* out, const uint64_t* in, int64_t rows, int64_t cols);
+
+/* ---- HIP-event timers on the context's stream (print_duration stand-in, ss_...h:188-192) ---- */
+int cognn_timer_begin(cognn_ctx*, int kind);
+int cognn_timer_end(cognn_ctx*, int kind);
+/* synchronises the stream; sums all completed begin/end pairs of `kind` since the last reset */
+int cognn_timer_read(cognn_ctx*, int kind, int64_t* launches, double* total_ms);
+int cognn_timer_reset(cognn_ctx*);
+
 #ifdef __cplusplus
 }
 #endif
