@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""bench.py — secret-shared GCN hot path on MI355X.
+
+A "step" is one pass of the hot path over one synthetic batch: by default the 8-party
+optimize-gcn-inference pass (GAS iterations 0-1, `-m 2` in the reference, tools/tmp_run_cluster.py:397-415)
+on the synthetic 2^20-vertex / 2^24-edge global graph of BASELINE.json configs[4], partition vid % 8.
+The k parties are mapped onto the N GPUs in contiguous blocks (N=1: all co-located, in-device exchange;
+N=8: one party per GPU, RCCL p2p), so the total work is fixed as N grows ("strong" scaling).
+
+`value` = whole-job edge-features aggregated per second: (directed edges) x (sum of the message widths of
+the step's message-passing rounds) / step time, inputs already resident in HBM.  The dealer ("offline")
+phase — Beaver product shares of the GEMMs — runs before the timed region, like the reference's
+preprocess phase (README.md:236-237), and is reported separately as offline_ms.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+
+def synth_graph(num_vertices, num_undirected, seed):
+    """Distinct undirected pairs without self loops, both directions emitted."""
+    rng = np.random.default_rng(seed)
+    keys = np.empty(0, dtype=np.int64)
+    while len(keys) < num_undirected:
+        m = num_undirected - len(keys)
+        a = rng.integers(0, num_vertices, size=m + m // 8 + 16, dtype=np.int64)
+        b = rng.integers(0, num_vertices, size=m + m // 8 + 16, dtype=np.int64)
+        ok = a != b
+        cand = np.minimum(a, b)[ok] * np.int64(num_vertices) + np.maximum(a, b)[ok]
+        fresh = np.setdiff1d(cand, keys)
+        if len(fresh) > m:
+            fresh = rng.permutation(fresh)[:m]
+        keys = np.union1d(keys, fresh)
+    lo = keys // num_vertices; hi = keys % num_vertices
+    return np.concatenate([lo, hi]), np.concatenate([hi, lo])
+
+
+WORKLOADS = {
+    # name: (parties, log2 V, log2 directed E, in, hid, labels, variant, iterations per step)
+    "config5": (8, 20, 24, 128, 64, 16, "optimize-gcn-inference", 2),
+    "config5-h16": (8, 20, 24, 128, 16, 16, "optimize-gcn-inference", 2),
+    "config5-train": (8, 20, 24, 128, 64, 16, "optimize-gcn", 6),
+    "small": (8, 14, 18, 128, 64, 16, "optimize-gcn-inference", 2),
+}
+
+
+def message_widths(variant, iters, hid, lab):
+    w = [hid, lab, 0, lab, 0, hid]          # getPlainNumPerOperand per GAS iteration (gcn.h:898-927); 0 = apply-only
+    return sum(w[i % 6] for i in range(iters))
+
+
+def cpu_baseline(args, wl):
+    """The numpy oracle on a bounded 1/64-scale sample of the same workload (rank 0, N=1 only)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import cognn_oracle as co
+    k, lv, le, in_dim, hid, lab, variant, iters = wl
+    lv2, le2 = max(lv - 6, 8), max(le - 6, 10)
+    V, Eu = 1 << lv2, 1 << (le2 - 1)
+    src, dst = co.synth_graph(V, Eu, 0xC06A11)
+    part = np.arange(V) % k
+    feats, labels = co.synth_features(V, in_dim, lab, 0xC06A12)
+    p = co.GnnParam(num_labels=lab, input_dim=in_dim, hidden_dim=hid, num_samples=V)
+    o = co.OracleEngine(k, src, dst, part, feats, labels, p, seed=0xC06A11, variant=variant)
+    t0 = time.perf_counter()
+    for it in range(iters):
+        o.iteration(it)
+    dt = time.perf_counter() - t0
+    ef = float(len(src)) * message_widths(variant, iters, hid, lab)
+    return {"value": ef / dt, "unit": "edges*feat/s", "cores": 1, "kind": "port",
+            "sample": "numpy oracle (oracle/cognn_oracle.py), %d-party %s pass on a 2^%d-vertex/2^%d-edge graph, "
+                      "in=%d hid=%d labels=%d, %.2f s" % (k, variant, lv2, le2, in_dim, hid, lab, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="config5", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--check", action="store_true", help="verify reconstruction linearity after the run")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run (WORLD_SIZE=%d)" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the engine has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from cognn_amd.engine import Engine, GnnParam
+    wl = WORKLOADS[args.workload]
+    k, lv, le, in_dim, hid, lab, variant, iters = wl
+    if k % world != 0:
+        raise SystemExit("the %d parties must divide evenly over %d GPUs" % (k, world))
+    V, Eu = 1 << lv, 1 << (le - 1)
+    t_setup = time.perf_counter()
+    src, dst = synth_graph(V, Eu, 0xC06A11)
+    part = (np.arange(V) % k).astype(np.int32)
+    param = GnnParam(num_labels=lab, input_dim=in_dim, hidden_dim=hid, num_samples=V, num_edges=len(src))
+    eng = Engine(k, src, dst, part, param, seed=0xC06A11, variant=variant, rank=rank, world=world, device=local_rank)
+    if world > 1:
+        from cognn_amd import dist as cdist
+        eng.set_exchange(cdist.make_exchange(torch.device("cuda", local_rank)))
+    for P in eng.hosted:                      # Bernoulli(0.01) bag-of-words features, uniform labels
+        vids = eng.party_vids(P)
+        rng = np.random.default_rng(0xC06A12 + P)
+        eng.set_party_data(P, (rng.random((len(vids), in_dim)) < 0.01).astype(np.float64), rng.integers(0, lab, size=len(vids)))
+    eng.start()
+    t_off = time.perf_counter()
+    eng.offline(0, iters)
+    torch.cuda.synchronize()
+    offline_ms = (time.perf_counter() - t_off) * 1e3
+    setup_s = time.perf_counter() - t_setup
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        eng.run(0, iters)
+    eng.enable_timing(True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        eng.run(0, iters)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    n_agg, ms_agg, bytes_agg = eng.timing(0)
+    n_part, ms_part, bytes_part = eng.timing(1)
+    n_gemm, ms_gemm, ops_gemm = eng.timing(2)
+    eng.enable_timing(False)
+
+    ms_per_step = dt / args.steps * 1e3
+    ef_per_step = float(len(src)) * message_widths(variant, iters, hid, lab)
+    value = ef_per_step / (dt / args.steps)
+    wlinfo = eng.workload()
+    out = {
+        "metric": "secret-shared GCN epoch time (s) + edges*feat/s per party",
+        "value": value, "unit": "edges*feat/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "u64", "data": "synthetic",
+        "config": {"workload": "%d-party %s pass (GAS iterations 0-%d) on a synthetic 2^%d-vertex/2^%d-edge global graph, "
+                               "partition vid %% %d, input_dim=%d hidden_dim=%d num_labels=%d, %d part%s per GPU"
+                               % (k, variant, iters - 1, lv, le, k, in_dim, hid, lab, k // world, "y" if k // world == 1 else "ies"),
+                   "name": args.workload, "parties": k, "exchange": "in-device" if world == 1 else "rccl-p2p"},
+        "epoch_time_s": dt / args.steps,
+        "edges_feat_per_s_per_party": value / k,
+        "offline_ms": offline_ms, "setup_s": setup_s,
+        "roofline": {"bound": "hbm", "kernel": "gather_csr_kernel (aggregate launch)",
+                     "achieved": (bytes_agg / 1e9) / (ms_agg / 1e3) if ms_agg > 0 else None, "peak": 8000.0, "unit": "GB/s",
+                     "frac": ((bytes_agg / 1e9) / (ms_agg / 1e3) / 8000.0) if ms_agg > 0 else None, "traffic": None,
+                     "launches": n_agg, "avg_ms": ms_agg / max(n_agg, 1), "algo_bytes_per_launch": bytes_agg / max(n_agg, 1)},
+        "kernels": {"gather_partials": {"launches": n_part, "avg_ms": ms_part / max(n_part, 1),
+                                        "GBps": (bytes_part / 1e9) / (ms_part / 1e3) if ms_part > 0 else None},
+                    "beaver_gemm_close": {"launches": n_gemm, "avg_ms": ms_gemm / max(n_gemm, 1),
+                                          "i8_TOPs": (ops_gemm / 1e12) / (ms_gemm / 1e3) if ms_gemm > 0 else None,
+                                          "frac_of_5000_TOPs": ((ops_gemm / 1e12) / (ms_gemm / 1e3) / 5000.0) if ms_gemm > 0 else None}},
+        "graph": wlinfo,
+    }
+    if args.check and world == 1:
+        a = eng.shares(0, 0); b = eng.shares(0, 1)
+        with np.errstate(over="ignore"):
+            rec = (a + b).astype(np.int64).astype(np.float64) / 65536.0
+        out["check"] = {"rows": int(rec.shape[0]), "cols": int(rec.shape[1]), "abs_max": float(np.abs(rec).max())}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args, wl)
+    elif rank == 0:
+        out["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(out))
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,46 @@
+"""Share-exchange / Beaver-reveal rounds over torch.distributed (backend "nccl" = RCCL over xGMI on the
+GPU box, "gloo" in the CPU tests).  Replaces the reference's TCP paths (CommSync::send/recvShareVecVec,
+include/comm_sync.h:245-277; TaskComm; Engine's channel mesh, include/engine.h:157-201): one logical
+message = one p2p op on a flat uint64 buffer, all messages of a round issued as one p2p group."""
+import ctypes
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from .engine_api import EXCHANGE_FN
+
+
+class _DevBuf:
+    """Raw device pointer exposed through __cuda_array_interface__ so torch can alias it without a copy."""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+
+
+def _wrap(ptr, nbytes, device):
+    if device.type == "cuda":
+        return torch.as_tensor(_DevBuf(ptr, nbytes), device=device)
+    buf = (ctypes.c_uint8 * nbytes).from_address(ptr)
+    return torch.from_numpy(np.frombuffer(buf, dtype=np.uint8))
+
+
+def make_exchange(device, group=None):
+    """Returns the cognn_exchange_fn callback for cognn_engine_set_exchange()."""
+
+    def _exchange(user, xfers, n):
+        try:
+            ops = []
+            for i in range(n):
+                x = xfers[i]
+                t = _wrap(x.ptr, x.bytes, device)
+                ops.append(dist.P2POp(dist.isend if x.is_send else dist.irecv, t, x.peer, group))
+            if ops:
+                for w in dist.batch_isend_irecv(ops):
+                    w.wait()
+            return 0
+        except Exception as ex:  # noqa: BLE001 - the C caller only understands a status code
+            print("cognn exchange failed: %r" % (ex,), flush=True)
+            return 1
+
+    return EXCHANGE_FN(_exchange)

@@ -258,8 +258,8 @@ def const_scale_trunc_pair(x0, x1, cfx, key_of):
 # ----------------------------------------------------------------------------------------
 # Oblivious mapper (OEP) and prefix aggregation (OGA) as plain index arithmetic on one share
 # ----------------------------------------------------------------------------------------
-def oep(src_pos, dst_pos, src, allow_missing=False):
-    """client/server_oblivious_mapper_online stand-in (ss_...h:752,760,818,848):
+def oep_loop(src_pos, dst_pos, src, allow_missing=False):
+    """client/server_oblivious_mapper_online stand-in (ss_...h:752,760,818,848), literal form:
     dst[r] = src[last index q with src_pos[q] == dst_pos[r]]; zero row if absent and allowed."""
     last = {}
     for q, p in enumerate(src_pos):
@@ -275,15 +275,52 @@ def oep(src_pos, dst_pos, src, allow_missing=False):
     return out
 
 
-def prefix_network_aggregate(pos, svv):
-    """prefix_network_aggregate(..., ADD_AGG, ...) stand-in (gcn.h:328-335): inclusive prefix sum
-    inside each run of equal consecutive pos; the run total sits at the run's last element."""
+def oep(src_pos, dst_pos, src, allow_missing=False):
+    """Vectorised oep_loop (same result; tests/test_oracle_cpu.py checks the two against each other)."""
+    sp = np.asarray(src_pos, dtype=np.int64); dp = np.asarray(dst_pos, dtype=np.int64)
+    out = np.zeros((len(dp), src.shape[1]), dtype=U64)
+    if len(dp) == 0:
+        return out
+    if len(sp) == 0:
+        if not allow_missing:
+            raise KeyError("oep: empty source")
+        return out
+    order = np.argsort(sp, kind="stable")
+    ss = sp[order]
+    j = np.searchsorted(ss, dp, side="right") - 1          # rightmost equal element = last occurrence
+    ok = (j >= 0) & (ss[np.maximum(j, 0)] == dp)
+    if not allow_missing and not ok.all():
+        raise KeyError("oep: position missing in source")
+    out[ok] = src[order[j[ok]]]
+    return out
+
+
+def prefix_network_aggregate_loop(pos, svv):
+    """prefix_network_aggregate(..., ADD_AGG, ...) stand-in (gcn.h:328-335), literal form: inclusive
+    prefix sum inside each run of equal consecutive pos; the run total sits at the run's last element."""
     out = svv.copy()
     with np.errstate(over="ignore"):
         for q in range(1, len(pos)):
             if pos[q] == pos[q - 1]:
                 out[q] = out[q] + out[q - 1]
     return out
+
+
+def prefix_network_aggregate(pos, svv):
+    """Vectorised prefix_network_aggregate_loop (segmented cumulative sum mod 2^64)."""
+    ps = np.asarray(pos, dtype=np.int64)
+    n = len(ps)
+    if n == 0:
+        return svv.copy()
+    with np.errstate(over="ignore"):
+        cs = np.cumsum(svv, axis=0, dtype=U64)
+        start = np.ones(n, dtype=bool)
+        start[1:] = ps[1:] != ps[:-1]
+        sidx = np.maximum.accumulate(np.where(start, np.arange(n), 0))     # index of each element's run start
+        base = np.zeros_like(cs)
+        has = sidx > 0
+        base[has] = cs[sidx[has] - 1]
+        return cs - base
 
 
 # ----------------------------------------------------------------------------------------
@@ -815,25 +852,24 @@ class PlainEngine:
 # Synthetic inputs: symmetric random graph, vid % k partition, Bernoulli features
 # ----------------------------------------------------------------------------------------
 def synth_graph(num_vertices, num_undirected, seed):
-    """num_undirected distinct undirected pairs without self loops, emitted in both directions."""
+    """num_undirected distinct undirected pairs without self loops, emitted in both directions
+    (reference datasets are symmetric: tools/data_transform.py:40)."""
     rng = np.random.default_rng(seed)
-    want = num_undirected
-    pairs = set()
-    while len(pairs) < want:
-        m = want - len(pairs)
-        a = rng.integers(0, num_vertices, size=m + 16)
-        b = rng.integers(0, num_vertices, size=m + 16)
-        for x, y in zip(a, b):
-            if x == y:
-                continue
-            p = (int(min(x, y)), int(max(x, y)))
-            if p not in pairs:
-                pairs.add(p)
-                if len(pairs) == want:
-                    break
-    pl = sorted(pairs)
-    src = np.array([p[0] for p in pl] + [p[1] for p in pl], dtype=np.int64)
-    dst = np.array([p[1] for p in pl] + [p[0] for p in pl], dtype=np.int64)
+    keys = np.empty(0, dtype=np.int64)
+    while len(keys) < num_undirected:
+        m = num_undirected - len(keys)
+        a = rng.integers(0, num_vertices, size=m + m // 8 + 16, dtype=np.int64)
+        b = rng.integers(0, num_vertices, size=m + m // 8 + 16, dtype=np.int64)
+        ok = a != b
+        lo = np.minimum(a, b)[ok]; hi = np.maximum(a, b)[ok]
+        cand = lo * np.int64(num_vertices) + hi
+        fresh = np.setdiff1d(cand, keys)                     # sorted, unique
+        if len(fresh) > m:
+            fresh = rng.permutation(fresh)[:m]
+        keys = np.union1d(keys, fresh)
+    lo = keys // num_vertices; hi = keys % num_vertices
+    src = np.concatenate([lo, hi]).astype(np.int64)
+    dst = np.concatenate([hi, lo]).astype(np.int64)
     return src, dst
 
 
