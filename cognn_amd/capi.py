@@ -91,7 +91,7 @@ def load(path=None):
     if not os.path.exists(path):
         raise CognnError("%s not found: build it with `make` (or __graft_entry__.build()); "
                          "the engine has no CPU fallback" % path)
-    lib = ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+    lib = ctypes.CDLL(path)
     for name, (res, args) in _SIGNATURES.items():
         fn = getattr(lib, name)
         fn.restype = res

@@ -97,6 +97,8 @@ struct cognn_engine {
     std::vector<std::vector<int32_t>> hostLabels;
     std::vector<double> w0, w1;
     double algo[3] = {0, 0, 0};
+    u64* wa[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // weight-averaging temporaries
+    u64* wa_recv[2] = {nullptr, nullptr};                                    // [world x elems] each
 
     int in() const { return cfg.input_dim; }
     int hid() const { return cfg.hidden_dim; }
@@ -385,31 +387,68 @@ void message_passing(cognn_engine* E, int F) {
 // weight averaging (gcn.h:747-802)
 // ---------------------------------------------------------------------------------------------
 void weight_average(cognn_engine* E, int64_t it, int layer) {
-    if (E->world > 1) throw EngineError("engine: weight averaging across ranks is not implemented yet (training needs world == 1)");
+    // Party 1 sums the owner shares of parties >= 1 plus its co-share of party 0's weights, party 0 sums its own
+    // share plus every other co-share (gcn.h:753-762); both scale by 1/k (training variant only, :763-764) and
+    // the results are redistributed (:765-778).  Each rank pre-sums its local contributions, so the exchange is
+    // one small message per rank towards each holder and one back.
     const int k = E->k;
     const int64_t elems = layer == 0 ? (int64_t)E->in() * E->hid() : (int64_t)E->hid() * E->lab();
-    Side* h0 = E->side(0, 0);      // party 0 accumulates here, party 1 in side(1,0)
-    Side* h1 = E->side(1, 0);
-    u64* sum0 = h0->small[0];
-    u64* sum1 = h1->small[0];
-    BE(cognn_memcpy_d2d(E->ctx, sum0, h0->W[layer], elems * 8));
-    for (int o = 1; o < k; ++o) BE(cognn_add_u64(E->ctx, sum0, sum0, E->side(o, 1)->W[layer], elems));
-    BE(cognn_memcpy_d2d(E->ctx, sum1, h1->W[layer], elems * 8));
-    for (int o = 2; o < k; ++o) BE(cognn_add_u64(E->ctx, sum1, sum1, E->side(o, 0)->W[layer], elems));
-    BE(cognn_add_u64(E->ctx, sum1, sum1, E->side(0, 1)->W[layer], elems));
-    if (E->cfg.variant == COGNN_VARIANT_OPTIMIZE_GCN) {   // gcn.h:763-764; absent in the inference variant
+    const size_t bytes = (size_t)elems * 8;
+    const int r0 = E->rank_of(0), r1 = E->rank_of(1);
+    u64* part[2] = {E->wa[0], E->wa[1]};
+    BE(cognn_memset0(E->ctx, part[0], bytes));
+    BE(cognn_memset0(E->ctx, part[1], bytes));
+    for (auto& s : E->sides) {
+        const int to = (s.owner == 0) ? s.p : 1 - s.p;     // (0,0)->sum0 (0,1)->sum1 ; (o,1)->sum0 (o,0)->sum1 for o>=1
+        BE(cognn_add_u64(E->ctx, part[to], part[to], s.W[layer], elems));
+    }
+    const int holder[2] = {r0, r1};
+    {
+        XList xl;
+        for (int h = 0; h < 2; ++h) {
+            if (E->rank != holder[h]) xl.send(holder[h], part[h], (int64_t)bytes);
+            else
+                for (int r = 0; r < E->world; ++r)
+                    if (r != E->rank) xl.recv(r, E->wa_recv[h] + (size_t)r * elems, (int64_t)bytes);
+        }
+        run_exchange(E, xl);
+    }
+    for (int h = 0; h < 2; ++h)
+        if (E->rank == holder[h])
+            for (int r = 0; r < E->world; ++r)
+                if (r != E->rank) BE(cognn_add_u64(E->ctx, part[h], part[h], E->wa_recv[h] + (size_t)r * elems, elems));
+    if (E->cfg.variant == COGNN_VARIANT_OPTIMIZE_GCN) {    // twoPartyGCNMatrixScale between parties 0 and 1
         cognn_keys tk = keys(E, COGNN_OWNER_WAVG, it, COGNN_OP_WAVG_TRUNC);
         const u64 ws = fx_trunc(1.0 / k);
-        u64* c0 = h0->small[1];
-        u64* c1 = h1->small[1];
-        BE(cognn_trunc_open_u64(E->ctx, c0, sum0, ws, &tk, 0, elems));
-        BE(cognn_trunc_open_u64(E->ctx, c1, sum1, ws, &tk, 1, elems));
-        BE(cognn_trunc_close_u64(E->ctx, sum0, c0, c1, &tk, 0, 0, elems));
-        BE(cognn_trunc_close_u64(E->ctx, sum1, nullptr, nullptr, &tk, 1, 0, elems));
+        u64* c0 = E->wa[2];
+        u64* c1 = E->wa[3];
+        if (E->rank == r0) BE(cognn_trunc_open_u64(E->ctx, c0, part[0], ws, &tk, 0, elems));
+        if (E->rank == r1) BE(cognn_trunc_open_u64(E->ctx, c1, part[1], ws, &tk, 1, elems));
+        if (r0 != r1) {
+            XList xl;
+            if (E->rank == r1) xl.send(r0, c1, (int64_t)bytes);
+            if (E->rank == r0) xl.recv(r1, c1, (int64_t)bytes);
+            run_exchange(E, xl);
+        }
+        if (E->rank == r0) BE(cognn_trunc_close_u64(E->ctx, part[0], c0, c1, &tk, 0, 0, elems));
+        if (E->rank == r1) BE(cognn_trunc_close_u64(E->ctx, part[1], nullptr, nullptr, &tk, 1, 0, elems));
     }
-    for (int o = 0; o < k; ++o) {                          // gcn.h:765-778
-        BE(cognn_memcpy_d2d(E->ctx, E->side(o, 0)->W[layer], o == 0 ? sum0 : sum1, elems * 8));
-        BE(cognn_memcpy_d2d(E->ctx, E->side(o, 1)->W[layer], o == 0 ? sum1 : sum0, elems * 8));
+    u64* avg[2] = {part[0], part[1]};                      // share 0 / share 1 of the averaged weights
+    {
+        XList xl;
+        for (int h = 0; h < 2; ++h) {
+            if (E->rank == holder[h]) {
+                for (int r = 0; r < E->world; ++r) if (r != E->rank) xl.send(r, part[h], (int64_t)bytes);
+            } else {
+                avg[h] = E->wa[4 + h];
+                xl.recv(holder[h], avg[h], (int64_t)bytes);
+            }
+        }
+        run_exchange(E, xl);
+    }
+    for (auto& s : E->sides) {                             // owner 0 keeps (s0, s1); owners >= 1 keep (s1, s0)
+        const int which = (s.owner == 0) ? s.p : 1 - s.p;
+        BE(cognn_memcpy_d2d(E->ctx, s.W[layer], avg[which], bytes));
     }
 }
 
@@ -689,6 +728,11 @@ void alloc_sides(cognn_engine* E) {
     E->Fmp = fm;
     E->table = dalloc<u64>(E, (size_t)E->tableRows * fm);
     E->aggOut = dalloc<u64>(E, (size_t)E->aggRows * fm);
+    {
+        const size_t welems = std::max((size_t)in * hid, (size_t)hid * lab);
+        for (int j = 0; j < 6; ++j) E->wa[j] = dalloc<u64>(E, welems);
+        for (int j = 0; j < 2; ++j) E->wa_recv[j] = dalloc<u64>(E, welems * (size_t)E->world);
+    }
     for (auto& s : E->sides) {
         const size_t n = (size_t)s.n;
         const size_t big = std::max<size_t>({n * (size_t)in, (size_t)in * hid, n * (size_t)fm, (size_t)hid * lab});

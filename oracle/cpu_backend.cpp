@@ -1,0 +1,299 @@
+// TEST INFRASTRUCTURE — NOT PRODUCT CODE.
+// Plain C++ (serial loops, host memory) implementation of every entry point of include/cognn_hip.h, bound
+// as the arithmetic backend of cognn_amd/host/engine.cpp in oracle/libcognn_engine_cpu.so.  It exists so that
+//   (1) the engine's host logic (layout, CSR construction, schedule, multi-rank exchange lists) can be
+//       checked on CPU against oracle/cognn_oracle.py, including world_size-2 runs over gloo, and
+//   (2) bench.py's cpu_baseline leg can time a compiled CPU port next to the GPU number.
+// Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library; the product
+// (cognn_amd/libcognn_hip.so) neither links nor falls back to it and fails loudly without a GPU.
+// Definitions follow DESIGN.md §3 and cognn_amd/csrc/cognn_spec.h (the numpy oracle restates them independently).
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../cognn_amd/csrc/cognn_spec.h"
+#include "../cognn_amd/host/backend.h"
+
+typedef uint64_t u64;
+
+struct cognn_ctx {
+    std::vector<std::chrono::high_resolution_clock::time_point> open[8];
+    double total_ms[8] = {0};
+    int64_t count[8] = {0};
+};
+
+static thread_local char g_err[512] = "";
+static int fail(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return 1;
+}
+#define REQ(c, msg) do { if (!(c)) return fail("%s", msg); } while (0)
+
+static inline cognn_opkeys K(const cognn_keys* k) {
+    cognn_opkeys r;
+    for (int i = 0; i < COGNN_SL_COUNT; ++i) r.k[i] = k->k[i];
+    return r;
+}
+static inline u64 trunc_r(const cognn_opkeys& k, int p, u64 i) {
+    u64 r0 = cognn_prng(k.k[COGNN_SL_R0], i);
+    return p == 0 ? r0 : (cognn_prng(k.k[COGNN_SL_R], i) & COGNN_TRUNC_MASK) - r0;
+}
+static inline u64 trunc_rp(const cognn_opkeys& k, int p, u64 i) {
+    u64 rp0 = cognn_prng(k.k[COGNN_SL_RP0], i);
+    return p == 0 ? rp0 : ((cognn_prng(k.k[COGNN_SL_R], i) & COGNN_TRUNC_MASK) >> COGNN_FX_BITS) - rp0;
+}
+static inline u64 beaver_mul(const cognn_opkeys& k, int p, u64 e, u64 g, u64 i, u64 bi) {
+    u64 a0 = cognn_prng(k.k[COGNN_SL_A0], i), b0 = cognn_prng(k.k[COGNN_SL_B0], bi), c0 = cognn_prng(k.k[COGNN_SL_C0], i);
+    if (p == 0) return e * b0 + a0 * g + c0;
+    u64 a1 = cognn_prng(k.k[COGNN_SL_A1], i), b1 = cognn_prng(k.k[COGNN_SL_B1], bi);
+    return e * g + e * b1 + a1 * g + ((a0 + a1) * (b0 + b1) - c0);
+}
+static inline u64 lidx(int64_t i, int64_t rows, int64_t cols, int transposed) {
+    if (!transposed) return (u64)i;
+    const u64 k = (u64)i / (u64)rows, m = (u64)i % (u64)rows;     // storage [cols x rows]
+    return m * (u64)cols + k;
+}
+
+extern "C" {
+
+int cognn_abi_version(void) { return COGNN_ABI_VERSION; }
+const char* cognn_last_error(void) { return g_err; }
+int cognn_ctx_create(int, void*, cognn_ctx** out) { REQ(out, "ctx_create: null"); *out = new cognn_ctx(); return 0; }
+int cognn_ctx_create_private(int d, cognn_ctx** out) { return cognn_ctx_create(d, nullptr, out); }
+int cognn_ctx_destroy(cognn_ctx* c) { delete c; return 0; }
+int cognn_ctx_sync(cognn_ctx*) { return 0; }
+int cognn_malloc(cognn_ctx*, void** p, size_t bytes) {
+    REQ(p, "malloc: null");
+    if (posix_memalign(p, 64, bytes ? bytes : 64) != 0) return fail("out of host memory");
+    return 0;
+}
+int cognn_free(cognn_ctx*, void* p) { free(p); return 0; }
+int cognn_memcpy_h2d(cognn_ctx*, void* d, const void* s, size_t n) { if (n) memcpy(d, s, n); return 0; }
+int cognn_memcpy_d2h(cognn_ctx*, void* d, const void* s, size_t n) { if (n) memcpy(d, s, n); return 0; }
+int cognn_memcpy_d2d(cognn_ctx*, void* d, const void* s, size_t n) { if (n) memmove(d, s, n); return 0; }
+int cognn_memset0(cognn_ctx*, void* d, size_t n) { if (n) memset(d, 0, n); return 0; }
+void cognn_make_keys(uint64_t seed, uint64_t owner, uint64_t iter, uint64_t op, cognn_keys* out) {
+    cognn_opkeys k = cognn_make_opkeys(seed, owner, iter, op);
+    for (int i = 0; i < COGNN_SL_COUNT; ++i) out->k[i] = k.k[i];
+}
+
+int cognn_fx_encode_f64(cognn_ctx*, const double* in, const double* rs, uint64_t* fx, int64_t rows, int64_t cols) {
+    for (int64_t i = 0; i < rows * cols; ++i) {
+        double v = in[i];
+        if (rs) v *= rs[i / cols];
+        fx[i] = (u64)(long long)llround(v * (double)COGNN_FX_ONE);
+    }
+    return 0;
+}
+int cognn_share_split_u64(cognn_ctx*, const uint64_t* fx, uint64_t key, uint64_t* s0, uint64_t* s1, int64_t n) {
+    for (int64_t i = 0; i < n; ++i) {
+        const u64 b = cognn_prng(key, (u64)i);
+        if (s0) s0[i] = fx[i] - b;
+        if (s1) s1[i] = b;
+    }
+    return 0;
+}
+int cognn_prng_fill_u64(cognn_ctx*, uint64_t* out, uint64_t key, int64_t n) {
+    for (int64_t i = 0; i < n; ++i) out[i] = cognn_prng(key, (u64)i);
+    return 0;
+}
+int cognn_gather_csr_u64(cognn_ctx*, uint64_t* out, const uint64_t* base, const uint64_t* table, const uint32_t* rowptr,
+                         const uint32_t* col, int64_t n_rows, int64_t F) {
+    std::vector<u64> acc((size_t)F);
+    for (int64_t r = 0; r < n_rows; ++r) {
+        for (int64_t j = 0; j < F; ++j) acc[j] = base ? base[r * F + j] : 0;
+        for (uint32_t e = rowptr[r]; e < rowptr[r + 1]; ++e) {
+            const u64* src = table + (size_t)col[e] * F;
+            for (int64_t j = 0; j < F; ++j) acc[j] += src[j];
+        }
+        for (int64_t j = 0; j < F; ++j) out[r * F + j] = acc[j];
+    }
+    return 0;
+}
+int cognn_scatter_add_rows_u64(cognn_ctx*, uint64_t* v, const uint64_t* part, const uint32_t* idx, int64_t n, int64_t F) {
+    for (int64_t q = 0; q < n; ++q)
+        for (int64_t j = 0; j < F; ++j) v[(size_t)idx[q] * F + j] += part[q * F + j];
+    return 0;
+}
+int cognn_ring_gemm_u64(cognn_ctx*, uint64_t* C, const uint64_t* A, const uint64_t* B, int64_t M, int64_t N, int64_t K,
+                        int transA, int accumulate) {
+    if (!accumulate) memset(C, 0, (size_t)M * N * 8);
+    for (int64_t m = 0; m < M; ++m)
+        for (int64_t k = 0; k < K; ++k) {
+            const u64 a = transA ? A[k * M + m] : A[m * K + k];
+            const u64* b = B + k * N;
+            u64* c = C + m * N;
+            for (int64_t n = 0; n < N; ++n) c[n] += a * b[n];
+        }
+    return 0;
+}
+int cognn_mask_open_u64(cognn_ctx*, uint64_t* E, const uint64_t* X, uint64_t key, int64_t rows, int64_t cols, int tr) {
+    for (int64_t i = 0; i < rows * cols; ++i) E[i] = X[i] - cognn_prng(key, lidx(i, rows, cols, tr));
+    return 0;
+}
+int cognn_add_u64(cognn_ctx*, uint64_t* o, const uint64_t* a, const uint64_t* b, int64_t n) {
+    for (int64_t i = 0; i < n; ++i) o[i] = a[i] + b[i];
+    return 0;
+}
+int cognn_sub_u64(cognn_ctx*, uint64_t* o, const uint64_t* a, const uint64_t* b, int64_t n) {
+    for (int64_t i = 0; i < n; ++i) o[i] = a[i] - b[i];
+    return 0;
+}
+int cognn_dealer_gemm_c1_u64(cognn_ctx* c, uint64_t* C1, const cognn_keys* keys, int64_t M, int64_t N, int64_t K, int transA,
+                             uint64_t* sa, uint64_t* sb) {
+    for (int64_t i = 0; i < M * K; ++i) {
+        const u64 li = lidx(i, M, K, transA);
+        sa[i] = cognn_prng(keys->k[COGNN_SL_A0], li) + cognn_prng(keys->k[COGNN_SL_A1], li);
+    }
+    for (int64_t i = 0; i < K * N; ++i) sb[i] = cognn_prng(keys->k[COGNN_SL_B0], (u64)i) + cognn_prng(keys->k[COGNN_SL_B1], (u64)i);
+    cognn_ring_gemm_u64(c, C1, sa, sb, M, N, K, transA, 0);
+    for (int64_t i = 0; i < M * N; ++i) C1[i] -= cognn_prng(keys->k[COGNN_SL_C0], (u64)i);
+    return 0;
+}
+int cognn_beaver_gemm_close_u64(cognn_ctx* c, uint64_t* Z, const uint64_t* E, const uint64_t* F, const uint64_t* c1,
+                                const cognn_keys* keys, int p, int64_t M, int64_t N, int64_t K, int transA, uint64_t* scratch) {
+    REQ(p == 0 || c1, "beaver_gemm_close: p=1 needs c1");
+    u64* Ap = scratch; u64* Bp = scratch + M * K;
+    for (int64_t i = 0; i < M * K; ++i) Ap[i] = cognn_prng(keys->k[p == 0 ? COGNN_SL_A0 : COGNN_SL_A1], lidx(i, M, K, transA));
+    for (int64_t i = 0; i < K * N; ++i) Bp[i] = cognn_prng(keys->k[p == 0 ? COGNN_SL_B0 : COGNN_SL_B1], (u64)i) + (p == 1 ? F[i] : 0);
+    for (int64_t i = 0; i < M * N; ++i) Z[i] = p == 0 ? cognn_prng(keys->k[COGNN_SL_C0], (u64)i) : c1[i];
+    cognn_ring_gemm_u64(c, Z, E, Bp, M, N, K, transA, 1);
+    return cognn_ring_gemm_u64(c, Z, Ap, F, M, N, K, transA, 1);
+}
+int cognn_trunc_open_u64(cognn_ctx*, uint64_t* c, const uint64_t* x, uint64_t mul, const cognn_keys* keys, int p, int64_t n) {
+    const cognn_opkeys k = K(keys);
+    for (int64_t i = 0; i < n; ++i) c[i] = x[i] * mul + trunc_r(k, p, (u64)i) + (p == 0 ? COGNN_TRUNC_OFFSET : 0);
+    return 0;
+}
+int cognn_trunc_close_u64(cognn_ctx*, uint64_t* out, const uint64_t* c0, const uint64_t* c1, const cognn_keys* keys, int p,
+                          int mode, int64_t n) {
+    REQ(p == 1 || (c0 && c1), "trunc_close: p=0 needs both opened values");
+    const cognn_opkeys k = K(keys);
+    for (int64_t i = 0; i < n; ++i) {
+        u64 y = p == 0 ? ((c0[i] + c1[i]) >> COGNN_FX_BITS) - (COGNN_TRUNC_OFFSET >> COGNN_FX_BITS) - trunc_rp(k, 0, (u64)i)
+                       : 0ull - trunc_rp(k, 1, (u64)i);
+        out[i] = mode == 1 ? out[i] - y : y;
+    }
+    return 0;
+}
+int cognn_rowscale_open_u64(cognn_ctx*, uint64_t* E, uint64_t* G, const uint64_t* V, const uint64_t* s, const cognn_keys* keys,
+                            int p, int64_t rows, int64_t F) {
+    for (int64_t i = 0; i < rows * F; ++i) E[i] = V[i] - cognn_prng(keys->k[p == 0 ? COGNN_SL_A0 : COGNN_SL_A1], (u64)i);
+    for (int64_t r = 0; r < rows; ++r) G[r] = s[r] - cognn_prng(keys->k[p == 0 ? COGNN_SL_B0 : COGNN_SL_B1], (u64)r);
+    return 0;
+}
+int cognn_rowscale_close_u64(cognn_ctx*, uint64_t* c, const uint64_t* E, const uint64_t* G, const cognn_keys* keys,
+                             const cognn_keys* tkeys, int p, int64_t rows, int64_t F) {
+    const cognn_opkeys k = K(keys), tk = K(tkeys);
+    for (int64_t i = 0; i < rows * F; ++i) {
+        const u64 row = (u64)(i / F);
+        c[i] = beaver_mul(k, p, E[i], G[row], (u64)i, row) + trunc_r(tk, p, (u64)i) + (p == 0 ? COGNN_TRUNC_OFFSET : 0);
+    }
+    return 0;
+}
+int cognn_relu_open_u64(cognn_ctx*, uint64_t* E, uint64_t* G, const uint64_t* z, const cognn_keys* keys, int p, int64_t n) {
+    for (int64_t i = 0; i < n; ++i) {
+        const u64 t0 = cognn_prng(keys->k[COGNN_SL_T0], (u64)i);
+        const u64 tp = p == 0 ? t0 : ((cognn_prng(keys->k[COGNN_SL_T], (u64)i) & 0xFFFFFull) | 1ull) - t0;
+        E[i] = z[i] - cognn_prng(keys->k[p == 0 ? COGNN_SL_A0 : COGNN_SL_A1], (u64)i);
+        G[i] = tp - cognn_prng(keys->k[p == 0 ? COGNN_SL_B0 : COGNN_SL_B1], (u64)i);
+    }
+    return 0;
+}
+int cognn_relu_mul_u64(cognn_ctx*, uint64_t* w, const uint64_t* E, const uint64_t* G, const cognn_keys* keys, int p, int64_t n) {
+    const cognn_opkeys k = K(keys);
+    for (int64_t i = 0; i < n; ++i) w[i] = beaver_mul(k, p, E[i], G[i], (u64)i, (u64)i);
+    return 0;
+}
+int cognn_relu_close_u64(cognn_ctx*, uint64_t* h, uint8_t* mask, const uint64_t* z, const uint64_t* w0, const uint64_t* w1, int64_t n) {
+    for (int64_t i = 0; i < n; ++i) {
+        const bool pos = (long long)(w0[i] + w1[i]) > 0;
+        h[i] = pos ? z[i] : 0;
+        if (mask) mask[i] = pos;
+    }
+    return 0;
+}
+int cognn_mask_select_u64(cognn_ctx*, uint64_t* out, const uint64_t* in, const uint8_t* mask, int64_t n) {
+    for (int64_t i = 0; i < n; ++i) out[i] = mask[i] ? in[i] : 0;
+    return 0;
+}
+int cognn_softmax_u64(cognn_ctx*, uint64_t* p_out, uint64_t* d_out, uint64_t* pfx_out, const uint64_t* z0, const uint64_t* z1,
+                      const int32_t* labels, const cognn_keys* keys, int p, int64_t rows, int64_t L, int64_t train_rows) {
+    REQ(p == 1 || (z0 && z1 && labels), "softmax: owner side needs z0, z1, labels");
+    for (int64_t r = 0; r < rows; ++r) {
+        const bool keep = r < train_rows;
+        long long m = 0, S = 0;
+        if (p == 0) {
+            m = (long long)(z0[r * L] + z1[r * L]);
+            for (int64_t j = 1; j < L; ++j) { long long v = (long long)(z0[r * L + j] + z1[r * L + j]); if (v > m) m = v; }
+            for (int64_t j = 0; j < L; ++j) S += cognn_exp_neg_q30(m - (long long)(z0[r * L + j] + z1[r * L + j]));
+        }
+        for (int64_t j = 0; j < L; ++j) {
+            const u64 rho = cognn_prng(keys->k[COGNN_SL_RHO], (u64)(r * L + j));
+            if (p == 1) {
+                if (p_out) p_out[r * L + j] = rho;
+                d_out[r * L + j] = keep ? rho : 0;
+                continue;
+            }
+            const long long e = cognn_exp_neg_q30(m - (long long)(z0[r * L + j] + z1[r * L + j]));
+            const u64 pf = (u64)(((e << 16) + (S >> 1)) / S);
+            const u64 p0 = pf - rho;
+            if (pfx_out) pfx_out[r * L + j] = pf;
+            if (p_out) p_out[r * L + j] = p0;
+            d_out[r * L + j] = keep ? p0 - (j == labels[r] ? COGNN_FX_ONE : 0) : 0;
+        }
+    }
+    return 0;
+}
+int cognn_metrics_q16(cognn_ctx*, const uint64_t* pfx, const int32_t* labels, const uint8_t* border, int64_t rows, int64_t L,
+                      int64_t train_rows, int64_t val_rows, int64_t* c, double* loss) {
+    for (int i = 0; i < 6; ++i) c[i] = 0;
+    double ls = 0;
+    for (int64_t r = 0; r < rows; ++r) {
+        int best = 0;
+        for (int64_t j = 1; j < L; ++j) if (pfx[r * L + j] > pfx[r * L + best]) best = (int)j;
+        const bool ok = best == labels[r], b = border && border[r], tr = r < train_rows, te = r >= train_rows + val_rows;
+        if (ok) { c[0]++; if (tr) c[1]++; if (tr && b) c[2]++; if (te) c[3]++; if (te && b) c[4]++; }
+        double pl = (double)pfx[r * L + labels[r]] / (double)COGNN_FX_ONE;
+        if (pl == 0.0) pl = 0.001;
+        ls += -log(pl);
+    }
+    *loss = ls;
+    return 0;
+}
+int cognn_transpose_u64(cognn_ctx*, uint64_t* out, const uint64_t* in, int64_t rows, int64_t cols) {
+    for (int64_t r = 0; r < rows; ++r)
+        for (int64_t c = 0; c < cols; ++c) out[c * rows + r] = in[r * cols + c];
+    return 0;
+}
+int cognn_timer_begin(cognn_ctx* c, int kind) { c->open[kind].push_back(std::chrono::high_resolution_clock::now()); return 0; }
+int cognn_timer_end(cognn_ctx* c, int kind) {
+    REQ(!c->open[kind].empty(), "timer_end: no open timer");
+    c->total_ms[kind] += std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - c->open[kind].back()).count();
+    c->open[kind].pop_back();
+    c->count[kind]++;
+    return 0;
+}
+int cognn_timer_read(cognn_ctx* c, int kind, int64_t* n, double* ms) { *n = c->count[kind]; *ms = c->total_ms[kind]; return 0; }
+int cognn_timer_reset(cognn_ctx* c) {
+    for (int k = 0; k < 8; ++k) { c->open[k].clear(); c->total_ms[k] = 0; c->count[k] = 0; }
+    return 0;
+}
+
+const cognn_backend* cognn_default_backend(void) {
+    static const cognn_backend be = {
+#define X(name) &name,
+        COGNN_BACKEND_FUNCS(X)
+#undef X
+    };
+    return &be;
+}
+
+}  // extern "C"

@@ -1,0 +1,53 @@
+"""Worker of tests/test_multirank_cpu.py: one rank of a world_size>1 engine run over gloo, with the engine's
+host code linked against the plain-C++ reference backend (oracle/libcognn_engine_cpu.so — test infrastructure)."""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+
+def main():
+    cfg = json.loads(sys.argv[1])
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ["RANK"]); world = int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import cognn_oracle as co
+    from cognn_amd import capi
+    capi.load(os.path.join(ROOT, "oracle", "libcognn_engine_cpu.so"))
+    from cognn_amd import dist as cdist
+    from cognn_amd.engine import Engine, GnnParam
+    k = cfg["k"]; V = cfg["V"]
+    src, dst = co.synth_graph(V, cfg["Eu"], cfg["gseed"])
+    part = np.array([v % k for v in range(V)], dtype=np.int32)
+    feats, labels = co.synth_features(V, cfg["in"], cfg["lab"], cfg["gseed"] + 1, density=0.2)
+    gp = GnnParam(num_labels=cfg["lab"], input_dim=cfg["in"], hidden_dim=cfg["hid"], num_samples=V, learning_rate=0.5)
+    eng = Engine(k, src, dst, part, gp, seed=cfg["seed"], variant=cfg["variant"], rank=rank, world=world, stream=0)
+    eng.set_exchange(cdist.make_exchange(torch.device("cpu")))
+    eng.set_global_data(feats, labels)
+    eng.start()
+    out = {}
+    m = k // world
+    for it in range(cfg["iters"]):
+        eng.run(it, it + 1)
+        for o in range(k):
+            if o // m == rank:
+                out["it%d_o%d_s0" % (it, o)] = eng.shares(o, 0)
+                for l in range(2):
+                    out["it%d_o%d_s0_w%d" % (it, o, l)] = eng.weight(o, 0, l)
+            if ((o + 1) % k) // m == rank:
+                out["it%d_o%d_s1" % (it, o)] = eng.shares(o, 1)
+                for l in range(2):
+                    out["it%d_o%d_s1_w%d" % (it, o, l)] = eng.weight(o, 1, l)
+    np.savez(cfg["out"] + ".rank%d.npz" % rank, **out)
+    eng.close()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

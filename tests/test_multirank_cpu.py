@@ -1,0 +1,89 @@
+"""N>1 path on CPU: world_size-2 (and 3) engine runs over torch.distributed/gloo, the same engine.cpp and the
+same cognn_amd/dist.py exchange callback the GPU box uses with RCCL, only the arithmetic backend is the plain-C++
+reference one (oracle/cpu_backend.cpp).  Every rank's shares are compared bit for bit with the oracle."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import cognn_oracle as co
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _build_cpu_engine():
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _run(cfg, world, tmp_path):
+    cfg = dict(cfg, out=str(tmp_path / "shares"))
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "multirank_worker.py"), json.dumps(cfg)], env=env))
+    for p in procs:
+        assert p.wait(timeout=300) == 0
+    got = {}
+    for r in range(world):
+        with np.load(cfg["out"] + ".rank%d.npz" % r) as z:
+            for key in z.files:
+                assert key not in got
+                got[key] = z[key]
+    return got
+
+
+def _check(cfg, world, tmp_path):
+    k, V = cfg["k"], cfg["V"]
+    src, dst = co.synth_graph(V, cfg["Eu"], cfg["gseed"])
+    part = [v % k for v in range(V)]
+    feats, labels = co.synth_features(V, cfg["in"], cfg["lab"], cfg["gseed"] + 1, density=0.2)
+    p = co.GnnParam(num_labels=cfg["lab"], input_dim=cfg["in"], hidden_dim=cfg["hid"], num_samples=V, learning_rate=0.5)
+    o = co.OracleEngine(k, src, dst, part, feats, labels, p, seed=cfg["seed"], variant=cfg["variant"])
+    got = _run(cfg, world, tmp_path)
+    for it in range(cfg["iters"]):
+        o.iteration(it)
+        for P in range(k):
+            a, b = o.shares(P)
+            assert np.array_equal(got["it%d_o%d_s0" % (it, P)], a), (it, P)
+            assert np.array_equal(got["it%d_o%d_s1" % (it, P)], b), (it, P)
+            c = (P + 1) % k
+            for l in range(2):
+                assert np.array_equal(got["it%d_o%d_s0_w%d" % (it, P, l)], o.states[P].localWeight[l]), (it, P, l)
+                assert np.array_equal(got["it%d_o%d_s1_w%d" % (it, P, l)], o.states[c].remoteWeight[l]), (it, P, l)
+
+
+BASE = dict(V=48, Eu=120, gseed=3, seed=17, hid=6, lab=4, variant="optimize-gcn", iters=6)
+BASE["in"] = 10
+
+
+def test_two_parties_two_ranks_training(tmp_path):
+    _check(dict(BASE, k=2), 2, tmp_path)
+
+
+def test_four_parties_two_ranks_training(tmp_path):
+    _check(dict(BASE, k=4), 2, tmp_path)
+
+
+def test_three_parties_three_ranks_training(tmp_path):
+    _check(dict(BASE, k=3), 3, tmp_path)
+
+
+def test_four_parties_four_ranks_inference(tmp_path):
+    _check(dict(BASE, k=4, variant="optimize-gcn-inference", iters=2), 4, tmp_path)
+
+
+def test_single_rank_host_logic_three_parties(tmp_path):
+    """world == 1 through the same worker: the engine's co-located path (in-device hand-off) on the CPU backend."""
+    _check(dict(BASE, k=3, iters=12), 1, tmp_path)
