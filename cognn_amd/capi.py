@@ -53,17 +53,18 @@ _SIGNATURES = {
     "cognn_gather_csr_u64": (_I, [_P, _P, _P, _P, _P, _P, _L, _L]),
     "cognn_scatter_add_rows_u64": (_I, [_P, _P, _P, _P, _L, _L]),
     "cognn_ring_gemm_u64": (_I, [_P, _P, _P, _P, _L, _L, _L, _I, _I]),
+    "cognn_ring_gemm2_u64": (_I, [_P, _P, _P, _P, _P, _L, _L, _L, _I, _I]),
     "cognn_mask_open_u64": (_I, [_P, _P, _P, _U, _L, _L, _I]),
     "cognn_add_u64": (_I, [_P, _P, _P, _P, _L]),
     "cognn_sub_u64": (_I, [_P, _P, _P, _P, _L]),
     "cognn_dealer_gemm_c1_u64": (_I, [_P, _P, _KP, _L, _L, _L, _I, _P, _P]),
-    "cognn_beaver_gemm_close_u64": (_I, [_P, _P, _P, _P, _P, _KP, _I, _L, _L, _L, _I, _P]),
+    "cognn_beaver_gemm_close_u64": (_I, [_P, _P, _P, _P, _P, _P, _KP, _I, _L, _L, _L, _I, _P]),
     "cognn_trunc_open_u64": (_I, [_P, _P, _P, _U, _KP, _I, _L]),
     "cognn_trunc_close_u64": (_I, [_P, _P, _P, _P, _KP, _I, _I, _L]),
     "cognn_rowscale_open_u64": (_I, [_P, _P, _P, _P, _P, _KP, _I, _L, _L]),
-    "cognn_rowscale_close_u64": (_I, [_P, _P, _P, _P, _KP, _KP, _I, _L, _L]),
+    "cognn_rowscale_close_u64": (_I, [_P, _P, _P, _P, _P, _P, _KP, _KP, _I, _L, _L]),
     "cognn_relu_open_u64": (_I, [_P, _P, _P, _P, _KP, _I, _L]),
-    "cognn_relu_mul_u64": (_I, [_P, _P, _P, _P, _KP, _I, _L]),
+    "cognn_relu_mul_u64": (_I, [_P, _P, _P, _P, _P, _P, _KP, _I, _L]),
     "cognn_relu_close_u64": (_I, [_P, _P, _P, _P, _P, _P, _L]),
     "cognn_mask_select_u64": (_I, [_P, _P, _P, _P, _L]),
     "cognn_softmax_u64": (_I, [_P, _P, _P, _P, _P, _P, _P, _KP, _I, _L, _L, _L]),
@@ -88,6 +89,12 @@ def load(path=None):
     if _lib is not None:
         return _lib
     path = path or LIB_PATH
+    try:
+        # Load order matters: torch ships its own libamdhip64.so.7; importing it first makes this library bind to
+        # the same HIP runtime instance instead of bringing a second one into the process.
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(path):
         raise CognnError("%s not found: build it with `make` (or __graft_entry__.build()); "
                          "the engine has no CPU fallback" % path)

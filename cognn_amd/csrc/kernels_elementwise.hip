@@ -150,15 +150,18 @@ struct RowscaleOpenG {   // G[r] = s_p[r] - b_p[r]
         st2(G, i, w, g);
     }
 };
-struct RowscaleClose {   // c_out = beaver(E, G[row]) + trunc mask
-    u64* c; const u64* E; const u64* G; cognn_opkeys k; cognn_opkeys tk; int p; uint32_t F;
+struct RowscaleClose {   // c_out = beaver(E0+E1, (G0+G1)[row]) + trunc mask
+    u64* c; const u64* E; const u64* E1; const u64* G; const u64* G1; cognn_opkeys k; cognn_opkeys tk; int p; uint32_t F;
     __device__ void operator()(int64_t i, int w) const {
         u64 e[2], r[2];
         ld2(E, i, w, e);
+        if (E1) { u64 e1[2]; ld2(E1, i, w, e1); e[0] += e1[0]; e[1] += e1[1]; }
         for (int j = 0; j < w; ++j) {
             u64 idx = (u64)(i + j);
             u64 row = (u64)((uint32_t)idx / F);
-            u64 z = beaver_mul(k, p, e[j], G[row], idx, row);
+            u64 g = G[row];
+            if (G1) g += G1[row];
+            u64 z = beaver_mul(k, p, e[j], g, idx, row);
             r[j] = z + trunc_r(tk, p, idx) + (p == 0 ? COGNN_TRUNC_OFFSET : 0ull);
         }
         st2(c, i, w, r);
@@ -181,10 +184,12 @@ struct ReluOpen {        // E = z - a_p ; G = t_p - b_p
     }
 };
 struct ReluMul {
-    u64* wout; const u64* E; const u64* G; cognn_opkeys k; int p;
+    u64* wout; const u64* E; const u64* E1; const u64* G; const u64* G1; cognn_opkeys k; int p;
     __device__ void operator()(int64_t i, int w) const {
         u64 e[2], g[2], r[2];
         ld2(E, i, w, e); ld2(G, i, w, g);
+        if (E1) { u64 t[2]; ld2(E1, i, w, t); e[0] += t[0]; e[1] += t[1]; }
+        if (G1) { u64 t[2]; ld2(G1, i, w, t); g[0] += t[0]; g[1] += t[1]; }
         for (int j = 0; j < 2; ++j) r[j] = beaver_mul(k, p, e[j], g[j], (u64)(i + j), (u64)(i + j));
         st2(wout, i, w, r);
     }
@@ -344,19 +349,20 @@ int cognn_rowscale_open_u64(cognn_ctx* ctx, uint64_t* E, uint64_t* G, const uint
     if (rc) return rc;
     return launch_ew(ctx, rows, RowscaleOpenG{(u64*)G, (const u64*)s, K(keys), p});
 }
-int cognn_rowscale_close_u64(cognn_ctx* ctx, uint64_t* c_out, const uint64_t* E, const uint64_t* G,
+int cognn_rowscale_close_u64(cognn_ctx* ctx, uint64_t* c_out, const uint64_t* E, const uint64_t* E1, const uint64_t* G, const uint64_t* G1,
                              const cognn_keys* keys, const cognn_keys* tkeys, int p, int64_t rows, int64_t F) {
-    CG_REQUIRE(ctx && c_out && E && G && keys && tkeys && al(c_out) && al(E), "cognn_rowscale_close_u64: bad arguments");
+    CG_REQUIRE(ctx && c_out && E && G && keys && tkeys && al(c_out) && al(E) && al(E1), "cognn_rowscale_close_u64: bad arguments");
     CG_REQUIRE(rows * F < (1ll << 32), "cognn_rowscale_close_u64: tensor too large");
-    return launch_ew(ctx, rows * F, RowscaleClose{(u64*)c_out, (const u64*)E, (const u64*)G, K(keys), K(tkeys), p, (uint32_t)F});
+    return launch_ew(ctx, rows * F, RowscaleClose{(u64*)c_out, (const u64*)E, (const u64*)E1, (const u64*)G, (const u64*)G1, K(keys), K(tkeys), p, (uint32_t)F});
 }
 int cognn_relu_open_u64(cognn_ctx* ctx, uint64_t* E, uint64_t* G, const uint64_t* z, const cognn_keys* keys, int p, int64_t n) {
     CG_REQUIRE(ctx && E && G && z && keys && al(E) && al(G) && al(z), "cognn_relu_open_u64: bad arguments");
     return launch_ew(ctx, n, ReluOpen{(u64*)E, (u64*)G, (const u64*)z, K(keys), p});
 }
-int cognn_relu_mul_u64(cognn_ctx* ctx, uint64_t* w, const uint64_t* E, const uint64_t* G, const cognn_keys* keys, int p, int64_t n) {
-    CG_REQUIRE(ctx && w && E && G && keys && al(w) && al(E) && al(G), "cognn_relu_mul_u64: bad arguments");
-    return launch_ew(ctx, n, ReluMul{(u64*)w, (const u64*)E, (const u64*)G, K(keys), p});
+int cognn_relu_mul_u64(cognn_ctx* ctx, uint64_t* w, const uint64_t* E, const uint64_t* E1, const uint64_t* G, const uint64_t* G1,
+                       const cognn_keys* keys, int p, int64_t n) {
+    CG_REQUIRE(ctx && w && E && G && keys && al(w) && al(E) && al(G) && al(E1) && al(G1), "cognn_relu_mul_u64: bad arguments");
+    return launch_ew(ctx, n, ReluMul{(u64*)w, (const u64*)E, (const u64*)E1, (const u64*)G, (const u64*)G1, K(keys), p});
 }
 int cognn_relu_close_u64(cognn_ctx* ctx, uint64_t* h, uint8_t* mask, const uint64_t* z, const uint64_t* w0, const uint64_t* w1, int64_t n) {
     CG_REQUIRE(ctx && h && z && w0 && w1 && al(h) && al(z) && al(w0) && al(w1), "cognn_relu_close_u64: bad arguments");

@@ -23,8 +23,8 @@ typedef int v16i __attribute__((ext_vector_type(16)));
 // generic split-K kernel: C (+)= op(A) . B
 // ------------------------------------------------------------------------------------------
 template <bool TA>
-__global__ __launch_bounds__(256) void ring_gemm_simple_kernel(u64* C, const u64* __restrict__ A, const u64* __restrict__ B,
-                                                                int M, int N, int K, int kchunk, int use_atomic) {
+__global__ __launch_bounds__(256) void ring_gemm_simple_kernel(u64* C, const u64* __restrict__ A, const u64* __restrict__ A2,
+                                                                const u64* __restrict__ B, int M, int N, int K, int kchunk, int use_atomic) {
     const int n = blockIdx.x * 64 + (threadIdx.x & 63);
     const int m = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (n >= N || m >= M) return;
@@ -32,7 +32,9 @@ __global__ __launch_bounds__(256) void ring_gemm_simple_kernel(u64* C, const u64
     const int k1 = min(K, k0 + kchunk);
     u64 acc = 0;
     for (int k = k0; k < k1; ++k) {
-        const u64 a = TA ? A[(size_t)k * M + m] : A[(size_t)m * K + k];
+        const size_t ai = TA ? (size_t)k * M + m : (size_t)m * K + k;
+        u64 a = A[ai];
+        if (A2) a += A2[ai];
         acc += a * B[(size_t)k * N + n];
     }
     if (use_atomic) atomicAdd((unsigned long long*)&C[(size_t)m * N + n], acc);
@@ -68,6 +70,7 @@ __device__ __forceinline__ void split4(const u64 v[4], uint32_t plane[8]) {
 // BN: output columns per workgroup (32 or 64). Waves are arranged kWavesM x (BN/32).
 template <int BN>
 __global__ __launch_bounds__(kWavesM * (BN / 32) * 64) void ring_gemm_mfma_kernel(u64* C, const u64* __restrict__ A,
+                                                                       const u64* __restrict__ A2,
                                                                        const u64* __restrict__ B, int M, int N, int K,
                                                                        int accumulate) {
     constexpr int WN = BN / 32;                 // waves along N
@@ -119,9 +122,18 @@ __global__ __launch_bounds__(kWavesM * (BN / 32) * 64) void ring_gemm_mfma_kerne
                 const u64x2* p = reinterpret_cast<const u64x2*>(A + (size_t)m * K + k);
                 if ((K & 1) == 0) { u64x2 t0 = p[0], t1 = p[1]; nxt[q][0] = t0.x; nxt[q][1] = t0.y; nxt[q][2] = t1.x; nxt[q][3] = t1.y; }
                 else { const u64* s = A + (size_t)m * K + k; nxt[q][0] = s[0]; nxt[q][1] = s[1]; nxt[q][2] = s[2]; nxt[q][3] = s[3]; }
+                if (A2) {
+                    const u64x2* p2 = reinterpret_cast<const u64x2*>(A2 + (size_t)m * K + k);
+                    if ((K & 1) == 0) { u64x2 t0 = p2[0], t1 = p2[1]; nxt[q][0] += t0.x; nxt[q][1] += t0.y; nxt[q][2] += t1.x; nxt[q][3] += t1.y; }
+                    else { const u64* s = A2 + (size_t)m * K + k; nxt[q][0] += s[0]; nxt[q][1] += s[1]; nxt[q][2] += s[2]; nxt[q][3] += s[3]; }
+                }
             } else {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) nxt[q][j] = (m < M && k + j < K) ? A[(size_t)m * K + k + j] : 0ull;
+                for (int j = 0; j < 4; ++j) {
+                    const bool ok = (m < M && k + j < K);
+                    nxt[q][j] = ok ? A[(size_t)m * K + k + j] : 0ull;
+                    if (ok && A2) nxt[q][j] += A2[(size_t)m * K + k + j];
+                }
             }
         }
     };
@@ -217,7 +229,7 @@ int fill(cognn_ctx* ctx, u64* out, u64 k0, u64 k1, int64_t rows, int64_t cols, i
     return 0;
 }
 
-int gemm_dispatch(cognn_ctx* ctx, u64* C, const u64* A, const u64* B, int64_t M, int64_t N, int64_t K, int transA, int accumulate) {
+int gemm_dispatch(cognn_ctx* ctx, u64* C, const u64* A, const u64* A2, const u64* B, int64_t M, int64_t N, int64_t K, int transA, int accumulate) {
     if (M <= 0 || N <= 0) return 0;
     if (K <= 0) {
         if (!accumulate) CG_HIP(hipMemsetAsync(C, 0, (size_t)M * N * 8, ctx->stream));
@@ -235,10 +247,10 @@ int gemm_dispatch(cognn_ctx* ctx, u64* C, const u64* A, const u64* B, int64_t M,
             dim3 grid((unsigned)std::min(nmb, 256), (unsigned)((N + BN - 1) / BN));
             if (BN == 32) {
                 CG_HIP(hipFuncSetAttribute((const void*)ring_gemm_mfma_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                hipLaunchKernelGGL(ring_gemm_mfma_kernel<32>, grid, dim3(kGemmThreads), lds, ctx->stream, C, A, B, (int)M, (int)N, (int)K, accumulate);
+                hipLaunchKernelGGL(ring_gemm_mfma_kernel<32>, grid, dim3(kGemmThreads), lds, ctx->stream, C, A, A2, B, (int)M, (int)N, (int)K, accumulate);
             } else {
                 CG_HIP(hipFuncSetAttribute((const void*)ring_gemm_mfma_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                hipLaunchKernelGGL(ring_gemm_mfma_kernel<64>, grid, dim3(kGemmThreads), lds, ctx->stream, C, A, B, (int)M, (int)N, (int)K, accumulate);
+                hipLaunchKernelGGL(ring_gemm_mfma_kernel<64>, grid, dim3(kGemmThreads), lds, ctx->stream, C, A, A2, B, (int)M, (int)N, (int)K, accumulate);
             }
             CG_LAUNCH_CHECK();
             return 0;
@@ -254,8 +266,8 @@ int gemm_dispatch(cognn_ctx* ctx, u64* C, const u64* A, const u64* B, int64_t M,
     if (!accumulate) CG_HIP(hipMemsetAsync(C, 0, (size_t)M * N * 8, ctx->stream));
     dim3 grid((unsigned)((N + 63) / 64), (unsigned)((M + 3) / 4), (unsigned)splits);
     CG_REQUIRE(grid.y <= 65535 && splits <= 65535, "ring_gemm: shape too large for generic path");
-    if (transA) hipLaunchKernelGGL(ring_gemm_simple_kernel<true>, grid, dim3(256), 0, ctx->stream, C, A, B, (int)M, (int)N, (int)K, kchunk, splits > 1);
-    else hipLaunchKernelGGL(ring_gemm_simple_kernel<false>, grid, dim3(256), 0, ctx->stream, C, A, B, (int)M, (int)N, (int)K, kchunk, splits > 1);
+    if (transA) hipLaunchKernelGGL(ring_gemm_simple_kernel<true>, grid, dim3(256), 0, ctx->stream, C, A, A2, B, (int)M, (int)N, (int)K, kchunk, splits > 1);
+    else hipLaunchKernelGGL(ring_gemm_simple_kernel<false>, grid, dim3(256), 0, ctx->stream, C, A, A2, B, (int)M, (int)N, (int)K, kchunk, splits > 1);
     CG_LAUNCH_CHECK();
     return 0;
 }
@@ -269,7 +281,16 @@ int cognn_ring_gemm_u64(cognn_ctx* ctx, uint64_t* C, const uint64_t* A, const ui
     CG_REQUIRE(ctx && C && A && B, "cognn_ring_gemm_u64: null argument");
     CG_REQUIRE(M >= 0 && N >= 0 && K >= 0 && M < (1ll << 31) && N < (1ll << 31) && K < (1ll << 31), "cognn_ring_gemm_u64: bad shape");
     CG_REQUIRE(cg_aligned16(A) && cg_aligned16(B) && cg_aligned16(C), "cognn_ring_gemm_u64: operands must be 16-byte aligned");
-    return gemm_dispatch(ctx, (u64*)C, (const u64*)A, (const u64*)B, M, N, K, transA, accumulate);
+    return gemm_dispatch(ctx, (u64*)C, (const u64*)A, nullptr, (const u64*)B, M, N, K, transA, accumulate);
+}
+
+int cognn_ring_gemm2_u64(cognn_ctx* ctx, uint64_t* C, const uint64_t* A1, const uint64_t* A2, const uint64_t* B,
+                         int64_t M, int64_t N, int64_t K, int transA, int accumulate) {
+    CG_REQUIRE(ctx && C && A1 && B, "cognn_ring_gemm2_u64: null argument");
+    CG_REQUIRE(M >= 0 && N >= 0 && K >= 0 && M < (1ll << 31) && N < (1ll << 31) && K < (1ll << 31), "cognn_ring_gemm2_u64: bad shape");
+    CG_REQUIRE(cg_aligned16(A1) && cg_aligned16(B) && cg_aligned16(C) && (A2 == nullptr || cg_aligned16(A2)),
+               "cognn_ring_gemm2_u64: operands must be 16-byte aligned");
+    return gemm_dispatch(ctx, (u64*)C, (const u64*)A1, (const u64*)A2, (const u64*)B, M, N, K, transA, accumulate);
 }
 
 int cognn_dealer_gemm_c1_u64(cognn_ctx* ctx, uint64_t* C1, const cognn_keys* keys, int64_t M, int64_t N, int64_t K,
@@ -278,7 +299,7 @@ int cognn_dealer_gemm_c1_u64(cognn_ctx* ctx, uint64_t* C1, const cognn_keys* key
     int rc;
     if ((rc = fill(ctx, (u64*)scratchA, keys->k[COGNN_SL_A0], keys->k[COGNN_SL_A1], M, K, transA, 1, nullptr))) return rc;
     if ((rc = fill(ctx, (u64*)scratchB, keys->k[COGNN_SL_B0], keys->k[COGNN_SL_B1], K, N, 0, 1, nullptr))) return rc;
-    if ((rc = gemm_dispatch(ctx, (u64*)C1, (const u64*)scratchA, (const u64*)scratchB, M, N, K, transA, 0))) return rc;
+    if ((rc = gemm_dispatch(ctx, (u64*)C1, (const u64*)scratchA, nullptr, (const u64*)scratchB, M, N, K, transA, 0))) return rc;
     const int64_t n = M * N;
     if (n > 0) {
         hipLaunchKernelGGL(sub_prng_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 8192)), dim3(256), 0, ctx->stream, (u64*)C1,
@@ -288,7 +309,7 @@ int cognn_dealer_gemm_c1_u64(cognn_ctx* ctx, uint64_t* C1, const cognn_keys* key
     return 0;
 }
 
-int cognn_beaver_gemm_close_u64(cognn_ctx* ctx, uint64_t* Z, const uint64_t* E, const uint64_t* F, const uint64_t* c1,
+int cognn_beaver_gemm_close_u64(cognn_ctx* ctx, uint64_t* Z, const uint64_t* E, const uint64_t* E1, const uint64_t* F, const uint64_t* c1,
                                 const cognn_keys* keys, int p, int64_t M, int64_t N, int64_t K, int transA, uint64_t* scratch) {
     CG_REQUIRE(ctx && Z && E && F && keys && scratch && (p == 0 || p == 1), "cognn_beaver_gemm_close_u64: bad arguments");
     CG_REQUIRE(p == 0 || c1, "cognn_beaver_gemm_close_u64: p=1 needs the dealer share c1");
@@ -300,8 +321,8 @@ int cognn_beaver_gemm_close_u64(cognn_ctx* ctx, uint64_t* Z, const uint64_t* E, 
     if ((rc = fill(ctx, Bp, keys->k[p == 0 ? COGNN_SL_B0 : COGNN_SL_B1], 0, K, N, 0, 0, p == 1 ? (const u64*)F : nullptr))) return rc;
     if (p == 0) { if ((rc = fill(ctx, (u64*)Z, keys->k[COGNN_SL_C0], 0, M, N, 0, 0, nullptr))) return rc; }
     else CG_HIP(hipMemcpyAsync(Z, c1, (size_t)M * N * 8, hipMemcpyDeviceToDevice, ctx->stream));
-    if ((rc = gemm_dispatch(ctx, (u64*)Z, (const u64*)E, Bp, M, N, K, transA, 1))) return rc;
-    return gemm_dispatch(ctx, (u64*)Z, Ap, (const u64*)F, M, N, K, transA, 1);
+    if ((rc = gemm_dispatch(ctx, (u64*)Z, (const u64*)E, (const u64*)E1, Bp, M, N, K, transA, 1))) return rc;
+    return gemm_dispatch(ctx, (u64*)Z, Ap, nullptr, (const u64*)F, M, N, K, transA, 1);
 }
 
 }  // extern "C"

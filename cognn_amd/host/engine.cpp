@@ -52,10 +52,10 @@ struct Side {
     u64* cur = nullptr;            // current vertex tensor share [n x curF]
     int curF = 0;
     u64* buf[2] = {nullptr, nullptr};
-    u64* ob[2] = {nullptr, nullptr};
-    u64* ib_store[2] = {nullptr, nullptr};
-    u64* ib[2] = {nullptr, nullptr};
-    u64* sum[2] = {nullptr, nullptr};
+    u64* ob[3] = {nullptr, nullptr, nullptr};      // outboxes: 0/1 = Beaver openings, 2 = truncation / product opening
+    u64* ib_store[3] = {nullptr, nullptr, nullptr};
+    u64* ib[3] = {nullptr, nullptr, nullptr};      // peer's outboxes (aliases when the peer is on this rank)
+    u64* fsum = nullptr;                           // opened F of a Beaver GEMM (small)
     u64* scratch = nullptr;
     u64* zbuf = nullptr;           // untruncated GEMM output
     u64* small[3] = {nullptr, nullptr, nullptr};   // [in x hid]-sized temporaries for the weight chain
@@ -188,13 +188,13 @@ void trunc_stage(cognn_engine* E, int64_t it, int op, u64 mul, const std::vector
     for (size_t i = 0; i < E->sides.size(); ++i) {
         Side& s = E->sides[i];
         cognn_keys k = keys(E, owner_override == ~0ull ? (u64)s.owner : owner_override, it, op);
-        BE(cognn_trunc_open_u64(E->ctx, s.ob[0], x[i], mul, &k, s.p, elems[i]));
+        BE(cognn_trunc_open_u64(E->ctx, s.ob[2], x[i], mul, &k, s.p, elems[i]));
     }
-    exchange_ob(E, 0, elems);
+    exchange_ob(E, 2, elems);
     for (size_t i = 0; i < E->sides.size(); ++i) {
         Side& s = E->sides[i];
         cognn_keys k = keys(E, owner_override == ~0ull ? (u64)s.owner : owner_override, it, op);
-        BE(cognn_trunc_close_u64(E->ctx, dst(s), s.p == 0 ? s.ob[0] : nullptr, s.p == 0 ? s.ib[0] : nullptr, &k, s.p, mode, elems[i]));
+        BE(cognn_trunc_close_u64(E->ctx, dst(s), s.p == 0 ? s.ob[2] : nullptr, s.p == 0 ? s.ib[2] : nullptr, &k, s.p, mode, elems[i]));
     }
 }
 
@@ -213,8 +213,7 @@ void gemm_stage(cognn_engine* E, int64_t it, XFn X, WFn Wm, SpecFn spec, DstFn d
     exchange_ob(E, 1, e1);
     for (size_t i = 0; i < E->sides.size(); ++i) {
         Side& s = E->sides[i];
-        BE(cognn_add_u64(E->ctx, s.sum[0], s.ob[0], s.ib[0], e0[i]));
-        BE(cognn_add_u64(E->ctx, s.sum[1], s.ob[1], s.ib[1], e1[i]));
+        BE(cognn_add_u64(E->ctx, s.fsum, s.ob[1], s.ib[1], e1[i]));
     }
     std::vector<u64*> z;
     for (size_t i = 0; i < E->sides.size(); ++i) {
@@ -232,7 +231,7 @@ void gemm_stage(cognn_engine* E, int64_t it, XFn X, WFn Wm, SpecFn spec, DstFn d
             c1 = f->second;
         }
         if (E->timing) BE(cognn_timer_begin(E->ctx, T_GEMM));
-        BE(cognn_beaver_gemm_close_u64(E->ctx, s.zbuf, s.sum[0], s.sum[1], c1, &k, s.p, g.M, g.N, g.K, g.transA, s.scratch));
+        BE(cognn_beaver_gemm_close_u64(E->ctx, s.zbuf, s.ob[0], s.ib[0], s.fsum, c1, &k, s.p, g.M, g.N, g.K, g.transA, s.scratch));
         if (E->timing) { BE(cognn_timer_end(E->ctx, T_GEMM)); E->algo[T_GEMM] += 2.0 * 36 * 2 * (double)g.M * g.K * g.N; }
         z.push_back(s.zbuf);
     }
@@ -252,20 +251,15 @@ void rowscale_stage(cognn_engine* E, int64_t it, int op, int top, int F, XFn X, 
     }
     exchange_ob(E, 0, eF);
     exchange_ob(E, 1, e1);
-    for (size_t i = 0; i < E->sides.size(); ++i) {
-        Side& s = E->sides[i];
-        BE(cognn_add_u64(E->ctx, s.sum[0], s.ob[0], s.ib[0], eF[i]));
-        BE(cognn_add_u64(E->ctx, s.sum[1], s.ob[1], s.ib[1], e1[i]));
-    }
-    for (auto& s : E->sides) {
+    for (auto& s : E->sides) {                              // the opened sums E0+E1, G0+G1 are formed inside the kernel
         cognn_keys k = keys(E, s.owner, it, op), tk = keys(E, s.owner, it, top);
-        BE(cognn_rowscale_close_u64(E->ctx, s.ob[0], s.sum[0], s.sum[1], &k, &tk, s.p, s.n, F));
+        BE(cognn_rowscale_close_u64(E->ctx, s.ob[2], s.ob[0], s.ib[0], s.ob[1], s.ib[1], &k, &tk, s.p, s.n, F));
     }
-    exchange_ob(E, 0, eF);
+    exchange_ob(E, 2, eF);
     for (size_t i = 0; i < E->sides.size(); ++i) {
         Side& s = E->sides[i];
         cognn_keys tk = keys(E, s.owner, it, top);
-        BE(cognn_trunc_close_u64(E->ctx, dst(s), s.p == 0 ? s.ob[0] : nullptr, s.p == 0 ? s.ib[0] : nullptr, &tk, s.p, 0, eF[i]));
+        BE(cognn_trunc_close_u64(E->ctx, dst(s), s.p == 0 ? s.ob[2] : nullptr, s.p == 0 ? s.ib[2] : nullptr, &tk, s.p, 0, eF[i]));
     }
 }
 
@@ -281,19 +275,14 @@ void relu_stage(cognn_engine* E, int64_t it) {
     exchange_ob(E, 1, eF);
     for (size_t i = 0; i < E->sides.size(); ++i) {
         Side& s = E->sides[i];
-        BE(cognn_add_u64(E->ctx, s.sum[0], s.ob[0], s.ib[0], eF[i]));
-        BE(cognn_add_u64(E->ctx, s.sum[1], s.ob[1], s.ib[1], eF[i]));
-    }
-    for (size_t i = 0; i < E->sides.size(); ++i) {
-        Side& s = E->sides[i];
         cognn_keys k = keys(E, s.owner, it, COGNN_OP_AP_RELU);
-        BE(cognn_relu_mul_u64(E->ctx, s.ob[0], s.sum[0], s.sum[1], &k, s.p, eF[i]));
+        BE(cognn_relu_mul_u64(E->ctx, s.ob[2], s.ob[0], s.ib[0], s.ob[1], s.ib[1], &k, s.p, eF[i]));
     }
-    exchange_ob(E, 0, eF);
+    exchange_ob(E, 2, eF);
     for (size_t i = 0; i < E->sides.size(); ++i) {
         Side& s = E->sides[i];
         u64* dstb = (s.cur == s.buf[1]) ? s.buf[0] : s.buf[1];
-        BE(cognn_relu_close_u64(E->ctx, dstb, s.relu_mask, s.cur, s.ob[0], s.ib[0], eF[i]));
+        BE(cognn_relu_close_u64(E->ctx, dstb, s.relu_mask, s.cur, s.ob[2], s.ib[2], eF[i]));
         s.cur = dstb;
     }
 }
@@ -489,13 +478,13 @@ void weight_update_chain(cognn_engine* E, int64_t it, int layer) {
         const int64_t train = (int64_t)((double)s.n * E->cfg.train_ratio);
         const u64 gs = train > 0 ? fx_trunc(1.0 / (double)train) : 0;
         cognn_keys k = keys(E, s.owner, it, COGNN_OP_AP_GSCALE_TRUNC);
-        BE(cognn_trunc_open_u64(E->ctx, s.ob[0], d[i], gs, &k, s.p, elems));
+        BE(cognn_trunc_open_u64(E->ctx, s.ob[2], d[i], gs, &k, s.p, elems));
     }
-    exchange_ob(E, 0, el);
+    exchange_ob(E, 2, el);
     for (size_t i = 0; i < E->sides.size(); ++i) {
         Side& s = E->sides[i];
         cognn_keys k = keys(E, s.owner, it, COGNN_OP_AP_GSCALE_TRUNC);
-        BE(cognn_trunc_close_u64(E->ctx, d2[i], s.p == 0 ? s.ob[0] : nullptr, s.p == 0 ? s.ib[0] : nullptr, &k, s.p, 0, elems));
+        BE(cognn_trunc_close_u64(E->ctx, d2[i], s.p == 0 ? s.ob[2] : nullptr, s.p == 0 ? s.ib[2] : nullptr, &k, s.p, 0, elems));
     }
     const u64 lr = fx_trunc(E->cfg.learning_rate);
     trunc_stage(E, it, COGNN_OP_AP_LR_TRUNC, lr, d2, el, [&](Side& s) { return s.W[layer]; }, 1);
@@ -743,11 +732,9 @@ void alloc_sides(cognn_engine* E) {
         s.h1 = dalloc<u64>(E, n * hid);
         s.g = dalloc<u64>(E, n * hid);
         s.relu_mask = dalloc<uint8_t>(E, n * hid);
-        for (int j = 0; j < 2; ++j) {
-            s.buf[j] = dalloc<u64>(E, n * fm);
-            s.ob[j] = dalloc<u64>(E, big);
-            s.sum[j] = dalloc<u64>(E, big);
-        }
+        for (int j = 0; j < 2; ++j) s.buf[j] = dalloc<u64>(E, n * fm);
+        for (int j = 0; j < 3; ++j) s.ob[j] = dalloc<u64>(E, big);
+        s.fsum = dalloc<u64>(E, std::max<size_t>({(size_t)in * hid, n * (size_t)fm, (size_t)hid * lab}));
         for (int j = 0; j < 3; ++j) s.small[j] = dalloc<u64>(E, (size_t)in * hid + (size_t)hid * lab);
         s.scratch = dalloc<u64>(E, big + std::max<size_t>({(size_t)in * hid, n * (size_t)fm, (size_t)hid * lab}));
         s.zbuf = dalloc<u64>(E, std::max<size_t>({(size_t)in * hid, n * (size_t)fm, (size_t)hid * lab}));
@@ -763,7 +750,7 @@ void alloc_sides(cognn_engine* E) {
     for (auto& s : E->sides) {
         const size_t n = (size_t)s.n;
         const size_t big = std::max<size_t>({n * (size_t)in, (size_t)in * hid, n * (size_t)fm, (size_t)hid * lab});
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < 3; ++j) {
             if (s.peer) s.ib[j] = s.peer->ob[j];           // in-device exchange: read the peer's outbox directly
             else { s.ib_store[j] = dalloc<u64>(E, big); s.ib[j] = s.ib_store[j]; }
         }

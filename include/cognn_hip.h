@@ -71,6 +71,9 @@ int cognn_scatter_add_rows_u64(cognn_ctx*, uint64_t* v, const uint64_t* partial,
 /* C[MxN] = (accumulate ? C : 0) + op(A)[MxK] . B[KxN]  mod 2^64.  transA: A is stored [KxM]. */
 int cognn_ring_gemm_u64(cognn_ctx*, uint64_t* C, const uint64_t* A, const uint64_t* B,
                         int64_t M, int64_t N, int64_t K, int transA, int accumulate);
+/* same with A = A1 + A2 formed on the fly (A2 may be NULL) */
+int cognn_ring_gemm2_u64(cognn_ctx*, uint64_t* C, const uint64_t* A1, const uint64_t* A2, const uint64_t* B,
+                         int64_t M, int64_t N, int64_t K, int transA, int accumulate);
 /* Beaver reveal share: E_p = X_p - prng(key, logical idx). transposed: X is stored [cols x rows]
  * while the logical (masked) matrix is its transpose [rows x cols]. */
 int cognn_mask_open_u64(cognn_ctx*, uint64_t* E, const uint64_t* X, uint64_t key, int64_t rows, int64_t cols, int transposed);
@@ -79,10 +82,10 @@ int cognn_sub_u64(cognn_ctx*, uint64_t* out, const uint64_t* a, const uint64_t* 
 /* dealer (offline): C1 = (A0+A1).(B0+B1) - C0 with all five streams evaluated from keys */
 int cognn_dealer_gemm_c1_u64(cognn_ctx*, uint64_t* C1, const cognn_keys* keys, int64_t M, int64_t N, int64_t K, int transA,
                              uint64_t* scratchA /*MxK*/, uint64_t* scratchB /*KxN*/);
-/* Z_p = p*E.F + E.B_p + A_p.F + C_p.  E [MxK] and F [KxN] are the opened values; A_p/B_p/C_0 come
- * from keys, C_1 from `c1` (p==1).  transA: E is stored [KxM] (as produced by cognn_mask_open_u64 with
- * transposed=1).  scratch: MxK + KxN u64. */
-int cognn_beaver_gemm_close_u64(cognn_ctx*, uint64_t* Z, const uint64_t* E, const uint64_t* F, const uint64_t* c1,
+/* Z_p = p*E.F + E.B_p + A_p.F + C_p with E = E0 + E1 (the two parties' opened shares; E1 may be NULL) [MxK]
+ * and F [KxN] the opened sum; A_p/B_p/C_0 come from keys, C_1 from `c1` (p==1).  transA: E is stored [KxM]
+ * (as produced by cognn_mask_open_u64 with transposed=1).  scratch: MxK + KxN u64. */
+int cognn_beaver_gemm_close_u64(cognn_ctx*, uint64_t* Z, const uint64_t* E0, const uint64_t* E1, const uint64_t* F, const uint64_t* c1,
                                 const cognn_keys* keys, int p, int64_t M, int64_t N, int64_t K, int transA, uint64_t* scratch);
 
 /* ---- truncation by 2^16 (implicit in every sci:: fixed-point op) ------------------------- */
@@ -97,13 +100,16 @@ int cognn_trunc_close_u64(cognn_ctx*, uint64_t* out, const uint64_t* c0, const u
 int cognn_rowscale_open_u64(cognn_ctx*, uint64_t* E, uint64_t* G, const uint64_t* V, const uint64_t* s,
                             const cognn_keys* keys, int p, int64_t rows, int64_t F);
 /* z_p = p*E*G + E*b_p + a_p*G + c_p, immediately followed by trunc_open with tkeys:
- * c_out = z_p + r_p (+2^61).  E [rows x F], G [rows] are the opened sums. */
-int cognn_rowscale_close_u64(cognn_ctx*, uint64_t* c_out, const uint64_t* E, const uint64_t* G,
+ * c_out = z_p + r_p (+2^61).  E = E0+E1 [rows x F], G = G0+G1 [rows]: the two parties' opened shares, summed
+ * on the fly (E1/G1 may be NULL when the sum was formed elsewhere). */
+int cognn_rowscale_close_u64(cognn_ctx*, uint64_t* c_out, const uint64_t* E0, const uint64_t* E1, const uint64_t* G0, const uint64_t* G1,
                              const cognn_keys* keys, const cognn_keys* tkeys, int p, int64_t rows, int64_t F);
 
 /* ---- sci::twoPartyGCNRelu / twoPartyGCNBackwardNNWithoutAH (gcn.h:549,705) ---------------- */
 int cognn_relu_open_u64(cognn_ctx*, uint64_t* E, uint64_t* G, const uint64_t* z, const cognn_keys* keys, int p, int64_t n);
-int cognn_relu_mul_u64(cognn_ctx*, uint64_t* w, const uint64_t* E, const uint64_t* G, const cognn_keys* keys, int p, int64_t n);
+/* w_p = Beaver product share of z*t from the opened E = E0+E1, G = G0+G1 (E1/G1 may be NULL) */
+int cognn_relu_mul_u64(cognn_ctx*, uint64_t* w, const uint64_t* E0, const uint64_t* E1, const uint64_t* G0, const uint64_t* G1,
+                       const cognn_keys* keys, int p, int64_t n);
 /* h_p = (int64)(w0+w1) > 0 ? z_p : 0; mask (1 byte/element, public) may be NULL */
 int cognn_relu_close_u64(cognn_ctx*, uint64_t* h, uint8_t* mask, const uint64_t* z, const uint64_t* w0, const uint64_t* w1, int64_t n);
 int cognn_mask_select_u64(cognn_ctx*, uint64_t* out, const uint64_t* in, const uint8_t* mask, int64_t n);

@@ -157,14 +157,21 @@ int cognn_dealer_gemm_c1_u64(cognn_ctx* c, uint64_t* C1, const cognn_keys* keys,
     for (int64_t i = 0; i < M * N; ++i) C1[i] -= cognn_prng(keys->k[COGNN_SL_C0], (u64)i);
     return 0;
 }
-int cognn_beaver_gemm_close_u64(cognn_ctx* c, uint64_t* Z, const uint64_t* E, const uint64_t* F, const uint64_t* c1,
+int cognn_ring_gemm2_u64(cognn_ctx* c, uint64_t* C, const uint64_t* A1, const uint64_t* A2, const uint64_t* B, int64_t M, int64_t N,
+                         int64_t K, int transA, int accumulate) {
+    if (!A2) return cognn_ring_gemm_u64(c, C, A1, B, M, N, K, transA, accumulate);
+    std::vector<u64> a((size_t)M * K);
+    for (int64_t i = 0; i < M * K; ++i) a[i] = A1[i] + A2[i];
+    return cognn_ring_gemm_u64(c, C, a.data(), B, M, N, K, transA, accumulate);
+}
+int cognn_beaver_gemm_close_u64(cognn_ctx* c, uint64_t* Z, const uint64_t* E, const uint64_t* E1, const uint64_t* F, const uint64_t* c1,
                                 const cognn_keys* keys, int p, int64_t M, int64_t N, int64_t K, int transA, uint64_t* scratch) {
     REQ(p == 0 || c1, "beaver_gemm_close: p=1 needs c1");
     u64* Ap = scratch; u64* Bp = scratch + M * K;
     for (int64_t i = 0; i < M * K; ++i) Ap[i] = cognn_prng(keys->k[p == 0 ? COGNN_SL_A0 : COGNN_SL_A1], lidx(i, M, K, transA));
     for (int64_t i = 0; i < K * N; ++i) Bp[i] = cognn_prng(keys->k[p == 0 ? COGNN_SL_B0 : COGNN_SL_B1], (u64)i) + (p == 1 ? F[i] : 0);
     for (int64_t i = 0; i < M * N; ++i) Z[i] = p == 0 ? cognn_prng(keys->k[COGNN_SL_C0], (u64)i) : c1[i];
-    cognn_ring_gemm_u64(c, Z, E, Bp, M, N, K, transA, 1);
+    cognn_ring_gemm2_u64(c, Z, E, E1, Bp, M, N, K, transA, 1);
     return cognn_ring_gemm_u64(c, Z, Ap, F, M, N, K, transA, 1);
 }
 int cognn_trunc_open_u64(cognn_ctx*, uint64_t* c, const uint64_t* x, uint64_t mul, const cognn_keys* keys, int p, int64_t n) {
@@ -189,12 +196,13 @@ int cognn_rowscale_open_u64(cognn_ctx*, uint64_t* E, uint64_t* G, const uint64_t
     for (int64_t r = 0; r < rows; ++r) G[r] = s[r] - cognn_prng(keys->k[p == 0 ? COGNN_SL_B0 : COGNN_SL_B1], (u64)r);
     return 0;
 }
-int cognn_rowscale_close_u64(cognn_ctx*, uint64_t* c, const uint64_t* E, const uint64_t* G, const cognn_keys* keys,
-                             const cognn_keys* tkeys, int p, int64_t rows, int64_t F) {
+int cognn_rowscale_close_u64(cognn_ctx*, uint64_t* c, const uint64_t* E, const uint64_t* E1, const uint64_t* G, const uint64_t* G1,
+                             const cognn_keys* keys, const cognn_keys* tkeys, int p, int64_t rows, int64_t F) {
     const cognn_opkeys k = K(keys), tk = K(tkeys);
     for (int64_t i = 0; i < rows * F; ++i) {
         const u64 row = (u64)(i / F);
-        c[i] = beaver_mul(k, p, E[i], G[row], (u64)i, row) + trunc_r(tk, p, (u64)i) + (p == 0 ? COGNN_TRUNC_OFFSET : 0);
+        const u64 e = E[i] + (E1 ? E1[i] : 0), g = G[row] + (G1 ? G1[row] : 0);
+        c[i] = beaver_mul(k, p, e, g, (u64)i, row) + trunc_r(tk, p, (u64)i) + (p == 0 ? COGNN_TRUNC_OFFSET : 0);
     }
     return 0;
 }
@@ -207,9 +215,10 @@ int cognn_relu_open_u64(cognn_ctx*, uint64_t* E, uint64_t* G, const uint64_t* z,
     }
     return 0;
 }
-int cognn_relu_mul_u64(cognn_ctx*, uint64_t* w, const uint64_t* E, const uint64_t* G, const cognn_keys* keys, int p, int64_t n) {
+int cognn_relu_mul_u64(cognn_ctx*, uint64_t* w, const uint64_t* E, const uint64_t* E1, const uint64_t* G, const uint64_t* G1,
+                       const cognn_keys* keys, int p, int64_t n) {
     const cognn_opkeys k = K(keys);
-    for (int64_t i = 0; i < n; ++i) w[i] = beaver_mul(k, p, E[i], G[i], (u64)i, (u64)i);
+    for (int64_t i = 0; i < n; ++i) w[i] = beaver_mul(k, p, E[i] + (E1 ? E1[i] : 0), G[i] + (G1 ? G1[i] : 0), (u64)i, (u64)i);
     return 0;
 }
 int cognn_relu_close_u64(cognn_ctx*, uint64_t* h, uint8_t* mask, const uint64_t* z, const uint64_t* w0, const uint64_t* w1, int64_t n) {

@@ -173,6 +173,13 @@ def test_ring_gemm(ctx, M, N, K, transA):
     ctx.call("cognn_ring_gemm_u64", ptr(Cd), ptr(Ad), ptr(Bd), M, N, K, transA, 1)
     with np.errstate(over="ignore"):
         assert np.array_equal(host(Cd), want + C0)
+    if not transA or K < 4000:
+        A2 = rand_u64(rng, (M, K))
+        A2d = dev(A2.T.copy() if transA else A2)
+        Cd = dev(C0)
+        ctx.call("cognn_ring_gemm2_u64", ptr(Cd), ptr(Ad), ptr(A2d), ptr(Bd), M, N, K, transA, 0)
+        with np.errstate(over="ignore"):
+            assert np.array_equal(host(Cd), co.ring_matmul(A + A2, B))
 
 
 def test_ring_gemm_limb_edge_values(ctx):
@@ -233,12 +240,10 @@ def test_rowscale_trunc_pair(ctx, F):
     E = [dev_empty((rows, F)) for _ in range(2)]; G = [dev_empty(rows) for _ in range(2)]
     for p, (vp, sp) in enumerate(((v0, s0), (v1, s1))):
         ctx.call("cognn_rowscale_open_u64", ptr(E[p]), ptr(G[p]), ptr(dev(vp)), ptr(dev(sp)), ctypes.byref(k), p, rows, F)
-    Es, Gs = dev_empty((rows, F)), dev_empty(rows)
-    ctx.call("cognn_add_u64", ptr(Es), ptr(E[0]), ptr(E[1]), rows * F)
-    ctx.call("cognn_add_u64", ptr(Gs), ptr(G[0]), ptr(G[1]), rows)
     c = [dev_empty((rows, F)) for _ in range(2)]
-    for p in range(2):
-        ctx.call("cognn_rowscale_close_u64", ptr(c[p]), ptr(Es), ptr(Gs), ctypes.byref(k), ctypes.byref(tk), p, rows, F)
+    for p in range(2):          # each side sums its own and the peer's opened shares inside the kernel
+        ctx.call("cognn_rowscale_close_u64", ptr(c[p]), ptr(E[p]), ptr(E[1 - p]), ptr(G[p]), ptr(G[1 - p]), ctypes.byref(k),
+                 ctypes.byref(tk), p, rows, F)
     o = [dev_empty((rows, F)) for _ in range(2)]
     ctx.call("cognn_trunc_close_u64", ptr(o[0]), ptr(c[0]), ptr(c[1]), ctypes.byref(tk), 0, 0, rows * F)
     ctx.call("cognn_trunc_close_u64", ptr(o[1]), None, None, ctypes.byref(tk), 1, 0, rows * F)
@@ -259,12 +264,9 @@ def test_relu_pair(ctx):
     zd = [dev(z0), dev(z1)]
     for p in range(2):
         ctx.call("cognn_relu_open_u64", ptr(E[p]), ptr(G[p]), ptr(zd[p]), ctypes.byref(k), p, n)
-    Es, Gs = dev_empty(n), dev_empty(n)
-    ctx.call("cognn_add_u64", ptr(Es), ptr(E[0]), ptr(E[1]), n)
-    ctx.call("cognn_add_u64", ptr(Gs), ptr(G[0]), ptr(G[1]), n)
     w = [dev_empty(n) for _ in range(2)]
     for p in range(2):
-        ctx.call("cognn_relu_mul_u64", ptr(w[p]), ptr(Es), ptr(Gs), ctypes.byref(k), p, n)
+        ctx.call("cognn_relu_mul_u64", ptr(w[p]), ptr(E[p]), ptr(E[1 - p]), ptr(G[p]), ptr(G[1 - p]), ctypes.byref(k), p, n)
     h = [dev_empty(n) for _ in range(2)]; mask = dev_empty(n, "u8")
     for p in range(2):
         ctx.call("cognn_relu_close_u64", ptr(h[p]), ptr(mask) if p == 0 else None, ptr(zd[p]), ptr(w[0]), ptr(w[1]), n)
@@ -326,15 +328,14 @@ def test_beaver_gemm_pair(ctx, M, N, K, transA):
     for p, (xp, wp) in enumerate(((X0, W0), (X1, W1))):
         ctx.call("cognn_mask_open_u64", ptr(E[p]), ptr(dev(stor(xp))), ctypes.c_uint64(kf(co.SL_A0 + p)), M, K, transA)
         ctx.call("cognn_mask_open_u64", ptr(Fm[p]), ptr(dev(wp)), ctypes.c_uint64(kf(co.SL_B0 + p)), K, N, 0)
-    Es, Fs = dev_empty(stor(X0).shape), dev_empty((K, N))
-    ctx.call("cognn_add_u64", ptr(Es), ptr(E[0]), ptr(E[1]), M * K)
+    Fs = dev_empty((K, N))
     ctx.call("cognn_add_u64", ptr(Fs), ptr(Fm[0]), ptr(Fm[1]), K * N)
     c1 = dev_empty((M, N)); sa = dev_empty(M * K + K * N)
     ctx.call("cognn_dealer_gemm_c1_u64", ptr(c1), ctypes.byref(k), M, N, K, transA, ptr(sa), ctypes.c_void_p(sa.data_ptr() + 8 * M * K))
     Z = [dev_empty((M, N)) for _ in range(2)]
     for p in range(2):
-        ctx.call("cognn_beaver_gemm_close_u64", ptr(Z[p]), ptr(Es), ptr(Fs), ptr(c1) if p == 1 else None, ctypes.byref(k), p,
-                 M, N, K, transA, ptr(sa))
+        ctx.call("cognn_beaver_gemm_close_u64", ptr(Z[p]), ptr(E[p]), ptr(E[1 - p]), ptr(Fs), ptr(c1) if p == 1 else None,
+                 ctypes.byref(k), p, M, N, K, transA, ptr(sa))
     z0, z1 = co.beaver_gemm_pair(X0, X1, W0, W1, kf)
     assert np.array_equal(host(Z[0]), z0) and np.array_equal(host(Z[1]), z1)
     with np.errstate(over="ignore"):
