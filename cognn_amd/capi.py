@@ -60,6 +60,9 @@ _SIGNATURES = {
     "cognn_dealer_gemm_c1_u64": (_I, [_P, _P, _KP, _L, _L, _L, _I, _P, _P]),
     "cognn_beaver_gemm_close_u64": (_I, [_P, _P, _P, _P, _P, _P, _KP, _I, _L, _L, _L, _I, _P]),
     "cognn_trunc_open_u64": (_I, [_P, _P, _P, _U, _KP, _I, _L]),
+    "cognn_trunc_open_add_u64": (_I, [_P, _P, _P, _P, _KP, _KP, _I, _L]),
+    "cognn_beaver_gemm_fusable": (_I, [_L, _L, _L, _I]),
+    "cognn_beaver_gemm_close_raw_u64": (_I, [_P, _P, _P, _P, _P, _KP, _I, _L, _L, _L, _P]),
     "cognn_trunc_close_u64": (_I, [_P, _P, _P, _P, _KP, _I, _I, _L]),
     "cognn_rowscale_open_u64": (_I, [_P, _P, _P, _P, _P, _KP, _I, _L, _L]),
     "cognn_rowscale_close_u64": (_I, [_P, _P, _P, _P, _P, _P, _KP, _KP, _I, _L, _L]),

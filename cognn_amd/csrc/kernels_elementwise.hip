@@ -110,6 +110,19 @@ struct TruncOpen {
         st2(c, i, w, r);
     }
 };
+struct TruncOpenAdd {    // c = x + C_p + r_p (+offset): opening of a raw Beaver product
+    u64* c; const u64* x; const u64* c1; u64 keyC0; cognn_opkeys k; int p;
+    __device__ void operator()(int64_t i, int w) const {
+        u64 v[2], a[2] = {0, 0}, r[2];
+        ld2(x, i, w, v);
+        if (p == 1) ld2(c1, i, w, a);
+        for (int j = 0; j < 2; ++j) {
+            const u64 cp = (p == 0) ? cognn_prng(keyC0, (u64)(i + j)) : a[j];
+            r[j] = v[j] + cp + trunc_r(k, p, (u64)(i + j)) + (p == 0 ? COGNN_TRUNC_OFFSET : 0ull);
+        }
+        st2(c, i, w, r);
+    }
+};
 struct TruncClose {
     u64* out; const u64* c0; const u64* c1; cognn_opkeys k; int p; int mode;
     __device__ void operator()(int64_t i, int w) const {
@@ -230,61 +243,83 @@ struct FxEncode {
     }
 };
 
-// one thread per row; L small (<= 64 labels)
+// G lanes per row (G = power of two >= L, <= 64): lane j owns column j, row reductions by shuffles, so
+// every global access is coalesced.
+template <int G>
 __global__ __launch_bounds__(kThreads) void softmax_kernel(u64* p_out, u64* d_out, u64* pfx_out, const u64* z0, const u64* z1,
                                                             const int32_t* labels, cognn_opkeys k, int p, int64_t rows, int L,
                                                             int64_t train_rows) {
-    int64_t r = (int64_t)blockIdx.x * kThreads + threadIdx.x;
-    if (r >= rows) return;
+    const int64_t r = ((int64_t)blockIdx.x * kThreads + threadIdx.x) / G;
+    const int j = threadIdx.x % G;
+    const bool valid = r < rows && j < L;
     const bool keep = r < train_rows;
+    const int64_t idx = r * L + j;
+    const u64 rho = valid ? cognn_prng(k.k[COGNN_SL_RHO], (u64)idx) : 0ull;
     if (p == 1) {
-        for (int j = 0; j < L; ++j) {
-            u64 rho = cognn_prng(k.k[COGNN_SL_RHO], (u64)(r * L + j));
-            if (p_out) p_out[r * L + j] = rho;
-            d_out[r * L + j] = keep ? rho : 0ull;
+        if (valid) {
+            if (p_out) p_out[idx] = rho;
+            d_out[idx] = keep ? rho : 0ull;
         }
         return;
     }
-    long long m = (long long)(z0[r * L] + z1[r * L]);
-    for (int j = 1; j < L; ++j) {
-        long long v = (long long)(z0[r * L + j] + z1[r * L + j]);
-        m = v > m ? v : m;
-    }
-    long long S = 0;
-    for (int j = 0; j < L; ++j) S += cognn_exp_neg_q30(m - (long long)(z0[r * L + j] + z1[r * L + j]));
-    const int lab = labels[r];
-    for (int j = 0; j < L; ++j) {
-        long long e = cognn_exp_neg_q30(m - (long long)(z0[r * L + j] + z1[r * L + j]));
-        u64 pf = (u64)(((e << 16) + (S >> 1)) / S);
-        u64 rho = cognn_prng(k.k[COGNN_SL_RHO], (u64)(r * L + j));
-        u64 p0 = pf - rho;
-        if (pfx_out) pfx_out[r * L + j] = pf;
-        if (p_out) p_out[r * L + j] = p0;
-        d_out[r * L + j] = keep ? (p0 - (j == lab ? COGNN_FX_ONE : 0ull)) : 0ull;
-    }
+    const long long NEG = -(1ll << 62);
+    long long z = valid ? (long long)(z0[idx] + z1[idx]) : NEG;
+    long long m = z;
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) { long long t = __shfl_xor(m, o, G); m = t > m ? t : m; }
+    long long e = valid ? cognn_exp_neg_q30(m - z) : 0;
+    long long S = e;
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) S += __shfl_xor(S, o, G);
+    if (!valid) return;
+    const u64 pf = (u64)(((e << 16) + (S >> 1)) / S);
+    const u64 p0 = pf - rho;
+    if (pfx_out) pfx_out[idx] = pf;
+    if (p_out) p_out[idx] = p0;
+    d_out[idx] = keep ? (p0 - (j == labels[r] ? COGNN_FX_ONE : 0ull)) : 0ull;
 }
 
+template <int G>
 __global__ __launch_bounds__(kThreads) void metrics_kernel(const u64* pfx, const int32_t* labels, const uint8_t* border,
                                                             int64_t rows, int L, int64_t train_rows, int64_t val_rows,
                                                             unsigned long long* counts, double* loss) {
-    int64_t r = (int64_t)blockIdx.x * kThreads + threadIdx.x;
-    if (r >= rows) return;
-    int best = 0; u64 bv = pfx[r * L];
-    for (int j = 1; j < L; ++j) { u64 v = pfx[r * L + j]; if (v > bv) { bv = v; best = j; } }
-    const int lab = labels[r];
-    const bool ok = best == lab;
-    const bool b = border ? border[r] != 0 : false;
-    const bool tr = r < train_rows, te = r >= train_rows + val_rows;
-    if (ok) {
-        atomicAdd(&counts[0], 1ull);
-        if (tr) atomicAdd(&counts[1], 1ull);
-        if (tr && b) atomicAdd(&counts[2], 1ull);
-        if (te) atomicAdd(&counts[3], 1ull);
-        if (te && b) atomicAdd(&counts[4], 1ull);
+    __shared__ unsigned long long s_cnt[5];
+    __shared__ double s_loss;
+    if (threadIdx.x < 5) s_cnt[threadIdx.x] = 0;
+    if (threadIdx.x == 0) s_loss = 0.0;
+    __syncthreads();
+    const int64_t r = ((int64_t)blockIdx.x * kThreads + threadIdx.x) / G;
+    const int j = threadIdx.x % G;
+    const bool valid = r < rows && j < L;
+    // argmax with first-max tie break: pack (value, -index)
+    u64 v = valid ? pfx[r * L + j] : 0ull;
+    int bj = valid ? j : (1 << 20);
+    u64 bv = v;
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) {
+        u64 ov = __shfl_xor(bv, o, G);
+        int oj = __shfl_xor(bj, o, G);
+        if (ov > bv || (ov == bv && oj < bj)) { bv = ov; bj = oj; }
     }
-    double pl = (double)pfx[r * L + lab] / (double)COGNN_FX_ONE;
-    if (pl == 0.0) pl = 0.001;                         /* gcn.h:613-615 */
-    atomicAdd(loss, -log(pl));
+    if (r < rows && j == 0) {
+        const int lab = labels[r];
+        const bool ok = bj == lab;
+        const bool b = border ? border[r] != 0 : false;
+        const bool tr = r < train_rows, te = r >= train_rows + val_rows;
+        if (ok) {
+            atomicAdd(&s_cnt[0], 1ull);
+            if (tr) atomicAdd(&s_cnt[1], 1ull);
+            if (tr && b) atomicAdd(&s_cnt[2], 1ull);
+            if (te) atomicAdd(&s_cnt[3], 1ull);
+            if (te && b) atomicAdd(&s_cnt[4], 1ull);
+        }
+        double pl = (double)pfx[r * L + lab] / (double)COGNN_FX_ONE;
+        if (pl == 0.0) pl = 0.001;                         /* gcn.h:613-615 */
+        atomicAdd(&s_loss, -log(pl));
+    }
+    __syncthreads();
+    if (threadIdx.x < 5 && s_cnt[threadIdx.x]) atomicAdd(&counts[threadIdx.x], s_cnt[threadIdx.x]);
+    if (threadIdx.x == 0) atomicAdd(loss, s_loss);
 }
 
 __global__ __launch_bounds__(kThreads) void transpose_kernel(u64* out, const u64* in, int64_t rows, int64_t cols) {
@@ -336,6 +371,11 @@ int cognn_trunc_open_u64(cognn_ctx* ctx, uint64_t* c, const uint64_t* x, uint64_
     CG_REQUIRE(ctx && c && x && keys && (p == 0 || p == 1) && al(c) && al(x), "cognn_trunc_open_u64: bad arguments");
     return launch_ew(ctx, n, TruncOpen{(u64*)c, (const u64*)x, mul, K(keys), p});
 }
+int cognn_trunc_open_add_u64(cognn_ctx* ctx, uint64_t* c, const uint64_t* x, const uint64_t* c1, const cognn_keys* gkeys,
+                             const cognn_keys* tkeys, int p, int64_t n) {
+    CG_REQUIRE(ctx && c && x && gkeys && tkeys && (p == 0 || (p == 1 && c1)) && al(c) && al(x) && al(c1), "cognn_trunc_open_add_u64: bad arguments");
+    return launch_ew(ctx, n, TruncOpenAdd{(u64*)c, (const u64*)x, (const u64*)c1, gkeys->k[COGNN_SL_C0], K(tkeys), p});
+}
 int cognn_trunc_close_u64(cognn_ctx* ctx, uint64_t* out, const uint64_t* c0, const uint64_t* c1, const cognn_keys* keys,
                           int p, int mode, int64_t n) {
     CG_REQUIRE(ctx && out && keys && (p == 0 || p == 1) && al(out) && al(c0) && al(c1), "cognn_trunc_close_u64: bad arguments");
@@ -376,10 +416,17 @@ int cognn_softmax_u64(cognn_ctx* ctx, uint64_t* p_out, uint64_t* d_out, uint64_t
                       const int32_t* labels, const cognn_keys* keys, int p, int64_t rows, int64_t L, int64_t train_rows) {
     CG_REQUIRE(ctx && d_out && keys && (p == 0 || p == 1), "cognn_softmax_u64: bad arguments");
     CG_REQUIRE(p == 1 || (z0 && z1 && labels), "cognn_softmax_u64: owner side needs z0, z1, labels");
-    CG_REQUIRE(L > 0 && L <= 4096, "cognn_softmax_u64: unsupported label count %lld", (long long)L);
+    CG_REQUIRE(L > 0 && L <= 64, "cognn_softmax_u64: unsupported label count %lld (max 64)", (long long)L);
     if (rows <= 0) return 0;
-    hipLaunchKernelGGL(softmax_kernel, dim3(cg_div_up(rows, kThreads)), dim3(kThreads), 0, ctx->stream, (u64*)p_out, (u64*)d_out,
-                       (u64*)pfx_out, (const u64*)z0, (const u64*)z1, labels, K(keys), p, rows, (int)L, train_rows);
+    int G = 1;
+    while (G < L) G <<= 1;
+#define CG_SM_CASE(g)                                                                                                       \
+    case g:                                                                                                                  \
+        hipLaunchKernelGGL(softmax_kernel<g>, dim3(cg_div_up(rows * g, kThreads)), dim3(kThreads), 0, ctx->stream, (u64*)p_out, \
+                           (u64*)d_out, (u64*)pfx_out, (const u64*)z0, (const u64*)z1, labels, K(keys), p, rows, (int)L, train_rows); \
+        break;
+    switch (G) { CG_SM_CASE(1) CG_SM_CASE(2) CG_SM_CASE(4) CG_SM_CASE(8) CG_SM_CASE(16) CG_SM_CASE(32) CG_SM_CASE(64) }
+#undef CG_SM_CASE
     CG_LAUNCH_CHECK();
     return 0;
 }
@@ -389,8 +436,16 @@ int cognn_metrics_q16(cognn_ctx* ctx, const uint64_t* pfx, const int32_t* labels
     CG_HIP(hipMemsetAsync(counts6, 0, 6 * sizeof(int64_t), ctx->stream));
     CG_HIP(hipMemsetAsync(loss, 0, sizeof(double), ctx->stream));
     if (rows <= 0) return 0;
-    hipLaunchKernelGGL(metrics_kernel, dim3(cg_div_up(rows, kThreads)), dim3(kThreads), 0, ctx->stream, (const u64*)pfx, labels,
-                       border, rows, (int)L, train_rows, val_rows, (unsigned long long*)counts6, loss);
+    CG_REQUIRE(L > 0 && L <= 64, "cognn_metrics_q16: unsupported label count %lld (max 64)", (long long)L);
+    int G = 1;
+    while (G < L) G <<= 1;
+#define CG_MT_CASE(g)                                                                                                     \
+    case g:                                                                                                                \
+        hipLaunchKernelGGL(metrics_kernel<g>, dim3(cg_div_up(rows * g, kThreads)), dim3(kThreads), 0, ctx->stream, (const u64*)pfx, \
+                           labels, border, rows, (int)L, train_rows, val_rows, (unsigned long long*)counts6, loss);       \
+        break;
+    switch (G) { CG_MT_CASE(1) CG_MT_CASE(2) CG_MT_CASE(4) CG_MT_CASE(8) CG_MT_CASE(16) CG_MT_CASE(32) CG_MT_CASE(64) }
+#undef CG_MT_CASE
     CG_LAUNCH_CHECK();
     return 0;
 }

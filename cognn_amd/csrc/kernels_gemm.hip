@@ -12,6 +12,7 @@
 // Generic path: a split-K VALU kernel for every other shape (transposed A, tiny M, huge K).
 #include "common.h"
 #include <algorithm>
+#include <cstdlib>
 #include "../../include/cognn_hip.h"
 
 namespace {
@@ -202,6 +203,229 @@ __global__ __launch_bounds__(kWavesM * (BN / 32) * 64) void ring_gemm_mfma_kerne
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Fused Beaver close (NN, N <= 64):  Z = [E0+E1 | A_p] . [B_p + p*F ; F] + Cin   in ONE launch.
+//   * the first K-segment streams the opened E from HBM (both parties' shares summed in registers),
+//   * the second K-segment generates the dealer mask A_p in registers from its counter-PRNG stream,
+//     so it costs no HBM traffic at all,
+//   * B's limb planes for both segments are pre-split once by a tiny kernel into the exact LDS image
+//     ([k-step][plane][col][32 + 16 pad bytes]) and copied per K step (L2-resident, 24 KiB per step).
+// 8 waves (4 along M x 2 along N), 128 x 64 output block, two LDS stages for A and B, one barrier per K step.
+// ------------------------------------------------------------------------------------------
+constexpr int kFusedBN = 64;
+constexpr int kBRow = 48;                                   // 32 k-bytes + 16 pad: conflict-free ds_read_b128
+constexpr int kBStage = 8 * kFusedBN * kBRow;               // 24576 bytes per K step
+constexpr int kFusedThreads = 512;
+
+__global__ __launch_bounds__(256) void prep_b_planes_kernel(unsigned char* planes, const u64* __restrict__ F, u64 keyB, int p,
+                                                             int K, int N, int nkt) {
+    // one thread per (global k-step, col, 4-k quad)
+    const int total = 2 * nkt * kFusedBN * 8;
+    for (int t = blockIdx.x * 256 + threadIdx.x; t < total; t += gridDim.x * 256) {
+        const int kq = t & 7, c = (t >> 3) % kFusedBN, ks = t / (8 * kFusedBN);
+        const int seg = ks / nkt, kt = ks % nkt;
+        u64 v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = kt * kKStep + kq * 4 + j;
+            u64 x = 0;
+            if (k < K && c < N) {
+                const u64 f = F[(size_t)k * N + c];
+                x = seg == 0 ? cognn_prng(keyB, (u64)k * (u64)N + (u64)c) + (p == 1 ? f : 0ull) : f;
+            }
+            v[j] = x;
+        }
+        uint32_t pl[8];
+        split4(v, pl);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            *reinterpret_cast<uint32_t*>(planes + (size_t)ks * kBStage + i * (kFusedBN * kBRow) + c * kBRow + kq * 4) = pl[i];
+    }
+}
+
+__device__ __forceinline__ void split8_store(const u64 v[8], unsigned char* dst_row16) {
+    // signed limb planes of 8 consecutive-k values -> one 8-byte store per plane at dst_row16 + plane*kPlaneStride
+    uint32_t lo[8], hi[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const u64 d = (v[j] + kBias) ^ kBias;
+        lo[j] = (uint32_t)d; hi[j] = (uint32_t)(d >> 32);
+    }
+    uint32_t pl[8][2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const uint32_t* l = lo + 4 * g;
+        const uint32_t* h = hi + 4 * g;
+        uint32_t a = __builtin_amdgcn_perm(l[1], l[0], 0x05010400u), b = __builtin_amdgcn_perm(l[1], l[0], 0x07030602u);
+        uint32_t c = __builtin_amdgcn_perm(l[3], l[2], 0x05010400u), d = __builtin_amdgcn_perm(l[3], l[2], 0x07030602u);
+        pl[0][g] = __builtin_amdgcn_perm(c, a, 0x05040100u); pl[1][g] = __builtin_amdgcn_perm(c, a, 0x07060302u);
+        pl[2][g] = __builtin_amdgcn_perm(d, b, 0x05040100u); pl[3][g] = __builtin_amdgcn_perm(d, b, 0x07060302u);
+        a = __builtin_amdgcn_perm(h[1], h[0], 0x05010400u); b = __builtin_amdgcn_perm(h[1], h[0], 0x07030602u);
+        c = __builtin_amdgcn_perm(h[3], h[2], 0x05010400u); d = __builtin_amdgcn_perm(h[3], h[2], 0x07030602u);
+        pl[4][g] = __builtin_amdgcn_perm(c, a, 0x05040100u); pl[5][g] = __builtin_amdgcn_perm(c, a, 0x07060302u);
+        pl[6][g] = __builtin_amdgcn_perm(d, b, 0x05040100u); pl[7][g] = __builtin_amdgcn_perm(d, b, 0x07060302u);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        uint2 w; w.x = pl[i][0]; w.y = pl[i][1];
+        *reinterpret_cast<uint2*>(dst_row16 + i * (2 * 128 * 16)) = w;
+    }
+}
+
+// Steps of one 128-row block alternate between the two K-segments (even: E from HBM, odd: PRNG mask), so a
+// memory tile has two full steps to land.  Each iteration reads the MFMA fragments of stage it&1 and, in the
+// shadow of its 36 MFMAs, converts and writes the tile of step it+1 into the other stage.  The two kinds of
+// iteration are separate straight-line bodies (no branches around the MFMAs) so that the scheduler can
+// interleave the limb split / PRNG VALU work with the matrix pipe.  Requires K % 8 == 0.
+template <int NKT, int DBG = 0>   // NKT: K steps per segment when known at compile time (0: run-time value)
+                                  // DBG (timing experiments only, results wrong): 1 no E loads, 2 no PRNG, 4 no MFMA
+__global__ __launch_bounds__(kFusedThreads) void beaver_gemm_fused_kernel(u64* Z, const u64* __restrict__ E0, const u64* __restrict__ E1,
+                                                                           const unsigned char* __restrict__ planes,
+                                                                           u64 keyA, int M, int N, int K, int nkt_rt) {
+    const int nkt = NKT > 0 ? NKT : nkt_rt;
+    // Z receives the raw product (no C_p): the dealer's product share is added by the consumer
+    // (cognn_trunc_open with addend), so this kernel issues no loads besides its operand streams.
+    constexpr int BM = 128;
+    constexpr int kAStage = 8 * 2 * BM * 16;                // 32768
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* sA = smem;                               // 2 stages
+    unsigned char* sB = smem + 2 * kAStage;                 // 2 stages
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int steps = 2 * nkt;                              // per m-block (even)
+    const int nmb = (M + BM - 1) / BM;
+    const int my_blocks = (nmb - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int total = my_blocks * steps;                    // even
+    const int trow = tid >> 2, tk8 = tid & 3;               // this thread's (row, 8-k group) of every A tile
+    if (total == 0) return;
+
+    u64x2 nE0[4], nE1[4];                                   // raw E0 / E1 values of the next E step (added at use)
+    u64x2 nB0, nB1, nB2;
+    auto load_B = [&](int it) {                             // planes are stored [seg][kt]; steps alternate seg 0 / 1
+        const int st = min(it, total - 1) % steps;
+        const u64x2* bp = reinterpret_cast<const u64x2*>(planes + (size_t)((st & 1) * nkt + (st >> 1)) * kBStage) + tid * 3;
+        nB0 = bp[0]; nB1 = bp[1]; nB2 = bp[2];
+    };
+    auto load_E = [&](int it) {                             // `it`: an E step (even); clamped, never branches
+        it = min(it, total - 2);
+        const int mb = blockIdx.x + (it / steps) * gridDim.x, kt = (it % steps) >> 1;
+        const int m = min(mb * BM + trow, M - 1), k = min(kt * kKStep + tk8 * 8, K - 8);
+        const u64x2* a = reinterpret_cast<const u64x2*>(E0 + (size_t)m * K + k);
+        const u64x2* b = reinterpret_cast<const u64x2*>((E1 ? E1 : E0) + (size_t)m * K + k);
+        if (DBG & 1) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { nE0[j].x = (u64)m; nE0[j].y = (u64)k; nE1[j].x = 1; nE1[j].y = 2; }
+            return;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { nE0[j] = a[j]; nE1[j] = b[j]; }
+    };
+    const u64 e1mask = E1 ? ~0ull : 0ull;
+    auto produce_E = [&](int it) {                          // tile of E step `it` -> LDS stage it&1
+        const int mb = blockIdx.x + (it / steps) * gridDim.x, kt = (it % steps) >> 1;
+        const bool ok = (mb * BM + trow < M) && (kt * kKStep + tk8 * 8 < K);
+        const u64 keep = ok ? ~0ull : 0ull;
+        u64 v[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            v[2 * j] = (nE0[j].x + (nE1[j].x & e1mask)) & keep;
+            v[2 * j + 1] = (nE0[j].y + (nE1[j].y & e1mask)) & keep;
+        }
+        split8_store(v, sA + (it & 1) * kAStage + (tk8 >> 1) * (BM * 16) + trow * 16 + (tk8 & 1) * 8);
+    };
+    auto produce_mask = [&](int it) {                       // tile of mask step `it` (dealer stream A_p) -> LDS stage it&1
+        const int mb = blockIdx.x + (it / steps) * gridDim.x, kt = (it % steps) >> 1;
+        const int m = mb * BM + trow, k = kt * kKStep + tk8 * 8;
+        const u64 keep = (m < M && k < K) ? ~0ull : 0ull;
+        u64 x = keyA + ((u64)m * (u64)K + (u64)k + 1ull) * COGNN_GAMMA;        // prng(key, idx) = mix64(key + (idx+1)*GAMMA)
+        u64 v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { v[j] = ((DBG & 2) ? x : cognn_mix64(x)) & keep; x += COGNN_GAMMA; }
+        split8_store(v, sA + (it & 1) * kAStage + (tk8 >> 1) * (BM * 16) + trow * 16 + (tk8 & 1) * 8);
+    };
+    auto store_B = [&](int it) {
+        u64x2* bd = reinterpret_cast<u64x2*>(sB + (it & 1) * kBStage) + tid * 3;
+        bd[0] = nB0; bd[1] = nB1; bd[2] = nB2;
+    };
+
+    v16i acc[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[s][r] = 0;
+
+    auto mfma_step = [&](int it) {
+        const int stage = it & 1;
+        const unsigned char* pa = sA + stage * kAStage + (lane >> 5) * (BM * 16) + (wm * 32 + (lane & 31)) * 16;
+        const unsigned char* pb = sB + stage * kBStage + (wn * 32 + (lane & 31)) * kBRow + (lane >> 5) * 16;
+        v4i bf[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) bf[i] = *reinterpret_cast<const v4i*>(pb + i * (kFusedBN * kBRow));
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {                       // A plane outermost: only one A fragment live at a time
+            const v4i af = *reinterpret_cast<const v4i*>(pa + i * (2 * BM * 16));
+#pragma unroll
+            for (int j = 0; j + i < 8; ++j) {
+                if (DBG & 4) { acc[i + j][0] += af[0] ^ bf[j][0]; continue; }
+                acc[i + j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af, bf[j], acc[i + j], 0, 0, 0);
+            }
+        }
+    };
+    // ask the scheduler to spread the tile-production VALU / LDS work of the block between its 36 MFMAs
+    auto interleave_hint = [&]() {
+        __builtin_amdgcn_sched_group_barrier(0x100, 9, 0);      // B fragments + first A fragment
+#pragma unroll
+        for (int q = 0; q < 36; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
+            __builtin_amdgcn_sched_group_barrier(0x002, 10, 0); // up to 10 VALU
+            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // 1 LDS write
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // 1 LDS read (next A fragment)
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // 1 global load
+        }
+    };
+    auto epilogue = [&](int it) {
+        const int mb = blockIdx.x + (it / steps) * gridDim.x;
+        const int col = wn * 32 + (lane & 31);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = mb * BM + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            const uint32_t hi = (uint32_t)acc[4][r] + ((uint32_t)acc[5][r] << 8) + ((uint32_t)acc[6][r] << 16) + ((uint32_t)acc[7][r] << 24);
+            u64 v = (u64)(long long)acc[0][r] + ((u64)(long long)acc[1][r] << 8) + ((u64)(long long)acc[2][r] << 16) +
+                    ((u64)(long long)acc[3][r] << 24) + ((u64)hi << 32);
+            if (row < M && col < N) Z[(size_t)row * N + col] = v;
+        }
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[s][r] = 0;
+    };
+
+    // prologue: stage 0 <- step 0 (E); registers <- B(1), E(2)
+    load_E(0); load_B(0);
+    produce_E(0); store_B(0);
+    load_B(1); load_E(2);
+    for (int blk = 0; blk < my_blocks; ++blk) {
+#pragma unroll
+        for (int it = blk * steps; it < (blk + 1) * steps; it += 2) {
+            // ---- even iteration: MFMAs of E step `it`; produce the mask tile of step it+1 (no memory operands) ----
+            __syncthreads();
+            produce_mask(it + 1); store_B(it + 1);
+            load_B(it + 2);
+            mfma_step(it);
+            interleave_hint();
+            // ---- odd iteration: MFMAs of mask step it+1; produce the E tile of step it+2 from the prefetched
+            //      registers, then prefetch the E tile two steps further ----
+            __syncthreads();
+            produce_E(it + 2); store_B(it + 2);             // past the end this writes an all-zero tile nobody reads
+            load_B(it + 3); load_E(it + 4);
+            mfma_step(it + 1);
+            interleave_hint();
+        }
+        epilogue((blk + 1) * steps - 1);                    // stores only: the prefetched tiles stay in flight
+    }
+}
+
 // element-wise helpers used by the Beaver composites -------------------------------------------
 __global__ __launch_bounds__(256) void prng_fill2_kernel(u64* out, u64 k0, u64 k1, int64_t rows, int64_t cols, int transposed,
                                                           int two, const u64* addend) {
@@ -309,13 +533,79 @@ int cognn_dealer_gemm_c1_u64(cognn_ctx* ctx, uint64_t* C1, const cognn_keys* key
     return 0;
 }
 
+}  // extern "C"
+
+namespace {
+__global__ __launch_bounds__(256) void add_cp_kernel(u64* Z, const u64* c1, u64 keyC0, int p, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        Z[i] += (p == 0) ? cognn_prng(keyC0, (u64)i) : c1[i];
+}
+int beaver_close_impl(cognn_ctx* ctx, uint64_t* Z, const uint64_t* E, const uint64_t* E1, const uint64_t* F, const uint64_t* c1,
+                      const cognn_keys* keys, int p, int64_t M, int64_t N, int64_t K, int transA, uint64_t* scratch, bool raw);
+}  // namespace
+
+extern "C" {
+
 int cognn_beaver_gemm_close_u64(cognn_ctx* ctx, uint64_t* Z, const uint64_t* E, const uint64_t* E1, const uint64_t* F, const uint64_t* c1,
                                 const cognn_keys* keys, int p, int64_t M, int64_t N, int64_t K, int transA, uint64_t* scratch) {
     CG_REQUIRE(ctx && Z && E && F && keys && scratch && (p == 0 || p == 1), "cognn_beaver_gemm_close_u64: bad arguments");
     CG_REQUIRE(p == 0 || c1, "cognn_beaver_gemm_close_u64: p=1 needs the dealer share c1");
+    return beaver_close_impl(ctx, Z, E, E1, F, c1, keys, p, M, N, K, transA, scratch, false);
+}
+
+int cognn_beaver_gemm_fusable(int64_t M, int64_t N, int64_t K, int transA) {
+    return (!transA && M >= 256 && N <= kFusedBN && K <= 4096 && K % 8 == 0 &&
+            (size_t)2 * ((K + kKStep - 1) / kKStep) * kBStage <= ((size_t)M * K + (size_t)K * N) * 8) ? 1 : 0;
+}
+
+int cognn_beaver_gemm_close_raw_u64(cognn_ctx* ctx, uint64_t* Z, const uint64_t* E, const uint64_t* E1, const uint64_t* F,
+                                    const cognn_keys* keys, int p, int64_t M, int64_t N, int64_t K, uint64_t* scratch) {
+    CG_REQUIRE(ctx && Z && E && F && keys && scratch && (p == 0 || p == 1), "cognn_beaver_gemm_close_raw_u64: bad arguments");
+    return beaver_close_impl(ctx, Z, E, E1, F, nullptr, keys, p, M, N, K, 0, scratch, true);
+}
+
+}  // extern "C"
+
+namespace {
+int beaver_close_impl(cognn_ctx* ctx, uint64_t* Z, const uint64_t* E, const uint64_t* E1, const uint64_t* F, const uint64_t* c1,
+                      const cognn_keys* keys, int p, int64_t M, int64_t N, int64_t K, int transA, uint64_t* scratch, bool raw) {
+    int rc;
+    if (cognn_beaver_gemm_fusable(M, N, K, transA)) {
+        const int nkt = (int)((K + kKStep - 1) / kKStep);
+        unsigned char* planes = (unsigned char*)scratch;           // 2*nkt*24 KiB of the (MxK + KxN)-word scratch
+        hipLaunchKernelGGL(prep_b_planes_kernel, dim3((unsigned)std::min(2 * nkt * kFusedBN * 8 / 256 + 1, 1024)), dim3(256), 0, ctx->stream,
+                           planes, (const u64*)F, keys->k[p == 0 ? COGNN_SL_B0 : COGNN_SL_B1], p, (int)K, (int)N, nkt);
+        CG_LAUNCH_CHECK();
+        const size_t lds = 2 * (size_t)(8 * 2 * 128 * 16) + 2 * (size_t)kBStage;
+        const int nmb = (int)((M + 127) / 128);
+        static const int dbg = getenv("COGNN_GEMM_DBG") ? atoi(getenv("COGNN_GEMM_DBG")) : 0;   // timing experiments only
+#define CG_FUSED_LAUNCH(...)                                                                                                       \
+    do {                                                                                                                            \
+        CG_HIP(hipFuncSetAttribute((const void*)beaver_gemm_fused_kernel<__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL((beaver_gemm_fused_kernel<__VA_ARGS__>), dim3((unsigned)std::min(nmb, 256)), dim3(kFusedThreads), lds, ctx->stream, \
+                           (u64*)Z, (const u64*)E, (const u64*)E1, planes, keys->k[p == 0 ? COGNN_SL_A0 : COGNN_SL_A1], (int)M,    \
+                           (int)N, (int)K, nkt);                                                                                    \
+    } while (0)
+        if (nkt == 4 && dbg == 1) CG_FUSED_LAUNCH(4, 1);
+        else if (nkt == 4 && dbg == 2) CG_FUSED_LAUNCH(4, 2);
+        else if (nkt == 4 && dbg == 3) CG_FUSED_LAUNCH(4, 3);
+        else if (nkt == 4 && dbg == 4) CG_FUSED_LAUNCH(4, 4);
+        else if (nkt == 4 && dbg == 7) CG_FUSED_LAUNCH(4, 7);
+        else if (nkt == 4) CG_FUSED_LAUNCH(4, 0);
+        else if (nkt == 2) CG_FUSED_LAUNCH(2, 0);
+        else CG_FUSED_LAUNCH(0, 0);
+#undef CG_FUSED_LAUNCH
+        CG_LAUNCH_CHECK();
+        if (raw) return 0;                                         // caller adds C_p (cognn_trunc_open_add_u64)
+        const int64_t n = M * N;
+        hipLaunchKernelGGL(add_cp_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 8192)), dim3(256), 0, ctx->stream, (u64*)Z,
+                           (const u64*)c1, keys->k[COGNN_SL_C0], p, n);
+        CG_LAUNCH_CHECK();
+        return 0;
+    }
+    CG_REQUIRE(!raw, "cognn_beaver_gemm_close_raw_u64: shape not supported by the fused kernel (%lld x %lld x %lld)", (long long)M, (long long)N, (long long)K);
     u64* Ap = (u64*)scratch;
     u64* Bp = Ap + (size_t)M * K;
-    int rc;
     // A_p (storage layout of E), B_p (+F for p==1), Z <- C_p
     if ((rc = fill(ctx, Ap, keys->k[p == 0 ? COGNN_SL_A0 : COGNN_SL_A1], 0, M, K, transA, 0, nullptr))) return rc;
     if ((rc = fill(ctx, Bp, keys->k[p == 0 ? COGNN_SL_B0 : COGNN_SL_B1], 0, K, N, 0, 0, p == 1 ? (const u64*)F : nullptr))) return rc;
@@ -324,5 +614,4 @@ int cognn_beaver_gemm_close_u64(cognn_ctx* ctx, uint64_t* Z, const uint64_t* E, 
     if ((rc = gemm_dispatch(ctx, (u64*)Z, (const u64*)E, (const u64*)E1, Bp, M, N, K, transA, 1))) return rc;
     return gemm_dispatch(ctx, (u64*)Z, Ap, nullptr, (const u64*)F, M, N, K, transA, 1);
 }
-
-}  // extern "C"
+}  // namespace

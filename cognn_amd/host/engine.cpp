@@ -216,6 +216,9 @@ void gemm_stage(cognn_engine* E, int64_t it, XFn X, WFn Wm, SpecFn spec, DstFn d
         BE(cognn_add_u64(E->ctx, s.fsum, s.ob[1], s.ib[1], e1[i]));
     }
     std::vector<u64*> z;
+    GemmSpec g0 = spec(E->sides[0]);
+    bool all_raw = true;
+    for (auto& s : E->sides) { GemmSpec g = spec(s); all_raw = all_raw && E->be->cognn_beaver_gemm_fusable(g.M, g.N, g.K, g.transA); }
     for (size_t i = 0; i < E->sides.size(); ++i) {
         Side& s = E->sides[i];
         GemmSpec g = spec(s);
@@ -231,13 +234,30 @@ void gemm_stage(cognn_engine* E, int64_t it, XFn X, WFn Wm, SpecFn spec, DstFn d
             c1 = f->second;
         }
         if (E->timing) BE(cognn_timer_begin(E->ctx, T_GEMM));
-        BE(cognn_beaver_gemm_close_u64(E->ctx, s.zbuf, s.ob[0], s.ib[0], s.fsum, c1, &k, s.p, g.M, g.N, g.K, g.transA, s.scratch));
+        if (all_raw) {
+            // fused single-launch product without C_p; C_p joins in the truncation opening below
+            BE(cognn_beaver_gemm_close_raw_u64(E->ctx, s.zbuf, s.ob[0], s.ib[0], s.fsum, &k, s.p, g.M, g.N, g.K, s.scratch));
+        } else {
+            BE(cognn_beaver_gemm_close_u64(E->ctx, s.zbuf, s.ob[0], s.ib[0], s.fsum, c1, &k, s.p, g.M, g.N, g.K, g.transA, s.scratch));
+        }
         if (E->timing) { BE(cognn_timer_end(E->ctx, T_GEMM)); E->algo[T_GEMM] += 2.0 * 36 * 2 * (double)g.M * g.K * g.N; }
+        if (all_raw) {
+            cognn_keys tk = keys(E, s.owner, it, g.top);
+            BE(cognn_trunc_open_add_u64(E->ctx, s.ob[2], s.zbuf, c1, &k, &tk, s.p, eo[i]));
+        }
         z.push_back(s.zbuf);
     }
     // all GEMMs of one stage share the truncation op id
-    GemmSpec g0 = spec(E->sides[0]);
-    trunc_stage(E, it, g0.top, 1, z, eo, dst, 0);
+    if (!all_raw) {
+        trunc_stage(E, it, g0.top, 1, z, eo, dst, 0);
+        return;
+    }
+    exchange_ob(E, 2, eo);
+    for (size_t i = 0; i < E->sides.size(); ++i) {
+        Side& s = E->sides[i];
+        cognn_keys tk = keys(E, s.owner, it, g0.top);
+        BE(cognn_trunc_close_u64(E->ctx, dst(s), s.p == 0 ? s.ob[2] : nullptr, s.p == 0 ? s.ib[2] : nullptr, &tk, s.p, 0, eo[i]));
+    }
 }
 
 // row scale by the (owner-known) normaliser followed by truncation; x(side) [n x F] -> dst(side)

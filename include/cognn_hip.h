@@ -88,9 +88,21 @@ int cognn_dealer_gemm_c1_u64(cognn_ctx*, uint64_t* C1, const cognn_keys* keys, i
 int cognn_beaver_gemm_close_u64(cognn_ctx*, uint64_t* Z, const uint64_t* E0, const uint64_t* E1, const uint64_t* F, const uint64_t* c1,
                                 const cognn_keys* keys, int p, int64_t M, int64_t N, int64_t K, int transA, uint64_t* scratch);
 
+/* Fast path of the same product for tall-skinny NN shapes: 1 when (M,N,K) is served by the single-launch fused
+ * kernel (E streamed once, A_p generated in registers, B limb planes pre-split). */
+int cognn_beaver_gemm_fusable(int64_t M, int64_t N, int64_t K, int transA);
+/* Raw product share WITHOUT the dealer's C_p: Z = p*E.F + E.B_p + A_p.F (fusable shapes only).  The consumer adds C_p
+ * while opening the truncation (cognn_trunc_open_add_u64), so the GEMM kernel has no loads besides its operands. */
+int cognn_beaver_gemm_close_raw_u64(cognn_ctx*, uint64_t* Z, const uint64_t* E0, const uint64_t* E1, const uint64_t* F,
+                                    const cognn_keys* keys, int p, int64_t M, int64_t N, int64_t K, uint64_t* scratch);
+
 /* ---- truncation by 2^16 (implicit in every sci:: fixed-point op) ------------------------- */
 /* c_p = mul * x_p + r_p (+2^61 if p==0) */
 int cognn_trunc_open_u64(cognn_ctx*, uint64_t* c, const uint64_t* x, uint64_t mul, const cognn_keys* keys, int p, int64_t n);
+/* c_p = x_p + C_p + r_p (+2^61 if p==0) with C_p = prng(gkeys C0 stream) for p==0 and c1[i] for p==1: truncation
+ * opening of a raw Beaver product (cognn_beaver_gemm_close_raw_u64) */
+int cognn_trunc_open_add_u64(cognn_ctx*, uint64_t* c, const uint64_t* x, const uint64_t* c1, const cognn_keys* gkeys,
+                             const cognn_keys* tkeys, int p, int64_t n);
 /* y_p = p==0 ? ((c0+c1)>>16) - 2^45 - rp0 : -rp1.  mode 0: out = y; mode 1: out = out - y
  * (twoPartyGCNApplyGradient, gcn.h:678,730). */
 int cognn_trunc_close_u64(cognn_ctx*, uint64_t* out, const uint64_t* c0, const uint64_t* c1, const cognn_keys* keys,

@@ -174,6 +174,18 @@ int cognn_beaver_gemm_close_u64(cognn_ctx* c, uint64_t* Z, const uint64_t* E, co
     cognn_ring_gemm2_u64(c, Z, E, E1, Bp, M, N, K, transA, 1);
     return cognn_ring_gemm_u64(c, Z, Ap, F, M, N, K, transA, 1);
 }
+int cognn_beaver_gemm_fusable(int64_t, int64_t, int64_t, int) { return 0; }   // the reference backend has one path only
+int cognn_beaver_gemm_close_raw_u64(cognn_ctx*, uint64_t*, const uint64_t*, const uint64_t*, const uint64_t*, const cognn_keys*, int,
+                                    int64_t, int64_t, int64_t, uint64_t*) {
+    return fail("beaver_gemm_close_raw: not provided by the reference backend");
+}
+int cognn_trunc_open_add_u64(cognn_ctx*, uint64_t* c, const uint64_t* x, const uint64_t* c1, const cognn_keys* gkeys,
+                             const cognn_keys* tkeys, int p, int64_t n) {
+    const cognn_opkeys tk = K(tkeys);
+    for (int64_t i = 0; i < n; ++i)
+        c[i] = x[i] + (p == 0 ? cognn_prng(gkeys->k[COGNN_SL_C0], (u64)i) : c1[i]) + trunc_r(tk, p, (u64)i) + (p == 0 ? COGNN_TRUNC_OFFSET : 0);
+    return 0;
+}
 int cognn_trunc_open_u64(cognn_ctx*, uint64_t* c, const uint64_t* x, uint64_t mul, const cognn_keys* keys, int p, int64_t n) {
     const cognn_opkeys k = K(keys);
     for (int64_t i = 0; i < n; ++i) c[i] = x[i] * mul + trunc_r(k, p, (u64)i) + (p == 0 ? COGNN_TRUNC_OFFSET : 0);

@@ -1,0 +1,77 @@
+#!/usr/bin/env python3
+"""Kernel micro-benchmarks on cuda:0 (HIP events via torch): the fused Beaver GEMM close and the CSR gather at
+config5 shapes.  Usage: python tools/microbench.py [gemm|gather|all] [--iters N]"""
+import argparse
+import ctypes
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from cognn_amd import capi  # noqa: E402
+
+
+def P(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def timeit(fn, iters):
+    fn(); torch.cuda.synchronize()
+    a = torch.cuda.Event(enable_timing=True); b = torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        fn()
+    b.record(); torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters
+
+
+def bench_gemm(ctx, iters, M=1 << 17, K=128, N=64):
+    g = torch.Generator(device="cuda"); g.manual_seed(1)
+    E0 = torch.randint(-2**62, 2**62, (M, K), dtype=torch.int64, device="cuda", generator=g)
+    E1 = torch.randint(-2**62, 2**62, (M, K), dtype=torch.int64, device="cuda", generator=g)
+    F = torch.randint(-2**62, 2**62, (K, N), dtype=torch.int64, device="cuda", generator=g)
+    c1 = torch.randint(-2**62, 2**62, (M, N), dtype=torch.int64, device="cuda", generator=g)
+    Z = torch.empty((M, N), dtype=torch.int64, device="cuda")
+    scratch = torch.empty(M * K + K * N, dtype=torch.int64, device="cuda")
+    k = capi.make_keys(1, 2, 3, capi.OP_PS_GEMM)
+    for p in (1, 0):
+        ms = timeit(lambda: ctx.call("cognn_beaver_gemm_close_u64", P(Z), P(E0), P(E1), P(F), P(c1) if p == 1 else None,
+                                     ctypes.byref(k), p, M, N, K, 0, P(scratch)), iters)
+        ops = 2.0 * 36 * 2 * M * K * N
+        print("beaver_gemm_close p=%d M=%d K=%d N=%d: %.3f ms  %.1f i8-TOP/s (%.1f%% of 5000)  E-stream %.0f GB/s"
+              % (p, M, K, N, ms, ops / ms / 1e9, ops / ms / 1e9 / 50.0, 2 * M * K * 8 / ms / 1e6))
+    A = E0; B = F; C = Z
+    ms = timeit(lambda: ctx.call("cognn_ring_gemm_u64", P(C), P(A), P(B), M, N, K, 0, 0), iters)
+    print("ring_gemm (single product) M=%d K=%d N=%d: %.3f ms  %.1f i8-TOP/s" % (M, K, N, ms, 36 * 2.0 * M * K * N / ms / 1e9))
+
+
+def bench_gather(ctx, iters, rows=1 << 21, table_rows=1 << 21, deg=12, F=64):
+    rng = np.random.default_rng(0)
+    d = rng.poisson(deg, size=rows)
+    rowptr = np.zeros(rows + 1, dtype=np.uint32); rowptr[1:] = np.cumsum(d)
+    col = rng.integers(0, table_rows, size=int(rowptr[-1]), dtype=np.uint32)
+    g = torch.Generator(device="cuda"); g.manual_seed(1)
+    table = torch.randint(-2**62, 2**62, (table_rows, F), dtype=torch.int64, device="cuda", generator=g)
+    out = torch.empty((rows, F), dtype=torch.int64, device="cuda")
+    rp = torch.from_numpy(rowptr.view(np.int32)).cuda(); cl = torch.from_numpy(col.view(np.int32)).cuda()
+    ms = timeit(lambda: ctx.call("cognn_gather_csr_u64", P(out), P(table), P(table), P(rp), P(cl), rows, F), iters)
+    E = int(rowptr[-1])
+    by = 8.0 * F * (E + 2 * rows) + 4.0 * E + 4.0 * (rows + 1)
+    print("gather_csr rows=%d edges=%d F=%d: %.3f ms  %.0f GB/s algorithmic (%.1f%% of 8000)" % (rows, E, F, ms, by / ms / 1e6, by / ms / 1e6 / 80.0))
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("what", nargs="?", default="all")
+    ap.add_argument("--iters", type=int, default=10)
+    a = ap.parse_args()
+    ctx = capi.Context(0)
+    if a.what in ("gemm", "all"):
+        bench_gemm(ctx, a.iters)
+        bench_gemm(ctx, a.iters, K=64, N=16)
+    if a.what in ("gather", "all"):
+        bench_gather(ctx, a.iters, F=64)
+        bench_gather(ctx, a.iters, F=16)
