@@ -8,10 +8,17 @@ HOSTCXX ?= g++
 HOSTFLAGS := -O2 -fPIC -std=c++17 -Wall -Wno-unused-function -Iinclude -I$(CSRC)
 HIPFLAGS := --offload-arch=$(ARCH) -O3 -fPIC -std=c++17 -Wall -Wno-unused-function -Iinclude -I$(CSRC)
 KERNEL_SRCS := $(CSRC)/capi.hip $(CSRC)/kernels_elementwise.hip $(CSRC)/kernels_gather.hip $(CSRC)/kernels_gemm.hip
-HOST_SRCS := $(wildcard $(HOST)/*.cpp)
+HOST_SRCS := $(filter-out $(HOST)/harness_main.cpp,$(wildcard $(HOST)/*.cpp))
+HARNESS := bin/gcn-optimize
 OBJS := $(KERNEL_SRCS:.hip=.o) $(HOST_SRCS:.cpp=.o)
 
-all: $(OUT)
+all: $(OUT) $(HARNESS)
+
+# the reference's command-line entry point (harness.cpp) over the engine; gcn-inference-optimize is the same binary
+$(HARNESS): $(HOST)/harness_main.cpp $(OUT) $(HOST)/graph.h include/cognn_engine.h
+	mkdir -p bin
+	$(HOSTCXX) $(HOSTFLAGS) -o $@ $(HOST)/harness_main.cpp -Lcognn_amd -lcognn_hip -Wl,-rpath,'$$ORIGIN/../cognn_amd' -Wl,-rpath,/opt/rocm/lib
+	ln -sf gcn-optimize bin/gcn-inference-optimize
 
 $(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/common.h $(CSRC)/cognn_spec.h include/cognn_hip.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
@@ -23,5 +30,5 @@ $(OUT): $(OBJS)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS) -lpthread
 
 clean:
-	rm -f $(OBJS) $(OUT)
+	rm -f $(OBJS) $(OUT) bin/gcn-optimize bin/gcn-inference-optimize
 .PHONY: all clean

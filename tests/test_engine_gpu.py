@@ -97,3 +97,34 @@ def test_reconstruction_tracks_plaintext_gcn():
             if rec.shape[1]:
                 assert np.abs(rec - pl.X[P]).max() < 2e-4      # fixed-point tolerance (f=16, +-1 LSB truncations)
     eng.close()
+
+
+# ---- BASELINE.json configs[1..3]: dataset-shaped synthetic stand-ins (the real Planetoid files are not available offline;
+# sizes from build_from_source/config/*.txt, partition vid % k as in tools/data_transform.py:19-27) ----
+DATASET_SHAPES = {
+    # name: (parties, vertices, directed edges, input_dim, hidden, labels, lr, train_ratio)
+    "cora-2p": (2, 2708, 10556, 1433, 16, 7, 0.5, 0.2),
+    "citeseer-2p": (2, 3312, 10016, 3703, 16, 6, 0.8, 0.2),
+    "pubmed-4p": (4, 19717, 128146, 500, 16, 3, 8.0, 0.05),
+}
+
+
+@pytest.mark.parametrize("name,iters", [("cora-2p", 12), ("citeseer-2p", 6), ("pubmed-4p", 6)])
+def test_dataset_shaped_training_bit_exact(name, iters):
+    from cognn_amd.engine import Engine, GnnParam
+    k, V, E, in_dim, hid, lab, lr, tr = DATASET_SHAPES[name]
+    src, dst = co.synth_graph(V, E // 2, 1)
+    part = np.array([v % k for v in range(V)], dtype=np.int32)
+    feats, labels = co.synth_features(V, in_dim, lab, 2, density=0.01)
+    kw = dict(num_labels=lab, input_dim=in_dim, hidden_dim=hid, num_samples=V, learning_rate=lr, train_ratio=tr,
+              val_ratio=0.2 if tr == 0.2 else 0.15, test_ratio=0.6 if tr == 0.2 else 0.8)
+    oracle = co.OracleEngine(k, src, dst, part, feats, labels, co.GnnParam(**kw), seed=0xC06A11)
+    eng = Engine(k, src, dst, part, GnnParam(**kw), seed=0xC06A11)
+    eng.set_global_data(feats, labels)
+    eng.start()
+    for it in range(iters):
+        oracle.iteration(it)
+        eng.run(it, it + 1)
+        if it % 6 in (1, 5) or it == iters - 1:
+            _compare(oracle, eng, k, it)
+    eng.close()

@@ -1,0 +1,111 @@
+"""The command-line entry point with the reference's file formats (edge list / vertex list / partition / config) and
+log lines, exercised on CPU through oracle/gcn-optimize-cpuref (same harness_main.cpp, graph.cpp and engine.cpp as
+bin/gcn-optimize, linked against the reference backend).  Metrics are compared with the oracle."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import cognn_oracle as co
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "oracle", "gcn-optimize-cpuref")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _build():
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
+
+
+def _write_inputs(d, k, V, Eu, in_dim, lab, hid):
+    src, dst = co.synth_graph(V, Eu, 9)
+    feats, labels = co.synth_features(V, in_dim, lab, 10, density=0.3)
+    with open(d / "edges.txt", "w") as f:                      # format: graph_io_util.h:121-147 ('#' comments, blank lines)
+        f.write("# src dst\n\n")
+        for s, t in zip(src, dst):
+            f.write("%d %d\n" % (s, t))
+    with open(d / "part.txt", "w") as f:                       # graph_io_util.h:67-73
+        for v in range(V):
+            f.write("%d %d\n" % (v, v % k))
+    with open(d / "vertices.txt", "w") as f:                   # tools/data_transform.py:55-56: '%d %f ... %d'
+        for v in range(V):
+            f.write("%d %s %d\n" % (v, " ".join("%f" % x for x in feats[v]), labels[v]))
+    with open(d / "config.txt", "w") as f:                     # task.h:126-160
+        f.write("num_layers : 2\nnum_labels : %d\ninput_dim : %d\nhidden_dim : %d\nnum_samples : %d\nnum_edges : %d\n"
+                "learning_rate : 0.5\ntrain_ratio : 0.2\nval_ratio : 0.2\ntest_ratio : 0.6" % (lab, in_dim, hid, V, len(src)))
+    return src, dst, feats, labels
+
+
+def _fnv1a(s):
+    h = 0xcbf29ce484222325
+    for c in s.encode():
+        h = ((h ^ c) * 0x100000001b3) & ((1 << 64) - 1)
+    return h
+
+
+def test_cli_runs_reference_formats_and_matches_oracle(tmp_path):
+    k, V, Eu, in_dim, lab, hid = 2, 40, 90, 6, 3, 4
+    src, dst, feats, labels = _write_inputs(tmp_path, k, V, Eu, in_dim, lab, hid)
+    setting = "cora-2s-test"
+    cmd = [BIN, "-t", str(k), "-g", str(k), "-i", "1", "-m", "12", "-p", "1", "-s", setting, "-r", "1",
+           str(tmp_path / "edges.txt"), str(tmp_path / "vertices.txt"), str(tmp_path / "part.txt"), str(tmp_path / "out.txt"),
+           str(tmp_path / "config.txt")]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stderr
+    out = res.stdout
+    assert len(re.findall(r"::iteration took [0-9.]+ seconds", out)) == 12
+    assert "::preprocess took" in out and "::preprocess_OM took" in out
+    p = co.GnnParam(num_labels=lab, input_dim=in_dim, hidden_dim=hid, num_samples=V, learning_rate=0.5)
+    o = co.OracleEngine(k, src, dst, [v % k for v in range(V)], feats, labels, p, seed=_fnv1a(setting))
+    o.run(12)
+    want = [m for m in o.metrics if m["party"] == 1]
+    for key, pat in (("loss", r"cross-entropy-loss = ([0-9.]+)"), ("full", r"full set accuracy = ([0-9.]+)"),
+                     ("train", r"training set accuracy = ([0-9.]+)\nborder"), ("test", r"\ntest set accuracy = ([0-9.]+)"),
+                     ("border_test", r"border test set accuracy = ([0-9.]+)")):
+        got = [float(x) for x in re.findall(pat, out)]
+        assert len(got) == 2
+        for g, w in zip(got, want):
+            assert abs(g - w[key]) < 1e-6, (key, got, [x[key] for x in want])
+    nv = re.findall(r"the number of vertices is (\d+), the number of border vertices is (\d+)", out)
+    assert [int(x) for x in nv[0]] == [want[0]["n"], want[0]["n_border"]]
+
+
+def test_cli_argument_errors(tmp_path):
+    r = subprocess.run([BIN, "-h"], capture_output=True, text=True)
+    assert r.returncode != 0 and "Usage" in r.stderr
+    r = subprocess.run([BIN, "-t", "2", "-g", "3", "a", "b", "c", "d", "e"], capture_output=True, text=True)
+    assert r.returncode != 0 and "divisor" in r.stderr
+    r = subprocess.run([BIN, "a"], capture_output=True, text=True)
+    assert r.returncode != 0 and "Must specify number of threads" in r.stderr
+    _write_inputs(tmp_path, 2, 20, 30, 4, 3, 3)
+    base = [BIN, "-t", "2", "-g", "2", "-i", "0", "-m", "2", "-s", "x"]
+    files = [str(tmp_path / n) for n in ("edges.txt", "vertices.txt", "part.txt", "out.txt", "config.txt")]
+    r = subprocess.run(base + files, capture_output=True, text=True)            # -r 1 missing
+    assert r.returncode != 0 and "no-dummy-edge" in r.stderr
+    r = subprocess.run(base + ["-r", "1"] + [str(tmp_path / "missing.txt")] + files[1:], capture_output=True, text=True)
+    assert r.returncode != 0 and "cannot open edge list file" in r.stderr
+    (tmp_path / "bad.txt").write_text("0 x\n")
+    r = subprocess.run(base + ["-r", "1", str(tmp_path / "bad.txt")] + files[1:], capture_output=True, text=True)
+    assert r.returncode != 0 and "Invalid format in graph topology input files." in r.stderr
+
+
+@pytest.mark.gpu
+def test_gpu_binary_matches_oracle(tmp_path):
+    """bin/gcn-optimize (HIP engine, no torch in the process) on the same files."""
+    exe = os.path.join(ROOT, "bin", "gcn-optimize")
+    assert os.path.exists(exe), "bin/gcn-optimize missing: run make"
+    k, V, Eu, in_dim, lab, hid = 3, 60, 140, 8, 4, 6
+    src, dst, feats, labels = _write_inputs(tmp_path, k, V, Eu, in_dim, lab, hid)
+    cmd = [exe, "-t", str(k), "-g", str(k), "-i", "0", "-m", "6", "-s", "gpu-harness", "-r", "1", "-n", "1",
+           str(tmp_path / "edges.txt"), str(tmp_path / "vertices.txt"), str(tmp_path / "part.txt"), str(tmp_path / "out.txt"),
+           str(tmp_path / "config.txt")]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr
+    p = co.GnnParam(num_labels=lab, input_dim=in_dim, hidden_dim=hid, num_samples=V, learning_rate=0.5)
+    o = co.OracleEngine(k, src, dst, [v % k for v in range(V)], feats, labels, p, seed=_fnv1a("gpu-harness"))
+    o.run(6)
+    want = [m for m in o.metrics if m["party"] == 0][0]
+    assert abs(float(re.findall(r"cross-entropy-loss = ([0-9.]+)", res.stdout)[0]) - want["loss"]) < 1e-6
+    assert abs(float(re.findall(r"full set accuracy = ([0-9.]+)", res.stdout)[0]) - want["full"]) < 1e-6
