@@ -305,6 +305,7 @@ __global__ __launch_bounds__(kFusedThreads) void beaver_gemm_fused_kernel(u64* Z
     auto load_B = [&](int it) {                             // planes are stored [seg][kt]; steps alternate seg 0 / 1
         const int st = min(it, total - 1) % steps;
         const u64x2* bp = reinterpret_cast<const u64x2*>(planes + (size_t)((st & 1) * nkt + (st >> 1)) * kBStage) + tid * 3;
+        if (DBG & 16) { nB0.x = (u64)it; nB0.y = 1; nB1 = nB0; nB2 = nB0; return; }
         nB0 = bp[0]; nB1 = bp[1]; nB2 = bp[2];
     };
     auto load_E = [&](int it) {                             // `it`: an E step (even); clamped, never branches
@@ -332,6 +333,7 @@ __global__ __launch_bounds__(kFusedThreads) void beaver_gemm_fused_kernel(u64* Z
             v[2 * j] = (nE0[j].x + (nE1[j].x & e1mask)) & keep;
             v[2 * j + 1] = (nE0[j].y + (nE1[j].y & e1mask)) & keep;
         }
+        if (DBG & 8) { if (v[0] == 0x1234567ull) Z[0] = v[1] ^ v[2] ^ v[3] ^ v[4] ^ v[5] ^ v[6] ^ v[7]; return; }
         split8_store(v, sA + (it & 1) * kAStage + (tk8 >> 1) * (BM * 16) + trow * 16 + (tk8 & 1) * 8);
     };
     auto produce_mask = [&](int it) {                       // tile of mask step `it` (dealer stream A_p) -> LDS stage it&1
@@ -342,10 +344,12 @@ __global__ __launch_bounds__(kFusedThreads) void beaver_gemm_fused_kernel(u64* Z
         u64 v[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) { v[j] = ((DBG & 2) ? x : cognn_mix64(x)) & keep; x += COGNN_GAMMA; }
+        if (DBG & 8) { if (v[0] == 0x1234567ull) Z[0] = v[1] ^ v[2] ^ v[3] ^ v[4] ^ v[5] ^ v[6] ^ v[7]; return; }
         split8_store(v, sA + (it & 1) * kAStage + (tk8 >> 1) * (BM * 16) + trow * 16 + (tk8 & 1) * 8);
     };
     auto store_B = [&](int it) {
         u64x2* bd = reinterpret_cast<u64x2*>(sB + (it & 1) * kBStage) + tid * 3;
+        if (DBG & 16) { if (nB0.x == 0x1234567ull) bd[0] = nB0; return; }
         bd[0] = nB0; bd[1] = nB1; bd[2] = nB2;
     };
 
@@ -410,15 +414,20 @@ __global__ __launch_bounds__(kFusedThreads) void beaver_gemm_fused_kernel(u64* Z
         for (int it = blk * steps; it < (blk + 1) * steps; it += 2) {
             // ---- even iteration: MFMAs of E step `it`; produce the mask tile of step it+1 (no memory operands) ----
             __syncthreads();
-            produce_mask(it + 1); store_B(it + 1);
+            store_B(it + 1);                                // B planes prefetched one step ago (older than the E tile in flight)
             load_B(it + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            produce_mask(it + 1);
             mfma_step(it);
             interleave_hint();
             // ---- odd iteration: MFMAs of mask step it+1; produce the E tile of step it+2 from the prefetched
             //      registers, then prefetch the E tile two steps further ----
             __syncthreads();
             produce_E(it + 2); store_B(it + 2);             // past the end this writes an all-zero tile nobody reads
-            load_B(it + 3); load_E(it + 4);
+            load_B(it + 3);
+            __builtin_amdgcn_sched_barrier(0);              // keep the B loads older than the E loads: the next step waits
+            load_E(it + 4);                                 // for B with the 16 E loads still in flight (counted vmcnt)
+            __builtin_amdgcn_sched_barrier(0);
             mfma_step(it + 1);
             interleave_hint();
         }
@@ -591,6 +600,9 @@ int beaver_close_impl(cognn_ctx* ctx, uint64_t* Z, const uint64_t* E, const uint
         else if (nkt == 4 && dbg == 3) CG_FUSED_LAUNCH(4, 3);
         else if (nkt == 4 && dbg == 4) CG_FUSED_LAUNCH(4, 4);
         else if (nkt == 4 && dbg == 7) CG_FUSED_LAUNCH(4, 7);
+        else if (nkt == 4 && dbg == 15) CG_FUSED_LAUNCH(4, 15);
+        else if (nkt == 4 && dbg == 23) CG_FUSED_LAUNCH(4, 23);
+        else if (nkt == 4 && dbg == 31) CG_FUSED_LAUNCH(4, 31);
         else if (nkt == 4) CG_FUSED_LAUNCH(4, 0);
         else if (nkt == 2) CG_FUSED_LAUNCH(2, 0);
         else CG_FUSED_LAUNCH(0, 0);

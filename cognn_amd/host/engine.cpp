@@ -647,12 +647,11 @@ void build_layout(cognn_engine* E) {
     for (int r = 0; r < E->world; ++r) if (r != E->rank) src_order.push_back(r);
     src_order.push_back(E->rank);                          // own-rank segments last, adjacent to the outbox
     for (int sr : src_order) {
-        if (sr == E->rank) { even(); E->inboxLocalOff = off; }
+        if (sr == E->rank) { even(); E->inboxLocalOff = off; continue; }   // same-rank producers: read in place, see build_csrs
         for (int g : E->cohosted)
             for (int Q = 0; Q < k; ++Q) {
                 if (Q == g || E->rank_of(Q) != sr) continue;
                 cognn_engine::Seg sg{Q, g, seg_rows(Q, g), off, -1, sr, E->rank};
-                if (sr == E->rank) sg.out_off = off;
                 E->segs.push_back(sg);
                 off += sg.rows;
             }
@@ -718,7 +717,19 @@ void build_csrs(cognn_engine* E) {
         for (size_t r = 0; r + 1 < self.rowptr.size(); ++r)
             for (uint32_t q = self.rowptr[r]; q < self.rowptr[r + 1]; ++q) lists[rbase + r].push_back((uint32_t)(rbase + self.col[q]));
     }
-    for (auto& sg : E->segs) {                              // received partial rows
+    // in-device exchange: when the producing party is hosted on this rank too, the co-party rows gather the producer's
+    // own-share rows directly (edge by edge) instead of going through materialised partial sums
+    for (int g : E->cohosted)
+        for (int Q : E->hosted) {
+            if (Q == g) continue;
+            const cognn::EdgeBlock& blk = G.party[Q].out[g];
+            const int64_t rbase = E->B_off[g];
+            for (size_t r = 0; r + 1 < blk.rowptr.size(); ++r) {
+                const uint32_t lr = G.row_of_vid[blk.rows_vid[r]];
+                for (uint32_t q = blk.rowptr[r]; q < blk.rowptr[r + 1]; ++q) lists[rbase + lr].push_back((uint32_t)(E->A_off[Q] + blk.col[q]));
+            }
+        }
+    for (auto& sg : E->segs) {                              // partial rows received from other ranks
         if (sg.dst_rank != E->rank) continue;
         const cognn::EdgeBlock& blk = G.party[sg.src_party].out[sg.dst_owner];
         const int64_t rbase = E->B_off[sg.dst_owner];
