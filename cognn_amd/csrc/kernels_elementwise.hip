@@ -209,9 +209,9 @@ struct ReluMul {
     }
 };
 struct ReluClose {
-    u64* h; uint8_t* mask; const u64* z; const u64* w0; const u64* w1;
+    u64* h; uint8_t* mask; const u64* z; const u64* w0; const u64* w1; u64* E; u64 key_open;
     __device__ void operator()(int64_t i, int w) const {
-        u64 a[2], b[2], v[2], r[2];
+        u64 a[2], b[2], v[2], r[2] = {0, 0};
         ld2(w0, i, w, a); ld2(w1, i, w, b); ld2(z, i, w, v);
         for (int j = 0; j < w; ++j) {
             bool pos = (long long)(a[j] + b[j]) > 0;
@@ -219,6 +219,10 @@ struct ReluClose {
             if (mask) mask[i + j] = pos ? 1 : 0;
         }
         st2(h, i, w, r);
+        if (E) {
+            u64 e[2] = {r[0] - cognn_prng(key_open, (u64)i), r[1] - cognn_prng(key_open, (u64)i + 1)};
+            st2(E, i, w, e);
+        }
     }
 };
 struct MaskSelect {
@@ -391,8 +395,8 @@ int cognn_trunc_close_u64(cognn_ctx* ctx, uint64_t* out, const uint64_t* c0, con
 }
 int cognn_rowscale_open_u64(cognn_ctx* ctx, uint64_t* E, uint64_t* G, const uint64_t* V, const uint64_t* s,
                             const cognn_keys* keys, int p, int64_t rows, int64_t F) {
-    CG_REQUIRE(ctx && E && G && V && s && keys && al(E) && al(G) && al(V) && al(s), "cognn_rowscale_open_u64: bad arguments");
-    int rc = launch_ew(ctx, rows * F, RowscaleOpenE{(u64*)E, (const u64*)V, K(keys), p});
+    CG_REQUIRE(ctx && G && s && keys && (E == nullptr || V) && al(E) && al(G) && al(V) && al(s), "cognn_rowscale_open_u64: bad arguments");
+    int rc = E ? launch_ew(ctx, rows * F, RowscaleOpenE{(u64*)E, (const u64*)V, K(keys), p}) : 0;   // E == NULL: opened elsewhere
     if (rc) return rc;
     return launch_ew(ctx, rows, RowscaleOpenG{(u64*)G, (const u64*)s, K(keys), p});
 }
@@ -413,7 +417,12 @@ int cognn_relu_mul_u64(cognn_ctx* ctx, uint64_t* w, const uint64_t* E, const uin
 }
 int cognn_relu_close_u64(cognn_ctx* ctx, uint64_t* h, uint8_t* mask, const uint64_t* z, const uint64_t* w0, const uint64_t* w1, int64_t n) {
     CG_REQUIRE(ctx && h && z && w0 && w1 && al(h) && al(z) && al(w0) && al(w1), "cognn_relu_close_u64: bad arguments");
-    return launch_ew(ctx, n, ReluClose{(u64*)h, mask, (const u64*)z, (const u64*)w0, (const u64*)w1});
+    return launch_ew(ctx, n, ReluClose{(u64*)h, mask, (const u64*)z, (const u64*)w0, (const u64*)w1, nullptr, 0});
+}
+int cognn_relu_close_open_u64(cognn_ctx* ctx, uint64_t* h, uint64_t* E, uint8_t* mask, const uint64_t* z, const uint64_t* w0, const uint64_t* w1,
+                              uint64_t key_open, int64_t n) {
+    CG_REQUIRE(ctx && h && E && z && w0 && w1 && al(h) && al(E) && al(z) && al(w0) && al(w1), "cognn_relu_close_open_u64: bad arguments");
+    return launch_ew(ctx, n, ReluClose{(u64*)h, mask, (const u64*)z, (const u64*)w0, (const u64*)w1, (u64*)E, key_open});
 }
 int cognn_mask_select_u64(cognn_ctx* ctx, uint64_t* out, const uint64_t* in, const uint8_t* mask, int64_t n) {
     CG_REQUIRE(ctx && out && in && mask && al(out) && al(in), "cognn_mask_select_u64: bad arguments");

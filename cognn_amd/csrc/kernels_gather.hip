@@ -32,6 +32,7 @@ template <> struct Chunk<2> {
     __device__ __forceinline__ void load(const u64* p) { v = *reinterpret_cast<const u64x2*>(p); }
     __device__ __forceinline__ void add(const Chunk& o) { v.x += o.v.x; v.y += o.v.y; }
     __device__ __forceinline__ void store(u64* p) const { *reinterpret_cast<u64x2*>(p) = v; }
+    __device__ __forceinline__ void sub_prng(u64 key, u64 idx) { v.x -= cognn_prng(key, idx); v.y -= cognn_prng(key, idx + 1); }
 };
 template <> struct Chunk<1> {
     u64 v;
@@ -39,13 +40,20 @@ template <> struct Chunk<1> {
     __device__ __forceinline__ void load(const u64* p) { v = *p; }
     __device__ __forceinline__ void add(const Chunk& o) { v += o.v; }
     __device__ __forceinline__ void store(u64* p) const { *p = v; }
+    __device__ __forceinline__ void sub_prng(u64 key, u64 idx) { v -= cognn_prng(key, idx); }
+};
+
+struct OpenSegs {                 // row segments whose output is written as a Beaver opening (value - dealer mask)
+    int n;
+    int begin[32], end[32];
+    u64 key[32];
 };
 
 template <int LPR, int W>
 __global__ __launch_bounds__(kThreads) void gather_csr_kernel(u64* out, const u64* base,
                                                                const u64* __restrict__ table,
                                                                const uint32_t* __restrict__ rowptr,
-                                                               const uint32_t* __restrict__ col, int n_rows, int F) {
+                                                               const uint32_t* __restrict__ col, int n_rows, int F, OpenSegs segs) {
     __shared__ uint32_t s_rp[kTileRows + 1];
     __shared__ uint32_t s_col[kColCap];
     constexpr int kGroups = kThreads / LPR;
@@ -69,6 +77,9 @@ __global__ __launch_bounds__(kThreads) void gather_csr_kernel(u64* out, const u6
         for (int lr = grp; lr < nr; lr += kGroups) {
             const uint32_t b = s_rp[lr], e = s_rp[lr + 1];
             const size_t orow = (size_t)(r0 + lr) * (size_t)F;
+            u64 okey = 0; int obeg = -1;
+            for (int sidx = 0; sidx < segs.n; ++sidx)
+                if (r0 + lr >= segs.begin[sidx] && r0 + lr < segs.end[sidx]) { okey = segs.key[sidx]; obeg = segs.begin[sidx]; }
             for (int c = ln; c < nchunk; c += LPR) {
                 const int off = c * W;
                 Chunk<W> acc;
@@ -96,6 +107,7 @@ __global__ __launch_bounds__(kThreads) void gather_csr_kernel(u64* out, const u6
                         acc.add(t);
                     }
                 }
+                if (obeg >= 0) acc.sub_prng(okey, (u64)(r0 + lr - obeg) * (u64)F + (u64)off);
                 acc.store(out + orow + off);
             }
         }
@@ -129,14 +141,14 @@ int pick_lpr(int nchunk) {
 
 template <int W>
 int launch_gather(cognn_ctx* ctx, u64* out, const u64* base, const u64* table, const uint32_t* rowptr, const uint32_t* col,
-                  int n_rows, int F) {
+                  int n_rows, int F, const OpenSegs& segs) {
     const int nchunk = F / W;
     const int lpr = pick_lpr(nchunk);
     const int ntiles = (n_rows + kTileRows - 1) / kTileRows;
     dim3 grid((unsigned)std::min(ntiles, 256 * 16)), block(kThreads);
 #define CG_GATHER_CASE(L)                                                                                              \
     case L:                                                                                                             \
-        hipLaunchKernelGGL((gather_csr_kernel<L, W>), grid, block, 0, ctx->stream, out, base, table, rowptr, col, n_rows, F); \
+        hipLaunchKernelGGL((gather_csr_kernel<L, W>), grid, block, 0, ctx->stream, out, base, table, rowptr, col, n_rows, F, segs); \
         break;
     switch (lpr) {
         CG_GATHER_CASE(1) CG_GATHER_CASE(2) CG_GATHER_CASE(4) CG_GATHER_CASE(8) CG_GATHER_CASE(16) CG_GATHER_CASE(32)
@@ -172,15 +184,35 @@ int launch_scatter(cognn_ctx* ctx, u64* v, const u64* partial, const uint32_t* r
 
 extern "C" {
 
+static int gather_impl(cognn_ctx* ctx, uint64_t* out, const uint64_t* base, const uint64_t* table, const uint32_t* rowptr,
+                       const uint32_t* col, int64_t n_rows, int64_t F, const OpenSegs& segs);
+
 int cognn_gather_csr_u64(cognn_ctx* ctx, uint64_t* out, const uint64_t* base, const uint64_t* table,
                          const uint32_t* rowptr, const uint32_t* col, int64_t n_rows, int64_t F) {
+    OpenSegs segs;
+    segs.n = 0;
+    return gather_impl(ctx, out, base, table, rowptr, col, n_rows, F, segs);
+}
+
+int cognn_gather_csr_open_u64(cognn_ctx* ctx, uint64_t* out, const uint64_t* base, const uint64_t* table,
+                              const uint32_t* rowptr, const uint32_t* col, int64_t n_rows, int64_t F,
+                              int32_t nseg, const int64_t* seg_begin, const int64_t* seg_end, const uint64_t* seg_key) {
+    CG_REQUIRE(nseg >= 0 && nseg <= 32 && (nseg == 0 || (seg_begin && seg_end && seg_key)), "cognn_gather_csr_open_u64: bad segment list");
+    OpenSegs segs;
+    segs.n = nseg;
+    for (int i = 0; i < nseg; ++i) { segs.begin[i] = (int)seg_begin[i]; segs.end[i] = (int)seg_end[i]; segs.key[i] = seg_key[i]; }
+    return gather_impl(ctx, out, base, table, rowptr, col, n_rows, F, segs);
+}
+
+static int gather_impl(cognn_ctx* ctx, uint64_t* out, const uint64_t* base, const uint64_t* table, const uint32_t* rowptr,
+                       const uint32_t* col, int64_t n_rows, int64_t F, const OpenSegs& segs) {
     CG_REQUIRE(ctx && out && table && rowptr, "cognn_gather_csr_u64: null argument");
     CG_REQUIRE(n_rows >= 0 && n_rows < (1ll << 31) && F > 0 && F < (1 << 20), "cognn_gather_csr_u64: bad shape %lld x %lld",
                (long long)n_rows, (long long)F);
     if (n_rows == 0) return 0;
     const bool vec = (F % 2 == 0) && cg_aligned16(out) && cg_aligned16(table) && (base == nullptr || cg_aligned16(base));
-    if (vec) return launch_gather<2>(ctx, (u64*)out, (const u64*)base, (const u64*)table, rowptr, col, (int)n_rows, (int)F);
-    return launch_gather<1>(ctx, (u64*)out, (const u64*)base, (const u64*)table, rowptr, col, (int)n_rows, (int)F);
+    if (vec) return launch_gather<2>(ctx, (u64*)out, (const u64*)base, (const u64*)table, rowptr, col, (int)n_rows, (int)F, segs);
+    return launch_gather<1>(ctx, (u64*)out, (const u64*)base, (const u64*)table, rowptr, col, (int)n_rows, (int)F, segs);
 }
 
 int cognn_scatter_add_rows_u64(cognn_ctx* ctx, uint64_t* v, const uint64_t* partial, const uint32_t* row_index,

@@ -83,6 +83,7 @@ struct cognn_engine {
     cognn_exchange_fn xfn = nullptr;
     void* xuser = nullptr;
     bool started = false, timing = false;
+    int64_t gemm_x_opened_for = -1;    // iteration whose PreScatter GEMM input was already opened by the previous ReLU close
     // share table of the current message-passing round
     int64_t tableRows = 0, aggRows = 0, inboxRows = 0, inboxLocalOff = 0, partRows = 0;
     int Fmp = 0;
@@ -200,12 +201,12 @@ void trunc_stage(cognn_engine* E, int64_t it, int op, u64 mul, const std::vector
 
 // Beaver GEMM for every side: X(side), Wm(side) -> truncated product written to dst(side)
 template <class XFn, class WFn, class SpecFn, class DstFn>
-void gemm_stage(cognn_engine* E, int64_t it, XFn X, WFn Wm, SpecFn spec, DstFn dst) {
+void gemm_stage(cognn_engine* E, int64_t it, XFn X, WFn Wm, SpecFn spec, DstFn dst, bool x_opened = false) {
     std::vector<int64_t> e0, e1, eo;
     for (auto& s : E->sides) {
         GemmSpec g = spec(s);
         cognn_keys k = keys(E, s.owner, it, g.op);
-        BE(cognn_mask_open_u64(E->ctx, s.ob[0], X(s), k.k[s.p == 0 ? COGNN_SL_A0 : COGNN_SL_A1], g.M, g.K, g.transA));
+        if (!x_opened) BE(cognn_mask_open_u64(E->ctx, s.ob[0], X(s), k.k[s.p == 0 ? COGNN_SL_A0 : COGNN_SL_A1], g.M, g.K, g.transA));
         BE(cognn_mask_open_u64(E->ctx, s.ob[1], Wm(s), k.k[s.p == 0 ? COGNN_SL_B0 : COGNN_SL_B1], g.K, g.N, 0));
         e0.push_back(g.M * g.K); e1.push_back(g.K * g.N); eo.push_back(g.M * g.N);
     }
@@ -262,18 +263,32 @@ void gemm_stage(cognn_engine* E, int64_t it, XFn X, WFn Wm, SpecFn spec, DstFn d
 
 // row scale by the (owner-known) normaliser followed by truncation; x(side) [n x F] -> dst(side)
 template <class XFn, class DstFn>
-void rowscale_stage(cognn_engine* E, int64_t it, int op, int top, int F, XFn X, DstFn dst) {
+void rowscale_stage(cognn_engine* E, int64_t it, int op, int top, int F, XFn X, DstFn dst, bool e_opened = false) {
+    // e_opened: X(side) already holds the opening E_p = V_p - a_p (written by the gather epilogue)
     std::vector<int64_t> eF, e1;
     for (auto& s : E->sides) {
         cognn_keys k = keys(E, s.owner, it, op);
-        BE(cognn_rowscale_open_u64(E->ctx, s.ob[0], s.ob[1], X(s), s.svec, &k, s.p, s.n, F));
+        BE(cognn_rowscale_open_u64(E->ctx, e_opened ? nullptr : s.ob[0], s.ob[1], X(s), s.svec, &k, s.p, s.n, F));
         eF.push_back((int64_t)s.n * F); e1.push_back(s.n);
     }
-    exchange_ob(E, 0, eF);
+    if (e_opened) {
+        XList xl;
+        for (size_t i = 0; i < E->sides.size(); ++i) {
+            Side& s = E->sides[i];
+            if (s.peer) continue;
+            xl.send(s.peer_rank, X(s), eF[i] * 8);
+            xl.recv(s.peer_rank, s.ib[0], eF[i] * 8);
+        }
+        run_exchange(E, xl);
+    } else {
+        exchange_ob(E, 0, eF);
+    }
     exchange_ob(E, 1, e1);
     for (auto& s : E->sides) {                              // the opened sums E0+E1, G0+G1 are formed inside the kernel
         cognn_keys k = keys(E, s.owner, it, op), tk = keys(E, s.owner, it, top);
-        BE(cognn_rowscale_close_u64(E->ctx, s.ob[2], s.ob[0], s.ib[0], s.ob[1], s.ib[1], &k, &tk, s.p, s.n, F));
+        const u64* e_own = e_opened ? X(s) : s.ob[0];
+        const u64* e_peer = e_opened ? (s.peer ? X(*s.peer) : s.ib[0]) : s.ib[0];
+        BE(cognn_rowscale_close_u64(E->ctx, s.ob[2], e_own, e_peer, s.ob[1], s.ib[1], &k, &tk, s.p, s.n, F));
     }
     exchange_ob(E, 2, eF);
     for (size_t i = 0; i < E->sides.size(); ++i) {
@@ -299,12 +314,16 @@ void relu_stage(cognn_engine* E, int64_t it) {
         BE(cognn_relu_mul_u64(E->ctx, s.ob[2], s.ob[0], s.ib[0], s.ob[1], s.ib[1], &k, s.p, eF[i]));
     }
     exchange_ob(E, 2, eF);
+    // H is the next iteration's PreScatter GEMM input (layer 1): write it straight into its h_t slot and emit the
+    // Beaver opening E_p = H_p - A_p of that product in the same pass (gcn.h:230-239 of iteration it+1)
     for (size_t i = 0; i < E->sides.size(); ++i) {
         Side& s = E->sides[i];
-        u64* dstb = (s.cur == s.buf[1]) ? s.buf[0] : s.buf[1];
-        BE(cognn_relu_close_u64(E->ctx, dstb, s.relu_mask, s.cur, s.ob[2], s.ib[2], eF[i]));
-        s.cur = dstb;
+        cognn_keys nk = keys(E, s.owner, it + 1, COGNN_OP_PS_GEMM);
+        BE(cognn_relu_close_open_u64(E->ctx, s.h1, s.ob[0], s.relu_mask, s.cur, s.ob[2], s.ib[2],
+                                     nk.k[s.p == 0 ? COGNN_SL_A0 : COGNN_SL_A1], eF[i]));
+        s.cur = s.h1;
     }
+    E->gemm_x_opened_for = it + 1;
 }
 
 void softmax_stage(cognn_engine* E, int64_t it) {
@@ -341,7 +360,7 @@ u64* table_seg(cognn_engine* E, Side& s, int F) {
     return E->table + off * F;
 }
 
-void message_passing(cognn_engine* E, int F) {
+void message_passing(cognn_engine* E, int F, int64_t it, bool open_scale) {
     // replicate the co-party's fresh share of every owner to the other ranks (ss_...h:997-1002 / :982)
     if (E->world > 1) {
         XList xl;
@@ -380,7 +399,20 @@ void message_passing(cognn_engine* E, int F) {
     }
     // aggregate: out = self + local in-edges + replica in-edges (owner rows) / + received partials (co rows)
     if (E->timing) BE(cognn_timer_begin(E->ctx, T_AGG));
-    BE(cognn_gather_csr_u64(E->ctx, E->aggOut, E->table, E->table, E->agg_rowptr, E->agg_col, E->aggRows, F));
+    if (open_scale) {
+        // the row scale that follows needs E_p = V_p - a_p: emit it from the gather epilogue instead of V_p
+        std::vector<int64_t> sb, se;
+        std::vector<u64> sk;
+        for (auto& s : E->sides) {
+            const int64_t off = s.p == 0 ? E->A_off[s.owner] : E->B_off[s.owner];
+            cognn_keys k = keys(E, s.owner, it, COGNN_OP_GA_SCALE);
+            sb.push_back(off); se.push_back(off + s.n); sk.push_back(k.k[s.p == 0 ? COGNN_SL_A0 : COGNN_SL_A1]);
+        }
+        BE(cognn_gather_csr_open_u64(E->ctx, E->aggOut, E->table, E->table, E->agg_rowptr, E->agg_col, E->aggRows, F,
+                                     (int32_t)sb.size(), sb.data(), se.data(), sk.data()));
+    } else {
+        BE(cognn_gather_csr_u64(E->ctx, E->aggOut, E->table, E->table, E->agg_rowptr, E->agg_col, E->aggRows, F));
+    }
     if (E->timing) {
         BE(cognn_timer_end(E->ctx, T_AGG));
         E->algo[T_AGG] += 8.0 * F * ((double)E->aggEdges + 2.0 * E->aggRows) + 4.0 * E->aggEdges + 4.0 * (E->aggRows + 1);
@@ -524,12 +556,13 @@ void run_iteration(cognn_engine* E, int64_t it) {
         const int F = mp_width(E, I.e);
         // ---- PreScatterComp (gcn.h:198-255) ----
         if (I.fwd) {
-            if (I.layer == 1)
+            const bool x_opened = (I.layer == 1 && E->gemm_x_opened_for == it);   // H already sits in h_t[1], opened
+            if (I.layer == 1 && !x_opened)
                 for (auto& s : E->sides) BE(cognn_memcpy_d2d(E->ctx, s.h1, s.cur, (size_t)s.n * E->hid() * 8));   // h_t[1]
             const bool scale_follows = I.e != 0;
             gemm_stage(E, it, [&](Side& s) { return s.cur; }, [&](Side& s) { return s.W[I.layer]; },
                        [&](Side& s) { return prescatter_spec(E, s, I.layer); },
-                       [&](Side& s) { return scale_follows ? s.buf[1] : table_seg(E, s, F); });
+                       [&](Side& s) { return scale_follows ? s.buf[1] : table_seg(E, s, F); }, x_opened);
             if (scale_follows)
                 rowscale_stage(E, it, COGNN_OP_PS_SCALE, COGNN_OP_PS_SCALE_TRUNC, F, [&](Side& s) { return s.buf[1]; },
                                [&](Side& s) { return table_seg(E, s, F); });
@@ -538,10 +571,12 @@ void run_iteration(cognn_engine* E, int64_t it) {
                            [&](Side& s) { return table_seg(E, s, F); });
         }
         // ---- Scatter / PreMerge / Gather ----
-        message_passing(E, F);
-        if ((it + 1) % I.ep != 0) {                        // gcn.h:470
+        const bool gscale = (it + 1) % I.ep != 0;          // gcn.h:470
+        const bool fuse_open = gscale && E->sides.size() <= 32;
+        message_passing(E, F, it, fuse_open);
+        if (gscale) {
             rowscale_stage(E, it, COGNN_OP_GA_SCALE, COGNN_OP_GA_SCALE_TRUNC, F, [&](Side& s) { return s.cur; },
-                           [&](Side& s) { return s.buf[1]; });
+                           [&](Side& s) { return s.buf[1]; }, fuse_open);
             for (auto& s : E->sides) s.cur = s.buf[1];
         }
     }

@@ -62,6 +62,12 @@ int cognn_prng_fill_u64(cognn_ctx*, uint64_t* out, uint64_t key, int64_t n);
  * CSR values are implicitly 1; rows with no entries are the reference's masked (dummy) rows. */
 int cognn_gather_csr_u64(cognn_ctx*, uint64_t* out, const uint64_t* base, const uint64_t* table,
                          const uint32_t* rowptr, const uint32_t* col, int64_t n_rows, int64_t F);
+/* Same gather, but rows inside one of the `nseg` row segments are written as the Beaver opening of the row scale that
+ * follows (twoPartyGCNVectorScale after GatherComp, gcn.h:476): out[r,j] = V[r,j] - prng(seg_key[s], (r-seg_begin[s])*F + j)
+ * where V is the gathered value; rows outside every segment are written as V.  nseg <= 32. */
+int cognn_gather_csr_open_u64(cognn_ctx*, uint64_t* out, const uint64_t* base, const uint64_t* table,
+                              const uint32_t* rowptr, const uint32_t* col, int64_t n_rows, int64_t F,
+                              int32_t nseg, const int64_t* seg_begin, const int64_t* seg_end, const uint64_t* seg_key);
 /* v[row_index[q],:] += partial[q,:]  (row_index entries distinct): receive side of the mirror
  * vertex update exchange (ss_...h:847-854 with allow-missing, then gcn.h:456). */
 int cognn_scatter_add_rows_u64(cognn_ctx*, uint64_t* v, const uint64_t* partial, const uint32_t* row_index,
@@ -109,6 +115,7 @@ int cognn_trunc_close_u64(cognn_ctx*, uint64_t* out, const uint64_t* c0, const u
                           int p, int mode, int64_t n);
 
 /* ---- sci::twoPartyGCNVectorScale (gcn.h:247,476): row scale by an additively shared vector - */
+/* E_p = V_p - a_p [rows x F] (skipped when E == NULL: already opened by cognn_gather_csr_open_u64), G_p = s_p - b_p [rows] */
 int cognn_rowscale_open_u64(cognn_ctx*, uint64_t* E, uint64_t* G, const uint64_t* V, const uint64_t* s,
                             const cognn_keys* keys, int p, int64_t rows, int64_t F);
 /* z_p = p*E*G + E*b_p + a_p*G + c_p, immediately followed by trunc_open with tkeys:
@@ -125,6 +132,9 @@ int cognn_relu_mul_u64(cognn_ctx*, uint64_t* w, const uint64_t* E0, const uint64
 /* h_p = (int64)(w0+w1) > 0 ? z_p : 0; mask (1 byte/element, public) may be NULL */
 int cognn_relu_close_u64(cognn_ctx*, uint64_t* h, uint8_t* mask, const uint64_t* z, const uint64_t* w0, const uint64_t* w1, int64_t n);
 int cognn_mask_select_u64(cognn_ctx*, uint64_t* out, const uint64_t* in, const uint8_t* mask, int64_t n);
+/* relu_close fused with the Beaver opening of the next product: also writes E[i] = h[i] - prng(key_open, i) */
+int cognn_relu_close_open_u64(cognn_ctx*, uint64_t* h, uint64_t* E, uint8_t* mask, const uint64_t* z, const uint64_t* w0, const uint64_t* w1,
+                              uint64_t key_open, int64_t n);
 
 /* ---- twoPartyGCNForwardNNPredictionWithoutWeight + getPlainShareVecVec (gcn.h:578-604) ---- */
 /* owner side (p=0): z=z0+z1 -> integer softmax pfx (Q16) ; p0 = pfx - rho ; d0 = p0 - onehot(label),

@@ -117,6 +117,15 @@ int cognn_gather_csr_u64(cognn_ctx*, uint64_t* out, const uint64_t* base, const 
     }
     return 0;
 }
+int cognn_gather_csr_open_u64(cognn_ctx* c, uint64_t* out, const uint64_t* base, const uint64_t* table, const uint32_t* rowptr,
+                              const uint32_t* col, int64_t n_rows, int64_t F, int32_t nseg, const int64_t* sb, const int64_t* se,
+                              const uint64_t* sk) {
+    cognn_gather_csr_u64(c, out, base, table, rowptr, col, n_rows, F);
+    for (int s = 0; s < nseg; ++s)
+        for (int64_t r = sb[s]; r < se[s]; ++r)
+            for (int64_t j = 0; j < F; ++j) out[r * F + j] -= cognn_prng(sk[s], (u64)((r - sb[s]) * F + j));
+    return 0;
+}
 int cognn_scatter_add_rows_u64(cognn_ctx*, uint64_t* v, const uint64_t* part, const uint32_t* idx, int64_t n, int64_t F) {
     for (int64_t q = 0; q < n; ++q)
         for (int64_t j = 0; j < F; ++j) v[(size_t)idx[q] * F + j] += part[q * F + j];
@@ -204,7 +213,7 @@ int cognn_trunc_close_u64(cognn_ctx*, uint64_t* out, const uint64_t* c0, const u
 }
 int cognn_rowscale_open_u64(cognn_ctx*, uint64_t* E, uint64_t* G, const uint64_t* V, const uint64_t* s, const cognn_keys* keys,
                             int p, int64_t rows, int64_t F) {
-    for (int64_t i = 0; i < rows * F; ++i) E[i] = V[i] - cognn_prng(keys->k[p == 0 ? COGNN_SL_A0 : COGNN_SL_A1], (u64)i);
+    if (E) for (int64_t i = 0; i < rows * F; ++i) E[i] = V[i] - cognn_prng(keys->k[p == 0 ? COGNN_SL_A0 : COGNN_SL_A1], (u64)i);
     for (int64_t r = 0; r < rows; ++r) G[r] = s[r] - cognn_prng(keys->k[p == 0 ? COGNN_SL_B0 : COGNN_SL_B1], (u64)r);
     return 0;
 }
@@ -239,6 +248,12 @@ int cognn_relu_close_u64(cognn_ctx*, uint64_t* h, uint8_t* mask, const uint64_t*
         h[i] = pos ? z[i] : 0;
         if (mask) mask[i] = pos;
     }
+    return 0;
+}
+int cognn_relu_close_open_u64(cognn_ctx* c, uint64_t* h, uint64_t* E, uint8_t* mask, const uint64_t* z, const uint64_t* w0, const uint64_t* w1,
+                              uint64_t key_open, int64_t n) {
+    cognn_relu_close_u64(c, h, mask, z, w0, w1, n);
+    for (int64_t i = 0; i < n; ++i) E[i] = h[i] - cognn_prng(key_open, (u64)i);
     return 0;
 }
 int cognn_mask_select_u64(cognn_ctx*, uint64_t* out, const uint64_t* in, const uint8_t* mask, int64_t n) {

@@ -340,3 +340,36 @@ def test_beaver_gemm_pair(ctx, M, N, K, transA):
     assert np.array_equal(host(Z[0]), z0) and np.array_equal(host(Z[1]), z1)
     with np.errstate(over="ignore"):
         assert np.array_equal(host(Z[0]) + host(Z[1]), co.ring_matmul(X, W))
+
+
+def test_gather_csr_open_epilogue(ctx):
+    """Gather whose output rows inside given segments are the Beaver opening V - prng(key, local index)."""
+    rng = np.random.default_rng(77)
+    n_rows, n_table, F = 300, 500, 16
+    rowptr, col = _random_csr(rng, n_rows, n_table, 6)
+    table = rand_u64(rng, (n_table, F)); base = rand_u64(rng, (n_rows, F))
+    sb = np.array([0, 130], dtype=np.int64); se = np.array([100, 300], dtype=np.int64)
+    sk = np.array([co.stream_key(1, 2, 3, 4, 0), co.stream_key(1, 5, 3, 4, 1)], dtype=np.uint64)
+    out = dev_empty((n_rows, F))
+    ctx.call("cognn_gather_csr_open_u64", ptr(out), ptr(dev(base)), ptr(dev(table)), ptr(dev(rowptr.view(np.int32))),
+             ptr(dev(col.view(np.int32))), n_rows, F, 2, ctypes.c_void_p(sb.ctypes.data), ctypes.c_void_p(se.ctypes.data),
+             ctypes.c_void_p(sk.ctypes.data))
+    want = _csr_ref(base, table, rowptr, col)
+    with np.errstate(over="ignore"):
+        for b, e, k in zip(sb, se, sk):
+            want[b:e] -= co.prng(int(k), (e - b) * F).reshape(e - b, F)
+    assert np.array_equal(host(out), want)
+
+
+def test_relu_close_open(ctx):
+    rng = np.random.default_rng(78)
+    n = 3001
+    z = rand_u64(rng, n); w0 = rand_u64(rng, n); w1 = rand_u64(rng, n)
+    key = co.stream_key(9, 9, 9, 9, 1)
+    h, E, mask = dev_empty(n), dev_empty(n), dev_empty(n, "u8")
+    ctx.call("cognn_relu_close_open_u64", ptr(h), ptr(E), ptr(mask), ptr(dev(z)), ptr(dev(w0)), ptr(dev(w1)), ctypes.c_uint64(key), n)
+    with np.errstate(over="ignore"):
+        pos = (w0 + w1).astype(np.int64) > 0
+        hw = np.where(pos, z, U64(0))
+        assert np.array_equal(host(h), hw) and np.array_equal(host(E), hw - co.prng(key, n))
+    assert np.array_equal(host(mask, np.uint8).astype(bool), pos)
