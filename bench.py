@@ -150,6 +150,12 @@ def main():
     n_gemm, ms_gemm, ops_gemm = eng.timing(2)
     eng.enable_timing(False)
 
+    # HBM traffic of the dominant kernel from the committed PMC passes (profiles/; collected with this same command)
+    traffic, traffic_src = None, None
+    pmc = os.path.join(ROOT, "profiles", "r01_c_gather_pmc_traffic.json")
+    if args.workload == "config5" and world == 1 and os.path.exists(pmc):
+        traffic = json.load(open(pmc)).get("aggregate_launch_avg_bytes")
+        traffic_src = "profiles/r01_c_gather_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH x2 gfx950 correction)"
     ms_per_step = dt / args.steps * 1e3
     ef_per_step = float(len(src)) * message_widths(variant, iters, hid, lab)
     value = ef_per_step / (dt / args.steps)
@@ -168,7 +174,8 @@ def main():
         "offline_ms": offline_ms, "setup_s": setup_s,
         "roofline": {"bound": "hbm", "kernel": "gather_csr_kernel (aggregate launch)",
                      "achieved": (bytes_agg / 1e9) / (ms_agg / 1e3) if ms_agg > 0 else None, "peak": 8000.0, "unit": "GB/s",
-                     "frac": ((bytes_agg / 1e9) / (ms_agg / 1e3) / 8000.0) if ms_agg > 0 else None, "traffic": None,
+                     "frac": ((bytes_agg / 1e9) / (ms_agg / 1e3) / 8000.0) if ms_agg > 0 else None, "traffic": traffic,
+                     "traffic_unit": "bytes per launch", "traffic_source": traffic_src,
                      "launches": n_agg, "avg_ms": ms_agg / max(n_agg, 1), "algo_bytes_per_launch": bytes_agg / max(n_agg, 1)},
         "kernels": {"gather_partials": {"launches": n_part, "avg_ms": ms_part / max(n_part, 1),
                                         "GBps": (bytes_part / 1e9) / (ms_part / 1e3) if ms_part > 0 else None},
