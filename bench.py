@@ -57,11 +57,12 @@ def message_widths(variant, iters, hid, lab):
 
 
 def cpu_baseline(args, wl):
-    """The numpy oracle on a bounded 1/64-scale sample of the same workload (rank 0, N=1 only)."""
+    """The numpy oracle on a bounded 1/16-scale sample of the same workload (rank 0, N=1 only): a few seconds of
+    single-core work inside the timed region (its Python-loop preprocessing is outside it)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import cognn_oracle as co
     k, lv, le, in_dim, hid, lab, variant, iters = wl
-    lv2, le2 = max(lv - 6, 8), max(le - 6, 10)
+    lv2, le2 = max(lv - 4, 8), max(le - 4, 10)
     V, Eu = 1 << lv2, 1 << (le2 - 1)
     src, dst = co.synth_graph(V, Eu, 0xC06A11)
     part = np.arange(V) % k
