@@ -44,6 +44,8 @@ struct Side {
     int peer_rank = 0;
     Side* peer = nullptr;          // non-null when the other share-holder is hosted on this rank
     u64* feat = nullptr;           // [n x in] input-feature share (localVertexSvvBackup / remoteVertexSvvsBackup)
+    u64* featE = nullptr;          // E_p = feat_p - A_p of the layer-0 product, opened once (fixed-operand mask reuse)
+    u64* featE_peer = nullptr;     // the peer's opening (alias when co-located)
     u64* W[2] = {nullptr, nullptr};
     u64* WT = nullptr;             // transposed W1 scratch [lab x hid]
     u64* h1 = nullptr;             // h_t of layer 1 [n x hid]   (vertexInterData["h_t"], gcn.h:230-231)
@@ -139,6 +141,13 @@ cognn_keys keys(cognn_engine* E, u64 owner, int64_t it, int op) {
     for (int i = 0; i < COGNN_SL_COUNT; ++i) k.k[i] = o.k[i];
     return k;
 }
+// layer-0 PreScatter product: the feature operand's mask A is dealt once (iteration 0), B and C per iteration
+cognn_keys feature_gemm_keys(cognn_engine* E, u64 owner, int64_t it) {
+    cognn_keys k = keys(E, owner, it, COGNN_OP_PS_GEMM), k0 = keys(E, owner, 0, COGNN_OP_PS_GEMM);
+    k.k[COGNN_SL_A0] = k0.k[COGNN_SL_A0];
+    k.k[COGNN_SL_A1] = k0.k[COGNN_SL_A1];
+    return k;
+}
 
 u64 fx_llround(double x) { return (u64)(long long)llround(x * (double)COGNN_FX_ONE); }
 u64 fx_trunc(double x) { return (u64)(x * (double)COGNN_FX_ONE); }   // static_cast as in gcn.h:676,678,764
@@ -180,6 +189,7 @@ struct GemmSpec {            // logical Z[MxN] = X[MxK] . Wm[KxN]
     int64_t M, N, K;
     int transA;
     int op, top;             // dealer op ids for the product and its truncation
+    bool feature = false;    // layer-0 product on the constant feature operand (opening cached in Side::featE)
 };
 
 // truncation of every side's `x` (elems) scaled by `mul`; result written/applied to dst(side)
@@ -203,14 +213,16 @@ void trunc_stage(cognn_engine* E, int64_t it, int op, u64 mul, const std::vector
 template <class XFn, class WFn, class SpecFn, class DstFn>
 void gemm_stage(cognn_engine* E, int64_t it, XFn X, WFn Wm, SpecFn spec, DstFn dst, bool x_opened = false) {
     std::vector<int64_t> e0, e1, eo;
+    const bool feature = spec(E->sides[0]).feature;
+    auto gkeys = [&](Side& s, const GemmSpec& g) { return g.feature ? feature_gemm_keys(E, s.owner, it) : keys(E, s.owner, it, g.op); };
     for (auto& s : E->sides) {
         GemmSpec g = spec(s);
-        cognn_keys k = keys(E, s.owner, it, g.op);
-        if (!x_opened) BE(cognn_mask_open_u64(E->ctx, s.ob[0], X(s), k.k[s.p == 0 ? COGNN_SL_A0 : COGNN_SL_A1], g.M, g.K, g.transA));
+        cognn_keys k = gkeys(s, g);
+        if (!x_opened && !feature) BE(cognn_mask_open_u64(E->ctx, s.ob[0], X(s), k.k[s.p == 0 ? COGNN_SL_A0 : COGNN_SL_A1], g.M, g.K, g.transA));
         BE(cognn_mask_open_u64(E->ctx, s.ob[1], Wm(s), k.k[s.p == 0 ? COGNN_SL_B0 : COGNN_SL_B1], g.K, g.N, 0));
         e0.push_back(g.M * g.K); e1.push_back(g.K * g.N); eo.push_back(g.M * g.N);
     }
-    exchange_ob(E, 0, e0);
+    if (!feature) exchange_ob(E, 0, e0);                    // the feature opening was exchanged once in start()
     exchange_ob(E, 1, e1);
     for (size_t i = 0; i < E->sides.size(); ++i) {
         Side& s = E->sides[i];
@@ -223,7 +235,9 @@ void gemm_stage(cognn_engine* E, int64_t it, XFn X, WFn Wm, SpecFn spec, DstFn d
     for (size_t i = 0; i < E->sides.size(); ++i) {
         Side& s = E->sides[i];
         GemmSpec g = spec(s);
-        cognn_keys k = keys(E, s.owner, it, g.op);
+        cognn_keys k = gkeys(s, g);
+        const u64* e_own = feature ? s.featE : s.ob[0];
+        const u64* e_peer = feature ? s.featE_peer : s.ib[0];
         const u64* c1 = nullptr;
         if (s.p == 1) {
             auto f = s.c1.find({it, g.op});
@@ -237,9 +251,9 @@ void gemm_stage(cognn_engine* E, int64_t it, XFn X, WFn Wm, SpecFn spec, DstFn d
         if (E->timing) BE(cognn_timer_begin(E->ctx, T_GEMM));
         if (all_raw) {
             // fused single-launch product without C_p; C_p joins in the truncation opening below
-            BE(cognn_beaver_gemm_close_raw_u64(E->ctx, s.zbuf, s.ob[0], s.ib[0], s.fsum, &k, s.p, g.M, g.N, g.K, s.scratch));
+            BE(cognn_beaver_gemm_close_raw_u64(E->ctx, s.zbuf, e_own, e_peer, s.fsum, &k, s.p, g.M, g.N, g.K, s.scratch));
         } else {
-            BE(cognn_beaver_gemm_close_u64(E->ctx, s.zbuf, s.ob[0], s.ib[0], s.fsum, c1, &k, s.p, g.M, g.N, g.K, g.transA, s.scratch));
+            BE(cognn_beaver_gemm_close_u64(E->ctx, s.zbuf, e_own, e_peer, s.fsum, c1, &k, s.p, g.M, g.N, g.K, g.transA, s.scratch));
         }
         if (E->timing) { BE(cognn_timer_end(E->ctx, T_GEMM)); E->algo[T_GEMM] += 2.0 * 36 * 2 * (double)g.M * g.K * g.N; }
         if (all_raw) {
@@ -515,7 +529,9 @@ int mp_width(cognn_engine* E, int e) {                    // getPlainNumPerOpera
 }
 
 GemmSpec prescatter_spec(cognn_engine* E, Side& s, int layer) {
-    return GemmSpec{s.n, layer == 0 ? E->hid() : E->lab(), layer == 0 ? E->in() : E->hid(), 0, COGNN_OP_PS_GEMM, COGNN_OP_PS_GEMM_TRUNC};
+    GemmSpec g{s.n, layer == 0 ? E->hid() : E->lab(), layer == 0 ? E->in() : E->hid(), 0, COGNN_OP_PS_GEMM, COGNN_OP_PS_GEMM_TRUNC};
+    g.feature = (layer == 0);
+    return g;
 }
 
 void weight_update_chain(cognn_engine* E, int64_t it, int layer) {
@@ -633,7 +649,7 @@ void run_offline(cognn_engine* E, int64_t it0, int64_t it1) {
                 have = true;
             }
             if (!have || s.c1.count({it, g.op})) continue;
-            cognn_keys k = keys(E, s.owner, it, g.op);
+            cognn_keys k = g.feature ? feature_gemm_keys(E, s.owner, it) : keys(E, s.owner, it, g.op);
             u64* c = dalloc<u64>(E, (size_t)(g.M * g.N));
             BE(cognn_dealer_gemm_c1_u64(E->ctx, c, &k, g.M, g.N, g.K, g.transA, s.scratch, s.scratch + g.M * g.K));
             s.c1[{it, g.op}] = c;
@@ -792,6 +808,7 @@ void alloc_sides(cognn_engine* E) {
         const size_t n = (size_t)s.n;
         const size_t big = std::max<size_t>({n * (size_t)in, (size_t)in * hid, n * (size_t)fm, (size_t)hid * lab});
         s.feat = dalloc<u64>(E, n * in);
+        s.featE = dalloc<u64>(E, n * in);
         s.W[0] = dalloc<u64>(E, (size_t)in * hid);
         s.W[1] = dalloc<u64>(E, (size_t)hid * lab);
         s.WT = dalloc<u64>(E, (size_t)hid * lab);
@@ -816,6 +833,7 @@ void alloc_sides(cognn_engine* E) {
     for (auto& s : E->sides) {
         const size_t n = (size_t)s.n;
         const size_t big = std::max<size_t>({n * (size_t)in, (size_t)in * hid, n * (size_t)fm, (size_t)hid * lab});
+        s.featE_peer = s.peer ? s.peer->featE : dalloc<u64>(E, n * (size_t)in);
         for (int j = 0; j < 3; ++j) {
             if (s.peer) s.ib[j] = s.peer->ob[j];           // in-device exchange: read the peer's outbox directly
             else { s.ib_store[j] = dalloc<u64>(E, big); s.ib[j] = s.ib_store[j]; }
@@ -867,6 +885,18 @@ void start(cognn_engine* E) {
             BE(cognn_share_split_u64(E->ctx, dW[l], wkey, s.p == 0 ? s.W[l] : nullptr, s.p == 1 ? s.W[l] : nullptr, elems));
         }
         s.cur = s.feat; s.curF = in;
+        // the layer-0 product's feature opening E_p = X_p - A_p, once for all epochs
+        cognn_keys fk = feature_gemm_keys(E, s.owner, 0);
+        BE(cognn_mask_open_u64(E->ctx, s.featE, s.feat, fk.k[s.p == 0 ? COGNN_SL_A0 : COGNN_SL_A1], (int64_t)n, in, 0));
+    }
+    {
+        XList xl;
+        for (auto& s : E->sides) {
+            if (s.peer) continue;
+            xl.send(s.peer_rank, s.featE, (int64_t)s.n * in * 8);
+            xl.recv(s.peer_rank, s.featE_peer, (int64_t)s.n * in * 8);
+        }
+        run_exchange(E, xl);
     }
     BE(cognn_ctx_sync(E->ctx));
     E->started = true;

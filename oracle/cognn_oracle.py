@@ -489,6 +489,12 @@ class OracleEngine:
     def key_of(self, owner, it, op):
         return lambda slot: stream_key(self.seed, owner, it, op, slot)
 
+    def key_of_feature_gemm(self, owner, it):
+        """Layer-0 PreScatter product X.W0: X (the input features) is the same tensor in every epoch, so its Beaver mask A
+        is dealt once (iteration 0) and E = X - A is opened once; W0's mask B and the product share C stay per-iteration
+        (fixed-operand mask reuse)."""
+        return lambda slot: stream_key(self.seed, owner, 0 if slot in (SL_A0, SL_A1) else it, OP_PS_GEMM, slot)
+
     # -- onAlgoKernelStart (gcn.h:854-887) + share distribution (ss_...h:205-232) ------------
     def _start(self, features, labels, weights):
         g = self.param; k = self.k
@@ -554,7 +560,7 @@ class OracleEngine:
             gsP.localInter[layer]["h_t"] = xA.copy()          # stored untransposed; used as X^T below
             gsC.remoteInter[layer]["h_t"] = xB.copy()
             zA, zB = beaver_gemm_pair(xA, xB, gsP.localWeight[layer], gsC.remoteWeight[layer],
-                                      self.key_of(P, it, OP_PS_GEMM))
+                                      self.key_of_feature_gemm(P, it) if layer == 0 else self.key_of(P, it, OP_PS_GEMM))
             xA, xB = trunc_pair(zA, zB, self.key_of(P, it, OP_PS_GEMM_TRUNC))
         if e != 0:
             zA, zB = beaver_rowscale_pair(xA, xB, sA, sB, self.key_of(P, it, OP_PS_SCALE))
