@@ -48,7 +48,12 @@ WORKLOADS = {
     "config5-h16": (8, 20, 24, 128, 16, 16, "optimize-gcn-inference", 2),
     "config5-train": (8, 20, 24, 128, 64, 16, "optimize-gcn", 6),
     "small": (8, 14, 18, 128, 64, 16, "optimize-gcn-inference", 2),
+    # BASELINE.json configs[1..3]: one training epoch on dataset-shaped synthetic graphs (exact V / E below)
+    "cora-2p": (2, None, None, 1433, 16, 7, "optimize-gcn", 6),
+    "citeseer-2p": (2, None, None, 3703, 16, 6, "optimize-gcn", 6),
+    "pubmed-4p": (4, None, None, 500, 16, 3, "optimize-gcn", 6),
 }
+DATASET_VE = {"cora-2p": (2708, 10556), "citeseer-2p": (3312, 10016), "pubmed-4p": (19717, 128146)}
 
 
 def message_widths(variant, iters, hid, lab):
@@ -108,7 +113,11 @@ def main():
     k, lv, le, in_dim, hid, lab, variant, iters = wl
     if k % world != 0:
         raise SystemExit("the %d parties must divide evenly over %d GPUs" % (k, world))
-    V, Eu = 1 << lv, 1 << (le - 1)
+    if args.workload in DATASET_VE:
+        V, Eu = DATASET_VE[args.workload][0], DATASET_VE[args.workload][1] // 2
+        lv, le = int(np.log2(V)), int(np.log2(2 * Eu))
+    else:
+        V, Eu = 1 << lv, 1 << (le - 1)
     t_setup = time.perf_counter()
     src, dst = synth_graph(V, Eu, 0xC06A11)
     part = (np.arange(V) % k).astype(np.int32)
@@ -166,9 +175,9 @@ def main():
         "value": value, "unit": "edges*feat/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "u64", "data": "synthetic",
-        "config": {"workload": "%d-party %s pass (GAS iterations 0-%d) on a synthetic 2^%d-vertex/2^%d-edge global graph, "
+        "config": {"workload": "%d-party %s pass (GAS iterations 0-%d) on a synthetic %d-vertex/%d-edge global graph, "
                                "partition vid %% %d, input_dim=%d hidden_dim=%d num_labels=%d, %d part%s per GPU"
-                               % (k, variant, iters - 1, lv, le, k, in_dim, hid, lab, k // world, "y" if k // world == 1 else "ies"),
+                               % (k, variant, iters - 1, V, 2 * Eu, k, in_dim, hid, lab, k // world, "y" if k // world == 1 else "ies"),
                    "name": args.workload, "parties": k, "exchange": "in-device" if world == 1 else "rccl-p2p"},
         "epoch_time_s": dt / args.steps,
         "edges_feat_per_s_per_party": value / k,

@@ -435,6 +435,146 @@ __global__ __launch_bounds__(kFusedThreads) void beaver_gemm_fused_kernel(u64* Z
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// TN products (weight gradients d = h_t^T . in, gcn.h:671,710): logical A [M x K] is stored [K x M], K = #vertices is
+// huge, the output [M x N] tiny.  Split-K over workgroups, 128 x 64 output block per workgroup (8 waves), both operands
+// streamed from HBM and limb-split per 32-deep K step, uint64 atomics for the partial outputs (integer adds commute,
+// so the result is exact and order-independent).
+//   BEAVER: Z += [E | A_p] . [B_p + p*F ; F] with E = E0+E1 and F from memory, A_p / B_p from their PRNG streams
+//           (both segments share the F tile of the step: 72 MFMAs per wave per step).
+//   plain : Z += (A1 + A2)^T-stored . B.
+// ------------------------------------------------------------------------------------------
+template <bool BEAVER>
+__global__ __launch_bounds__(512) void ring_gemm_tn_kernel(u64* Z, const u64* __restrict__ E0, const u64* __restrict__ E1,
+                                                           const u64* __restrict__ F, u64 keyA, u64 keyB, int p, int M, int N,
+                                                           int K, int steps_per_split) {
+    constexpr int BM = 128;
+    constexpr int kATile = 8 * 2 * BM * 16;                 // 32768: [plane][k-half][row][16]
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* sA0 = smem;                              // E tile
+    // smem + kATile: mask tile (BEAVER), addressed as sA0 + kATile
+    unsigned char* sB0 = smem + 2 * kATile;                 // B' planes [plane][col][48]
+    unsigned char* sB1 = sB0 + kBStage;                     // F planes (BEAVER)
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.x * BM;
+    const int nkt = (K + kKStep - 1) / kKStep;
+    const int kt0 = blockIdx.y * steps_per_split;
+    const int kt1 = min(nkt, kt0 + steps_per_split);
+    // A-side task: column m of the storage (= logical row), 8 consecutive k
+    const int am = tid & 127, akq = tid >> 7;               // akq in 0..3
+    // B-side task: column n, 4 consecutive k
+    const int bn = tid & 63, bkq = tid >> 6;                // bkq in 0..7
+
+    v16i acc[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[s][r] = 0;
+
+    u64 ea[8], eb[8], fv[4];
+    auto load_step = [&](int kt) {
+        const int k = kt * kKStep + akq * 8;
+        const int m = m0 + am;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const bool ok = (m < M && k + j < K);
+            const size_t o = (size_t)min(k + j, K - 1) * M + min(m, M - 1);
+            ea[j] = ok ? E0[o] : 0ull;
+            eb[j] = (ok && E1) ? E1[o] : 0ull;
+        }
+        const int kb = kt * kKStep + bkq * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool ok = (bn < N && kb + j < K);
+            fv[j] = ok ? F[(size_t)min(kb + j, K - 1) * N + min(bn, N - 1)] : 0ull;
+        }
+    };
+
+    if (kt0 < kt1) load_step(kt0);
+    for (int kt = kt0; kt < kt1; ++kt) {
+        // ---- produce the step's tiles ----
+        {
+            u64 v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = ea[j] + eb[j];
+            unsigned char* dst = (akq >> 1) * (BM * 16) + am * 16 + (akq & 1) * 8 + sA0;
+            split8_store(v, dst);
+            if (BEAVER) {
+                const int k = kt * kKStep + akq * 8;
+                const int m = m0 + am;
+                u64 x = keyA + ((u64)m * (u64)K + (u64)k + 1ull) * COGNN_GAMMA;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { v[j] = (m < M && k + j < K) ? cognn_mix64(x) : 0ull; x += COGNN_GAMMA; }
+                split8_store(v, dst + kATile);
+            }
+            const int kb = kt * kKStep + bkq * 4;
+            u64 w[4];
+            uint32_t pl[8];
+            if (BEAVER) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    w[j] = (bn < N && kb + j < K) ? cognn_prng(keyB, (u64)(kb + j) * (u64)N + (u64)bn) + (p == 1 ? fv[j] : 0ull) : 0ull;
+                split4(w, pl);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) *reinterpret_cast<uint32_t*>(sB0 + i * (kFusedBN * kBRow) + bn * kBRow + bkq * 4) = pl[i];
+                split4(fv, pl);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) *reinterpret_cast<uint32_t*>(sB1 + i * (kFusedBN * kBRow) + bn * kBRow + bkq * 4) = pl[i];
+            } else {
+                split4(fv, pl);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) *reinterpret_cast<uint32_t*>(sB0 + i * (kFusedBN * kBRow) + bn * kBRow + bkq * 4) = pl[i];
+            }
+        }
+        if (kt + 1 < kt1) load_step(kt + 1);                // in flight during the MFMAs
+        __syncthreads();
+        // ---- MFMAs ----
+        const unsigned char* pa = sA0 + (lane >> 5) * (BM * 16) + (wm * 32 + (lane & 31)) * 16;
+        const unsigned char* pb = sB0 + (wn * 32 + (lane & 31)) * kBRow + (lane >> 5) * 16;
+#pragma unroll
+        for (int seg = 0; seg < (BEAVER ? 2 : 1); ++seg) {
+            v4i bf[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) bf[i] = *reinterpret_cast<const v4i*>(pb + seg * kBStage + i * (kFusedBN * kBRow));
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const v4i af = *reinterpret_cast<const v4i*>(pa + seg * kATile + i * (2 * BM * 16));
+#pragma unroll
+                for (int j = 0; j + i < 8; ++j) acc[i + j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af, bf[j], acc[i + j], 0, 0, 0);
+            }
+        }
+        __syncthreads();                                    // tiles are single-buffered
+    }
+    // ---- partial output -> atomics ----
+    const int col = wn * 32 + (lane & 31);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const uint32_t hi = (uint32_t)acc[4][r] + ((uint32_t)acc[5][r] << 8) + ((uint32_t)acc[6][r] << 16) + ((uint32_t)acc[7][r] << 24);
+        const u64 v = (u64)(long long)acc[0][r] + ((u64)(long long)acc[1][r] << 8) + ((u64)(long long)acc[2][r] << 16) +
+                      ((u64)(long long)acc[3][r] << 24) + ((u64)hi << 32);
+        if (row < M && col < N && kt0 < kt1) atomicAdd((unsigned long long*)&Z[(size_t)row * N + col], v);
+    }
+}
+
+// launches the TN kernel on Z (which already holds the value to accumulate onto)
+template <bool BEAVER>
+int launch_tn(cognn_ctx* ctx, u64* Z, const u64* E0, const u64* E1, const u64* F, u64 keyA, u64 keyB, int p, int64_t M, int64_t N, int64_t K) {
+    const int nkt = (int)((K + kKStep - 1) / kKStep);
+    const int nmb = (int)((M + 127) / 128);
+    int splits = std::max(1, std::min(nkt, (512 + nmb - 1) / nmb));
+    const int sps = (nkt + splits - 1) / splits;
+    splits = (nkt + sps - 1) / sps;
+    const size_t lds = 2 * (size_t)(8 * 2 * 128 * 16) + 2 * (size_t)kBStage;
+    CG_HIP(hipFuncSetAttribute((const void*)ring_gemm_tn_kernel<BEAVER>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(ring_gemm_tn_kernel<BEAVER>, dim3((unsigned)nmb, (unsigned)splits), dim3(512), lds, ctx->stream, Z, E0, E1, F, keyA,
+                       keyB, p, (int)M, (int)N, (int)K, sps);
+    CG_LAUNCH_CHECK();
+    return 0;
+}
+
 // element-wise helpers used by the Beaver composites -------------------------------------------
 __global__ __launch_bounds__(256) void prng_fill2_kernel(u64* out, u64 k0, u64 k1, int64_t rows, int64_t cols, int transposed,
                                                           int two, const u64* addend) {
@@ -488,6 +628,10 @@ int gemm_dispatch(cognn_ctx* ctx, u64* C, const u64* A, const u64* A2, const u64
             CG_LAUNCH_CHECK();
             return 0;
         }
+    }
+    if (transA && N <= kFusedBN && K >= 256 && M * N <= (1ll << 22)) {
+        if (!accumulate) CG_HIP(hipMemsetAsync(C, 0, (size_t)M * N * 8, ctx->stream));
+        return launch_tn<false>(ctx, C, A, A2, B, 0, 0, 0, M, N, K);
     }
     // generic path
     int kchunk = (int)K, splits = 1;
@@ -616,6 +760,13 @@ int beaver_close_impl(cognn_ctx* ctx, uint64_t* Z, const uint64_t* E, const uint
         return 0;
     }
     CG_REQUIRE(!raw, "cognn_beaver_gemm_close_raw_u64: shape not supported by the fused kernel (%lld x %lld x %lld)", (long long)M, (long long)N, (long long)K);
+    if (transA && N <= kFusedBN && K >= 256 && M * N <= (1ll << 22)) {
+        // Z <- C_p, then one split-K launch adds E.(B_p + pF) + A_p.F
+        if (p == 0) { if ((rc = fill(ctx, (u64*)Z, keys->k[COGNN_SL_C0], 0, M, N, 0, 0, nullptr))) return rc; }
+        else CG_HIP(hipMemcpyAsync(Z, c1, (size_t)M * N * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        return launch_tn<true>(ctx, (u64*)Z, (const u64*)E, (const u64*)E1, (const u64*)F, keys->k[p == 0 ? COGNN_SL_A0 : COGNN_SL_A1],
+                               keys->k[p == 0 ? COGNN_SL_B0 : COGNN_SL_B1], p, M, N, K);
+    }
     u64* Ap = (u64*)scratch;
     u64* Bp = Ap + (size_t)M * K;
     // A_p (storage layout of E), B_p (+F for p==1), Z <- C_p
