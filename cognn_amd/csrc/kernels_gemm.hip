@@ -277,7 +277,8 @@ __device__ __forceinline__ void split8_store(const u64 v[8], unsigned char* dst_
 // shadow of its 36 MFMAs, converts and writes the tile of step it+1 into the other stage.  The two kinds of
 // iteration are separate straight-line bodies (no branches around the MFMAs) so that the scheduler can
 // interleave the limb split / PRNG VALU work with the matrix pipe.  Requires K % 8 == 0.
-template <int NKT, int DBG = 0>   // NKT: K steps per segment when known at compile time (0: run-time value)
+template <int NKT, int DBG = 0, bool KALIGNED = true>   // NKT: K steps per segment when known at compile time (0: run-time value)
+                                  // KALIGNED: K % 8 == 0 (16-byte vector loads of whole 8-k groups); otherwise guarded 8-byte loads
                                   // DBG (timing experiments only, results wrong): 1 no E loads, 2 no PRNG, 4 no MFMA
 __global__ __launch_bounds__(kFusedThreads) void beaver_gemm_fused_kernel(u64* Z, const u64* __restrict__ E0, const u64* __restrict__ E1,
                                                                            const unsigned char* __restrict__ planes,
@@ -311,6 +312,19 @@ __global__ __launch_bounds__(kFusedThreads) void beaver_gemm_fused_kernel(u64* Z
     auto load_E = [&](int it) {                             // `it`: an E step (even); clamped, never branches
         it = min(it, total - 2);
         const int mb = blockIdx.x + (it / steps) * gridDim.x, kt = (it % steps) >> 1;
+        if (!KALIGNED) {                                    // ragged K: element-wise guarded loads (zero beyond K)
+            const int m = min(mb * BM + trow, M - 1), k0 = kt * kKStep + tk8 * 8;
+            const u64* a = E0 + (size_t)m * K;
+            const u64* b = (E1 ? E1 : E0) + (size_t)m * K;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int ka = min(k0 + 2 * j, K - 1), kb = min(k0 + 2 * j + 1, K - 1);
+                const u64 ma = (k0 + 2 * j < K) ? ~0ull : 0ull, mb2 = (k0 + 2 * j + 1 < K) ? ~0ull : 0ull;
+                nE0[j].x = a[ka] & ma; nE0[j].y = a[kb] & mb2;
+                nE1[j].x = b[ka] & ma; nE1[j].y = b[kb] & mb2;
+            }
+            return;
+        }
         const int m = min(mb * BM + trow, M - 1), k = min(kt * kKStep + tk8 * 8, K - 8);
         const u64x2* a = reinterpret_cast<const u64x2*>(E0 + (size_t)m * K + k);
         const u64x2* b = reinterpret_cast<const u64x2*>((E1 ? E1 : E0) + (size_t)m * K + k);
@@ -343,7 +357,11 @@ __global__ __launch_bounds__(kFusedThreads) void beaver_gemm_fused_kernel(u64* Z
         u64 x = keyA + ((u64)m * (u64)K + (u64)k + 1ull) * COGNN_GAMMA;        // prng(key, idx) = mix64(key + (idx+1)*GAMMA)
         u64 v[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { v[j] = ((DBG & 2) ? x : cognn_mix64(x)) & keep; x += COGNN_GAMMA; }
+        for (int j = 0; j < 8; ++j) {
+            const u64 kj = (KALIGNED || k + j < K) ? keep : 0ull;
+            v[j] = ((DBG & 2) ? x : cognn_mix64(x)) & kj;
+            x += COGNN_GAMMA;
+        }
         if (DBG & 8) { if (v[0] == 0x1234567ull) Z[0] = v[1] ^ v[2] ^ v[3] ^ v[4] ^ v[5] ^ v[6] ^ v[7]; return; }
         split8_store(v, sA + (it & 1) * kAStage + (tk8 >> 1) * (BM * 16) + trow * 16 + (tk8 & 1) * 8);
     };
@@ -707,7 +725,7 @@ int cognn_beaver_gemm_close_u64(cognn_ctx* ctx, uint64_t* Z, const uint64_t* E, 
 }
 
 int cognn_beaver_gemm_fusable(int64_t M, int64_t N, int64_t K, int transA) {
-    return (!transA && M >= 256 && N <= kFusedBN && K <= 4096 && K % 8 == 0 &&
+    return (!transA && M >= 256 && N <= kFusedBN && K <= 4096 &&
             (size_t)2 * ((K + kKStep - 1) / kKStep) * kBStage <= ((size_t)M * K + (size_t)K * N) * 8) ? 1 : 0;
 }
 
@@ -747,6 +765,7 @@ int beaver_close_impl(cognn_ctx* ctx, uint64_t* Z, const uint64_t* E, const uint
         else if (nkt == 4 && dbg == 15) CG_FUSED_LAUNCH(4, 15);
         else if (nkt == 4 && dbg == 23) CG_FUSED_LAUNCH(4, 23);
         else if (nkt == 4 && dbg == 31) CG_FUSED_LAUNCH(4, 31);
+        else if (K % 8 != 0) CG_FUSED_LAUNCH(0, 0, false);
         else if (nkt == 4) CG_FUSED_LAUNCH(4, 0);
         else if (nkt == 2) CG_FUSED_LAUNCH(2, 0);
         else CG_FUSED_LAUNCH(0, 0);

@@ -314,7 +314,8 @@ def test_softmax_pair_and_metrics(ctx, L):
     assert abs(float(host(loss, np.float64)[0]) - want_loss) < 1e-9 * max(1.0, abs(want_loss))   # fp tolerance: atomics order
 
 
-@pytest.mark.parametrize("M,N,K,transA", [(300, 64, 128, 0), (270, 7, 16, 0), (16, 7, 300, 1), (1433, 16, 270, 1)])
+@pytest.mark.parametrize("M,N,K,transA", [(300, 64, 128, 0), (270, 7, 16, 0), (16, 7, 300, 1), (1433, 16, 270, 1),
+                                             (300, 16, 77, 0), (1354, 16, 1433, 0), (260, 7, 7, 0), (64, 16, 2000, 1)])
 def test_beaver_gemm_pair(ctx, M, N, K, transA):
     """Full Beaver product: mask-open, exchange, dealer C1, close; vs oracle twoPartyGCNMatMul stand-in."""
     rng = np.random.default_rng(M * 3 + N)
