@@ -112,6 +112,14 @@ class Engine:
     def offline(self, it0, it1):
         _check(self.lib.cognn_engine_offline(self.h, it0, it1))
 
+    def offline_save(self, directory):
+        _check(self.lib.cognn_engine_offline_save(self.h, str(directory).encode()))
+
+    def offline_load(self, directory, it0, it1):
+        n = ctypes.c_int64()
+        _check(self.lib.cognn_engine_offline_load(self.h, str(directory).encode(), it0, it1, ctypes.byref(n)))
+        return n.value
+
     def run(self, it0, it1):
         _check(self.lib.cognn_engine_run(self.h, it0, it1))
 

@@ -41,6 +41,7 @@ enum { T_AGG = 0, T_PART = 1, T_GEMM = 2 };
 
 struct Side {
     int owner = 0, p = 0, n = 0;
+    std::map<std::pair<int64_t, int>, int64_t> c1_elems;   // size of every dealt product share
     int peer_rank = 0;
     Side* peer = nullptr;          // non-null when the other share-holder is hosted on this rank
     u64* feat = nullptr;           // [n x in] input-feature share (localVertexSvvBackup / remoteVertexSvvsBackup)
@@ -245,6 +246,7 @@ void gemm_stage(cognn_engine* E, int64_t it, XFn X, WFn Wm, SpecFn spec, DstFn d
                 u64* c = dalloc<u64>(E, (size_t)eo[i]);
                 BE(cognn_dealer_gemm_c1_u64(E->ctx, c, &k, g.M, g.N, g.K, g.transA, s.scratch, s.scratch + g.M * g.K));
                 f = s.c1.emplace(std::make_pair(it, g.op), c).first;
+                s.c1_elems[{it, g.op}] = eo[i];
             }
             c1 = f->second;
         }
@@ -653,6 +655,7 @@ void run_offline(cognn_engine* E, int64_t it0, int64_t it1) {
             u64* c = dalloc<u64>(E, (size_t)(g.M * g.N));
             BE(cognn_dealer_gemm_c1_u64(E->ctx, c, &k, g.M, g.N, g.K, g.transA, s.scratch, s.scratch + g.M * g.K));
             s.c1[{it, g.op}] = c;
+            s.c1_elems[{it, g.op}] = g.M * g.N;
         }
     }
 }
@@ -1014,6 +1017,58 @@ int cognn_engine_offline(cognn_engine* E, int64_t it0, int64_t it1) {
     return guard([&] {
         if (!E || !E->started) throw EngineError("cognn_engine_offline: engine not started");
         run_offline(E, it0, it1);
+    });
+}
+static std::string c1_path(cognn_engine* E, const char* dir, const Side& s, int64_t it, int op) {
+    char buf[512];
+    snprintf(buf, sizeof(buf), "%s/c1_r%d_o%d_i%lld_op%d.bin", dir, E->rank, s.owner, (long long)it, op);
+    return buf;
+}
+int cognn_engine_offline_save(cognn_engine* E, const char* dir) {
+    return guard([&] {
+        if (!E || !dir) throw EngineError("cognn_engine_offline_save: bad arguments");
+        for (auto& s : E->sides)
+            for (auto& kv : s.c1) {
+                const int64_t elems = s.c1_elems[kv.first];
+                std::vector<u64> host((size_t)elems);
+                BE(cognn_memcpy_d2h(E->ctx, host.data(), kv.second, (size_t)elems * 8));
+                const std::string path = c1_path(E, dir, s, kv.first.first, kv.first.second);
+                FILE* f = fopen(path.c_str(), "wb");
+                if (!f) throw EngineError("cognn_engine_offline_save: cannot write " + path);
+                const u64 hdr[3] = {0x31435F4E4E474F43ull /* "COGNN_C1" */, E->cfg.seed, (u64)elems};
+                const bool ok = fwrite(hdr, 8, 3, f) == 3 && fwrite(host.data(), 8, (size_t)elems, f) == (size_t)elems;
+                fclose(f);
+                if (!ok) throw EngineError("cognn_engine_offline_save: short write to " + path);
+            }
+    });
+}
+int cognn_engine_offline_load(cognn_engine* E, const char* dir, int64_t it0, int64_t it1, int64_t* loaded) {
+    return guard([&] {
+        if (!E || !dir || !E->started) throw EngineError("cognn_engine_offline_load: bad arguments or engine not started");
+        int64_t n = 0;
+        const int ops[2] = {COGNN_OP_PS_GEMM, COGNN_OP_AP_GEMM};
+        for (auto& s : E->sides) {
+            if (s.p != 1) continue;
+            for (int64_t it = it0; it < it1; ++it)
+                for (int op : ops) {
+                    if (s.c1.count({it, op})) continue;
+                    FILE* f = fopen(c1_path(E, dir, s, it, op).c_str(), "rb");
+                    if (!f) continue;
+                    u64 hdr[3];
+                    if (fread(hdr, 8, 3, f) == 3 && hdr[0] == 0x31435F4E4E474F43ull && hdr[1] == E->cfg.seed && hdr[2] < (1ull << 40)) {
+                        std::vector<u64> host((size_t)hdr[2]);
+                        if (fread(host.data(), 8, host.size(), f) == host.size()) {
+                            u64* c = dalloc<u64>(E, host.size());
+                            BE(cognn_memcpy_h2d(E->ctx, c, host.data(), host.size() * 8));
+                            s.c1[{it, op}] = c;
+                            s.c1_elems[{it, op}] = (int64_t)host.size();
+                            ++n;
+                        }
+                    }
+                    fclose(f);
+                }
+        }
+        if (loaded) *loaded = n;
     });
 }
 int cognn_engine_run(cognn_engine* E, int64_t it0, int64_t it1) {

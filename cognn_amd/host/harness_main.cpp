@@ -188,10 +188,23 @@ int main(int argc, char* argv[]) {
         std::cout << tileIndex << " Initialize graph algo kernel" << std::endl;
         if (cognn_engine_start(e)) { std::cerr << cognn_engine_last_error() << std::endl; return -1; }
         print_duration(t_pre, "preprocess");
+        // offline phase and its cache: ./preprocess/<setting>/ is written by a run without -n and reused by `-n 1`
+        // (README.md:215-216, 306-307 of the reference); what is missing is dealt on demand
+        std::string cacheDir = "preprocess/" + setting;
+        for (auto& ch : cacheDir) if (ch == ' ') ch = '_';
         if (!noPreprocess) {
             auto t_om = std::chrono::high_resolution_clock::now();
             if (cognn_engine_offline(e, 0, (int64_t)maxIters)) { std::cerr << cognn_engine_last_error() << std::endl; return -1; }
             print_duration(t_om, "preprocess_OM");
+            if (!getenv("COGNN_NO_PREPROCESS_CACHE")) {
+                const std::string cmd = "mkdir -p '" + cacheDir + "'";
+                if (system(cmd.c_str()) == 0 && cognn_engine_offline_save(e, cacheDir.c_str()))
+                    std::cerr << "warning: offline cache not written: " << cognn_engine_last_error() << std::endl;
+            }
+        } else {
+            int64_t loaded = 0;
+            if (cognn_engine_offline_load(e, cacheDir.c_str(), 0, (int64_t)maxIters, &loaded) == 0)
+                std::cout << tileIndex << " Reused " << loaded << " offline products from " << cacheDir << std::endl;
         }
         std::cout << tileIndex << " Begin algo kernel iteration" << std::endl;
         const int epoch = 3 * gp.num_layers;

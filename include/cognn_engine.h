@@ -65,6 +65,12 @@ int cognn_engine_set_weights(cognn_engine* e, const double* w0, const double* w1
 int cognn_engine_start(cognn_engine* e);
 /* dealer ("offline") phase for iterations [begin,end): Beaver-triple product shares of every GEMM */
 int cognn_engine_offline(cognn_engine* e, int64_t iter_begin, int64_t iter_end);
+/* Offline-phase cache on disk, the counterpart of the reference's preprocess/<setting>/ directory reused with `-n 1`
+ * (include/harness.h:140-146, README.md:215-216): save writes every dealt product share held on this rank to
+ * <dir>/c1_r<rank>_o<owner>_i<iter>_op<op>.bin (header: magic, seed, M*N); load reads whatever matching files exist and
+ * returns the number loaded in *loaded (missing ones are dealt on demand). */
+int cognn_engine_offline_save(cognn_engine* e, const char* dir);
+int cognn_engine_offline_load(cognn_engine* e, const char* dir, int64_t iter_begin, int64_t iter_end, int64_t* loaded);
 /* GAS iterations [begin,end) (ss_...h:239-248) */
 int cognn_engine_run(cognn_engine* e, int64_t iter_begin, int64_t iter_end);
 /* current vertex tensor share of `owner` held by side 0 (owner) / 1 (co-party); host_out may be NULL to query shape */

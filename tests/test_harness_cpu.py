@@ -109,3 +109,20 @@ def test_gpu_binary_matches_oracle(tmp_path):
     want = [m for m in o.metrics if m["party"] == 0][0]
     assert abs(float(re.findall(r"cross-entropy-loss = ([0-9.]+)", res.stdout)[0]) - want["loss"]) < 1e-6
     assert abs(float(re.findall(r"full set accuracy = ([0-9.]+)", res.stdout)[0]) - want["full"]) < 1e-6
+
+
+def test_offline_cache_roundtrip(tmp_path):
+    """`-n 1` reuses the preprocess/<setting>/ products written by an earlier run; the results do not change."""
+    k, V, Eu, in_dim, lab, hid = 2, 40, 90, 8, 3, 4
+    _write_inputs(tmp_path, k, V, Eu, in_dim, lab, hid)
+    files = [str(tmp_path / n) for n in ("edges.txt", "vertices.txt", "part.txt", "out.txt", "config.txt")]
+    base = [BIN, "-t", "2", "-g", "2", "-i", "0", "-m", "6", "-s", "cache/test-1", "-r", "1"]
+    r1 = subprocess.run(base + files, capture_output=True, text=True, cwd=tmp_path, timeout=120)
+    assert r1.returncode == 0, r1.stderr
+    cached = os.listdir(tmp_path / "preprocess" / "cache" / "test-1")
+    assert len(cached) == 2 * 5            # 2 co-party sides x (2 forward + 3 backward) Beaver products per epoch
+    r2 = subprocess.run(base + ["-n", "1"] + files, capture_output=True, text=True, cwd=tmp_path, timeout=120)
+    assert r2.returncode == 0, r2.stderr
+    assert "Reused 10 offline products" in r2.stdout
+    pick = lambda out: re.findall(r"(cross-entropy-loss|accuracy) = ([0-9.]+)", out)
+    assert pick(r1.stdout) == pick(r2.stdout) and len(pick(r1.stdout)) == 6
