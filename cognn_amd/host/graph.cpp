@@ -155,4 +155,35 @@ void load_edge_list_file(const std::string& path, std::vector<int64_t>& src, std
     }
 }
 
+static const char kBinMagic[8] = {'C', 'O', 'G', 'N', 'N', 'B', 'G', '1'};
+
+bool is_binary_graph_file(const std::string& path) {
+    std::ifstream in(path, std::ios::binary);
+    char m[8];
+    return in.is_open() && in.read(m, 8) && std::equal(m, m + 8, kBinMagic);
+}
+
+void load_binary_graph_file(const std::string& path, std::vector<int64_t>& src, std::vector<int64_t>& dst, std::vector<int32_t>& part) {
+    std::ifstream in(path, std::ios::binary);
+    char m[8];
+    uint64_t nv = 0, ne = 0;
+    if (!in.is_open() || !in.read(m, 8) || !std::equal(m, m + 8, kBinMagic) || !in.read((char*)&nv, 8) || !in.read((char*)&ne, 8) ||
+        nv >= (1ull << 31) || ne >= (1ull << 40))
+        throw std::runtime_error("Invalid format in graph topology input files.");
+    src.resize(ne); dst.resize(ne); part.resize(nv);
+    if (!in.read((char*)src.data(), (std::streamsize)(ne * 8)) || !in.read((char*)dst.data(), (std::streamsize)(ne * 8)) ||
+        !in.read((char*)part.data(), (std::streamsize)(nv * 4)))
+        throw std::runtime_error("Invalid format in graph topology input files.");
+}
+
+void save_binary_graph_file(const std::string& path, const std::vector<int64_t>& src, const std::vector<int64_t>& dst,
+                            const std::vector<int32_t>& part) {
+    std::ofstream out(path, std::ios::binary);
+    if (!out.is_open()) throw std::runtime_error("cannot write " + path);
+    const uint64_t nv = part.size(), ne = src.size();
+    out.write(kBinMagic, 8); out.write((const char*)&nv, 8); out.write((const char*)&ne, 8);
+    out.write((const char*)src.data(), (std::streamsize)(ne * 8)); out.write((const char*)dst.data(), (std::streamsize)(ne * 8));
+    out.write((const char*)part.data(), (std::streamsize)(nv * 4));
+}
+
 }  // namespace cognn

@@ -47,4 +47,12 @@ PartitionedGraph build_partitioned_graph(int k, int64_t num_vertices, int64_t nu
 void load_partition_file(const std::string& path, std::vector<int32_t>& part);
 void load_edge_list_file(const std::string& path, std::vector<int64_t>& src, std::vector<int64_t>& dst);
 
+// Binary graph container for graphs whose text form is unwieldy (2^20 vertices / 2^24 edges = hundreds of MB of text):
+//   "COGNNBG1" | u64 num_vertices | u64 num_edges | i64 src[num_edges] | i64 dst[num_edges] | i32 part[num_vertices]
+// Same content as the edge-list + partition text files (graph_io_util.h:67-164); little endian.
+bool is_binary_graph_file(const std::string& path);
+void load_binary_graph_file(const std::string& path, std::vector<int64_t>& src, std::vector<int64_t>& dst, std::vector<int32_t>& part);
+void save_binary_graph_file(const std::string& path, const std::vector<int64_t>& src, const std::vector<int64_t>& dst,
+                            const std::vector<int32_t>& part);
+
 }  // namespace cognn

@@ -136,9 +136,13 @@ int main(int argc, char* argv[]) {
         auto t_pre = std::chrono::high_resolution_clock::now();
         std::vector<int32_t> part;
         std::vector<int64_t> src, dst;
-        cognn::load_partition_file(partitionFile, part);
+        if (cognn::is_binary_graph_file(edgelistFile)) {
+            cognn::load_binary_graph_file(edgelistFile, src, dst, part);            // binary container: edges + partition in one file
+        } else {
+            cognn::load_partition_file(partitionFile, part);
+            cognn::load_edge_list_file(edgelistFile, src, dst);
+        }
         for (auto& t : part) { t /= (int32_t)(graphTileCount / threadCount); }      // tileMergeFactor (graph_io_util.h:76)
-        cognn::load_edge_list_file(edgelistFile, src, dst);
         cognn_engine_config cfg{};
         cfg.num_parties = k; cfg.rank = 0; cfg.world = 1;
         cfg.variant = inference ? COGNN_VARIANT_OPTIMIZE_GCN_INFERENCE : COGNN_VARIANT_OPTIMIZE_GCN;

@@ -126,3 +126,18 @@ def test_offline_cache_roundtrip(tmp_path):
     assert "Reused 10 offline products" in r2.stdout
     pick = lambda out: re.findall(r"(cross-entropy-loss|accuracy) = ([0-9.]+)", out)
     assert pick(r1.stdout) == pick(r2.stdout) and len(pick(r1.stdout)) == 6
+
+
+def test_binary_graph_container_gives_identical_run(tmp_path):
+    k, V, Eu, in_dim, lab, hid = 2, 40, 90, 8, 3, 4
+    _write_inputs(tmp_path, k, V, Eu, in_dim, lab, hid)
+    subprocess.check_call([os.sys.executable, os.path.join(ROOT, "tools", "convert_graph.py"), str(tmp_path / "edges.txt"),
+                           str(tmp_path / "part.txt"), str(tmp_path / "graph.cgb")])
+    tail = [str(tmp_path / n) for n in ("vertices.txt", "part.txt", "out.txt", "config.txt")]
+    base = [BIN, "-t", "2", "-g", "2", "-i", "1", "-m", "2", "-s", "bin", "-r", "1", "-n", "1"]
+    a = subprocess.run(base + [str(tmp_path / "edges.txt")] + tail, capture_output=True, text=True, cwd=tmp_path, timeout=120)
+    b = subprocess.run(base + [str(tmp_path / "graph.cgb")] + tail[:1] + ["ignored"] + tail[2:], capture_output=True, text=True,
+                       cwd=tmp_path, timeout=120)
+    assert a.returncode == 0 and b.returncode == 0, a.stderr + b.stderr
+    pick = lambda out: re.findall(r"(cross-entropy-loss|accuracy) = ([0-9.]+)", out)
+    assert pick(a.stdout) == pick(b.stdout) and len(pick(a.stdout)) == 6
