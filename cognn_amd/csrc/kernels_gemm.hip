@@ -215,34 +215,11 @@ __global__ __launch_bounds__(kWavesM * (BN / 32) * 64) void ring_gemm_mfma_kerne
 constexpr int kFusedBN = 64;
 constexpr int kBRow = 48;                                   // 32 k-bytes + 16 pad: conflict-free ds_read_b128
 constexpr int kBStage = 8 * kFusedBN * kBRow;               // 24576 bytes per K step
-constexpr int kFusedThreads = 512;
+constexpr int kNnBRow = 32;                                 // fused NN kernel: 32 k-bytes per column, k-halves XOR-swizzled by
+constexpr int kNnBStage = 8 * kFusedBN * kNnBRow;           // column bit 3 (conflict-free ds_read_b128 without padding): 16 KiB / step
+__device__ __forceinline__ int nn_b_off(int c, int h) { return c * kNnBRow + ((h ^ ((c >> 3) & 1)) << 4); }
 
-__global__ __launch_bounds__(256) void prep_b_planes_kernel(unsigned char* planes, const u64* __restrict__ F, u64 keyB, int p,
-                                                             int K, int N, int nkt) {
-    // one thread per (global k-step, col, 4-k quad)
-    const int total = 2 * nkt * kFusedBN * 8;
-    for (int t = blockIdx.x * 256 + threadIdx.x; t < total; t += gridDim.x * 256) {
-        const int kq = t & 7, c = (t >> 3) % kFusedBN, ks = t / (8 * kFusedBN);
-        const int seg = ks / nkt, kt = ks % nkt;
-        u64 v[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int k = kt * kKStep + kq * 4 + j;
-            u64 x = 0;
-            if (k < K && c < N) {
-                const u64 f = F[(size_t)k * N + c];
-                x = seg == 0 ? cognn_prng(keyB, (u64)k * (u64)N + (u64)c) + (p == 1 ? f : 0ull) : f;
-            }
-            v[j] = x;
-        }
-        uint32_t pl[8];
-        split4(v, pl);
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-            *reinterpret_cast<uint32_t*>(planes + (size_t)ks * kBStage + i * (kFusedBN * kBRow) + c * kBRow + kq * 4) = pl[i];
-    }
-}
-
+template <int BM>
 __device__ __forceinline__ void split8_store(const u64 v[8], unsigned char* dst_row16) {
     // signed limb planes of 8 consecutive-k values -> one 8-byte store per plane at dst_row16 + plane*kPlaneStride
     uint32_t lo[8], hi[8];
@@ -268,188 +245,236 @@ __device__ __forceinline__ void split8_store(const u64 v[8], unsigned char* dst_
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         uint2 w; w.x = pl[i][0]; w.y = pl[i][1];
-        *reinterpret_cast<uint2*>(dst_row16 + i * (2 * 128 * 16)) = w;
+        *reinterpret_cast<uint2*>(dst_row16 + i * (2 * BM * 16)) = w;
     }
 }
 
-// Steps of one 128-row block alternate between the two K-segments (even: E from HBM, odd: PRNG mask), so a
-// memory tile has two full steps to land.  Each iteration reads the MFMA fragments of stage it&1 and, in the
-// shadow of its 36 MFMAs, converts and writes the tile of step it+1 into the other stage.  The two kinds of
-// iteration are separate straight-line bodies (no branches around the MFMAs) so that the scheduler can
-// interleave the limb split / PRNG VALU work with the matrix pipe.  Requires K % 8 == 0.
-template <int NKT, int DBG = 0, bool KALIGNED = true>   // NKT: K steps per segment when known at compile time (0: run-time value)
-                                  // KALIGNED: K % 8 == 0 (16-byte vector loads of whole 8-k groups); otherwise guarded 8-byte loads
-                                  // DBG (timing experiments only, results wrong): 1 no E loads, 2 no PRNG, 4 no MFMA
-__global__ __launch_bounds__(kFusedThreads) void beaver_gemm_fused_kernel(u64* Z, const u64* __restrict__ E0, const u64* __restrict__ E1,
-                                                                           const unsigned char* __restrict__ planes,
-                                                                           u64 keyA, int M, int N, int K, int nkt_rt) {
-    const int nkt = NKT > 0 ? NKT : nkt_rt;
-    // Z receives the raw product (no C_p): the dealer's product share is added by the consumer
-    // (cognn_trunc_open with addend), so this kernel issues no loads besides its operand streams.
-    constexpr int BM = 128;
-    constexpr int kAStage = 8 * 2 * BM * 16;                // 32768
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* sA = smem;                               // 2 stages
-    unsigned char* sB = smem + 2 * kAStage;                 // 2 stages
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int steps = 2 * nkt;                              // per m-block (even)
-    const int nmb = (M + BM - 1) / BM;
-    const int my_blocks = (nmb - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
-    const int total = my_blocks * steps;                    // even
-    const int trow = tid >> 2, tk8 = tid & 3;               // this thread's (row, 8-k group) of every A tile
-    if (total == 0) return;
-
-    u64x2 nE0[4], nE1[4];                                   // raw E0 / E1 values of the next E step (added at use)
-    u64x2 nB0, nB1, nB2;
-    auto load_B = [&](int it) {                             // planes are stored [seg][kt]; steps alternate seg 0 / 1
-        const int st = min(it, total - 1) % steps;
-        const u64x2* bp = reinterpret_cast<const u64x2*>(planes + (size_t)((st & 1) * nkt + (st >> 1)) * kBStage) + tid * 3;
-        if (DBG & 16) { nB0.x = (u64)it; nB0.y = 1; nB1 = nB0; nB2 = nB0; return; }
-        nB0 = bp[0]; nB1 = bp[1]; nB2 = bp[2];
-    };
-    auto load_E = [&](int it) {                             // `it`: an E step (even); clamped, never branches
-        it = min(it, total - 2);
-        const int mb = blockIdx.x + (it / steps) * gridDim.x, kt = (it % steps) >> 1;
-        if (!KALIGNED) {                                    // ragged K: element-wise guarded loads (zero beyond K)
-            const int m = min(mb * BM + trow, M - 1), k0 = kt * kKStep + tk8 * 8;
-            const u64* a = E0 + (size_t)m * K;
-            const u64* b = (E1 ? E1 : E0) + (size_t)m * K;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int ka = min(k0 + 2 * j, K - 1), kb = min(k0 + 2 * j + 1, K - 1);
-                const u64 ma = (k0 + 2 * j < K) ? ~0ull : 0ull, mb2 = (k0 + 2 * j + 1 < K) ? ~0ull : 0ull;
-                nE0[j].x = a[ka] & ma; nE0[j].y = a[kb] & mb2;
-                nE1[j].x = b[ka] & ma; nE1[j].y = b[kb] & mb2;
-            }
-            return;
-        }
-        const int m = min(mb * BM + trow, M - 1), k = min(kt * kKStep + tk8 * 8, K - 8);
-        const u64x2* a = reinterpret_cast<const u64x2*>(E0 + (size_t)m * K + k);
-        const u64x2* b = reinterpret_cast<const u64x2*>((E1 ? E1 : E0) + (size_t)m * K + k);
-        if (DBG & 1) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { nE0[j].x = (u64)m; nE0[j].y = (u64)k; nE1[j].x = 1; nE1[j].y = 2; }
-            return;
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { nE0[j] = a[j]; nE1[j] = b[j]; }
-    };
-    const u64 e1mask = E1 ? ~0ull : 0ull;
-    auto produce_E = [&](int it) {                          // tile of E step `it` -> LDS stage it&1
-        const int mb = blockIdx.x + (it / steps) * gridDim.x, kt = (it % steps) >> 1;
-        const bool ok = (mb * BM + trow < M) && (kt * kKStep + tk8 * 8 < K);
-        const u64 keep = ok ? ~0ull : 0ull;
-        u64 v[8];
+// ------------------------------------------------------------------------------------------
+// Wave-specialised fused Beaver close (NN, N <= 64), same contract as beaver_gemm_fused_kernel.
+// Measured on gfx950 (tools/valu_probe.hip): VALU work issued by the wave that also issues the MFMAs hardly overlaps with
+// them, VALU work of ANOTHER wave on the same SIMD overlaps almost completely.  So the 8 waves of a workgroup split roles:
+//   waves 0..3 (consumers, one per SIMD): B planes global -> LDS, fragment reads, 36 MFMAs per step, epilogue;
+//   waves 4..7 (producers, one per SIMD): E0+E1 stream, dealer mask PRNG, signed-limb split, A tile -> LDS.
+// Every K step covers 16 k of BOTH segments - MFMA k-slots 0..15 = E[:, 16t..16t+15] against (B_p + pF), slots 16..31 =
+// A_p[:, 16t..16t+15] against F - so all steps cost the same on both sides.  Two LDS stages, one barrier per step.
+//   CN = 2: consumers 2(M) x 2(N), 64 x 64 block;  CN = 1 (N <= 32): consumers 4(M) x 1, 128 x 32 block.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void prep_b_planes_ws_kernel(unsigned char* planes, const u64* __restrict__ F, u64 keyB, int p,
+                                                                int K, int N, int nst) {
+    // one thread per (k step, col, 4-k quad); quads 0..3: segment 0 (B_p + pF), quads 4..7: segment 1 (F)
+    const int total = nst * kFusedBN * 8;
+    for (int t = blockIdx.x * 256 + threadIdx.x; t < total; t += gridDim.x * 256) {
+        const int kq = t & 7, c = (t >> 3) % kFusedBN, st = t / (8 * kFusedBN);
+        const int seg = kq >> 2;
+        u64 v[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            v[2 * j] = (nE0[j].x + (nE1[j].x & e1mask)) & keep;
-            v[2 * j + 1] = (nE0[j].y + (nE1[j].y & e1mask)) & keep;
-        }
-        if (DBG & 8) { if (v[0] == 0x1234567ull) Z[0] = v[1] ^ v[2] ^ v[3] ^ v[4] ^ v[5] ^ v[6] ^ v[7]; return; }
-        split8_store(v, sA + (it & 1) * kAStage + (tk8 >> 1) * (BM * 16) + trow * 16 + (tk8 & 1) * 8);
-    };
-    auto produce_mask = [&](int it) {                       // tile of mask step `it` (dealer stream A_p) -> LDS stage it&1
-        const int mb = blockIdx.x + (it / steps) * gridDim.x, kt = (it % steps) >> 1;
-        const int m = mb * BM + trow, k = kt * kKStep + tk8 * 8;
-        const u64 keep = (m < M && k < K) ? ~0ull : 0ull;
-        u64 x = keyA + ((u64)m * (u64)K + (u64)k + 1ull) * COGNN_GAMMA;        // prng(key, idx) = mix64(key + (idx+1)*GAMMA)
-        u64 v[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const u64 kj = (KALIGNED || k + j < K) ? keep : 0ull;
-            v[j] = ((DBG & 2) ? x : cognn_mix64(x)) & kj;
-            x += COGNN_GAMMA;
-        }
-        if (DBG & 8) { if (v[0] == 0x1234567ull) Z[0] = v[1] ^ v[2] ^ v[3] ^ v[4] ^ v[5] ^ v[6] ^ v[7]; return; }
-        split8_store(v, sA + (it & 1) * kAStage + (tk8 >> 1) * (BM * 16) + trow * 16 + (tk8 & 1) * 8);
-    };
-    auto store_B = [&](int it) {
-        u64x2* bd = reinterpret_cast<u64x2*>(sB + (it & 1) * kBStage) + tid * 3;
-        if (DBG & 16) { if (nB0.x == 0x1234567ull) bd[0] = nB0; return; }
-        bd[0] = nB0; bd[1] = nB1; bd[2] = nB2;
-    };
-
-    v16i acc[8];
-#pragma unroll
-    for (int s = 0; s < 8; ++s)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[s][r] = 0;
-
-    auto mfma_step = [&](int it) {
-        const int stage = it & 1;
-        const unsigned char* pa = sA + stage * kAStage + (lane >> 5) * (BM * 16) + (wm * 32 + (lane & 31)) * 16;
-        const unsigned char* pb = sB + stage * kBStage + (wn * 32 + (lane & 31)) * kBRow + (lane >> 5) * 16;
-        v4i bf[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) bf[i] = *reinterpret_cast<const v4i*>(pb + i * (kFusedBN * kBRow));
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {                       // A plane outermost: only one A fragment live at a time
-            const v4i af = *reinterpret_cast<const v4i*>(pa + i * (2 * BM * 16));
-#pragma unroll
-            for (int j = 0; j + i < 8; ++j) {
-                if (DBG & 4) { acc[i + j][0] += af[0] ^ bf[j][0]; continue; }
-                acc[i + j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af, bf[j], acc[i + j], 0, 0, 0);
+            const int k = st * 16 + (kq & 3) * 4 + j;
+            u64 x = 0;
+            if (k < K && c < N) {
+                const u64 f = F[(size_t)k * N + c];
+                x = seg == 0 ? cognn_prng(keyB, (u64)k * (u64)N + (u64)c) + (p == 1 ? f : 0ull) : f;
             }
+            v[j] = x;
         }
-    };
-    // ask the scheduler to spread the tile-production VALU / LDS work of the block between its 36 MFMAs
-    auto interleave_hint = [&]() {
-        __builtin_amdgcn_sched_group_barrier(0x100, 9, 0);      // B fragments + first A fragment
+        uint32_t pl[8];
+        split4(v, pl);
 #pragma unroll
-        for (int q = 0; q < 36; ++q) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
-            __builtin_amdgcn_sched_group_barrier(0x002, 10, 0); // up to 10 VALU
-            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // 1 LDS write
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // 1 LDS read (next A fragment)
-            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // 1 global load
-        }
-    };
-    auto epilogue = [&](int it) {
-        const int mb = blockIdx.x + (it / steps) * gridDim.x;
-        const int col = wn * 32 + (lane & 31);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = mb * BM + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            const uint32_t hi = (uint32_t)acc[4][r] + ((uint32_t)acc[5][r] << 8) + ((uint32_t)acc[6][r] << 16) + ((uint32_t)acc[7][r] << 24);
-            u64 v = (u64)(long long)acc[0][r] + ((u64)(long long)acc[1][r] << 8) + ((u64)(long long)acc[2][r] << 16) +
-                    ((u64)(long long)acc[3][r] << 24) + ((u64)hi << 32);
-            if (row < M && col < N) Z[(size_t)row * N + col] = v;
-        }
+        for (int i = 0; i < 8; ++i)
+            *reinterpret_cast<uint32_t*>(planes + (size_t)st * kNnBStage + i * (kFusedBN * kNnBRow) + nn_b_off(c, seg) + (kq & 3) * 4) = pl[i];
+    }
+}
+
+// Pipeline: during iteration t the producers write tile t+2 (A and B planes, LDS slot (t+2) % 3) while the consumers run
+// the MFMAs of tile t from fragments already in registers and pre-read the first fragments of tile t+1; one barrier per
+// iteration.  (A barrier-free ring with per-wave progress counters in LDS was measured and is slower: the polling costs more
+// than the decoupling gains.)
+template <int NST, bool FULL, bool KALIGNED, int CN, int DBG = 0>   // DBG (timing experiments only, results wrong): 1 no E loads, 2 no PRNG,
+                                                       // 4 no MFMA, 8 no limb split / LDS writes, 16 no B copy.  NST: K steps when known
+                                                       // at compile time (0: run-time); FULL: M % BM == 0 and K % 16 == 0 (no edge
+                                                       // masks); KALIGNED: K % 4 == 0 (16-byte loads)
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void beaver_gemm_ws_kernel(u64* Z, const u64* __restrict__ E0, const u64* __restrict__ E1, const unsigned char* __restrict__ planes,
+                           u64 keyA, int M, int N, int K, int nst_rt) {
+    constexpr int BM = CN == 2 ? 64 : 128;
+    constexpr int R = BM / 64;                              // rows per producer thread
+    constexpr int S = 3;                                    // LDS slots (tile t lives in slot t % S)
+    constexpr int kAStage = 8 * 2 * BM * 16;
+    constexpr int kPlane = 2 * BM * 16;
+    constexpr int kBPlane = kFusedBN * kNnBRow;
+    const int nst = NST > 0 ? NST : nst_rt;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* sA = smem;
+    unsigned char* sB = smem + S * kAStage;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nmb = (M + BM - 1) / BM;
+    const int my_blocks = (nmb - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int total = my_blocks * nst;
+    if (total == 0) return;
+
+    if (wave < 4) {
+        // ================= consumers =================
+        const int wm = CN == 2 ? (wave >> 1) : wave, wn = CN == 2 ? (wave & 1) : 0;
+        v16i acc[8];
 #pragma unroll
         for (int s = 0; s < 8; ++s)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[s][r] = 0;
-    };
-
-    // prologue: stage 0 <- step 0 (E); registers <- B(1), E(2)
-    load_E(0); load_B(0);
-    produce_E(0); store_B(0);
-    load_B(1); load_E(2);
-    for (int blk = 0; blk < my_blocks; ++blk) {
+        const v16i zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        const unsigned char* pa0 = sA + (lane >> 5) * (BM * 16) + (wm * 32 + (lane & 31)) * 16;
+        const unsigned char* pb0 = sB + nn_b_off(wn * 32 + (lane & 31), lane >> 5);
+        v4i bfa[8], bfb[8], afa, afb;                       // two fragment sets: (bfa, afa) even tiles, (bfb, afb) odd tiles
+        __syncthreads();                                    // tiles 0 and 1 are in LDS
 #pragma unroll
-        for (int it = blk * steps; it < (blk + 1) * steps; it += 2) {
-            // ---- even iteration: MFMAs of E step `it`; produce the mask tile of step it+1 (no memory operands) ----
-            __syncthreads();
-            store_B(it + 1);                                // B planes prefetched one step ago (older than the E tile in flight)
-            load_B(it + 2);
-            __builtin_amdgcn_sched_barrier(0);
-            produce_mask(it + 1);
-            mfma_step(it);
-            interleave_hint();
-            // ---- odd iteration: MFMAs of mask step it+1; produce the E tile of step it+2 from the prefetched
-            //      registers, then prefetch the E tile two steps further ----
-            __syncthreads();
-            produce_E(it + 2); store_B(it + 2);             // past the end this writes an all-zero tile nobody reads
-            load_B(it + 3);
-            __builtin_amdgcn_sched_barrier(0);              // keep the B loads older than the E loads: the next step waits
-            load_E(it + 4);                                 // for B with the 16 E loads still in flight (counted vmcnt)
-            __builtin_amdgcn_sched_barrier(0);
-            mfma_step(it + 1);
-            interleave_hint();
+        for (int i = 0; i < 8; ++i) bfa[i] = *reinterpret_cast<const v4i*>(pb0 + i * kBPlane);
+        afa = *reinterpret_cast<const v4i*>(pa0);
+        int sc = 0, sn = 1;                                 // slot of the current / next tile
+#define CG_WS_CONSUME(t_, bf_, af0_, bfn_, afn0_)                                                                          \
+    do {                                                                                                                  \
+        const unsigned char* pa_ = pa0 + sc * kAStage;                                                                    \
+        if (!(DBG & 4)) {                                                                                                 \
+            v4i af_[8];                                                                                                   \
+            af_[0] = af0_;                                                                                                \
+            _Pragma("unroll") for (int i = 1; i < 8; ++i) af_[i] = *reinterpret_cast<const v4i*>(pa_ + i * kPlane);       \
+            _Pragma("unroll") for (int i = 0; i < 8; ++i) bfn_[i] = *reinterpret_cast<const v4i*>(pb0 + sn * kNnBStage + i * kBPlane); \
+            afn0_ = *reinterpret_cast<const v4i*>(pa0 + sn * kAStage);                                                    \
+            if (((t_) % nst) == 0) {     /* first step of a block: accumulators start from the inline-constant zero */   \
+                _Pragma("unroll") for (int j = 0; j < 8; ++j) acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af_[0], bf_[j], zero16, 0, 0, 0); \
+            } else {                                                                                                      \
+                _Pragma("unroll") for (int j = 0; j < 8; ++j) acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af_[0], bf_[j], acc[j], 0, 0, 0); \
+            }                                                                                                             \
+            _Pragma("unroll") for (int i = 1; i < 8; ++i) {                                                               \
+                _Pragma("unroll") for (int j = 0; j + i < 8; ++j)                                                         \
+                    acc[i + j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af_[i], bf_[j], acc[i + j], 0, 0, 0);              \
+            }                                                                                                             \
+        }                                                                                                                 \
+        if (!(DBG & 32) && ((t_) % nst) == nst - 1) {                                                                     \
+            const int mb_ = blockIdx.x + ((t_) / nst) * gridDim.x;                                                        \
+            const int col_ = wn * 32 + (lane & 31);                                                                       \
+            _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                              \
+                const int row_ = mb_ * BM + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);                           \
+                const uint32_t hi_ = (uint32_t)acc[4][r] + ((uint32_t)acc[5][r] << 8) + ((uint32_t)acc[6][r] << 16) +     \
+                                     ((uint32_t)acc[7][r] << 24);                                                         \
+                const long long lo_ = (long long)acc[0][r] + (long long)acc[1][r] * 256 + (long long)acc[2][r] * 65536 +  \
+                                      (long long)acc[3][r] * 16777216;                                                    \
+                if ((FULL || row_ < M) && col_ < N) Z[(size_t)row_ * N + col_] = (u64)lo_ + ((u64)hi_ << 32);             \
+            }                                                                                                             \
+        }                                                                                                                 \
+        sc = sn; sn = (sn == S - 1) ? 0 : sn + 1;                                                                         \
+        __syncthreads();                                                                                                  \
+    } while (0)
+        for (int t = 0; t < total; t += 2) {
+            CG_WS_CONSUME(t, bfa, afa, bfb, afb);
+            if (t + 1 < total) CG_WS_CONSUME(t + 1, bfb, afb, bfa, afa);
         }
-        epilogue((blk + 1) * steps - 1);                    // stores only: the prefetched tiles stay in flight
+#undef CG_WS_CONSUME
+    } else {
+        // ================= producers =================
+        const int ptid = tid - 256, trow = ptid >> 2, q = ptid & 3;
+        u64x2 ea0[R][2], ea1[R][2], eb0[R][2], eb1[R][2], ec0[R][2], ec1[R][2], ed0[R][2], ed1[R][2];   // E0 / E1 values of four tiles in flight
+        u64x2 ba0, ba1, ba2, ba3, bb0, bb1, bb2, bb3;       // B planes of two steps in flight (16 KiB per step / 256 threads)
+        const u64* E1p = E1 ? E1 : E0;
+        const u64 e1mask = E1 ? ~0ull : 0ull;
+#define CG_WS_LOAD_B(t_, x0_, x1_, x2_, x3_)                                                                               \
+    do {                                                                                                                  \
+        if (!(DBG & 16)) {                                                                                                \
+            const u64x2* bp_ = reinterpret_cast<const u64x2*>(planes + (size_t)(min((t_), total - 1) % nst) * kNnBStage) + ptid; \
+            x0_ = bp_[0]; x1_ = bp_[256]; x2_ = bp_[512]; x3_ = bp_[768];                                                  \
+        }                                                                                                                 \
+    } while (0)
+#define CG_WS_STORE_B(slot_, x0_, x1_, x2_, x3_)                                                                           \
+    do {                                                                                                                  \
+        if (!(DBG & 16)) {                                                                                                \
+            u64x2* bd_ = reinterpret_cast<u64x2*>(sB + (slot_) * kNnBStage) + ptid;                                        \
+            bd_[0] = x0_; bd_[256] = x1_; bd_[512] = x2_; bd_[768] = x3_;                                                  \
+        }                                                                                                                 \
+    } while (0)
+#define CG_WS_LOAD_TILE(t_, s0_, s1_)                                                                                      \
+    do {                                                                                                                  \
+        const int tt_ = min((t_), total - 1);                                                                             \
+        const int mb_ = blockIdx.x + (tt_ / nst) * gridDim.x, k_ = (tt_ % nst) * 16 + q * 4;                              \
+        _Pragma("unroll") for (int r = 0; r < R; ++r) {                                                                   \
+            const int m_ = FULL ? mb_ * BM + trow + 64 * r : min(mb_ * BM + trow + 64 * r, M - 1);                        \
+            if (DBG & 1) {                                                                                                \
+                s0_[r][0].x = (u64)m_; s0_[r][0].y = (u64)k_; s0_[r][1] = s0_[r][0]; s1_[r][0] = s0_[r][0]; s1_[r][1] = s0_[r][0]; \
+            } else if (KALIGNED) {                                                                                        \
+                const int kc_ = FULL ? k_ : min(k_, K - 4);                                                               \
+                const u64x2* a_ = reinterpret_cast<const u64x2*>(E0 + (size_t)m_ * K + kc_);                              \
+                const u64x2* b_ = reinterpret_cast<const u64x2*>(E1p + (size_t)m_ * K + kc_);                             \
+                s0_[r][0] = a_[0]; s0_[r][1] = a_[1]; s1_[r][0] = b_[0]; s1_[r][1] = b_[1];                                \
+            } else {                                                                                                      \
+                const u64* a_ = E0 + (size_t)m_ * K;                                                                      \
+                const u64* b_ = E1p + (size_t)m_ * K;                                                                     \
+                const int k0_ = min(k_, K - 1), k1_ = min(k_ + 1, K - 1), k2_ = min(k_ + 2, K - 1), k3_ = min(k_ + 3, K - 1); \
+                s0_[r][0].x = a_[k0_]; s0_[r][0].y = a_[k1_]; s0_[r][1].x = a_[k2_]; s0_[r][1].y = a_[k3_];                 \
+                s1_[r][0].x = b_[k0_]; s1_[r][0].y = b_[k1_]; s1_[r][1].x = b_[k2_]; s1_[r][1].y = b_[k3_];                 \
+            }                                                                                                             \
+        }                                                                                                                 \
+    } while (0)
+#define CG_WS_PRODUCE(t_, slot_, s0_, s1_)                                                                                 \
+    do {                                                                                                                  \
+        const int mb_ = blockIdx.x + ((t_) / nst) * gridDim.x, k_ = ((t_) % nst) * 16 + q * 4;                            \
+        unsigned char* dst_ = sA + (slot_) * kAStage + q * 4;                                                             \
+        _Pragma("unroll") for (int r = 0; r < R; ++r) {                                                                   \
+            const int m_ = mb_ * BM + trow + 64 * r;                                                                      \
+            u64 v_[4], w_[4];                                                                                             \
+            v_[0] = s0_[r][0].x + (s1_[r][0].x & e1mask); v_[1] = s0_[r][0].y + (s1_[r][0].y & e1mask);                    \
+            v_[2] = s0_[r][1].x + (s1_[r][1].x & e1mask); v_[3] = s0_[r][1].y + (s1_[r][1].y & e1mask);                    \
+            u64 x_ = keyA + ((u64)m_ * (u64)K + (u64)k_ + 1ull) * COGNN_GAMMA;                                            \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) { w_[j] = (DBG & 2) ? x_ : cognn_mix64(x_); x_ += COGNN_GAMMA; } \
+            if (!FULL) {                                                                                                  \
+                _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                           \
+                    const u64 keep_ = (m_ < M && k_ + j < K) ? ~0ull : 0ull;                                              \
+                    v_[j] &= keep_; w_[j] &= keep_;                                                                       \
+                }                                                                                                         \
+            }                                                                                                             \
+            if (DBG & 8) { if ((v_[0] ^ w_[0]) == 0x1234567ull) Z[0] = v_[1] ^ v_[2] ^ v_[3] ^ w_[1] ^ w_[2] ^ w_[3]; continue; } \
+            uint32_t pe_[8], pm_[8];                                                                                      \
+            split4(v_, pe_); split4(w_, pm_);                                                                             \
+            unsigned char* d_ = dst_ + (trow + 64 * r) * 16;                                                              \
+            _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                               \
+                *reinterpret_cast<uint32_t*>(d_ + i * kPlane) = pe_[i];                                                   \
+                *reinterpret_cast<uint32_t*>(d_ + i * kPlane + BM * 16) = pm_[i];                                         \
+            }                                                                                                             \
+        }                                                                                                                 \
+    } while (0)
+        // prologue: tiles 0 and 1 -> slots 0 and 1; then the four E register sets hold tiles 2..5, the two B sets steps 2 and 3
+        CG_WS_LOAD_TILE(0, ea0, ea1);
+        CG_WS_LOAD_TILE(1, eb0, eb1);
+        CG_WS_LOAD_B(0, ba0, ba1, ba2, ba3);
+        CG_WS_LOAD_B(1, bb0, bb1, bb2, bb3);
+        CG_WS_LOAD_TILE(2, ec0, ec1);
+        CG_WS_LOAD_TILE(3, ed0, ed1);
+        CG_WS_PRODUCE(0, 0, ea0, ea1);
+        CG_WS_STORE_B(0, ba0, ba1, ba2, ba3);
+        CG_WS_LOAD_TILE(4, ea0, ea1);
+        CG_WS_LOAD_B(2, ba0, ba1, ba2, ba3);
+        if (total > 1) CG_WS_PRODUCE(1, 1, eb0, eb1);
+        CG_WS_STORE_B(1, bb0, bb1, bb2, bb3);
+        CG_WS_LOAD_TILE(5, eb0, eb1);
+        CG_WS_LOAD_B(3, bb0, bb1, bb2, bb3);
+        __syncthreads();
+        int sp = 2;                                         // slot written in this iteration = (t + 2) % 3
+#define CG_WS_PRODUCER_ITER(t_, s0_, s1_, x0_, x1_, x2_, x3_)                                                              \
+    do {                                                                                                                  \
+        if ((t_) + 2 < total) CG_WS_PRODUCE((t_) + 2, sp, s0_, s1_);                                                      \
+        CG_WS_LOAD_TILE((t_) + 6, s0_, s1_);                                                                              \
+        CG_WS_STORE_B(sp, x0_, x1_, x2_, x3_);                                                                            \
+        CG_WS_LOAD_B((t_) + 4, x0_, x1_, x2_, x3_);                                                                       \
+        sp = (sp == S - 1) ? 0 : sp + 1;                                                                                  \
+        __syncthreads();                                                                                                  \
+    } while (0)
+        for (int t = 0; t < total; t += 4) {
+            CG_WS_PRODUCER_ITER(t, ec0, ec1, ba0, ba1, ba2, ba3);
+            if (t + 1 < total) CG_WS_PRODUCER_ITER(t + 1, ed0, ed1, bb0, bb1, bb2, bb3);
+            if (t + 2 < total) CG_WS_PRODUCER_ITER(t + 2, ea0, ea1, ba0, ba1, ba2, ba3);
+            if (t + 3 < total) CG_WS_PRODUCER_ITER(t + 3, eb0, eb1, bb0, bb1, bb2, bb3);
+        }
+#undef CG_WS_PRODUCER_ITER
+#undef CG_WS_LOAD_TILE
+#undef CG_WS_PRODUCE
+#undef CG_WS_LOAD_B
+#undef CG_WS_STORE_B
     }
 }
 
@@ -518,14 +543,14 @@ __global__ __launch_bounds__(512) void ring_gemm_tn_kernel(u64* Z, const u64* __
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = ea[j] + eb[j];
             unsigned char* dst = (akq >> 1) * (BM * 16) + am * 16 + (akq & 1) * 8 + sA0;
-            split8_store(v, dst);
+            split8_store<128>(v, dst);
             if (BEAVER) {
                 const int k = kt * kKStep + akq * 8;
                 const int m = m0 + am;
                 u64 x = keyA + ((u64)m * (u64)K + (u64)k + 1ull) * COGNN_GAMMA;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) { v[j] = (m < M && k + j < K) ? cognn_mix64(x) : 0ull; x += COGNN_GAMMA; }
-                split8_store(v, dst + kATile);
+                split8_store<128>(v, dst + kATile);
             }
             const int kb = kt * kKStep + bkq * 4;
             u64 w[4];
@@ -726,7 +751,7 @@ int cognn_beaver_gemm_close_u64(cognn_ctx* ctx, uint64_t* Z, const uint64_t* E, 
 
 int cognn_beaver_gemm_fusable(int64_t M, int64_t N, int64_t K, int transA) {
     return (!transA && M >= 256 && N <= kFusedBN && K <= 4096 &&
-            (size_t)2 * ((K + kKStep - 1) / kKStep) * kBStage <= ((size_t)M * K + (size_t)K * N) * 8) ? 1 : 0;
+            (size_t)((K + 15) / 16) * kNnBStage <= ((size_t)M * K + (size_t)K * N) * 8) ? 1 : 0;
 }
 
 int cognn_beaver_gemm_close_raw_u64(cognn_ctx* ctx, uint64_t* Z, const uint64_t* E, const uint64_t* E1, const uint64_t* F,
@@ -742,36 +767,41 @@ int beaver_close_impl(cognn_ctx* ctx, uint64_t* Z, const uint64_t* E, const uint
                       const cognn_keys* keys, int p, int64_t M, int64_t N, int64_t K, int transA, uint64_t* scratch, bool raw) {
     int rc;
     if (cognn_beaver_gemm_fusable(M, N, K, transA)) {
-        const int nkt = (int)((K + kKStep - 1) / kKStep);
-        unsigned char* planes = (unsigned char*)scratch;           // 2*nkt*24 KiB of the (MxK + KxN)-word scratch
-        hipLaunchKernelGGL(prep_b_planes_kernel, dim3((unsigned)std::min(2 * nkt * kFusedBN * 8 / 256 + 1, 1024)), dim3(256), 0, ctx->stream,
-                           planes, (const u64*)F, keys->k[p == 0 ? COGNN_SL_B0 : COGNN_SL_B1], p, (int)K, (int)N, nkt);
+        unsigned char* planes = (unsigned char*)scratch;           // B limb planes, 16 KiB per K step, in the (MxK + KxN)-word scratch
+        const int nst = (int)((K + 15) / 16);
+        hipLaunchKernelGGL(prep_b_planes_ws_kernel, dim3((unsigned)std::min(nst * kFusedBN * 8 / 256 + 1, 1024)), dim3(256), 0, ctx->stream,
+                           planes, (const u64*)F, keys->k[p == 0 ? COGNN_SL_B0 : COGNN_SL_B1], p, (int)K, (int)N, nst);
         CG_LAUNCH_CHECK();
-        const size_t lds = 2 * (size_t)(8 * 2 * 128 * 16) + 2 * (size_t)kBStage;
-        const int nmb = (int)((M + 127) / 128);
-        static const int dbg = getenv("COGNN_GEMM_DBG") ? atoi(getenv("COGNN_GEMM_DBG")) : 0;   // timing experiments only
-#define CG_FUSED_LAUNCH(...)                                                                                                       \
+        const int cn = N <= 32 ? 1 : 2, bm = cn == 2 ? 64 : 128;
+        const size_t lds = 3 * ((size_t)(8 * 2 * bm * 16) + (size_t)kNnBStage);
+        const int nmb = (int)((M + bm - 1) / bm);
+        const bool full = (M % bm == 0) && (K % 16 == 0), kal = (K % 4 == 0);
+#define CG_WS_LAUNCH(...)                                                                                                          \
     do {                                                                                                                            \
-        CG_HIP(hipFuncSetAttribute((const void*)beaver_gemm_fused_kernel<__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        hipLaunchKernelGGL((beaver_gemm_fused_kernel<__VA_ARGS__>), dim3((unsigned)std::min(nmb, 256)), dim3(kFusedThreads), lds, ctx->stream, \
-                           (u64*)Z, (const u64*)E, (const u64*)E1, planes, keys->k[p == 0 ? COGNN_SL_A0 : COGNN_SL_A1], (int)M,    \
-                           (int)N, (int)K, nkt);                                                                                    \
+        CG_HIP(hipFuncSetAttribute((const void*)beaver_gemm_ws_kernel<__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL((beaver_gemm_ws_kernel<__VA_ARGS__>), dim3((unsigned)std::min(nmb, 256)), dim3(512), lds, ctx->stream,   \
+                       (u64*)Z, (const u64*)E, (const u64*)E1, planes, keys->k[p == 0 ? COGNN_SL_A0 : COGNN_SL_A1], (int)M,    \
+                       (int)N, (int)K, nst);                                                                                    \
     } while (0)
-        if (nkt == 4 && dbg == 1) CG_FUSED_LAUNCH(4, 1);
-        else if (nkt == 4 && dbg == 2) CG_FUSED_LAUNCH(4, 2);
-        else if (nkt == 4 && dbg == 3) CG_FUSED_LAUNCH(4, 3);
-        else if (nkt == 4 && dbg == 4) CG_FUSED_LAUNCH(4, 4);
-        else if (nkt == 4 && dbg == 7) CG_FUSED_LAUNCH(4, 7);
-        else if (nkt == 4 && dbg == 15) CG_FUSED_LAUNCH(4, 15);
-        else if (nkt == 4 && dbg == 23) CG_FUSED_LAUNCH(4, 23);
-        else if (nkt == 4 && dbg == 31) CG_FUSED_LAUNCH(4, 31);
-        else if (K % 8 != 0) CG_FUSED_LAUNCH(0, 0, false);
-        else if (nkt == 4) CG_FUSED_LAUNCH(4, 0);
-        else if (nkt == 2) CG_FUSED_LAUNCH(2, 0);
-        else CG_FUSED_LAUNCH(0, 0);
-#undef CG_FUSED_LAUNCH
+        if (cn == 2) {
+            static const int dbg = getenv("COGNN_GEMM_DBG") ? atoi(getenv("COGNN_GEMM_DBG")) : 0;   // timing experiments only
+            if (full && nst == 8 && dbg == 1) CG_WS_LAUNCH(8, true, true, 2, 1);
+            else if (full && nst == 8 && dbg == 2) CG_WS_LAUNCH(8, true, true, 2, 2);
+            else if (full && nst == 8 && dbg == 4) CG_WS_LAUNCH(8, true, true, 2, 4);
+            else if (full && nst == 8 && dbg == 27) CG_WS_LAUNCH(8, true, true, 2, 27);
+            else if (full && nst == 8) CG_WS_LAUNCH(8, true, true, 2);
+            else if (full) CG_WS_LAUNCH(0, true, true, 2);
+            else if (kal) CG_WS_LAUNCH(0, false, true, 2);
+            else CG_WS_LAUNCH(0, false, false, 2);
+        } else {
+            if (full && nst == 4) CG_WS_LAUNCH(4, true, true, 1);
+            else if (full) CG_WS_LAUNCH(0, true, true, 1);
+            else if (kal) CG_WS_LAUNCH(0, false, true, 1);
+            else CG_WS_LAUNCH(0, false, false, 1);
+        }
+#undef CG_WS_LAUNCH
         CG_LAUNCH_CHECK();
-        if (raw) return 0;                                         // caller adds C_p (cognn_trunc_open_add_u64)
+        if (raw) return 0;                                     // caller adds C_p (cognn_trunc_open_add_u64)
         const int64_t n = M * N;
         hipLaunchKernelGGL(add_cp_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 8192)), dim3(256), 0, ctx->stream, (u64*)Z,
                            (const u64*)c1, keys->k[COGNN_SL_C0], p, n);
