@@ -25,19 +25,33 @@ def _wrap(ptr, nbytes, device):
     return torch.from_numpy(np.frombuffer(buf, dtype=np.uint8))
 
 
-def make_exchange(device, group=None):
-    """Returns the cognn_exchange_fn callback for cognn_engine_set_exchange()."""
+def make_exchange(device, group=None, host_staged=False):
+    """Returns the cognn_exchange_fn callback for cognn_engine_set_exchange().
+
+    host_staged: move every message through a host bounce buffer (device -> host, p2p, host -> device).  For process
+    groups whose backend cannot send device memory (gloo) - e.g. several ranks sharing one GPU in the tests, or a cluster
+    without GPU-direct transport; with RCCL leave it off."""
 
     def _exchange(user, xfers, n):
         try:
-            ops = []
+            ops, post = [], []
             for i in range(n):
                 x = xfers[i]
                 t = _wrap(x.ptr, x.bytes, device)
-                ops.append(dist.P2POp(dist.isend if x.is_send else dist.irecv, t, x.peer, group))
+                if host_staged and device.type == "cuda":
+                    if x.is_send:
+                        h = t.cpu()                         # synchronises with the engine's (default) stream
+                    else:
+                        h = torch.empty(x.bytes, dtype=torch.uint8)
+                        post.append((t, h))
+                    ops.append(dist.P2POp(dist.isend if x.is_send else dist.irecv, h, x.peer, group))
+                else:
+                    ops.append(dist.P2POp(dist.isend if x.is_send else dist.irecv, t, x.peer, group))
             if ops:
                 for w in dist.batch_isend_irecv(ops):
                     w.wait()
+            for t, h in post:
+                t.copy_(h)
             return 0
         except Exception as ex:  # noqa: BLE001 - the C caller only understands a status code
             print("cognn exchange failed: %r" % (ex,), flush=True)

@@ -19,7 +19,9 @@ def main():
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import cognn_oracle as co
     from cognn_amd import capi
-    capi.load(os.path.join(ROOT, "oracle", "libcognn_engine_cpu.so"))
+    hip = cfg.get("backend") == "hip"                      # tests/test_multirank_gpu.py: ranks share cuda:0, gloo moves host copies
+    if not hip:
+        capi.load(os.path.join(ROOT, "oracle", "libcognn_engine_cpu.so"))
     from cognn_amd import dist as cdist
     from cognn_amd.engine import Engine, GnnParam
     k = cfg["k"]; V = cfg["V"]
@@ -28,7 +30,7 @@ def main():
     feats, labels = co.synth_features(V, cfg["in"], cfg["lab"], cfg["gseed"] + 1, density=0.2)
     gp = GnnParam(num_labels=cfg["lab"], input_dim=cfg["in"], hidden_dim=cfg["hid"], num_samples=V, learning_rate=0.5)
     eng = Engine(k, src, dst, part, gp, seed=cfg["seed"], variant=cfg["variant"], rank=rank, world=world, stream=0)
-    eng.set_exchange(cdist.make_exchange(torch.device("cpu")))
+    eng.set_exchange(cdist.make_exchange(torch.device("cuda", 0), host_staged=True) if hip else cdist.make_exchange(torch.device("cpu")))
     eng.set_global_data(feats, labels)
     eng.start()
     out = {}

@@ -1,0 +1,28 @@
+"""N>1 path on the HIP backend: 2 and 4 engine ranks share the one GPU of the box (every rank runs the real kernels on
+cuda:0), messages travel as host copies over gloo (cognn_amd/dist.py host_staged) because two RCCL ranks cannot share a
+device.  Exercises what the CPU multi-rank tests cannot: the rank-aware share-table layout, the partial-sum launch and the
+inbox/outbox segments with the HIP kernels.  Every rank's shares are compared bit for bit with the oracle."""
+import pytest
+
+from test_multirank_cpu import BASE, _check
+
+pytestmark = pytest.mark.gpu
+
+
+def test_four_parties_two_ranks_training_hip(tmp_path):
+    _check(dict(BASE, k=4, backend="hip"), 2, tmp_path)
+
+
+def test_four_parties_four_ranks_inference_hip(tmp_path):
+    _check(dict(BASE, k=4, variant="optimize-gcn-inference", iters=2, backend="hip"), 4, tmp_path)
+
+
+def test_three_parties_three_ranks_training_hip(tmp_path):
+    _check(dict(BASE, k=3, backend="hip"), 3, tmp_path)
+
+
+def test_eight_parties_two_ranks_wide_rows_hip(tmp_path):
+    # wider rows and more vertices: 16-byte gather path, MFMA GEMM shapes, k >= 3 replication across ranks
+    cfg = dict(BASE, k=8, V=4096, Eu=16384, hid=16, lab=8, variant="optimize-gcn-inference", iters=2, backend="hip")
+    cfg["in"] = 32
+    _check(cfg, 2, tmp_path)
