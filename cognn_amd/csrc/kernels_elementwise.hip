@@ -125,7 +125,7 @@ struct TruncOpenAdd {    // c = x + C_p + r_p (+offset): opening of a raw Beaver
     }
 };
 struct TruncClose {
-    u64* out; const u64* c0; const u64* c1; cognn_opkeys k; int p; int mode;
+    u64* out; const u64* c0; const u64* c1; cognn_opkeys k; int p; int mode; u64* E; u64 key_open;
     __device__ void operator()(int64_t i, int w) const {
         u64 y[2];
         if (p == 0) {
@@ -142,6 +142,10 @@ struct TruncClose {
             y[0] = o[0] - y[0]; y[1] = o[1] - y[1];
         }
         st2(out, i, w, y);
+        if (E) {
+            u64 e[2] = {y[0] - cognn_prng(key_open, (u64)i), y[1] - cognn_prng(key_open, (u64)i + 1)};
+            st2(E, i, w, e);
+        }
     }
 };
 struct RowscaleOpenE {   // E = V - a_p
@@ -181,29 +185,43 @@ struct RowscaleClose {   // c_out = beaver(E0+E1, (G0+G1)[row]) + trunc mask
         st2(c, i, w, r);
     }
 };
-struct ReluOpen {        // E = z - a_p ; G = t_p - b_p
+struct ReluOpen {        // E = z - a_p ; G = t_p - b_p (G optional: the dealer can publish g = t - b offline, see ReluMul)
     u64* E; u64* G; const u64* z; cognn_opkeys k; int p;
     __device__ void operator()(int64_t i, int w) const {
         u64 v[2], e[2], g[2];
         ld2(z, i, w, v);
         for (int j = 0; j < 2; ++j) {
             u64 idx = (u64)(i + j);
-            u64 t0 = cognn_prng(k.k[COGNN_SL_T0], idx);
-            u64 tp = t0;
-            if (p == 1) tp = ((cognn_prng(k.k[COGNN_SL_T], idx) & 0xFFFFFull) | 1ull) - t0;
             e[j] = v[j] - cognn_prng(k.k[p == 0 ? COGNN_SL_A0 : COGNN_SL_A1], idx);
-            g[j] = tp - cognn_prng(k.k[p == 0 ? COGNN_SL_B0 : COGNN_SL_B1], idx);
+            if (G) {
+                u64 t0 = cognn_prng(k.k[COGNN_SL_T0], idx);
+                u64 tp = t0;
+                if (p == 1) tp = ((cognn_prng(k.k[COGNN_SL_T], idx) & 0xFFFFFull) | 1ull) - t0;
+                g[j] = tp - cognn_prng(k.k[p == 0 ? COGNN_SL_B0 : COGNN_SL_B1], idx);
+            }
         }
-        st2(E, i, w, e); st2(G, i, w, g);
+        st2(E, i, w, e);
+        if (G) st2(G, i, w, g);
     }
 };
 struct ReluMul {
+    // G == nullptr: g = t - (b0 + b1) is independent of the inputs (b masks t perfectly), so the dealer publishes it in the
+    // offline phase and no G opening is exchanged online; here it is regenerated from the dealer streams like every mask
     u64* wout; const u64* E; const u64* E1; const u64* G; const u64* G1; cognn_opkeys k; int p;
     __device__ void operator()(int64_t i, int w) const {
         u64 e[2], g[2], r[2];
-        ld2(E, i, w, e); ld2(G, i, w, g);
+        ld2(E, i, w, e);
         if (E1) { u64 t[2]; ld2(E1, i, w, t); e[0] += t[0]; e[1] += t[1]; }
-        if (G1) { u64 t[2]; ld2(G1, i, w, t); g[0] += t[0]; g[1] += t[1]; }
+        if (G) {
+            ld2(G, i, w, g);
+            if (G1) { u64 t[2]; ld2(G1, i, w, t); g[0] += t[0]; g[1] += t[1]; }
+        } else {
+            for (int j = 0; j < 2; ++j) {
+                u64 idx = (u64)(i + j);
+                g[j] = ((cognn_prng(k.k[COGNN_SL_T], idx) & 0xFFFFFull) | 1ull) - cognn_prng(k.k[COGNN_SL_B0], idx) -
+                       cognn_prng(k.k[COGNN_SL_B1], idx);
+            }
+        }
         for (int j = 0; j < 2; ++j) r[j] = beaver_mul(k, p, e[j], g[j], (u64)(i + j), (u64)(i + j));
         st2(wout, i, w, r);
     }
@@ -391,7 +409,13 @@ int cognn_trunc_close_u64(cognn_ctx* ctx, uint64_t* out, const uint64_t* c0, con
                           int p, int mode, int64_t n) {
     CG_REQUIRE(ctx && out && keys && (p == 0 || p == 1) && al(out) && al(c0) && al(c1), "cognn_trunc_close_u64: bad arguments");
     CG_REQUIRE(p == 1 || (c0 && c1), "cognn_trunc_close_u64: p=0 needs both opened values");
-    return launch_ew(ctx, n, TruncClose{(u64*)out, (const u64*)c0, (const u64*)c1, K(keys), p, mode});
+    return launch_ew(ctx, n, TruncClose{(u64*)out, (const u64*)c0, (const u64*)c1, K(keys), p, mode, nullptr, 0});
+}
+int cognn_trunc_close_open_u64(cognn_ctx* ctx, uint64_t* out, uint64_t* E, const uint64_t* c0, const uint64_t* c1, const cognn_keys* keys,
+                               int p, uint64_t key_open, int64_t n) {
+    CG_REQUIRE(ctx && out && E && keys && (p == 0 || p == 1) && al(out) && al(E) && al(c0) && al(c1), "cognn_trunc_close_open_u64: bad arguments");
+    CG_REQUIRE(p == 1 || (c0 && c1), "cognn_trunc_close_open_u64: p=0 needs both opened values");
+    return launch_ew(ctx, n, TruncClose{(u64*)out, (const u64*)c0, (const u64*)c1, K(keys), p, 0, (u64*)E, key_open});
 }
 int cognn_rowscale_open_u64(cognn_ctx* ctx, uint64_t* E, uint64_t* G, const uint64_t* V, const uint64_t* s,
                             const cognn_keys* keys, int p, int64_t rows, int64_t F) {
@@ -407,12 +431,12 @@ int cognn_rowscale_close_u64(cognn_ctx* ctx, uint64_t* c_out, const uint64_t* E,
     return launch_ew(ctx, rows * F, RowscaleClose{(u64*)c_out, (const u64*)E, (const u64*)E1, (const u64*)G, (const u64*)G1, K(keys), K(tkeys), p, (uint32_t)F});
 }
 int cognn_relu_open_u64(cognn_ctx* ctx, uint64_t* E, uint64_t* G, const uint64_t* z, const cognn_keys* keys, int p, int64_t n) {
-    CG_REQUIRE(ctx && E && G && z && keys && al(E) && al(G) && al(z), "cognn_relu_open_u64: bad arguments");
+    CG_REQUIRE(ctx && E && z && keys && al(E) && al(G) && al(z), "cognn_relu_open_u64: bad arguments");
     return launch_ew(ctx, n, ReluOpen{(u64*)E, (u64*)G, (const u64*)z, K(keys), p});
 }
 int cognn_relu_mul_u64(cognn_ctx* ctx, uint64_t* w, const uint64_t* E, const uint64_t* E1, const uint64_t* G, const uint64_t* G1,
                        const cognn_keys* keys, int p, int64_t n) {
-    CG_REQUIRE(ctx && w && E && G && keys && al(w) && al(E) && al(G) && al(E1) && al(G1), "cognn_relu_mul_u64: bad arguments");
+    CG_REQUIRE(ctx && w && E && keys && (G || !G1) && al(w) && al(E) && al(G) && al(E1) && al(G1), "cognn_relu_mul_u64: bad arguments");
     return launch_ew(ctx, n, ReluMul{(u64*)w, (const u64*)E, (const u64*)E1, (const u64*)G, (const u64*)G1, K(keys), p});
 }
 int cognn_relu_close_u64(cognn_ctx* ctx, uint64_t* h, uint8_t* mask, const uint64_t* z, const uint64_t* w0, const uint64_t* w1, int64_t n) {

@@ -210,9 +210,25 @@ void trunc_stage(cognn_engine* E, int64_t it, int op, u64 mul, const std::vector
     }
 }
 
+// closing step of a truncation; open_next (optional) returns the mask key of the op that consumes dst(side): the close then
+// also writes that op's opening E = dst - mask into ob[0] (one pass less, see cognn_trunc_close_open_u64)
+using OpenNext = std::function<u64(Side&)>;
+template <class DstFn>
+void trunc_close_all(cognn_engine* E, int64_t it, int top, DstFn dst, const std::vector<int64_t>& elems, const OpenNext& open_next) {
+    for (size_t i = 0; i < E->sides.size(); ++i) {
+        Side& s = E->sides[i];
+        cognn_keys tk = keys(E, s.owner, it, top);
+        const u64* c0 = s.p == 0 ? s.ob[2] : nullptr;
+        const u64* c1 = s.p == 0 ? s.ib[2] : nullptr;
+        if (open_next) BE(cognn_trunc_close_open_u64(E->ctx, dst(s), s.ob[0], c0, c1, &tk, s.p, open_next(s), elems[i]));
+        else BE(cognn_trunc_close_u64(E->ctx, dst(s), c0, c1, &tk, s.p, 0, elems[i]));
+    }
+}
+
 // Beaver GEMM for every side: X(side), Wm(side) -> truncated product written to dst(side)
 template <class XFn, class WFn, class SpecFn, class DstFn>
-void gemm_stage(cognn_engine* E, int64_t it, XFn X, WFn Wm, SpecFn spec, DstFn dst, bool x_opened = false) {
+void gemm_stage(cognn_engine* E, int64_t it, XFn X, WFn Wm, SpecFn spec, DstFn dst, bool x_opened = false,
+                const OpenNext& open_next = nullptr) {
     std::vector<int64_t> e0, e1, eo;
     const bool feature = spec(E->sides[0]).feature;
     auto gkeys = [&](Side& s, const GemmSpec& g) { return g.feature ? feature_gemm_keys(E, s.owner, it) : keys(E, s.owner, it, g.op); };
@@ -266,25 +282,32 @@ void gemm_stage(cognn_engine* E, int64_t it, XFn X, WFn Wm, SpecFn spec, DstFn d
     }
     // all GEMMs of one stage share the truncation op id
     if (!all_raw) {
-        trunc_stage(E, it, g0.top, 1, z, eo, dst, 0);
+        for (size_t i = 0; i < E->sides.size(); ++i) {
+            Side& s = E->sides[i];
+            cognn_keys tk = keys(E, s.owner, it, g0.top);
+            BE(cognn_trunc_open_u64(E->ctx, s.ob[2], z[i], 1, &tk, s.p, eo[i]));
+        }
+        exchange_ob(E, 2, eo);
+        trunc_close_all(E, it, g0.top, dst, eo, open_next);
         return;
     }
     exchange_ob(E, 2, eo);
-    for (size_t i = 0; i < E->sides.size(); ++i) {
-        Side& s = E->sides[i];
-        cognn_keys tk = keys(E, s.owner, it, g0.top);
-        BE(cognn_trunc_close_u64(E->ctx, dst(s), s.p == 0 ? s.ob[2] : nullptr, s.p == 0 ? s.ib[2] : nullptr, &tk, s.p, 0, eo[i]));
-    }
+    trunc_close_all(E, it, g0.top, dst, eo, open_next);
 }
 
 // row scale by the (owner-known) normaliser followed by truncation; x(side) [n x F] -> dst(side)
+enum { E_FROM_X = 0, E_IN_X = 1, E_IN_OB0 = 2 };
 template <class XFn, class DstFn>
-void rowscale_stage(cognn_engine* E, int64_t it, int op, int top, int F, XFn X, DstFn dst, bool e_opened = false) {
-    // e_opened: X(side) already holds the opening E_p = V_p - a_p (written by the gather epilogue)
+void rowscale_stage(cognn_engine* E, int64_t it, int op, int top, int F, XFn X, DstFn dst, int e_mode = E_FROM_X,
+                    const OpenNext& open_next = nullptr) {
+    // e_mode: E_FROM_X  open E_p = X_p - a_p here;
+    //         E_IN_X    X(side) already holds E_p (written by the gather epilogue);
+    //         E_IN_OB0  ob[0] already holds E_p (written by the truncation close that produced X)
+    const bool e_opened = e_mode == E_IN_X;
     std::vector<int64_t> eF, e1;
     for (auto& s : E->sides) {
         cognn_keys k = keys(E, s.owner, it, op);
-        BE(cognn_rowscale_open_u64(E->ctx, e_opened ? nullptr : s.ob[0], s.ob[1], X(s), s.svec, &k, s.p, s.n, F));
+        BE(cognn_rowscale_open_u64(E->ctx, e_mode == E_FROM_X ? s.ob[0] : nullptr, s.ob[1], X(s), s.svec, &k, s.p, s.n, F));
         eF.push_back((int64_t)s.n * F); e1.push_back(s.n);
     }
     if (e_opened) {
@@ -307,27 +330,24 @@ void rowscale_stage(cognn_engine* E, int64_t it, int op, int top, int F, XFn X, 
         BE(cognn_rowscale_close_u64(E->ctx, s.ob[2], e_own, e_peer, s.ob[1], s.ib[1], &k, &tk, s.p, s.n, F));
     }
     exchange_ob(E, 2, eF);
-    for (size_t i = 0; i < E->sides.size(); ++i) {
-        Side& s = E->sides[i];
-        cognn_keys tk = keys(E, s.owner, it, top);
-        BE(cognn_trunc_close_u64(E->ctx, dst(s), s.p == 0 ? s.ob[2] : nullptr, s.p == 0 ? s.ib[2] : nullptr, &tk, s.p, 0, eF[i]));
-    }
+    trunc_close_all(E, it, top, dst, eF, open_next);
 }
 
-void relu_stage(cognn_engine* E, int64_t it) {
+void relu_stage(cognn_engine* E, int64_t it, bool e_opened) {
+    // e_opened: ob[0] already holds E = z - a (written by the truncation close that produced z)
     const int F = E->hid();
     std::vector<int64_t> eF;
     for (auto& s : E->sides) {
         cognn_keys k = keys(E, s.owner, it, COGNN_OP_AP_RELU);
-        BE(cognn_relu_open_u64(E->ctx, s.ob[0], s.ob[1], s.cur, &k, s.p, (int64_t)s.n * F));
+        // only E = z - a is opened online: g = t - b is input-independent and published by the dealer offline
+        if (!e_opened) BE(cognn_relu_open_u64(E->ctx, s.ob[0], nullptr, s.cur, &k, s.p, (int64_t)s.n * F));
         eF.push_back((int64_t)s.n * F);
     }
     exchange_ob(E, 0, eF);
-    exchange_ob(E, 1, eF);
     for (size_t i = 0; i < E->sides.size(); ++i) {
         Side& s = E->sides[i];
         cognn_keys k = keys(E, s.owner, it, COGNN_OP_AP_RELU);
-        BE(cognn_relu_mul_u64(E->ctx, s.ob[2], s.ob[0], s.ib[0], s.ob[1], s.ib[1], &k, s.p, eF[i]));
+        BE(cognn_relu_mul_u64(E->ctx, s.ob[2], s.ob[0], s.ib[0], nullptr, nullptr, &k, s.p, eF[i]));
     }
     exchange_ob(E, 2, eF);
     // H is the next iteration's PreScatter GEMM input (layer 1): write it straight into its h_t slot and emit the
@@ -567,6 +587,7 @@ void weight_update_chain(cognn_engine* E, int64_t it, int layer) {
 
 void run_iteration(cognn_engine* E, int64_t it) {
     const IterInfo I = iter_info(E, it);
+    bool relu_opened = false;
     if (I.e == 0) {                                        // ss_...h:695, 938: back to the input features
         for (auto& s : E->sides) { s.cur = s.feat; s.curF = E->in(); }
     }
@@ -578,12 +599,15 @@ void run_iteration(cognn_engine* E, int64_t it) {
             if (I.layer == 1 && !x_opened)
                 for (auto& s : E->sides) BE(cognn_memcpy_d2d(E->ctx, s.h1, s.cur, (size_t)s.n * E->hid() * 8));   // h_t[1]
             const bool scale_follows = I.e != 0;
+            // the truncation close of the product also opens the row scale that consumes it
+            OpenNext open_scale = [&](Side& s) { return keys(E, s.owner, it, COGNN_OP_PS_SCALE).k[s.p == 0 ? COGNN_SL_A0 : COGNN_SL_A1]; };
             gemm_stage(E, it, [&](Side& s) { return s.cur; }, [&](Side& s) { return s.W[I.layer]; },
                        [&](Side& s) { return prescatter_spec(E, s, I.layer); },
-                       [&](Side& s) { return scale_follows ? s.buf[1] : table_seg(E, s, F); }, x_opened);
+                       [&](Side& s) { return scale_follows ? s.buf[1] : table_seg(E, s, F); }, x_opened,
+                       scale_follows ? open_scale : OpenNext());
             if (scale_follows)
                 rowscale_stage(E, it, COGNN_OP_PS_SCALE, COGNN_OP_PS_SCALE_TRUNC, F, [&](Side& s) { return s.buf[1]; },
-                               [&](Side& s) { return table_seg(E, s, F); });
+                               [&](Side& s) { return table_seg(E, s, F); }, E_IN_OB0);
         } else {
             rowscale_stage(E, it, COGNN_OP_PS_SCALE, COGNN_OP_PS_SCALE_TRUNC, F, [&](Side& s) { return s.cur; },
                            [&](Side& s) { return table_seg(E, s, F); });
@@ -592,15 +616,19 @@ void run_iteration(cognn_engine* E, int64_t it) {
         const bool gscale = (it + 1) % I.ep != 0;          // gcn.h:470
         const bool fuse_open = gscale && E->sides.size() <= 32;
         message_passing(E, F, it, fuse_open);
+        relu_opened = false;
         if (gscale) {
+            // a hidden forward layer feeds the ReLU next: the close of this scale already opens it
+            relu_opened = I.fwd && I.e != I.f - 1;
+            OpenNext open_relu = [&](Side& s) { return keys(E, s.owner, it, COGNN_OP_AP_RELU).k[s.p == 0 ? COGNN_SL_A0 : COGNN_SL_A1]; };
             rowscale_stage(E, it, COGNN_OP_GA_SCALE, COGNN_OP_GA_SCALE_TRUNC, F, [&](Side& s) { return s.cur; },
-                           [&](Side& s) { return s.buf[1]; }, fuse_open);
+                           [&](Side& s) { return s.buf[1]; }, fuse_open ? E_IN_X : E_FROM_X, relu_opened ? open_relu : OpenNext());
             for (auto& s : E->sides) s.cur = s.buf[1];
         }
     }
     // ---- ApplyComp (gcn.h:515-811) ----
     if (I.fwd) {
-        if (I.e != I.f - 1) relu_stage(E, it);
+        if (I.e != I.f - 1) relu_stage(E, it, relu_opened);
         else softmax_stage(E, it);
         for (auto& s : E->sides) s.curF = (I.e != I.f - 1) ? E->hid() : E->lab();
         return;

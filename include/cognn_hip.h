@@ -113,6 +113,10 @@ int cognn_trunc_open_add_u64(cognn_ctx*, uint64_t* c, const uint64_t* x, const u
  * (twoPartyGCNApplyGradient, gcn.h:678,730). */
 int cognn_trunc_close_u64(cognn_ctx*, uint64_t* out, const uint64_t* c0, const uint64_t* c1, const cognn_keys* keys,
                           int p, int mode, int64_t n);
+/* mode-0 close that also emits the mask opening of the op that consumes the result: out = y, E = y - prng(key_open, i)
+ * (E_p = X_p - A_p of the next Beaver product / row scale / ReLU, gcn.h:233,247,549) - one pass instead of two. */
+int cognn_trunc_close_open_u64(cognn_ctx*, uint64_t* out, uint64_t* E, const uint64_t* c0, const uint64_t* c1, const cognn_keys* keys,
+                               int p, uint64_t key_open, int64_t n);
 
 /* ---- sci::twoPartyGCNVectorScale (gcn.h:247,476): row scale by an additively shared vector - */
 /* E_p = V_p - a_p [rows x F] (skipped when E == NULL: already opened by cognn_gather_csr_open_u64), G_p = s_p - b_p [rows] */
@@ -125,8 +129,11 @@ int cognn_rowscale_close_u64(cognn_ctx*, uint64_t* c_out, const uint64_t* E0, co
                              const cognn_keys* keys, const cognn_keys* tkeys, int p, int64_t rows, int64_t F);
 
 /* ---- sci::twoPartyGCNRelu / twoPartyGCNBackwardNNWithoutAH (gcn.h:549,705) ---------------- */
+/* E_p = z_p - a_p, G_p = t_p - b_p.  G may be NULL: g = t - b does not depend on the inputs, so the dealer can publish it
+ * in the offline phase and only E (and later w) travel online; cognn_relu_mul_u64 then takes G0 = G1 = NULL. */
 int cognn_relu_open_u64(cognn_ctx*, uint64_t* E, uint64_t* G, const uint64_t* z, const cognn_keys* keys, int p, int64_t n);
-/* w_p = Beaver product share of z*t from the opened E = E0+E1, G = G0+G1 (E1/G1 may be NULL) */
+/* w_p = Beaver product share of z*t from the opened E = E0+E1, G = G0+G1 (E1/G1 may be NULL; G0 NULL: dealer-published g,
+ * regenerated from the dealer streams) */
 int cognn_relu_mul_u64(cognn_ctx*, uint64_t* w, const uint64_t* E0, const uint64_t* E1, const uint64_t* G0, const uint64_t* G1,
                        const cognn_keys* keys, int p, int64_t n);
 /* h_p = (int64)(w0+w1) > 0 ? z_p : 0; mask (1 byte/element, public) may be NULL */

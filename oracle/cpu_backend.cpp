@@ -211,6 +211,13 @@ int cognn_trunc_close_u64(cognn_ctx*, uint64_t* out, const uint64_t* c0, const u
     }
     return 0;
 }
+int cognn_trunc_close_open_u64(cognn_ctx* c, uint64_t* out, uint64_t* E, const uint64_t* c0, const uint64_t* c1, const cognn_keys* keys,
+                               int p, uint64_t key_open, int64_t n) {
+    const int rc = cognn_trunc_close_u64(c, out, c0, c1, keys, p, 0, n);
+    if (rc) return rc;
+    for (int64_t i = 0; i < n; ++i) E[i] = out[i] - cognn_prng(key_open, (u64)i);
+    return 0;
+}
 int cognn_rowscale_open_u64(cognn_ctx*, uint64_t* E, uint64_t* G, const uint64_t* V, const uint64_t* s, const cognn_keys* keys,
                             int p, int64_t rows, int64_t F) {
     if (E) for (int64_t i = 0; i < rows * F; ++i) E[i] = V[i] - cognn_prng(keys->k[p == 0 ? COGNN_SL_A0 : COGNN_SL_A1], (u64)i);
@@ -232,14 +239,20 @@ int cognn_relu_open_u64(cognn_ctx*, uint64_t* E, uint64_t* G, const uint64_t* z,
         const u64 t0 = cognn_prng(keys->k[COGNN_SL_T0], (u64)i);
         const u64 tp = p == 0 ? t0 : ((cognn_prng(keys->k[COGNN_SL_T], (u64)i) & 0xFFFFFull) | 1ull) - t0;
         E[i] = z[i] - cognn_prng(keys->k[p == 0 ? COGNN_SL_A0 : COGNN_SL_A1], (u64)i);
-        G[i] = tp - cognn_prng(keys->k[p == 0 ? COGNN_SL_B0 : COGNN_SL_B1], (u64)i);
+        if (G) G[i] = tp - cognn_prng(keys->k[p == 0 ? COGNN_SL_B0 : COGNN_SL_B1], (u64)i);
     }
     return 0;
 }
 int cognn_relu_mul_u64(cognn_ctx*, uint64_t* w, const uint64_t* E, const uint64_t* E1, const uint64_t* G, const uint64_t* G1,
                        const cognn_keys* keys, int p, int64_t n) {
     const cognn_opkeys k = K(keys);
-    for (int64_t i = 0; i < n; ++i) w[i] = beaver_mul(k, p, E[i] + (E1 ? E1[i] : 0), G[i] + (G1 ? G1[i] : 0), (u64)i, (u64)i);
+    for (int64_t i = 0; i < n; ++i) {
+        // G == NULL: dealer-published g = t - (b0 + b1)
+        const u64 g = G ? G[i] + (G1 ? G1[i] : 0)
+                        : ((cognn_prng(keys->k[COGNN_SL_T], (u64)i) & 0xFFFFFull) | 1ull) - cognn_prng(keys->k[COGNN_SL_B0], (u64)i) -
+                              cognn_prng(keys->k[COGNN_SL_B1], (u64)i);
+        w[i] = beaver_mul(k, p, E[i] + (E1 ? E1[i] : 0), g, (u64)i, (u64)i);
+    }
     return 0;
 }
 int cognn_relu_close_u64(cognn_ctx*, uint64_t* h, uint8_t* mask, const uint64_t* z, const uint64_t* w0, const uint64_t* w1, int64_t n) {

@@ -214,6 +214,14 @@ def test_trunc_pair(ctx):
         rec = (host(o0) + host(o1)).astype(np.int64)
     exact = x.astype(np.int64) >> 16
     assert np.all((rec - exact >= 0) & (rec - exact <= 1))               # floor or floor+1
+    # close + opening of the consuming op in one pass: E = y - mask(key_open)
+    ko = 0x1234567890ABCDEF
+    for p, (cc0, cc1, w) in enumerate(((c0, c1, w0), (None, None, w1))):
+        o = dev_empty(n); e = dev_empty(n)
+        ctx.call("cognn_trunc_close_open_u64", ptr(o), ptr(e), ptr(cc0) if cc0 is not None else None,
+                 ptr(cc1) if cc1 is not None else None, ctypes.byref(k), p, ctypes.c_uint64(ko), n)
+        with np.errstate(over="ignore"):
+            assert np.array_equal(host(o), w) and np.array_equal(host(e), w - co.prng_shape(ko, (n,)))
     # mode 1 (apply gradient): out -= y, with a public multiplier
     W = rand_u64(rng, n); Wd0 = dev(W); Wd1 = dev(W)
     mul = 32768
@@ -274,6 +282,14 @@ def test_relu_pair(ctx):
     assert np.array_equal(host(h[0]), h0) and np.array_equal(host(h[1]), h1)
     assert np.array_equal(host(mask, np.uint8).astype(bool), pos)
     assert np.array_equal(pos, z.astype(np.int64) > 0)
+    # dealer-published g (no G opening online): same product shares, bit for bit
+    E2 = [dev_empty(n) for _ in range(2)]; w2 = [dev_empty(n) for _ in range(2)]
+    for p in range(2):
+        ctx.call("cognn_relu_open_u64", ptr(E2[p]), None, ptr(zd[p]), ctypes.byref(k), p, n)
+    for p in range(2):
+        ctx.call("cognn_relu_mul_u64", ptr(w2[p]), ptr(E2[p]), ptr(E2[1 - p]), None, None, ctypes.byref(k), p, n)
+    for p in range(2):
+        assert np.array_equal(host(E2[p]), host(E[p])) and np.array_equal(host(w2[p]), host(w[p]))
     sel = dev_empty(n)
     ctx.call("cognn_mask_select_u64", ptr(sel), ptr(zd[0]), ptr(mask), n)
     assert np.array_equal(host(sel), np.where(pos, z0, U64(0)))
