@@ -61,12 +61,39 @@ def message_widths(variant, iters, hid, lab):
     return sum(w[i % 6] for i in range(iters))
 
 
+def _cpu_engine_run(wl, shift, threads, steps):
+    """One child process of oracle/cpu_engine_bench.py (plain-C++ reference backend under the same engine host code)."""
+    import subprocess
+    k, lv, le, in_dim, hid, lab, variant, iters = wl
+    lv2, le2 = max(lv - shift, 8), max(le - shift, 10)
+    env = dict(os.environ, OMP_NUM_THREADS=str(threads), HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "cpu_engine_bench.py"), str(k), str(lv2), str(le2), str(in_dim),
+                          str(hid), str(lab), variant, str(iters), str(steps)], env=env, capture_output=True, text=True, timeout=600)
+    if out.returncode != 0:
+        raise RuntimeError(out.stderr[-2000:])
+    r = json.loads(out.stdout.strip().splitlines()[-1])
+    return r["seconds_per_pass"], float(r["edges"]), lv2, le2
+
+
 def cpu_baseline(args, wl):
-    """The numpy oracle on a bounded 1/16-scale sample of the same workload (rank 0, N=1 only): a few seconds of
-    single-core work inside the timed region (its Python-loop preprocessing is outside it)."""
+    """CPU restatement of the same pass, timed on this box's host cores on a bounded sample (rank 0, N=1 only).  Preferred:
+    the engine's host code on the plain-C++ reference backend (oracle/libcognn_engine_cpu.so, OpenMP), all cores on a
+    1/4-scale graph plus one single-thread pass on a 1/16-scale graph; fallback (library not built): the numpy oracle."""
+    k, lv, le, in_dim, hid, lab, variant, iters = wl
+    widths = message_widths(variant, iters, hid, lab)
+    try:
+        cores = len(os.sched_getaffinity(0))
+        dt_all, edges_all, lva, lea = _cpu_engine_run(wl, 2, cores, 2)
+        dt_1, edges_1, lv1, le1 = _cpu_engine_run(wl, 4, 1, 1)
+        return {"value": edges_all * widths / dt_all, "unit": "edges*feat/s", "cores": cores, "kind": "port",
+                "value_1core": edges_1 * widths / dt_1,
+                "sample": "engine host code on the plain-C++ reference backend (oracle/cpu_backend.cpp, OpenMP): %d-party %s pass, "
+                          "in=%d hid=%d labels=%d; %d threads on a 2^%d-vertex/2^%d-edge graph: %.2f s per pass; 1 thread on "
+                          "2^%d/2^%d: %.2f s per pass" % (k, variant, in_dim, hid, lab, cores, lva, lea, dt_all, lv1, le1, dt_1)}
+    except Exception as ex:  # noqa: BLE001 - the baseline must not take the bench down
+        sys.stderr.write("cpu_baseline: C++ reference backend unavailable (%r), using the numpy oracle\n" % (ex,))
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import cognn_oracle as co
-    k, lv, le, in_dim, hid, lab, variant, iters = wl
     lv2, le2 = max(lv - 4, 8), max(le - 4, 10)
     V, Eu = 1 << lv2, 1 << (le2 - 1)
     src, dst = co.synth_graph(V, Eu, 0xC06A11)
@@ -78,7 +105,7 @@ def cpu_baseline(args, wl):
     for it in range(iters):
         o.iteration(it)
     dt = time.perf_counter() - t0
-    ef = float(len(src)) * message_widths(variant, iters, hid, lab)
+    ef = float(len(src)) * widths
     return {"value": ef / dt, "unit": "edges*feat/s", "cores": 1, "kind": "port",
             "sample": "numpy oracle (oracle/cognn_oracle.py), %d-party %s pass on a 2^%d-vertex/2^%d-edge graph, "
                       "in=%d hid=%d labels=%d, %.2f s" % (k, variant, lv2, le2, in_dim, hid, lab, dt)}

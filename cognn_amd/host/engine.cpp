@@ -177,6 +177,19 @@ void exchange_ob(cognn_engine* E, int j, const std::vector<int64_t>& elems) {
     }
     run_exchange(E, xl);
 }
+// two outboxes in ONE round (fewer, larger p2p groups: every round costs a host round trip through the exchange callback)
+void exchange_ob2(cognn_engine* E, int j0, const std::vector<int64_t>& e0, int j1, const std::vector<int64_t>& e1) {
+    XList xl;
+    for (size_t i = 0; i < E->sides.size(); ++i) {
+        Side& s = E->sides[i];
+        if (s.peer) continue;
+        xl.send(s.peer_rank, s.ob[j0], e0[i] * 8);
+        xl.recv(s.peer_rank, s.ib[j0], e0[i] * 8);
+        xl.send(s.peer_rank, s.ob[j1], e1[i] * 8);
+        xl.recv(s.peer_rank, s.ib[j1], e1[i] * 8);
+    }
+    run_exchange(E, xl);
+}
 std::vector<int64_t> per_side(cognn_engine* E, int64_t (*f)(cognn_engine*, Side&)) {
     std::vector<int64_t> r;
     for (auto& s : E->sides) r.push_back(f(E, s));
@@ -239,8 +252,8 @@ void gemm_stage(cognn_engine* E, int64_t it, XFn X, WFn Wm, SpecFn spec, DstFn d
         BE(cognn_mask_open_u64(E->ctx, s.ob[1], Wm(s), k.k[s.p == 0 ? COGNN_SL_B0 : COGNN_SL_B1], g.K, g.N, 0));
         e0.push_back(g.M * g.K); e1.push_back(g.K * g.N); eo.push_back(g.M * g.N);
     }
-    if (!feature) exchange_ob(E, 0, e0);                    // the feature opening was exchanged once in start()
-    exchange_ob(E, 1, e1);
+    if (!feature) exchange_ob2(E, 0, e0, 1, e1);            // the feature opening was exchanged once in start()
+    else exchange_ob(E, 1, e1);
     for (size_t i = 0; i < E->sides.size(); ++i) {
         Side& s = E->sides[i];
         BE(cognn_add_u64(E->ctx, s.fsum, s.ob[1], s.ib[1], e1[i]));
@@ -317,12 +330,13 @@ void rowscale_stage(cognn_engine* E, int64_t it, int op, int top, int F, XFn X, 
             if (s.peer) continue;
             xl.send(s.peer_rank, X(s), eF[i] * 8);
             xl.recv(s.peer_rank, s.ib[0], eF[i] * 8);
+            xl.send(s.peer_rank, s.ob[1], e1[i] * 8);
+            xl.recv(s.peer_rank, s.ib[1], e1[i] * 8);
         }
         run_exchange(E, xl);
     } else {
-        exchange_ob(E, 0, eF);
+        exchange_ob2(E, 0, eF, 1, e1);
     }
-    exchange_ob(E, 1, e1);
     for (auto& s : E->sides) {                              // the opened sums E0+E1, G0+G1 are formed inside the kernel
         cognn_keys k = keys(E, s.owner, it, op), tk = keys(E, s.owner, it, top);
         const u64* e_own = e_opened ? X(s) : s.ob[0];

@@ -1,5 +1,5 @@
 // TEST INFRASTRUCTURE — NOT PRODUCT CODE.
-// Plain C++ (serial loops, host memory) implementation of every entry point of include/cognn_hip.h, bound
+// Plain C++ (simple loops, host memory) implementation of every entry point of include/cognn_hip.h, bound
 // as the arithmetic backend of cognn_amd/host/engine.cpp in oracle/libcognn_engine_cpu.so.  It exists so that
 //   (1) the engine's host logic (layout, CSR construction, schedule, multi-rank exchange lists) can be
 //       checked on CPU against oracle/cognn_oracle.py, including world_size-2 runs over gloo, and
@@ -17,6 +17,9 @@
 
 #include "../cognn_amd/csrc/cognn_spec.h"
 #include "../cognn_amd/host/backend.h"
+
+// OpenMP over loops whose iterations are independent (bench.py's cpu_baseline uses all host cores; tests run with 1 thread)
+#define CG_PAR _Pragma("omp parallel for schedule(static)")
 
 typedef uint64_t u64;
 
@@ -85,6 +88,7 @@ void cognn_make_keys(uint64_t seed, uint64_t owner, uint64_t iter, uint64_t op, 
 }
 
 int cognn_fx_encode_f64(cognn_ctx*, const double* in, const double* rs, uint64_t* fx, int64_t rows, int64_t cols) {
+    CG_PAR
     for (int64_t i = 0; i < rows * cols; ++i) {
         double v = in[i];
         if (rs) v *= rs[i / cols];
@@ -93,6 +97,7 @@ int cognn_fx_encode_f64(cognn_ctx*, const double* in, const double* rs, uint64_t
     return 0;
 }
 int cognn_share_split_u64(cognn_ctx*, const uint64_t* fx, uint64_t key, uint64_t* s0, uint64_t* s1, int64_t n) {
+    CG_PAR
     for (int64_t i = 0; i < n; ++i) {
         const u64 b = cognn_prng(key, (u64)i);
         if (s0) s0[i] = fx[i] - b;
@@ -101,13 +106,15 @@ int cognn_share_split_u64(cognn_ctx*, const uint64_t* fx, uint64_t key, uint64_t
     return 0;
 }
 int cognn_prng_fill_u64(cognn_ctx*, uint64_t* out, uint64_t key, int64_t n) {
+    CG_PAR
     for (int64_t i = 0; i < n; ++i) out[i] = cognn_prng(key, (u64)i);
     return 0;
 }
 int cognn_gather_csr_u64(cognn_ctx*, uint64_t* out, const uint64_t* base, const uint64_t* table, const uint32_t* rowptr,
                          const uint32_t* col, int64_t n_rows, int64_t F) {
-    std::vector<u64> acc((size_t)F);
+    CG_PAR
     for (int64_t r = 0; r < n_rows; ++r) {
+        std::vector<u64> acc((size_t)F);                    // out may alias base/table rows of other segments, never row r's sources
         for (int64_t j = 0; j < F; ++j) acc[j] = base ? base[r * F + j] : 0;
         for (uint32_t e = rowptr[r]; e < rowptr[r + 1]; ++e) {
             const u64* src = table + (size_t)col[e] * F;
@@ -134,6 +141,7 @@ int cognn_scatter_add_rows_u64(cognn_ctx*, uint64_t* v, const uint64_t* part, co
 int cognn_ring_gemm_u64(cognn_ctx*, uint64_t* C, const uint64_t* A, const uint64_t* B, int64_t M, int64_t N, int64_t K,
                         int transA, int accumulate) {
     if (!accumulate) memset(C, 0, (size_t)M * N * 8);
+    CG_PAR
     for (int64_t m = 0; m < M; ++m)
         for (int64_t k = 0; k < K; ++k) {
             const u64 a = transA ? A[k * M + m] : A[m * K + k];
@@ -144,25 +152,31 @@ int cognn_ring_gemm_u64(cognn_ctx*, uint64_t* C, const uint64_t* A, const uint64
     return 0;
 }
 int cognn_mask_open_u64(cognn_ctx*, uint64_t* E, const uint64_t* X, uint64_t key, int64_t rows, int64_t cols, int tr) {
+    CG_PAR
     for (int64_t i = 0; i < rows * cols; ++i) E[i] = X[i] - cognn_prng(key, lidx(i, rows, cols, tr));
     return 0;
 }
 int cognn_add_u64(cognn_ctx*, uint64_t* o, const uint64_t* a, const uint64_t* b, int64_t n) {
+    CG_PAR
     for (int64_t i = 0; i < n; ++i) o[i] = a[i] + b[i];
     return 0;
 }
 int cognn_sub_u64(cognn_ctx*, uint64_t* o, const uint64_t* a, const uint64_t* b, int64_t n) {
+    CG_PAR
     for (int64_t i = 0; i < n; ++i) o[i] = a[i] - b[i];
     return 0;
 }
 int cognn_dealer_gemm_c1_u64(cognn_ctx* c, uint64_t* C1, const cognn_keys* keys, int64_t M, int64_t N, int64_t K, int transA,
                              uint64_t* sa, uint64_t* sb) {
+    CG_PAR
     for (int64_t i = 0; i < M * K; ++i) {
         const u64 li = lidx(i, M, K, transA);
         sa[i] = cognn_prng(keys->k[COGNN_SL_A0], li) + cognn_prng(keys->k[COGNN_SL_A1], li);
     }
+    CG_PAR
     for (int64_t i = 0; i < K * N; ++i) sb[i] = cognn_prng(keys->k[COGNN_SL_B0], (u64)i) + cognn_prng(keys->k[COGNN_SL_B1], (u64)i);
     cognn_ring_gemm_u64(c, C1, sa, sb, M, N, K, transA, 0);
+    CG_PAR
     for (int64_t i = 0; i < M * N; ++i) C1[i] -= cognn_prng(keys->k[COGNN_SL_C0], (u64)i);
     return 0;
 }
@@ -170,6 +184,7 @@ int cognn_ring_gemm2_u64(cognn_ctx* c, uint64_t* C, const uint64_t* A1, const ui
                          int64_t K, int transA, int accumulate) {
     if (!A2) return cognn_ring_gemm_u64(c, C, A1, B, M, N, K, transA, accumulate);
     std::vector<u64> a((size_t)M * K);
+    CG_PAR
     for (int64_t i = 0; i < M * K; ++i) a[i] = A1[i] + A2[i];
     return cognn_ring_gemm_u64(c, C, a.data(), B, M, N, K, transA, accumulate);
 }
@@ -177,8 +192,11 @@ int cognn_beaver_gemm_close_u64(cognn_ctx* c, uint64_t* Z, const uint64_t* E, co
                                 const cognn_keys* keys, int p, int64_t M, int64_t N, int64_t K, int transA, uint64_t* scratch) {
     REQ(p == 0 || c1, "beaver_gemm_close: p=1 needs c1");
     u64* Ap = scratch; u64* Bp = scratch + M * K;
+    CG_PAR
     for (int64_t i = 0; i < M * K; ++i) Ap[i] = cognn_prng(keys->k[p == 0 ? COGNN_SL_A0 : COGNN_SL_A1], lidx(i, M, K, transA));
+    CG_PAR
     for (int64_t i = 0; i < K * N; ++i) Bp[i] = cognn_prng(keys->k[p == 0 ? COGNN_SL_B0 : COGNN_SL_B1], (u64)i) + (p == 1 ? F[i] : 0);
+    CG_PAR
     for (int64_t i = 0; i < M * N; ++i) Z[i] = p == 0 ? cognn_prng(keys->k[COGNN_SL_C0], (u64)i) : c1[i];
     cognn_ring_gemm2_u64(c, Z, E, E1, Bp, M, N, K, transA, 1);
     return cognn_ring_gemm_u64(c, Z, Ap, F, M, N, K, transA, 1);
@@ -197,6 +215,7 @@ int cognn_trunc_open_add_u64(cognn_ctx*, uint64_t* c, const uint64_t* x, const u
 }
 int cognn_trunc_open_u64(cognn_ctx*, uint64_t* c, const uint64_t* x, uint64_t mul, const cognn_keys* keys, int p, int64_t n) {
     const cognn_opkeys k = K(keys);
+    CG_PAR
     for (int64_t i = 0; i < n; ++i) c[i] = x[i] * mul + trunc_r(k, p, (u64)i) + (p == 0 ? COGNN_TRUNC_OFFSET : 0);
     return 0;
 }
@@ -204,6 +223,7 @@ int cognn_trunc_close_u64(cognn_ctx*, uint64_t* out, const uint64_t* c0, const u
                           int mode, int64_t n) {
     REQ(p == 1 || (c0 && c1), "trunc_close: p=0 needs both opened values");
     const cognn_opkeys k = K(keys);
+    CG_PAR
     for (int64_t i = 0; i < n; ++i) {
         u64 y = p == 0 ? ((c0[i] + c1[i]) >> COGNN_FX_BITS) - (COGNN_TRUNC_OFFSET >> COGNN_FX_BITS) - trunc_rp(k, 0, (u64)i)
                        : 0ull - trunc_rp(k, 1, (u64)i);
@@ -215,18 +235,21 @@ int cognn_trunc_close_open_u64(cognn_ctx* c, uint64_t* out, uint64_t* E, const u
                                int p, uint64_t key_open, int64_t n) {
     const int rc = cognn_trunc_close_u64(c, out, c0, c1, keys, p, 0, n);
     if (rc) return rc;
+    CG_PAR
     for (int64_t i = 0; i < n; ++i) E[i] = out[i] - cognn_prng(key_open, (u64)i);
     return 0;
 }
 int cognn_rowscale_open_u64(cognn_ctx*, uint64_t* E, uint64_t* G, const uint64_t* V, const uint64_t* s, const cognn_keys* keys,
                             int p, int64_t rows, int64_t F) {
     if (E) for (int64_t i = 0; i < rows * F; ++i) E[i] = V[i] - cognn_prng(keys->k[p == 0 ? COGNN_SL_A0 : COGNN_SL_A1], (u64)i);
+    CG_PAR
     for (int64_t r = 0; r < rows; ++r) G[r] = s[r] - cognn_prng(keys->k[p == 0 ? COGNN_SL_B0 : COGNN_SL_B1], (u64)r);
     return 0;
 }
 int cognn_rowscale_close_u64(cognn_ctx*, uint64_t* c, const uint64_t* E, const uint64_t* E1, const uint64_t* G, const uint64_t* G1,
                              const cognn_keys* keys, const cognn_keys* tkeys, int p, int64_t rows, int64_t F) {
     const cognn_opkeys k = K(keys), tk = K(tkeys);
+    CG_PAR
     for (int64_t i = 0; i < rows * F; ++i) {
         const u64 row = (u64)(i / F);
         const u64 e = E[i] + (E1 ? E1[i] : 0), g = G[row] + (G1 ? G1[row] : 0);
@@ -235,6 +258,7 @@ int cognn_rowscale_close_u64(cognn_ctx*, uint64_t* c, const uint64_t* E, const u
     return 0;
 }
 int cognn_relu_open_u64(cognn_ctx*, uint64_t* E, uint64_t* G, const uint64_t* z, const cognn_keys* keys, int p, int64_t n) {
+    CG_PAR
     for (int64_t i = 0; i < n; ++i) {
         const u64 t0 = cognn_prng(keys->k[COGNN_SL_T0], (u64)i);
         const u64 tp = p == 0 ? t0 : ((cognn_prng(keys->k[COGNN_SL_T], (u64)i) & 0xFFFFFull) | 1ull) - t0;
@@ -246,6 +270,7 @@ int cognn_relu_open_u64(cognn_ctx*, uint64_t* E, uint64_t* G, const uint64_t* z,
 int cognn_relu_mul_u64(cognn_ctx*, uint64_t* w, const uint64_t* E, const uint64_t* E1, const uint64_t* G, const uint64_t* G1,
                        const cognn_keys* keys, int p, int64_t n) {
     const cognn_opkeys k = K(keys);
+    CG_PAR
     for (int64_t i = 0; i < n; ++i) {
         // G == NULL: dealer-published g = t - (b0 + b1)
         const u64 g = G ? G[i] + (G1 ? G1[i] : 0)
@@ -256,6 +281,7 @@ int cognn_relu_mul_u64(cognn_ctx*, uint64_t* w, const uint64_t* E, const uint64_
     return 0;
 }
 int cognn_relu_close_u64(cognn_ctx*, uint64_t* h, uint8_t* mask, const uint64_t* z, const uint64_t* w0, const uint64_t* w1, int64_t n) {
+    CG_PAR
     for (int64_t i = 0; i < n; ++i) {
         const bool pos = (long long)(w0[i] + w1[i]) > 0;
         h[i] = pos ? z[i] : 0;
@@ -266,16 +292,19 @@ int cognn_relu_close_u64(cognn_ctx*, uint64_t* h, uint8_t* mask, const uint64_t*
 int cognn_relu_close_open_u64(cognn_ctx* c, uint64_t* h, uint64_t* E, uint8_t* mask, const uint64_t* z, const uint64_t* w0, const uint64_t* w1,
                               uint64_t key_open, int64_t n) {
     cognn_relu_close_u64(c, h, mask, z, w0, w1, n);
+    CG_PAR
     for (int64_t i = 0; i < n; ++i) E[i] = h[i] - cognn_prng(key_open, (u64)i);
     return 0;
 }
 int cognn_mask_select_u64(cognn_ctx*, uint64_t* out, const uint64_t* in, const uint8_t* mask, int64_t n) {
+    CG_PAR
     for (int64_t i = 0; i < n; ++i) out[i] = mask[i] ? in[i] : 0;
     return 0;
 }
 int cognn_softmax_u64(cognn_ctx*, uint64_t* p_out, uint64_t* d_out, uint64_t* pfx_out, const uint64_t* z0, const uint64_t* z1,
                       const int32_t* labels, const cognn_keys* keys, int p, int64_t rows, int64_t L, int64_t train_rows) {
     REQ(p == 1 || (z0 && z1 && labels), "softmax: owner side needs z0, z1, labels");
+    CG_PAR
     for (int64_t r = 0; r < rows; ++r) {
         const bool keep = r < train_rows;
         long long m = 0, S = 0;
@@ -305,7 +334,7 @@ int cognn_metrics_q16(cognn_ctx*, const uint64_t* pfx, const int32_t* labels, co
                       int64_t train_rows, int64_t val_rows, int64_t* c, double* loss) {
     for (int i = 0; i < 6; ++i) c[i] = 0;
     double ls = 0;
-    for (int64_t r = 0; r < rows; ++r) {
+    for (int64_t r = 0; r < rows; ++r) {                    // serial: counters and an order-dependent float sum
         int best = 0;
         for (int64_t j = 1; j < L; ++j) if (pfx[r * L + j] > pfx[r * L + best]) best = (int)j;
         const bool ok = best == labels[r], b = border && border[r], tr = r < train_rows, te = r >= train_rows + val_rows;

@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""TEST INFRASTRUCTURE (bench.py's cpu_baseline leg only): times the engine's host code linked against the plain-C++
+reference backend (oracle/libcognn_engine_cpu.so, OpenMP over the independent loop iterations) on a synthetic workload and
+prints one JSON line.  Usage: cpu_engine_bench.py K LOG2_V LOG2_E IN HID LAB VARIANT ITERS STEPS"""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import numpy as np  # noqa: E402
+
+
+def main():
+    k, lv, le, in_dim, hid, lab = (int(x) for x in sys.argv[1:7])
+    variant, iters, steps = sys.argv[7], int(sys.argv[8]), int(sys.argv[9])
+    import cognn_oracle as co
+    from cognn_amd import capi
+    capi.load(os.path.join(ROOT, "oracle", "libcognn_engine_cpu.so"))
+    from cognn_amd.engine import Engine, GnnParam
+    V, Eu = 1 << lv, 1 << (le - 1)
+    src, dst = co.synth_graph(V, Eu, 0xC06A11)
+    part = (np.arange(V) % k).astype(np.int32)
+    gp = GnnParam(num_labels=lab, input_dim=in_dim, hidden_dim=hid, num_samples=V, num_edges=len(src))
+    eng = Engine(k, src, dst, part, gp, seed=0xC06A11, variant=variant, stream=0)
+    for P in eng.hosted:
+        vids = eng.party_vids(P)
+        rng = np.random.default_rng(0xC06A12 + P)
+        eng.set_party_data(P, (rng.random((len(vids), in_dim)) < 0.01).astype(np.float64), rng.integers(0, lab, size=len(vids)))
+    eng.start()
+    eng.offline(0, iters)
+    eng.run(0, iters)                                     # warm-up pass
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        eng.run(0, iters)
+    dt = (time.perf_counter() - t0) / steps
+    eng.close()
+    print(json.dumps({"seconds_per_pass": dt, "edges": int(len(src)), "threads": int(os.environ.get("OMP_NUM_THREADS", os.cpu_count()))}))
+
+
+if __name__ == "__main__":
+    main()
