@@ -83,6 +83,13 @@ def cpu_baseline(args, wl):
     widths = message_widths(variant, iters, hid, lab)
     try:
         cores = len(os.sched_getaffinity(0))
+        try:                                                # cgroup v2 CPU quota, when one is set
+            q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+            if q != "max":
+                cores = max(1, min(cores, int(int(q) / int(per))))
+        except (OSError, ValueError):
+            pass
+        cores = min(cores, 16)                              # a one-GPU box's CPU share is 16 cores; more threads only oversubscribe
         dt_all, edges_all, lva, lea = _cpu_engine_run(wl, 2, cores, 2)
         dt_1, edges_1, lv1, le1 = _cpu_engine_run(wl, 4, 1, 1)
         return {"value": edges_all * widths / dt_all, "unit": "edges*feat/s", "cores": cores, "kind": "port",
