@@ -32,13 +32,17 @@ __device__ __forceinline__ u64 trunc_rp(const cognn_opkeys& k, int p, u64 idx) {
     return ((cognn_prng(k.k[COGNN_SL_R], idx) & COGNN_TRUNC_MASK) >> COGNN_FX_BITS) - rp0;
 }
 // z_p = p*e*g + e*b_p + a_p*g + c_p for an element-wise Beaver product with masks a (idx) and b (bidx)
-__device__ __forceinline__ u64 beaver_mul(const cognn_opkeys& k, int p, u64 e, u64 g, u64 idx, u64 bidx) {
-    u64 a0 = cognn_prng(k.k[COGNN_SL_A0], idx), b0 = cognn_prng(k.k[COGNN_SL_B0], bidx);
+// (b0, b1 = the b masks of both parties, evaluated by the caller: one pair serves a whole row of a row scale; b1 unused for p == 0)
+__device__ __forceinline__ u64 beaver_mul_b(const cognn_opkeys& k, int p, u64 e, u64 g, u64 idx, u64 b0, u64 b1) {
+    u64 a0 = cognn_prng(k.k[COGNN_SL_A0], idx);
     u64 c0 = cognn_prng(k.k[COGNN_SL_C0], idx);
     if (p == 0) return e * b0 + a0 * g + c0;
-    u64 a1 = cognn_prng(k.k[COGNN_SL_A1], idx), b1 = cognn_prng(k.k[COGNN_SL_B1], bidx);
+    u64 a1 = cognn_prng(k.k[COGNN_SL_A1], idx);
     u64 c1 = (a0 + a1) * (b0 + b1) - c0;
     return e * g + e * b1 + a1 * g + c1;
+}
+__device__ __forceinline__ u64 beaver_mul(const cognn_opkeys& k, int p, u64 e, u64 g, u64 idx, u64 bidx) {
+    return beaver_mul_b(k, p, e, g, idx, cognn_prng(k.k[COGNN_SL_B0], bidx), p == 1 ? cognn_prng(k.k[COGNN_SL_B1], bidx) : 0ull);
 }
 
 // generic pair launcher: thread t handles flat elements 2t, 2t+1
@@ -174,13 +178,24 @@ struct RowscaleClose {   // c_out = beaver(E0+E1, (G0+G1)[row]) + trunc mask
         u64 e[2], r[2];
         ld2(E, i, w, e);
         if (E1) { u64 e1[2]; ld2(E1, i, w, e1); e[0] += e1[0]; e[1] += e1[1]; }
-        for (int j = 0; j < w; ++j) {
-            u64 idx = (u64)(i + j);
-            u64 row = (u64)((uint32_t)idx / F);
+        if (w == 2 && (F & 1u) == 0) {                      // even width: both elements of the pair sit in one row
+            const u64 row = (u64)((uint32_t)i / F);
             u64 g = G[row];
             if (G1) g += G1[row];
-            u64 z = beaver_mul(k, p, e[j], g, idx, row);
-            r[j] = z + trunc_r(tk, p, idx) + (p == 0 ? COGNN_TRUNC_OFFSET : 0ull);
+            const u64 b0 = cognn_prng(k.k[COGNN_SL_B0], row), b1 = p == 1 ? cognn_prng(k.k[COGNN_SL_B1], row) : 0ull;
+            for (int j = 0; j < 2; ++j) {
+                const u64 idx = (u64)(i + j);
+                r[j] = beaver_mul_b(k, p, e[j], g, idx, b0, b1) + trunc_r(tk, p, idx) + (p == 0 ? COGNN_TRUNC_OFFSET : 0ull);
+            }
+        } else {
+            for (int j = 0; j < w; ++j) {
+                u64 idx = (u64)(i + j);
+                u64 row = (u64)((uint32_t)idx / F);
+                u64 g = G[row];
+                if (G1) g += G1[row];
+                u64 z = beaver_mul(k, p, e[j], g, idx, row);
+                r[j] = z + trunc_r(tk, p, idx) + (p == 0 ? COGNN_TRUNC_OFFSET : 0ull);
+            }
         }
         st2(c, i, w, r);
     }
