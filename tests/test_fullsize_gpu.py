@@ -1,0 +1,72 @@
+"""BASELINE.json's full configuration (configs[4]: 8-party optimize-gcn-inference, 2^20 vertices / 2^24 directed edges,
+in=128 hid=64 labels=16) through the HIP engine, checked with size-independent properties - the oracle cannot run at this
+size in test time:
+  * determinism: the same dealer seed gives bit-identical shares on a second engine instance;
+  * mask cancellation: a different dealer seed gives completely different shares, yet the reconstruction s0 + s1 agrees
+    within the fixed-point tolerance of the protocol's probabilistic truncations (every truncation is floor or floor + 1 ulp
+    depending on its mask) - any mis-indexed mask, share or CSR entry destroys it;
+  * structure: the revealed softmax rows (reconstruction + one-hot label) are probability vectors."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+K, LV, LE, IN, HID, LAB = 8, 20, 24, 128, 64, 16
+
+
+def _run(seed, graph, feats):
+    from cognn_amd.engine import Engine, GnnParam
+    src, dst = graph
+    V = 1 << LV
+    part = (np.arange(V) % K).astype(np.int32)
+    gp = GnnParam(num_labels=LAB, input_dim=IN, hidden_dim=HID, num_samples=V, num_edges=len(src))
+    eng = Engine(K, src, dst, part, gp, seed=seed, variant="optimize-gcn-inference")
+    labels = {}
+    for P in eng.hosted:
+        f, l = feats[P]
+        eng.set_party_data(P, f, l)
+        labels[P] = l
+    eng.start()
+    eng.run(0, 2)
+    out = {P: (eng.shares(P, 0), eng.shares(P, 1)) for P in range(K)}
+    eng.close()
+    return out, labels
+
+
+def test_config5_full_size_properties():
+    import bench
+    V = 1 << LV
+    graph = bench.synth_graph(V, 1 << (LE - 1), 0xC06A11)
+    feats = {}
+    for P in range(K):
+        n = len(range(P, V, K))
+        rng = np.random.default_rng(0xC06A12 + P)
+        feats[P] = ((rng.random((n, IN)) < 0.01).astype(np.float64), rng.integers(0, LAB, size=n))
+    a, labels = _run(11, graph, feats)
+    b, _ = _run(11, graph, feats)
+    c, _ = _run(12, graph, feats)
+    worst = 0.0
+    for P in range(K):
+        assert a[P][0].shape == (V // K, LAB)
+        assert np.array_equal(a[P][0], b[P][0]) and np.array_equal(a[P][1], b[P][1])           # determinism
+        assert not np.array_equal(a[P][0], c[P][0])                                               # fresh masks
+        with np.errstate(over="ignore"):
+            ra = (a[P][0] + a[P][1]).astype(np.int64) / 65536.0                                   # p - y, Q16
+            rc = (c[P][0] + c[P][1]).astype(np.int64) / 65536.0
+        d = np.abs(ra - rc)
+        worst = max(worst, float(d.max()))
+        assert d.max() < 2e-4 and d.mean() < 1e-5, (P, d.max(), d.mean())
+        train = int(len(ra) * 0.2)                                                                # GnnParam default train_ratio
+        assert np.all(ra[train:] == 0)                                                            # gcn.h:639-641: rows past the train set are zeroed
+        rows = ra[: min(train, 4096)]
+        onehot = np.eye(LAB)[labels[P][: len(rows)]]
+        prob = rows + onehot
+        assert np.all(prob > -1e-3) and np.all(prob < 1 + 1e-3)
+        assert np.allclose(prob.sum(axis=1), 1.0, atol=2e-3)
+    print("full-size reconstruction agreement across dealer seeds: max |diff| = %.2e" % worst)
