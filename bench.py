@@ -196,10 +196,10 @@ def main():
 
     # HBM traffic of the dominant kernel from the committed PMC passes (profiles/; collected with this same command)
     traffic, traffic_src = None, None
-    pmc = os.path.join(ROOT, "profiles", "r01_c_gather_pmc_traffic.json")
+    pmc = os.path.join(ROOT, "profiles", "r01_h_pmc_traffic.json")
     if args.workload == "config5" and world == 1 and os.path.exists(pmc):
         traffic = json.load(open(pmc)).get("aggregate_launch_avg_bytes")
-        traffic_src = "profiles/r01_c_gather_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH x2 gfx950 correction)"
+        traffic_src = "profiles/r01_h_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH x2 gfx950 correction)"
     ms_per_step = dt / args.steps * 1e3
     ef_per_step = float(len(src)) * message_widths(variant, iters, hid, lab)
     value = ef_per_step / (dt / args.steps)
