@@ -202,9 +202,17 @@ int cognn_beaver_gemm_close_u64(cognn_ctx* c, uint64_t* Z, const uint64_t* E, co
     return cognn_ring_gemm_u64(c, Z, Ap, F, M, N, K, transA, 1);
 }
 int cognn_beaver_gemm_fusable(int64_t, int64_t, int64_t, int) { return 0; }   // the reference backend has one path only
-int cognn_beaver_gemm_close_raw_u64(cognn_ctx*, uint64_t*, const uint64_t*, const uint64_t*, const uint64_t*, const cognn_keys*, int,
-                                    int64_t, int64_t, int64_t, uint64_t*) {
-    return fail("beaver_gemm_close_raw: not provided by the reference backend");
+// product without the dealer share C_p (the engine never asks this backend for it - cognn_beaver_gemm_fusable is 0 - but the
+// differential tests compare the HIP fast path with it)
+int cognn_beaver_gemm_close_raw_u64(cognn_ctx* c, uint64_t* Z, const uint64_t* E, const uint64_t* E1, const uint64_t* F, const cognn_keys* keys,
+                                    int p, int64_t M, int64_t N, int64_t K, uint64_t* scratch) {
+    u64* Ap = scratch; u64* Bp = scratch + M * K;
+    CG_PAR
+    for (int64_t i = 0; i < M * K; ++i) Ap[i] = cognn_prng(keys->k[p == 0 ? COGNN_SL_A0 : COGNN_SL_A1], (u64)i);
+    CG_PAR
+    for (int64_t i = 0; i < K * N; ++i) Bp[i] = cognn_prng(keys->k[p == 0 ? COGNN_SL_B0 : COGNN_SL_B1], (u64)i) + (p == 1 ? F[i] : 0);
+    cognn_ring_gemm2_u64(c, Z, E, E1, Bp, M, N, K, 0, 0);
+    return cognn_ring_gemm_u64(c, Z, Ap, F, M, N, K, 0, 1);
 }
 int cognn_trunc_open_add_u64(cognn_ctx*, uint64_t* c, const uint64_t* x, const uint64_t* c1, const cognn_keys* gkeys,
                              const cognn_keys* tkeys, int p, int64_t n) {
