@@ -7,6 +7,10 @@ OUT := cognn_amd/libcognn_hip.so
 HOSTCXX ?= g++
 HOSTFLAGS := -O2 -fPIC -std=c++17 -Wall -Wno-unused-function -Iinclude -I$(CSRC)
 HIPFLAGS := --offload-arch=$(ARCH) -O3 -fPIC -std=c++17 -Wall -Wno-unused-function -Iinclude -I$(CSRC)
+# make ABLATION=1: also build the timing-only (wrong-result) variants of the Beaver GEMM selected by COGNN_GEMM_DBG
+ifdef ABLATION
+HIPFLAGS += -DCOGNN_GEMM_ABLATION
+endif
 KERNEL_SRCS := $(CSRC)/capi.hip $(CSRC)/kernels_elementwise.hip $(CSRC)/kernels_gather.hip $(CSRC)/kernels_gemm.hip
 HOST_SRCS := $(filter-out $(HOST)/harness_main.cpp,$(wildcard $(HOST)/*.cpp))
 HARNESS := bin/gcn-optimize

@@ -784,12 +784,15 @@ int beaver_close_impl(cognn_ctx* ctx, uint64_t* Z, const uint64_t* E, const uint
                        (int)N, (int)K, nst);                                                                                    \
     } while (0)
         if (cn == 2) {
-            static const int dbg = getenv("COGNN_GEMM_DBG") ? atoi(getenv("COGNN_GEMM_DBG")) : 0;   // timing experiments only
+#ifdef COGNN_GEMM_ABLATION   // timing experiments only (`make ABLATION=1`, tools/abl_gemm.sh): these variants compute wrong results
+            static const int dbg = getenv("COGNN_GEMM_DBG") ? atoi(getenv("COGNN_GEMM_DBG")) : 0;
             if (full && nst == 8 && dbg == 1) CG_WS_LAUNCH(8, true, true, 2, 1);
             else if (full && nst == 8 && dbg == 2) CG_WS_LAUNCH(8, true, true, 2, 2);
             else if (full && nst == 8 && dbg == 4) CG_WS_LAUNCH(8, true, true, 2, 4);
             else if (full && nst == 8 && dbg == 27) CG_WS_LAUNCH(8, true, true, 2, 27);
-            else if (full && nst == 8) CG_WS_LAUNCH(8, true, true, 2);
+            else
+#endif
+            if (full && nst == 8) CG_WS_LAUNCH(8, true, true, 2);
             else if (full) CG_WS_LAUNCH(0, true, true, 2);
             else if (kal) CG_WS_LAUNCH(0, false, true, 2);
             else CG_WS_LAUNCH(0, false, false, 2);
