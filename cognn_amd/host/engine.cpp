@@ -47,6 +47,7 @@ struct Side {
     u64* feat = nullptr;           // [n x in] input-feature share (localVertexSvvBackup / remoteVertexSvvsBackup)
     u64* featE = nullptr;          // E_p = feat_p - A_p of the layer-0 product, opened once (fixed-operand mask reuse)
     u64* featE_peer = nullptr;     // the peer's opening (alias when co-located)
+    const u64* featSum = nullptr;  // E = E_0 + E_1 of that product, summed once in start() (one copy per co-located pair)
     u64* W[2] = {nullptr, nullptr};
     u64* WT = nullptr;             // transposed W1 scratch [lab x hid]
     u64* h1 = nullptr;             // h_t of layer 1 [n x hid]   (vertexInterData["h_t"], gcn.h:230-231)
@@ -266,8 +267,8 @@ void gemm_stage(cognn_engine* E, int64_t it, XFn X, WFn Wm, SpecFn spec, DstFn d
         Side& s = E->sides[i];
         GemmSpec g = spec(s);
         cognn_keys k = gkeys(s, g);
-        const u64* e_own = feature ? s.featE : s.ob[0];
-        const u64* e_peer = feature ? s.featE_peer : s.ib[0];
+        const u64* e_own = feature ? s.featSum : s.ob[0];   // the constant operand's opening is already the sum of both shares
+        const u64* e_peer = feature ? nullptr : s.ib[0];
         const u64* c1 = nullptr;
         if (s.p == 1) {
             auto f = s.c1.find({it, g.op});
@@ -943,6 +944,13 @@ void start(cognn_engine* E) {
         }
         run_exchange(E, xl);
     }
+    // E = E_0 + E_1 is constant over the whole run: sum it once (in place; a co-located pair shares the owner side's copy, so
+    // its two GEMMs read the same 8*n*in bytes)
+    for (auto& s : E->sides) {
+        if (s.peer && s.p == 1) continue;
+        BE(cognn_add_u64(E->ctx, s.featE, s.featE, s.featE_peer, (int64_t)s.n * in));
+    }
+    for (auto& s : E->sides) s.featSum = (s.peer && s.p == 1) ? s.peer->featE : s.featE;
     BE(cognn_ctx_sync(E->ctx));
     E->started = true;
 }
