@@ -602,6 +602,197 @@ __global__ __launch_bounds__(512) void ring_gemm_tn_kernel(u64* Z, const u64* __
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Wave-specialised TN Beaver close (weight gradients): Z[M x N] += [E | A_p]^T-stored . [B_p + pF ; F], K = #vertices.
+// Same role split and LDS pipeline as beaver_gemm_ws_kernel (4 consumer + 4 producer waves, three slots, one barrier per
+// step, 16 k of both segments per step), but BOTH operands stream from HBM and are limb-split by the producers:
+//   A side: thread (m, 4 consecutive k) reads E0/E1[k][m] (lanes along m: coalesced 512-byte row segments) and generates A_p;
+//   B side: thread (n, 4 consecutive k) reads F[k][n] and generates B_p.
+// One workgroup owns a 64 x 64 output block and a K range (split-K); partial outputs are added with uint64 atomics
+// (integer adds commute: exact and order-independent).  Consumer waves whose 32 columns lie beyond N skip their MFMAs.
+// ------------------------------------------------------------------------------------------
+// LDS layout of a TN tile (A and B alike, 2 KiB per plane): [plane][k quad (4)][k half (2)][row or column (64)][4 bytes],
+// the 256-byte row block of half 1 XOR-ed with 128: the producers' lanes run along m / n (that is what makes their global
+// loads coalesced), so 64 lanes write 64 consecutive dwords - conflict-free - and a consumer lane assembles its 16-byte
+// fragment from four dwords 512 bytes apart (lanes 0-31 / 32-63 land on disjoint bank halves).  A row-major [row][16 B]
+// tile would make every producer write a 4- to 8-way bank conflict (measured: 145 us instead of 75 us for the big product).
+__device__ __forceinline__ int tn_off(int rc, int h, int kq) { return kq * 512 + h * 256 + ((rc * 4) ^ (h << 7)); }
+
+template <int DBG>   // timing experiments only (make ABLATION=1): 1 no loads, 2 no PRNG, 4 no MFMA, 8 no split / LDS writes
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void beaver_gemm_tn_ws_kernel(u64* Z, const u64* __restrict__ E0, const u64* __restrict__ E1, const u64* __restrict__ F, u64 keyA, u64 keyB,
+                              int p, int M, int N, int K, int steps_per_split) {
+    constexpr int BM = 64, S = 3;
+    constexpr int kPlane = 2048;
+    constexpr int kStage = 8 * kPlane;                      // 16 KiB per tile (A and B each)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* sA = smem;
+    unsigned char* sB = smem + S * kStage;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.x * BM;
+    const int nst = (K + 15) / 16;
+    const int st0 = blockIdx.y * steps_per_split;
+    const int total = min(nst, st0 + steps_per_split) - st0;
+    if (total <= 0) return;
+
+    if (wave < 4) {
+        // ================= consumers =================
+        const int wm = wave >> 1, wn = wave & 1;
+        const bool active = wn * 32 < N && m0 + wm * 32 < M && !(DBG & 4);   // wave-uniform: this wave's 32 x 32 block holds real outputs
+        v16i acc[8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[s][r] = 0;
+        const unsigned char* pa0 = sA + tn_off(wm * 32 + (lane & 31), lane >> 5, 0);
+        const unsigned char* pb0 = sB + tn_off(wn * 32 + (lane & 31), lane >> 5, 0);
+#define CG_TN_FRAG(dst_, base_)                                                                                            \
+    do {                                                                                                                  \
+        dst_[0] = *reinterpret_cast<const int*>(base_); dst_[1] = *reinterpret_cast<const int*>((base_) + 512);            \
+        dst_[2] = *reinterpret_cast<const int*>((base_) + 1024); dst_[3] = *reinterpret_cast<const int*>((base_) + 1536);  \
+    } while (0)
+        v4i bfa[8], bfb[8], afa, afb;
+        __syncthreads();                                    // tiles 0 and 1 are in LDS
+#pragma unroll
+        for (int i = 0; i < 8; ++i) CG_TN_FRAG(bfa[i], pb0 + i * kPlane);
+        CG_TN_FRAG(afa, pa0);
+        int sc = 0, sn = 1;
+#define CG_TN_CONSUME(bf_, af0_, bfn_, afn0_)                                                                              \
+    do {                                                                                                                  \
+        if (active) {                                                                                                     \
+            const unsigned char* pa_ = pa0 + sc * kStage;                                                                 \
+            v4i af_[8];                                                                                                   \
+            af_[0] = af0_;                                                                                                \
+            _Pragma("unroll") for (int i = 1; i < 8; ++i) CG_TN_FRAG(af_[i], pa_ + i * kPlane);                           \
+            _Pragma("unroll") for (int i = 0; i < 8; ++i) CG_TN_FRAG(bfn_[i], pb0 + sn * kStage + i * kPlane);            \
+            CG_TN_FRAG(afn0_, pa0 + sn * kStage);                                                                         \
+            _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                               \
+                _Pragma("unroll") for (int j = 0; j + i < 8; ++j)                                                         \
+                    acc[i + j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af_[i], bf_[j], acc[i + j], 0, 0, 0);              \
+            }                                                                                                             \
+        }                                                                                                                 \
+        sc = sn; sn = (sn == S - 1) ? 0 : sn + 1;                                                                         \
+        __syncthreads();                                                                                                  \
+    } while (0)
+        for (int t = 0; t < total; t += 2) {
+            CG_TN_CONSUME(bfa, afa, bfb, afb);
+            if (t + 1 < total) CG_TN_CONSUME(bfb, afb, bfa, afa);
+        }
+#undef CG_TN_CONSUME
+#undef CG_TN_FRAG
+        if (active) {
+            const int col = wn * 32 + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const uint32_t hi = (uint32_t)acc[4][r] + ((uint32_t)acc[5][r] << 8) + ((uint32_t)acc[6][r] << 16) + ((uint32_t)acc[7][r] << 24);
+                const long long lo = (long long)acc[0][r] + (long long)acc[1][r] * 256 + (long long)acc[2][r] * 65536 +
+                                     (long long)acc[3][r] * 16777216;
+                if (row < M && col < N) atomicAdd((unsigned long long*)&Z[(size_t)row * N + col], (u64)lo + ((u64)hi << 32));
+            }
+        }
+    } else {
+        // ================= producers =================
+        const int ptid = tid - 256, pm = ptid & 63, kq = ptid >> 6;          // A task: row m0+pm; B task: column pm; both: k quad kq
+        const u64* E1p = E1 ? E1 : E0;
+        const u64 e1mask = E1 ? ~0ull : 0ull;
+        const int mrow = min(m0 + pm, M - 1), ncol = min(pm, N - 1);
+        const u64 mkeep = (m0 + pm < M) ? ~0ull : 0ull, nkeep = (pm < N) ? ~0ull : 0ull;
+        const int o0 = tn_off(pm, 0, kq), o1 = tn_off(pm, 1, kq);            // segment 0 (E / B_p + pF) and segment 1 (A_p / F) positions
+        u64 a0a[4], a1a[4], fa[4], a0b[4], a1b[4], fb[4], a0c[4], a1c[4], fc[4], a0d[4], a1d[4], fd[4];   // four tiles in flight
+#define CG_TN_LOAD(t_, e0_, e1_, f_)                                                                                       \
+    do {                                                                                                                  \
+        const int k_ = (st0 + min((t_), total - 1)) * 16 + kq * 4;                                                        \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                   \
+            const size_t kk_ = (size_t)min(k_ + j, K - 1);                                                                \
+            if (DBG & 1) { e0_[j] = kk_; e1_[j] = kk_ + 1; f_[j] = kk_ + 2; continue; }                                   \
+            e0_[j] = E0[kk_ * M + mrow]; e1_[j] = E1p[kk_ * M + mrow]; f_[j] = F[kk_ * N + ncol];                          \
+        }                                                                                                                 \
+    } while (0)
+#define CG_TN_PRODUCE(t_, slot_, e0_, e1_, f_)                                                                             \
+    do {                                                                                                                  \
+        const int k_ = (st0 + (t_)) * 16 + kq * 4;                                                                        \
+        u64 v_[4], w_[4], bp_[4], ff_[4];                                                                                 \
+        u64 xa_ = keyA + ((u64)(m0 + pm) * (u64)K + (u64)k_ + 1ull) * COGNN_GAMMA;                                        \
+        u64 xb_ = keyB + ((u64)k_ * (u64)N + (u64)pm + 1ull) * COGNN_GAMMA;                                               \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                   \
+            const u64 kk_ = (k_ + j < K) ? ~0ull : 0ull;                                                                  \
+            v_[j] = (e0_[j] + (e1_[j] & e1mask)) & mkeep & kk_;                                                           \
+            w_[j] = ((DBG & 2) ? xa_ : cognn_mix64(xa_)) & mkeep & kk_;                                                   \
+            ff_[j] = f_[j] & nkeep & kk_;                                                                                 \
+            bp_[j] = (((DBG & 2) ? xb_ : cognn_mix64(xb_)) & nkeep & kk_) + (p == 1 ? ff_[j] : 0ull);                     \
+            xa_ += COGNN_GAMMA; xb_ += (u64)N * COGNN_GAMMA;                                                              \
+        }                                                                                                                 \
+        if (DBG & 8) { if ((v_[0] ^ w_[1] ^ bp_[2] ^ ff_[3]) == 0x1234567ull) Z[0] = v_[1] ^ w_[0] ^ bp_[0] ^ ff_[0]; break; } \
+        uint32_t pe_[8], pm_[8], pb_[8], pf_[8];                                                                          \
+        split4(v_, pe_); split4(w_, pm_); split4(bp_, pb_); split4(ff_, pf_);                                             \
+        unsigned char* da_ = sA + (slot_) * kStage;                                                                       \
+        unsigned char* db_ = sB + (slot_) * kStage;                                                                       \
+        _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                                   \
+            *reinterpret_cast<uint32_t*>(da_ + i * kPlane + o0) = pe_[i];                                                 \
+            *reinterpret_cast<uint32_t*>(da_ + i * kPlane + o1) = pm_[i];                                                 \
+            *reinterpret_cast<uint32_t*>(db_ + i * kPlane + o0) = pb_[i];                                                 \
+            *reinterpret_cast<uint32_t*>(db_ + i * kPlane + o1) = pf_[i];                                                 \
+        }                                                                                                                 \
+    } while (0)
+        CG_TN_LOAD(0, a0a, a1a, fa);
+        CG_TN_LOAD(1, a0b, a1b, fb);
+        CG_TN_LOAD(2, a0c, a1c, fc);
+        CG_TN_LOAD(3, a0d, a1d, fd);
+        CG_TN_PRODUCE(0, 0, a0a, a1a, fa);
+        CG_TN_LOAD(4, a0a, a1a, fa);
+        if (total > 1) CG_TN_PRODUCE(1, 1, a0b, a1b, fb);
+        CG_TN_LOAD(5, a0b, a1b, fb);
+        __syncthreads();
+        int sp = 2;
+#define CG_TN_ITER(t_, e0_, e1_, f_)                                                                                       \
+    do {                                                                                                                  \
+        if ((t_) + 2 < total) CG_TN_PRODUCE((t_) + 2, sp, e0_, e1_, f_);                                                  \
+        CG_TN_LOAD((t_) + 6, e0_, e1_, f_);                                                                               \
+        sp = (sp == S - 1) ? 0 : sp + 1;                                                                                  \
+        __syncthreads();                                                                                                  \
+    } while (0)
+        for (int t = 0; t < total; t += 4) {
+            CG_TN_ITER(t, a0c, a1c, fc);
+            if (t + 1 < total) CG_TN_ITER(t + 1, a0d, a1d, fd);
+            if (t + 2 < total) CG_TN_ITER(t + 2, a0a, a1a, fa);
+            if (t + 3 < total) CG_TN_ITER(t + 3, a0b, a1b, fb);
+        }
+#undef CG_TN_ITER
+#undef CG_TN_LOAD
+#undef CG_TN_PRODUCE
+    }
+}
+
+int launch_tn_ws(cognn_ctx* ctx, u64* Z, const u64* E0, const u64* E1, const u64* F, u64 keyA, u64 keyB, int p, int64_t M, int64_t N, int64_t K) {
+    const int nst = (int)((K + 15) / 16);
+    const int nmb = (int)((M + 63) / 64);
+    int splits = std::max(1, std::min(nst, (256 + nmb - 1) / nmb));      // one workgroup per CU: the pipeline prologue is paid once
+    const int sps = (nst + splits - 1) / splits;
+    splits = (nst + sps - 1) / sps;
+    const size_t lds = 3 * 2 * (size_t)(8 * 2048);
+#define CG_TN_LAUNCH(D)                                                                                                            \
+    do {                                                                                                                            \
+        CG_HIP(hipFuncSetAttribute((const void*)beaver_gemm_tn_ws_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL(beaver_gemm_tn_ws_kernel<D>, dim3((unsigned)nmb, (unsigned)splits), dim3(512), lds, ctx->stream, Z, E0, E1, F, keyA, \
+                           keyB, p, (int)M, (int)N, (int)K, sps);                                                                   \
+    } while (0)
+#ifdef COGNN_GEMM_ABLATION
+    static const int dbg = getenv("COGNN_GEMM_DBG") ? atoi(getenv("COGNN_GEMM_DBG")) : 0;
+    if (dbg == 1) CG_TN_LAUNCH(1);
+    else if (dbg == 2) CG_TN_LAUNCH(2);
+    else if (dbg == 4) CG_TN_LAUNCH(4);
+    else if (dbg == 8) CG_TN_LAUNCH(8);
+    else if (dbg == 14) CG_TN_LAUNCH(14);
+    else if (dbg == 11) CG_TN_LAUNCH(11);
+    else
+#endif
+    CG_TN_LAUNCH(0);
+#undef CG_TN_LAUNCH
+    CG_LAUNCH_CHECK();
+    return 0;
+}
+
 // launches the TN kernel on Z (which already holds the value to accumulate onto)
 template <bool BEAVER>
 int launch_tn(cognn_ctx* ctx, u64* Z, const u64* E0, const u64* E1, const u64* F, u64 keyA, u64 keyB, int p, int64_t M, int64_t N, int64_t K) {
@@ -816,8 +1007,8 @@ int beaver_close_impl(cognn_ctx* ctx, uint64_t* Z, const uint64_t* E, const uint
         // Z <- C_p, then one split-K launch adds E.(B_p + pF) + A_p.F
         if (p == 0) { if ((rc = fill(ctx, (u64*)Z, keys->k[COGNN_SL_C0], 0, M, N, 0, 0, nullptr))) return rc; }
         else CG_HIP(hipMemcpyAsync(Z, c1, (size_t)M * N * 8, hipMemcpyDeviceToDevice, ctx->stream));
-        return launch_tn<true>(ctx, (u64*)Z, (const u64*)E, (const u64*)E1, (const u64*)F, keys->k[p == 0 ? COGNN_SL_A0 : COGNN_SL_A1],
-                               keys->k[p == 0 ? COGNN_SL_B0 : COGNN_SL_B1], p, M, N, K);
+        return launch_tn_ws(ctx, (u64*)Z, (const u64*)E, (const u64*)E1, (const u64*)F, keys->k[p == 0 ? COGNN_SL_A0 : COGNN_SL_A1],
+                            keys->k[p == 0 ? COGNN_SL_B0 : COGNN_SL_B1], p, M, N, K);
     }
     u64* Ap = (u64*)scratch;
     u64* Bp = Ap + (size_t)M * K;

@@ -52,6 +52,25 @@ def bench_gemm(ctx, iters, M=1 << 17, K=128, N=64):
     print("ring_gemm (single product) M=%d K=%d N=%d: %.3f ms  %.1f i8-TOP/s" % (M, K, N, ms, 36 * 2.0 * M * K * N / ms / 1e9))
 
 
+def bench_gemm_tn(ctx, iters, M=128, N=64, K=1 << 17):
+    """weight-gradient product d = h_t^T . in (gcn.h:671,710): logical A [M x K] stored [K x M], K = #vertices"""
+    g = torch.Generator(device="cuda"); g.manual_seed(2)
+    E0 = torch.randint(-2**62, 2**62, (K, M), dtype=torch.int64, device="cuda", generator=g)
+    E1 = torch.randint(-2**62, 2**62, (K, M), dtype=torch.int64, device="cuda", generator=g)
+    F = torch.randint(-2**62, 2**62, (K, N), dtype=torch.int64, device="cuda", generator=g)
+    c1 = torch.randint(-2**62, 2**62, (M, N), dtype=torch.int64, device="cuda", generator=g)
+    Z = torch.empty((M, N), dtype=torch.int64, device="cuda")
+    scratch = torch.empty(M * K + K * N, dtype=torch.int64, device="cuda")
+    k = capi.make_keys(1, 2, 3, capi.OP_AP_GEMM)
+    for p in (1, 0):
+        ms = timeit(lambda: ctx.call("cognn_beaver_gemm_close_u64", P(Z), P(E0), P(E1), P(F), P(c1) if p == 1 else None,
+                                     ctypes.byref(k), p, M, N, K, 1, P(scratch)), iters)
+        ops = 2.0 * 36 * 2 * M * K * N
+        gb = 8.0 * (2 * M * K + K * N) / 1e9
+        print("beaver_gemm_close TN p=%d M=%d K=%d N=%d: %.3f ms  %.1f i8-TOP/s  operand streams %.0f GB/s"
+              % (p, M, K, N, ms, ops / ms / 1e9, gb / (ms / 1e3)))
+
+
 def bench_gather(ctx, iters, rows=1 << 21, table_rows=1 << 21, deg=12, F=64):
     rng = np.random.default_rng(0)
     d = rng.poisson(deg, size=rows)
@@ -76,6 +95,9 @@ if __name__ == "__main__":
     if a.what in ("gemm", "all"):
         bench_gemm(ctx, a.iters)
         bench_gemm(ctx, a.iters, K=64, N=16)
+    if a.what in ("gemm_tn", "all"):
+        bench_gemm_tn(ctx, a.iters)
+        bench_gemm_tn(ctx, a.iters, M=64, N=16)
     if a.what in ("gather", "all"):
         bench_gather(ctx, a.iters, F=64)
         bench_gather(ctx, a.iters, F=16)
