@@ -86,7 +86,7 @@ struct MaskOpen {       // E = X - prng(key, logical idx)
         ld2(X, i, w, x);
         for (int j = 0; j < 2; ++j) {
             u64 idx = (u64)(i + j);
-            if (transposed) {              // X stored [cols x rows]; logical element (m,k) = X[k][m]
+            if (transposed == 1) {         // X stored [cols x rows]; logical element (m,k) = X[k][m]  (2: mask in storage order)
                 u64 k = idx / (u64)rows, m = idx % (u64)rows;
                 idx = m * (u64)cols + k;
             }

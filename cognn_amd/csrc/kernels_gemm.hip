@@ -621,7 +621,7 @@ __device__ __forceinline__ int tn_off(int rc, int h, int kq) { return kq * 512 +
 template <int DBG>   // timing experiments only (make ABLATION=1): 1 no loads, 2 no PRNG, 4 no MFMA, 8 no split / LDS writes
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void beaver_gemm_tn_ws_kernel(u64* Z, const u64* __restrict__ E0, const u64* __restrict__ E1, const u64* __restrict__ F, u64 keyA, u64 keyB,
-                              int p, int M, int N, int K, int steps_per_split) {
+                              int p, int M, int N, int K, int steps_per_split, int a_storage) {
     constexpr int BM = 64, S = 3;
     constexpr int kPlane = 2048;
     constexpr int kStage = 8 * kPlane;                      // 16 KiB per tile (A and B each)
@@ -699,6 +699,7 @@ void beaver_gemm_tn_ws_kernel(u64* Z, const u64* __restrict__ E0, const u64* __r
         const int mrow = min(m0 + pm, M - 1), ncol = min(pm, N - 1);
         const u64 mkeep = (m0 + pm < M) ? ~0ull : 0ull, nkeep = (pm < N) ? ~0ull : 0ull;
         const int o0 = tn_off(pm, 0, kq), o1 = tn_off(pm, 1, kq);            // segment 0 (E / B_p + pF) and segment 1 (A_p / F) positions
+        const u64 a_step = a_storage ? (u64)M * COGNN_GAMMA : COGNN_GAMMA;
         u64 a0a[4], a1a[4], fa[4], a0b[4], a1b[4], fb[4], a0c[4], a1c[4], fc[4], a0d[4], a1d[4], fd[4];   // four tiles in flight
 #define CG_TN_LOAD(t_, e0_, e1_, f_)                                                                                       \
     do {                                                                                                                  \
@@ -713,7 +714,8 @@ void beaver_gemm_tn_ws_kernel(u64* Z, const u64* __restrict__ E0, const u64* __r
     do {                                                                                                                  \
         const int k_ = (st0 + (t_)) * 16 + kq * 4;                                                                        \
         u64 v_[4], w_[4], bp_[4], ff_[4];                                                                                 \
-        u64 xa_ = keyA + ((u64)(m0 + pm) * (u64)K + (u64)k_ + 1ull) * COGNN_GAMMA;                                        \
+        /* A mask index: logical (m, k) -> m K + k, or storage order k M + m when the operand's untransposed mask is reused */ \
+        u64 xa_ = keyA + ((a_storage ? (u64)k_ * (u64)M + (u64)(m0 + pm) : (u64)(m0 + pm) * (u64)K + (u64)k_) + 1ull) * COGNN_GAMMA; \
         u64 xb_ = keyB + ((u64)k_ * (u64)N + (u64)pm + 1ull) * COGNN_GAMMA;                                               \
         _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                   \
             const u64 kk_ = (k_ + j < K) ? ~0ull : 0ull;                                                                  \
@@ -721,7 +723,7 @@ void beaver_gemm_tn_ws_kernel(u64* Z, const u64* __restrict__ E0, const u64* __r
             w_[j] = ((DBG & 2) ? xa_ : cognn_mix64(xa_)) & mkeep & kk_;                                                   \
             ff_[j] = f_[j] & nkeep & kk_;                                                                                 \
             bp_[j] = (((DBG & 2) ? xb_ : cognn_mix64(xb_)) & nkeep & kk_) + (p == 1 ? ff_[j] : 0ull);                     \
-            xa_ += COGNN_GAMMA; xb_ += (u64)N * COGNN_GAMMA;                                                              \
+            xa_ += a_step; xb_ += (u64)N * COGNN_GAMMA;                                                                   \
         }                                                                                                                 \
         if (DBG & 8) { if ((v_[0] ^ w_[1] ^ bp_[2] ^ ff_[3]) == 0x1234567ull) Z[0] = v_[1] ^ w_[0] ^ bp_[0] ^ ff_[0]; break; } \
         uint32_t pe_[8], pm_[8], pb_[8], pf_[8];                                                                          \
@@ -764,7 +766,8 @@ void beaver_gemm_tn_ws_kernel(u64* Z, const u64* __restrict__ E0, const u64* __r
     }
 }
 
-int launch_tn_ws(cognn_ctx* ctx, u64* Z, const u64* E0, const u64* E1, const u64* F, u64 keyA, u64 keyB, int p, int64_t M, int64_t N, int64_t K) {
+int launch_tn_ws(cognn_ctx* ctx, u64* Z, const u64* E0, const u64* E1, const u64* F, u64 keyA, u64 keyB, int p, int64_t M, int64_t N, int64_t K,
+                 int a_storage) {
     const int nst = (int)((K + 15) / 16);
     const int nmb = (int)((M + 63) / 64);
     int splits = std::max(1, std::min(nst, (256 + nmb - 1) / nmb));      // one workgroup per CU: the pipeline prologue is paid once
@@ -775,7 +778,7 @@ int launch_tn_ws(cognn_ctx* ctx, u64* Z, const u64* E0, const u64* E1, const u64
     do {                                                                                                                            \
         CG_HIP(hipFuncSetAttribute((const void*)beaver_gemm_tn_ws_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
         hipLaunchKernelGGL(beaver_gemm_tn_ws_kernel<D>, dim3((unsigned)nmb, (unsigned)splits), dim3(512), lds, ctx->stream, Z, E0, E1, F, keyA, \
-                           keyB, p, (int)M, (int)N, (int)K, sps);                                                                   \
+                           keyB, p, (int)M, (int)N, (int)K, sps, a_storage);                                                        \
     } while (0)
 #ifdef COGNN_GEMM_ABLATION
     static const int dbg = getenv("COGNN_GEMM_DBG") ? atoi(getenv("COGNN_GEMM_DBG")) : 0;
@@ -816,7 +819,7 @@ __global__ __launch_bounds__(256) void prng_fill2_kernel(u64* out, u64 k0, u64 k
     const int64_t n = rows * cols;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         u64 idx = (u64)i;
-        if (transposed) { const u64 k = idx / (u64)rows, m = idx % (u64)rows; idx = m * (u64)cols + k; }
+        if (transposed == 1) { const u64 k = idx / (u64)rows, m = idx % (u64)rows; idx = m * (u64)cols + k; }   // 2: storage order
         u64 v = cognn_prng(k0, idx);
         if (two) v += cognn_prng(k1, idx);
         if (addend) v += addend[i];
@@ -1008,7 +1011,7 @@ int beaver_close_impl(cognn_ctx* ctx, uint64_t* Z, const uint64_t* E, const uint
         if (p == 0) { if ((rc = fill(ctx, (u64*)Z, keys->k[COGNN_SL_C0], 0, M, N, 0, 0, nullptr))) return rc; }
         else CG_HIP(hipMemcpyAsync(Z, c1, (size_t)M * N * 8, hipMemcpyDeviceToDevice, ctx->stream));
         return launch_tn_ws(ctx, (u64*)Z, (const u64*)E, (const u64*)E1, (const u64*)F, keys->k[p == 0 ? COGNN_SL_A0 : COGNN_SL_A1],
-                            keys->k[p == 0 ? COGNN_SL_B0 : COGNN_SL_B1], p, M, N, K);
+                            keys->k[p == 0 ? COGNN_SL_B0 : COGNN_SL_B1], p, M, N, K, transA == 2);
     }
     u64* Ap = (u64*)scratch;
     u64* Bp = Ap + (size_t)M * K;

@@ -144,8 +144,9 @@ cognn_keys keys(cognn_engine* E, u64 owner, int64_t it, int op) {
     return k;
 }
 // layer-0 PreScatter product: the feature operand's mask A is dealt once (iteration 0), B and C per iteration
-cognn_keys feature_gemm_keys(cognn_engine* E, u64 owner, int64_t it) {
-    cognn_keys k = keys(E, owner, it, COGNN_OP_PS_GEMM), k0 = keys(E, owner, 0, COGNN_OP_PS_GEMM);
+// (op = COGNN_OP_PS_GEMM for the forward product, COGNN_OP_AP_GEMM for the layer-0 weight gradient on the transposed features)
+cognn_keys feature_gemm_keys(cognn_engine* E, u64 owner, int64_t it, int op = COGNN_OP_PS_GEMM) {
+    cognn_keys k = keys(E, owner, it, op), k0 = keys(E, owner, 0, COGNN_OP_PS_GEMM);
     k.k[COGNN_SL_A0] = k0.k[COGNN_SL_A0];
     k.k[COGNN_SL_A1] = k0.k[COGNN_SL_A1];
     return k;
@@ -204,7 +205,8 @@ struct GemmSpec {            // logical Z[MxN] = X[MxK] . Wm[KxN]
     int64_t M, N, K;
     int transA;
     int op, top;             // dealer op ids for the product and its truncation
-    bool feature = false;    // layer-0 product on the constant feature operand (opening cached in Side::featE)
+    int feature = 0;         // constant feature operand, opening cached in Side::featSum: 1 layer-0 forward product X.W0,
+                             // 2 layer-0 weight gradient X^T.g (same mask, transposed use: transA = 2)
 };
 
 // truncation of every side's `x` (elems) scaled by `mul`; result written/applied to dst(side)
@@ -244,8 +246,8 @@ template <class XFn, class WFn, class SpecFn, class DstFn>
 void gemm_stage(cognn_engine* E, int64_t it, XFn X, WFn Wm, SpecFn spec, DstFn dst, bool x_opened = false,
                 const OpenNext& open_next = nullptr) {
     std::vector<int64_t> e0, e1, eo;
-    const bool feature = spec(E->sides[0]).feature;
-    auto gkeys = [&](Side& s, const GemmSpec& g) { return g.feature ? feature_gemm_keys(E, s.owner, it) : keys(E, s.owner, it, g.op); };
+    const bool feature = spec(E->sides[0]).feature != 0;
+    auto gkeys = [&](Side& s, const GemmSpec& g) { return g.feature ? feature_gemm_keys(E, s.owner, it, g.op) : keys(E, s.owner, it, g.op); };
     for (auto& s : E->sides) {
         GemmSpec g = spec(s);
         cognn_keys k = gkeys(s, g);
@@ -567,7 +569,15 @@ int mp_width(cognn_engine* E, int e) {                    // getPlainNumPerOpera
 
 GemmSpec prescatter_spec(cognn_engine* E, Side& s, int layer) {
     GemmSpec g{s.n, layer == 0 ? E->hid() : E->lab(), layer == 0 ? E->in() : E->hid(), 0, COGNN_OP_PS_GEMM, COGNN_OP_PS_GEMM_TRUNC};
-    g.feature = (layer == 0);
+    g.feature = (layer == 0) ? 1 : 0;
+    return g;
+}
+
+// d = h_t^T . in (gcn.h:671,710); for layer 0 h_t is the transposed feature tensor: mask and opening of the forward product
+GemmSpec wgrad_spec(cognn_engine* E, Side& s, int layer) {
+    GemmSpec g{layer == 0 ? E->in() : E->hid(), layer == 0 ? E->hid() : E->lab(), s.n, layer == 0 ? 2 : 1, COGNN_OP_AP_GEMM,
+               COGNN_OP_AP_GEMM_TRUNC};
+    g.feature = layer == 0 ? 2 : 0;
     return g;
 }
 
@@ -665,10 +675,8 @@ void run_iteration(cognn_engine* E, int64_t it) {
         return;
     }
     // d = h_t^T . in ; scale ; W -= lr d ; out = g  (gcn.h:671-684, 710-736)
-    const int Min = I.layer == 0 ? E->in() : E->hid();
-    const int Nout = I.layer == 0 ? E->hid() : E->lab();
     gemm_stage(E, it, [&](Side& s) { return I.layer == 0 ? s.feat : s.h1; }, [&](Side& s) { return s.cur; },
-               [&](Side& s) { return GemmSpec{Min, Nout, s.n, 1, COGNN_OP_AP_GEMM, COGNN_OP_AP_GEMM_TRUNC}; },
+               [&](Side& s) { return wgrad_spec(E, s, I.layer); },
                [&](Side& s) { return s.small[0]; });
     weight_update_chain(E, it, I.layer);
     for (auto& s : E->sides) {
@@ -690,11 +698,11 @@ void run_offline(cognn_engine* E, int64_t it0, int64_t it1) {
             else if (!I.fwd && (I.e - I.f) % 2 == 0 && I.layer == I.f - 1) {
                 g = GemmSpec{s.n, E->hid(), E->lab(), 0, COGNN_OP_AP_GEMM, COGNN_OP_AP_GEMM_TRUNC}; have = true;
             } else if (!I.fwd && (I.e - I.f) % 2 == 1) {
-                g = GemmSpec{I.layer == 0 ? E->in() : E->hid(), I.layer == 0 ? E->hid() : E->lab(), s.n, 1, COGNN_OP_AP_GEMM, COGNN_OP_AP_GEMM_TRUNC};
+                g = wgrad_spec(E, s, I.layer);
                 have = true;
             }
             if (!have || s.c1.count({it, g.op})) continue;
-            cognn_keys k = g.feature ? feature_gemm_keys(E, s.owner, it) : keys(E, s.owner, it, g.op);
+            cognn_keys k = g.feature ? feature_gemm_keys(E, s.owner, it, g.op) : keys(E, s.owner, it, g.op);
             u64* c = dalloc<u64>(E, (size_t)(g.M * g.N));
             BE(cognn_dealer_gemm_c1_u64(E->ctx, c, &k, g.M, g.N, g.K, g.transA, s.scratch, s.scratch + g.M * g.K));
             s.c1[{it, g.op}] = c;

@@ -74,7 +74,10 @@ int cognn_scatter_add_rows_u64(cognn_ctx*, uint64_t* v, const uint64_t* partial,
                                int64_t n_partial, int64_t F);
 
 /* ---- ring GEMM on shares: the local part of sci::twoPartyGCNMatMul (gcn.h:233,665,671,710) - */
-/* C[MxN] = (accumulate ? C : 0) + op(A)[MxK] . B[KxN]  mod 2^64.  transA: A is stored [KxM]. */
+/* C[MxN] = (accumulate ? C : 0) + op(A)[MxK] . B[KxN]  mod 2^64.  transA != 0: A is stored [KxM].
+ * In the Beaver entry points transA selects how the A mask streams are indexed: 1 = by the logical element (m, k),
+ * 2 = by the storage element (k, m) - the mask was dealt for the operand's untransposed use and its opening is reused
+ * (the input features serve the layer-0 forward product X.W and the layer-0 weight gradient X^T.g, gcn.h:233,710). */
 int cognn_ring_gemm_u64(cognn_ctx*, uint64_t* C, const uint64_t* A, const uint64_t* B,
                         int64_t M, int64_t N, int64_t K, int transA, int accumulate);
 /* same with A = A1 + A2 formed on the fly (A2 may be NULL) */

@@ -148,13 +148,18 @@ def ring_matmul(a, b):
         return np.matmul(a.astype(U64), b.astype(U64))
 
 
-def beaver_gemm_pair(x0, x1, w0, w1, key_of):
-    """sci::twoPartyGCNMatMul stand-in (gcn.h:233,665,671,710): Z = X.W mod 2^64 (no truncation)."""
+def beaver_gemm_pair(x0, x1, w0, w1, key_of, a_of_transposed=False):
+    """sci::twoPartyGCNMatMul stand-in (gcn.h:233,665,671,710): Z = X.W mod 2^64 (no truncation).
+    a_of_transposed: X is the transpose of a tensor whose Beaver mask was dealt for its untransposed use ([K x M] row-major
+    streams); that mask - and therefore that opening - is reused."""
     M, K = x0.shape
     K2, N = w0.shape
     assert K == K2
     with np.errstate(over="ignore"):
-        a0 = prng_shape(key_of(SL_A0), (M, K)); a1 = prng_shape(key_of(SL_A1), (M, K))
+        if a_of_transposed:
+            a0 = prng_shape(key_of(SL_A0), (K, M)).T.copy(); a1 = prng_shape(key_of(SL_A1), (K, M)).T.copy()
+        else:
+            a0 = prng_shape(key_of(SL_A0), (M, K)); a1 = prng_shape(key_of(SL_A1), (M, K))
         b0 = prng_shape(key_of(SL_B0), (K, N)); b1 = prng_shape(key_of(SL_B1), (K, N))
         c0 = prng_shape(key_of(SL_C0), (M, N))
         c1 = ring_matmul(a0 + a1, b0 + b1) - c0               # dealer, offline
@@ -495,6 +500,12 @@ class OracleEngine:
         (fixed-operand mask reuse)."""
         return lambda slot: stream_key(self.seed, owner, 0 if slot in (SL_A0, SL_A1) else it, OP_PS_GEMM, slot)
 
+    def key_of_feature_wgrad(self, owner, it):
+        """Layer-0 weight gradient X^T.g (gcn.h:710): the left operand is the same feature tensor, transposed, so it keeps the
+        A mask of key_of_feature_gemm (indexed in storage order); B and C come from this iteration's OP_AP_GEMM streams."""
+        return lambda slot: (stream_key(self.seed, owner, 0, OP_PS_GEMM, slot) if slot in (SL_A0, SL_A1)
+                             else stream_key(self.seed, owner, it, OP_AP_GEMM, slot))
+
     # -- onAlgoKernelStart (gcn.h:854-887) + share distribution (ss_...h:205-232) ------------
     def _start(self, features, labels, weights):
         g = self.param; k = self.k
@@ -660,7 +671,12 @@ class OracleEngine:
                     LI["g"] = None; RI["g"] = None             # g' skipped for the first layer
             else:                                             # gcn.h:671-684 / 710-736
                 hA = LI["h_t"].T.copy(); hB = RI["h_t"].T.copy()
-                zA, zB = beaver_gemm_pair(hA, hB, inA, inB, self.key_of(P, it, OP_AP_GEMM))
+                if layer == 0:
+                    # h_t is the transposed input-feature tensor (gcn.h:230-231): its mask and opening are those of the
+                    # layer-0 forward product (dealt once, iteration 0); B and C are fresh
+                    zA, zB = beaver_gemm_pair(hA, hB, inA, inB, self.key_of_feature_wgrad(P, it), a_of_transposed=True)
+                else:
+                    zA, zB = beaver_gemm_pair(hA, hB, inA, inB, self.key_of(P, it, OP_AP_GEMM))
                 dA, dB = trunc_pair(zA, zB, self.key_of(P, it, OP_AP_GEMM_TRUNC))
                 gscale = fx_encode_trunc(1.0 / train) if train > 0 else U64(0)
                 dA, dB = const_scale_trunc_pair(dA, dB, gscale, self.key_of(P, it, OP_AP_GSCALE_TRUNC))

@@ -59,7 +59,7 @@ static inline u64 beaver_mul(const cognn_opkeys& k, int p, u64 e, u64 g, u64 i, 
     return e * g + e * b1 + a1 * g + ((a0 + a1) * (b0 + b1) - c0);
 }
 static inline u64 lidx(int64_t i, int64_t rows, int64_t cols, int transposed) {
-    if (!transposed) return (u64)i;
+    if (transposed != 1) return (u64)i;                    // 0: row-major; 2: transposed storage, mask indexed in storage order
     const u64 k = (u64)i / (u64)rows, m = (u64)i % (u64)rows;     // storage [cols x rows]
     return m * (u64)cols + k;
 }
