@@ -331,7 +331,8 @@ def test_softmax_pair_and_metrics(ctx, L):
 
 
 @pytest.mark.parametrize("M,N,K,transA", [(300, 64, 128, 0), (270, 7, 16, 0), (16, 7, 300, 1), (1433, 16, 270, 1),
-                                             (300, 16, 77, 0), (1354, 16, 1433, 0), (260, 7, 7, 0), (64, 16, 2000, 1)])
+                                             (300, 16, 77, 0), (1354, 16, 1433, 0), (260, 7, 7, 0), (64, 16, 2000, 1),
+                                             (128, 64, 1000, 2), (24, 5, 300, 2)])
 def test_beaver_gemm_pair(ctx, M, N, K, transA):
     """Full Beaver product: mask-open, exchange, dealer C1, close; vs oracle twoPartyGCNMatMul stand-in."""
     rng = np.random.default_rng(M * 3 + N)
@@ -353,7 +354,7 @@ def test_beaver_gemm_pair(ctx, M, N, K, transA):
     for p in range(2):
         ctx.call("cognn_beaver_gemm_close_u64", ptr(Z[p]), ptr(E[p]), ptr(E[1 - p]), ptr(Fs), ptr(c1) if p == 1 else None,
                  ctypes.byref(k), p, M, N, K, transA, ptr(sa))
-    z0, z1 = co.beaver_gemm_pair(X0, X1, W0, W1, kf)
+    z0, z1 = co.beaver_gemm_pair(X0, X1, W0, W1, kf, a_of_transposed=(transA == 2))
     assert np.array_equal(host(Z[0]), z0) and np.array_equal(host(Z[1]), z1)
     with np.errstate(over="ignore"):
         assert np.array_equal(host(Z[0]) + host(Z[1]), co.ring_matmul(X, W))
