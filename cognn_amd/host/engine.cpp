@@ -48,6 +48,8 @@ struct Side {
     u64* featE = nullptr;          // E_p = feat_p - A_p of the layer-0 product, opened once (fixed-operand mask reuse)
     u64* featE_peer = nullptr;     // the peer's opening (alias when co-located)
     const u64* featSum = nullptr;  // E = E_0 + E_1 of that product, summed once in start() (one copy per co-located pair)
+    u64* h1E = nullptr;            // E_p = h_p - A_p of the layer-1 forward product (written by the ReLU close); kept for the epoch:
+    u64* h1E_peer = nullptr;       // the layer-1 weight gradient h^T.g reuses mask and opening (alias when co-located)
     u64* W[2] = {nullptr, nullptr};
     u64* WT = nullptr;             // transposed W1 scratch [lab x hid]
     u64* h1 = nullptr;             // h_t of layer 1 [n x hid]   (vertexInterData["h_t"], gcn.h:230-231)
@@ -152,6 +154,9 @@ cognn_keys feature_gemm_keys(cognn_engine* E, u64 owner, int64_t it, int op = CO
     return k;
 }
 
+struct GemmSpec;
+cognn_keys gemm_keys(cognn_engine* E, Side& s, int64_t it, const GemmSpec& g);
+
 u64 fx_llround(double x) { return (u64)(long long)llround(x * (double)COGNN_FX_ONE); }
 u64 fx_trunc(double x) { return (u64)(x * (double)COGNN_FX_ONE); }   // static_cast as in gcn.h:676,678,764
 
@@ -207,7 +212,11 @@ struct GemmSpec {            // logical Z[MxN] = X[MxK] . Wm[KxN]
     int op, top;             // dealer op ids for the product and its truncation
     int feature = 0;         // constant feature operand, opening cached in Side::featSum: 1 layer-0 forward product X.W0,
                              // 2 layer-0 weight gradient X^T.g (same mask, transposed use: transA = 2)
+    int xsrc = 0;            // where the opening of X comes from: X_OPEN_HERE, X_H1E_FRESH (written by the ReLU close of the previous
+                             // iteration, still to be exchanged), X_H1E_REUSE (the layer-1 forward opening, exchanged two iterations ago)
+    int64_t akey_it = -1;    // iteration whose COGNN_OP_PS_GEMM A streams mask X (X_H1E_REUSE); -1: this product's own streams
 };
+enum { X_OPEN_HERE = 0, X_H1E_FRESH = 1, X_H1E_REUSE = 2 };
 
 // truncation of every side's `x` (elems) scaled by `mul`; result written/applied to dst(side)
 template <class DstFn>
@@ -224,6 +233,19 @@ void trunc_stage(cognn_engine* E, int64_t it, int op, u64 mul, const std::vector
         cognn_keys k = keys(E, owner_override == ~0ull ? (u64)s.owner : owner_override, it, op);
         BE(cognn_trunc_close_u64(E->ctx, dst(s), s.p == 0 ? s.ob[2] : nullptr, s.p == 0 ? s.ib[2] : nullptr, &k, s.p, mode, elems[i]));
     }
+}
+
+// dealer streams of a Beaver product: its own (owner, iteration, op) streams, except that a reused operand keeps the A streams
+// it was first masked with
+cognn_keys gemm_keys(cognn_engine* E, Side& s, int64_t it, const GemmSpec& g) {
+    if (g.feature) return feature_gemm_keys(E, s.owner, it, g.op);
+    cognn_keys k = keys(E, s.owner, it, g.op);
+    if (g.akey_it >= 0) {
+        cognn_keys ka = keys(E, s.owner, g.akey_it, COGNN_OP_PS_GEMM);
+        k.k[COGNN_SL_A0] = ka.k[COGNN_SL_A0];
+        k.k[COGNN_SL_A1] = ka.k[COGNN_SL_A1];
+    }
+    return k;
 }
 
 // closing step of a truncation; open_next (optional) returns the mask key of the op that consumes dst(side): the close then
@@ -247,16 +269,32 @@ void gemm_stage(cognn_engine* E, int64_t it, XFn X, WFn Wm, SpecFn spec, DstFn d
                 const OpenNext& open_next = nullptr) {
     std::vector<int64_t> e0, e1, eo;
     const bool feature = spec(E->sides[0]).feature != 0;
-    auto gkeys = [&](Side& s, const GemmSpec& g) { return g.feature ? feature_gemm_keys(E, s.owner, it, g.op) : keys(E, s.owner, it, g.op); };
+    const int xsrc = x_opened ? X_H1E_FRESH : spec(E->sides[0]).xsrc;
+    auto gkeys = [&](Side& s, const GemmSpec& g) { return gemm_keys(E, s, it, g); };
     for (auto& s : E->sides) {
         GemmSpec g = spec(s);
         cognn_keys k = gkeys(s, g);
-        if (!x_opened && !feature) BE(cognn_mask_open_u64(E->ctx, s.ob[0], X(s), k.k[s.p == 0 ? COGNN_SL_A0 : COGNN_SL_A1], g.M, g.K, g.transA));
+        if (xsrc == X_OPEN_HERE && !feature)
+            BE(cognn_mask_open_u64(E->ctx, s.ob[0], X(s), k.k[s.p == 0 ? COGNN_SL_A0 : COGNN_SL_A1], g.M, g.K, g.transA));
         BE(cognn_mask_open_u64(E->ctx, s.ob[1], Wm(s), k.k[s.p == 0 ? COGNN_SL_B0 : COGNN_SL_B1], g.K, g.N, 0));
         e0.push_back(g.M * g.K); e1.push_back(g.K * g.N); eo.push_back(g.M * g.N);
     }
-    if (!feature) exchange_ob2(E, 0, e0, 1, e1);            // the feature opening was exchanged once in start()
-    else exchange_ob(E, 1, e1);
+    if (feature || xsrc == X_H1E_REUSE) {
+        exchange_ob(E, 1, e1);                              // the opening of X was exchanged earlier (start() / two iterations ago)
+    } else if (xsrc == X_H1E_FRESH) {
+        XList xl;                                           // the ReLU close left E_p in h1E: it travels with the W opening
+        for (size_t i = 0; i < E->sides.size(); ++i) {
+            Side& s = E->sides[i];
+            if (s.peer) continue;
+            xl.send(s.peer_rank, s.h1E, e0[i] * 8);
+            xl.recv(s.peer_rank, s.h1E_peer, e0[i] * 8);
+            xl.send(s.peer_rank, s.ob[1], e1[i] * 8);
+            xl.recv(s.peer_rank, s.ib[1], e1[i] * 8);
+        }
+        run_exchange(E, xl);
+    } else {
+        exchange_ob2(E, 0, e0, 1, e1);
+    }
     for (size_t i = 0; i < E->sides.size(); ++i) {
         Side& s = E->sides[i];
         BE(cognn_add_u64(E->ctx, s.fsum, s.ob[1], s.ib[1], e1[i]));
@@ -269,8 +307,8 @@ void gemm_stage(cognn_engine* E, int64_t it, XFn X, WFn Wm, SpecFn spec, DstFn d
         Side& s = E->sides[i];
         GemmSpec g = spec(s);
         cognn_keys k = gkeys(s, g);
-        const u64* e_own = feature ? s.featSum : s.ob[0];   // the constant operand's opening is already the sum of both shares
-        const u64* e_peer = feature ? nullptr : s.ib[0];
+        const u64* e_own = feature ? s.featSum : xsrc != X_OPEN_HERE ? s.h1E : s.ob[0];   // featSum is already the sum of both shares
+        const u64* e_peer = feature ? nullptr : xsrc != X_OPEN_HERE ? s.h1E_peer : s.ib[0];
         const u64* c1 = nullptr;
         if (s.p == 1) {
             auto f = s.c1.find({it, g.op});
@@ -372,7 +410,7 @@ void relu_stage(cognn_engine* E, int64_t it, bool e_opened) {
     for (size_t i = 0; i < E->sides.size(); ++i) {
         Side& s = E->sides[i];
         cognn_keys nk = keys(E, s.owner, it + 1, COGNN_OP_PS_GEMM);
-        BE(cognn_relu_close_open_u64(E->ctx, s.h1, s.ob[0], s.relu_mask, s.cur, s.ob[2], s.ib[2],
+        BE(cognn_relu_close_open_u64(E->ctx, s.h1, s.h1E, s.relu_mask, s.cur, s.ob[2], s.ib[2],
                                      nk.k[s.p == 0 ? COGNN_SL_A0 : COGNN_SL_A1], eF[i]));
         s.cur = s.h1;
     }
@@ -574,10 +612,12 @@ GemmSpec prescatter_spec(cognn_engine* E, Side& s, int layer) {
 }
 
 // d = h_t^T . in (gcn.h:671,710); for layer 0 h_t is the transposed feature tensor: mask and opening of the forward product
-GemmSpec wgrad_spec(cognn_engine* E, Side& s, int layer) {
-    GemmSpec g{layer == 0 ? E->in() : E->hid(), layer == 0 ? E->hid() : E->lab(), s.n, layer == 0 ? 2 : 1, COGNN_OP_AP_GEMM,
-               COGNN_OP_AP_GEMM_TRUNC};
-    g.feature = layer == 0 ? 2 : 0;
+// for layer 1 h_t is the transposed hidden activation whose opening the layer-1 forward product left in h1E two GAS
+// iterations earlier (same epoch): mask and opening are reused too
+GemmSpec wgrad_spec(cognn_engine* E, Side& s, int layer, int64_t it) {
+    GemmSpec g{layer == 0 ? E->in() : E->hid(), layer == 0 ? E->hid() : E->lab(), s.n, 2, COGNN_OP_AP_GEMM, COGNN_OP_AP_GEMM_TRUNC};
+    if (layer == 0) g.feature = 2;
+    else { g.xsrc = X_H1E_REUSE; g.akey_it = it - (it % (3 * E->cfg.num_layers)) + layer; }   // the forward iteration of that layer
     return g;
 }
 
@@ -620,9 +660,15 @@ void run_iteration(cognn_engine* E, int64_t it) {
         const int F = mp_width(E, I.e);
         // ---- PreScatterComp (gcn.h:198-255) ----
         if (I.fwd) {
-            const bool x_opened = (I.layer == 1 && E->gemm_x_opened_for == it);   // H already sits in h_t[1], opened
-            if (I.layer == 1 && !x_opened)
-                for (auto& s : E->sides) BE(cognn_memcpy_d2d(E->ctx, s.h1, s.cur, (size_t)s.n * E->hid() * 8));   // h_t[1]
+            bool x_opened = (I.layer == 1 && E->gemm_x_opened_for == it);   // H already sits in h_t[1], its opening in h1E
+            if (I.layer == 1 && !x_opened) {               // (not reached in a normal run: the ReLU close of iteration it-1 does both)
+                for (auto& s : E->sides) {
+                    BE(cognn_memcpy_d2d(E->ctx, s.h1, s.cur, (size_t)s.n * E->hid() * 8));   // h_t[1]
+                    cognn_keys k = keys(E, s.owner, it, COGNN_OP_PS_GEMM);
+                    BE(cognn_mask_open_u64(E->ctx, s.h1E, s.cur, k.k[s.p == 0 ? COGNN_SL_A0 : COGNN_SL_A1], s.n, E->hid(), 0));
+                }
+                x_opened = true;
+            }
             const bool scale_follows = I.e != 0;
             // the truncation close of the product also opens the row scale that consumes it
             OpenNext open_scale = [&](Side& s) { return keys(E, s.owner, it, COGNN_OP_PS_SCALE).k[s.p == 0 ? COGNN_SL_A0 : COGNN_SL_A1]; };
@@ -676,7 +722,7 @@ void run_iteration(cognn_engine* E, int64_t it) {
     }
     // d = h_t^T . in ; scale ; W -= lr d ; out = g  (gcn.h:671-684, 710-736)
     gemm_stage(E, it, [&](Side& s) { return I.layer == 0 ? s.feat : s.h1; }, [&](Side& s) { return s.cur; },
-               [&](Side& s) { return wgrad_spec(E, s, I.layer); },
+               [&](Side& s) { return wgrad_spec(E, s, I.layer, it); },
                [&](Side& s) { return s.small[0]; });
     weight_update_chain(E, it, I.layer);
     for (auto& s : E->sides) {
@@ -698,11 +744,11 @@ void run_offline(cognn_engine* E, int64_t it0, int64_t it1) {
             else if (!I.fwd && (I.e - I.f) % 2 == 0 && I.layer == I.f - 1) {
                 g = GemmSpec{s.n, E->hid(), E->lab(), 0, COGNN_OP_AP_GEMM, COGNN_OP_AP_GEMM_TRUNC}; have = true;
             } else if (!I.fwd && (I.e - I.f) % 2 == 1) {
-                g = wgrad_spec(E, s, I.layer);
+                g = wgrad_spec(E, s, I.layer, it);
                 have = true;
             }
             if (!have || s.c1.count({it, g.op})) continue;
-            cognn_keys k = g.feature ? feature_gemm_keys(E, s.owner, it, g.op) : keys(E, s.owner, it, g.op);
+            cognn_keys k = gemm_keys(E, s, it, g);
             u64* c = dalloc<u64>(E, (size_t)(g.M * g.N));
             BE(cognn_dealer_gemm_c1_u64(E->ctx, c, &k, g.M, g.N, g.K, g.transA, s.scratch, s.scratch + g.M * g.K));
             s.c1[{it, g.op}] = c;
@@ -867,6 +913,7 @@ void alloc_sides(cognn_engine* E) {
         s.W[1] = dalloc<u64>(E, (size_t)hid * lab);
         s.WT = dalloc<u64>(E, (size_t)hid * lab);
         s.h1 = dalloc<u64>(E, n * hid);
+        s.h1E = dalloc<u64>(E, n * hid);
         s.g = dalloc<u64>(E, n * hid);
         s.relu_mask = dalloc<uint8_t>(E, n * hid);
         for (int j = 0; j < 2; ++j) s.buf[j] = dalloc<u64>(E, n * fm);
@@ -888,6 +935,7 @@ void alloc_sides(cognn_engine* E) {
         const size_t n = (size_t)s.n;
         const size_t big = std::max<size_t>({n * (size_t)in, (size_t)in * hid, n * (size_t)fm, (size_t)hid * lab});
         s.featE_peer = s.peer ? s.peer->featE : dalloc<u64>(E, n * (size_t)in);
+        s.h1E_peer = s.peer ? s.peer->h1E : dalloc<u64>(E, n * (size_t)hid);
         for (int j = 0; j < 3; ++j) {
             if (s.peer) s.ib[j] = s.peer->ob[j];           // in-device exchange: read the peer's outbox directly
             else { s.ib_store[j] = dalloc<u64>(E, big); s.ib[j] = s.ib_store[j]; }

@@ -506,6 +506,10 @@ class OracleEngine:
         return lambda slot: (stream_key(self.seed, owner, 0, OP_PS_GEMM, slot) if slot in (SL_A0, SL_A1)
                              else stream_key(self.seed, owner, it, OP_AP_GEMM, slot))
 
+    def key_of_hidden_wgrad(self, owner, it, it_fwd):
+        return lambda slot: (stream_key(self.seed, owner, it_fwd, OP_PS_GEMM, slot) if slot in (SL_A0, SL_A1)
+                             else stream_key(self.seed, owner, it, OP_AP_GEMM, slot))
+
     # -- onAlgoKernelStart (gcn.h:854-887) + share distribution (ss_...h:205-232) ------------
     def _start(self, features, labels, weights):
         g = self.param; k = self.k
@@ -676,7 +680,9 @@ class OracleEngine:
                     # layer-0 forward product (dealt once, iteration 0); B and C are fresh
                     zA, zB = beaver_gemm_pair(hA, hB, inA, inB, self.key_of_feature_wgrad(P, it), a_of_transposed=True)
                 else:
-                    zA, zB = beaver_gemm_pair(hA, hB, inA, inB, self.key_of(P, it, OP_AP_GEMM))
+                    # h_t is the transposed hidden activation of this epoch: mask and opening of the layer-1 forward product
+                    # (GAS iteration it - e + layer) are reused the same way
+                    zA, zB = beaver_gemm_pair(hA, hB, inA, inB, self.key_of_hidden_wgrad(P, it, it - e + layer), a_of_transposed=True)
                 dA, dB = trunc_pair(zA, zB, self.key_of(P, it, OP_AP_GEMM_TRUNC))
                 gscale = fx_encode_trunc(1.0 / train) if train > 0 else U64(0)
                 dA, dB = const_scale_trunc_pair(dA, dB, gscale, self.key_of(P, it, OP_AP_GSCALE_TRUNC))
