@@ -65,6 +65,7 @@ _SIGNATURES = {
     "cognn_trunc_open_add_u64": (_I, [_P, _P, _P, _P, _KP, _KP, _I, _L]),
     "cognn_beaver_gemm_fusable": (_I, [_L, _L, _L, _I]),
     "cognn_beaver_gemm_close_raw_u64": (_I, [_P, _P, _P, _P, _P, _KP, _I, _L, _L, _L, _P]),
+    "cognn_beaver_gemm_close2_u64": (_I, [_P, _P, _P, _P, _P, _P, _P, _KP, _I, _L, _L, _L, _I, _P, _I]),
     "cognn_trunc_close_u64": (_I, [_P, _P, _P, _P, _KP, _I, _I, _L]),
     "cognn_trunc_close_open_u64": (_I, [_P, _P, _P, _P, _P, _KP, _I, _U, _L]),
     "cognn_rowscale_open_u64": (_I, [_P, _P, _P, _P, _P, _KP, _I, _L, _L]),

@@ -259,8 +259,8 @@ __device__ __forceinline__ void split8_store(const u64 v[8], unsigned char* dst_
 // A_p[:, 16t..16t+15] against F - so all steps cost the same on both sides.  Two LDS stages, one barrier per step.
 //   CN = 2: consumers 2(M) x 2(N), 64 x 64 block;  CN = 1 (N <= 32): consumers 4(M) x 1, 128 x 32 block.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void prep_b_planes_ws_kernel(unsigned char* planes, const u64* __restrict__ F, u64 keyB, int p,
-                                                                int K, int N, int nst) {
+__global__ __launch_bounds__(256) void prep_b_planes_ws_kernel(unsigned char* planes, const u64* __restrict__ F, const u64* __restrict__ F1,
+                                                                u64 keyB, int p, int K, int N, int nst) {
     // one thread per (k step, col, 4-k quad); quads 0..3: segment 0 (B_p + pF), quads 4..7: segment 1 (F)
     const int total = nst * kFusedBN * 8;
     for (int t = blockIdx.x * 256 + threadIdx.x; t < total; t += gridDim.x * 256) {
@@ -272,7 +272,7 @@ __global__ __launch_bounds__(256) void prep_b_planes_ws_kernel(unsigned char* pl
             const int k = st * 16 + (kq & 3) * 4 + j;
             u64 x = 0;
             if (k < K && c < N) {
-                const u64 f = F[(size_t)k * N + c];
+                const u64 f = F[(size_t)k * N + c] + (F1 ? F1[(size_t)k * N + c] : 0ull);
                 x = seg == 0 ? cognn_prng(keyB, (u64)k * (u64)N + (u64)c) + (p == 1 ? f : 0ull) : f;
             }
             v[j] = x;
@@ -620,8 +620,8 @@ __device__ __forceinline__ int tn_off(int rc, int h, int kq) { return kq * 512 +
 
 template <int DBG>   // timing experiments only (make ABLATION=1): 1 no loads, 2 no PRNG, 4 no MFMA, 8 no split / LDS writes
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
-void beaver_gemm_tn_ws_kernel(u64* Z, const u64* __restrict__ E0, const u64* __restrict__ E1, const u64* __restrict__ F, u64 keyA, u64 keyB,
-                              int p, int M, int N, int K, int steps_per_split, int a_storage) {
+void beaver_gemm_tn_ws_kernel(u64* Z, const u64* __restrict__ E0, const u64* __restrict__ E1, const u64* __restrict__ F,
+                              const u64* __restrict__ F1, u64 keyA, u64 keyB, int p, int M, int N, int K, int steps_per_split, int a_storage) {
     constexpr int BM = 64, S = 3;
     constexpr int kPlane = 2048;
     constexpr int kStage = 8 * kPlane;                      // 16 KiB per tile (A and B each)
@@ -696,21 +696,23 @@ void beaver_gemm_tn_ws_kernel(u64* Z, const u64* __restrict__ E0, const u64* __r
         const int ptid = tid - 256, pm = ptid & 63, kq = ptid >> 6;          // A task: row m0+pm; B task: column pm; both: k quad kq
         const u64* E1p = E1 ? E1 : E0;
         const u64 e1mask = E1 ? ~0ull : 0ull;
+        const u64* F1p = F1 ? F1 : F;
+        const u64 f1mask = F1 ? ~0ull : 0ull;
         const int mrow = min(m0 + pm, M - 1), ncol = min(pm, N - 1);
         const u64 mkeep = (m0 + pm < M) ? ~0ull : 0ull, nkeep = (pm < N) ? ~0ull : 0ull;
         const int o0 = tn_off(pm, 0, kq), o1 = tn_off(pm, 1, kq);            // segment 0 (E / B_p + pF) and segment 1 (A_p / F) positions
         const u64 a_step = a_storage ? (u64)M * COGNN_GAMMA : COGNN_GAMMA;
-        u64 a0a[4], a1a[4], fa[4], a0b[4], a1b[4], fb[4], a0c[4], a1c[4], fc[4], a0d[4], a1d[4], fd[4];   // four tiles in flight
-#define CG_TN_LOAD(t_, e0_, e1_, f_)                                                                                       \
+        u64 a0a[4], a1a[4], fa[4], ga[4], a0b[4], a1b[4], fb[4], gb[4], a0c[4], a1c[4], fc[4], gc[4], a0d[4], a1d[4], fd[4], gd[4];   // four tiles in flight
+#define CG_TN_LOAD(t_, e0_, e1_, f_, g_)                                                                                   \
     do {                                                                                                                  \
         const int k_ = (st0 + min((t_), total - 1)) * 16 + kq * 4;                                                        \
         _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                   \
             const size_t kk_ = (size_t)min(k_ + j, K - 1);                                                                \
-            if (DBG & 1) { e0_[j] = kk_; e1_[j] = kk_ + 1; f_[j] = kk_ + 2; continue; }                                   \
-            e0_[j] = E0[kk_ * M + mrow]; e1_[j] = E1p[kk_ * M + mrow]; f_[j] = F[kk_ * N + ncol];                          \
+            if (DBG & 1) { e0_[j] = kk_; e1_[j] = kk_ + 1; f_[j] = kk_ + 2; g_[j] = kk_ + 3; continue; }                  \
+            e0_[j] = E0[kk_ * M + mrow]; e1_[j] = E1p[kk_ * M + mrow]; f_[j] = F[kk_ * N + ncol]; g_[j] = F1p[kk_ * N + ncol]; \
         }                                                                                                                 \
     } while (0)
-#define CG_TN_PRODUCE(t_, slot_, e0_, e1_, f_)                                                                             \
+#define CG_TN_PRODUCE(t_, slot_, e0_, e1_, f_, g_)                                                                         \
     do {                                                                                                                  \
         const int k_ = (st0 + (t_)) * 16 + kq * 4;                                                                        \
         u64 v_[4], w_[4], bp_[4], ff_[4];                                                                                 \
@@ -721,7 +723,7 @@ void beaver_gemm_tn_ws_kernel(u64* Z, const u64* __restrict__ E0, const u64* __r
             const u64 kk_ = (k_ + j < K) ? ~0ull : 0ull;                                                                  \
             v_[j] = (e0_[j] + (e1_[j] & e1mask)) & mkeep & kk_;                                                           \
             w_[j] = ((DBG & 2) ? xa_ : cognn_mix64(xa_)) & mkeep & kk_;                                                   \
-            ff_[j] = f_[j] & nkeep & kk_;                                                                                 \
+            ff_[j] = (f_[j] + (g_[j] & f1mask)) & nkeep & kk_;                                                            \
             bp_[j] = (((DBG & 2) ? xb_ : cognn_mix64(xb_)) & nkeep & kk_) + (p == 1 ? ff_[j] : 0ull);                     \
             xa_ += a_step; xb_ += (u64)N * COGNN_GAMMA;                                                                   \
         }                                                                                                                 \
@@ -737,28 +739,28 @@ void beaver_gemm_tn_ws_kernel(u64* Z, const u64* __restrict__ E0, const u64* __r
             *reinterpret_cast<uint32_t*>(db_ + i * kPlane + o1) = pf_[i];                                                 \
         }                                                                                                                 \
     } while (0)
-        CG_TN_LOAD(0, a0a, a1a, fa);
-        CG_TN_LOAD(1, a0b, a1b, fb);
-        CG_TN_LOAD(2, a0c, a1c, fc);
-        CG_TN_LOAD(3, a0d, a1d, fd);
-        CG_TN_PRODUCE(0, 0, a0a, a1a, fa);
-        CG_TN_LOAD(4, a0a, a1a, fa);
-        if (total > 1) CG_TN_PRODUCE(1, 1, a0b, a1b, fb);
-        CG_TN_LOAD(5, a0b, a1b, fb);
+        CG_TN_LOAD(0, a0a, a1a, fa, ga);
+        CG_TN_LOAD(1, a0b, a1b, fb, gb);
+        CG_TN_LOAD(2, a0c, a1c, fc, gc);
+        CG_TN_LOAD(3, a0d, a1d, fd, gd);
+        CG_TN_PRODUCE(0, 0, a0a, a1a, fa, ga);
+        CG_TN_LOAD(4, a0a, a1a, fa, ga);
+        if (total > 1) CG_TN_PRODUCE(1, 1, a0b, a1b, fb, gb);
+        CG_TN_LOAD(5, a0b, a1b, fb, gb);
         __syncthreads();
         int sp = 2;
-#define CG_TN_ITER(t_, e0_, e1_, f_)                                                                                       \
+#define CG_TN_ITER(t_, e0_, e1_, f_, g_)                                                                                   \
     do {                                                                                                                  \
-        if ((t_) + 2 < total) CG_TN_PRODUCE((t_) + 2, sp, e0_, e1_, f_);                                                  \
-        CG_TN_LOAD((t_) + 6, e0_, e1_, f_);                                                                               \
+        if ((t_) + 2 < total) CG_TN_PRODUCE((t_) + 2, sp, e0_, e1_, f_, g_);                                              \
+        CG_TN_LOAD((t_) + 6, e0_, e1_, f_, g_);                                                                           \
         sp = (sp == S - 1) ? 0 : sp + 1;                                                                                  \
         __syncthreads();                                                                                                  \
     } while (0)
         for (int t = 0; t < total; t += 4) {
-            CG_TN_ITER(t, a0c, a1c, fc);
-            if (t + 1 < total) CG_TN_ITER(t + 1, a0d, a1d, fd);
-            if (t + 2 < total) CG_TN_ITER(t + 2, a0a, a1a, fa);
-            if (t + 3 < total) CG_TN_ITER(t + 3, a0b, a1b, fb);
+            CG_TN_ITER(t, a0c, a1c, fc, gc);
+            if (t + 1 < total) CG_TN_ITER(t + 1, a0d, a1d, fd, gd);
+            if (t + 2 < total) CG_TN_ITER(t + 2, a0a, a1a, fa, ga);
+            if (t + 3 < total) CG_TN_ITER(t + 3, a0b, a1b, fb, gb);
         }
 #undef CG_TN_ITER
 #undef CG_TN_LOAD
@@ -766,8 +768,8 @@ void beaver_gemm_tn_ws_kernel(u64* Z, const u64* __restrict__ E0, const u64* __r
     }
 }
 
-int launch_tn_ws(cognn_ctx* ctx, u64* Z, const u64* E0, const u64* E1, const u64* F, u64 keyA, u64 keyB, int p, int64_t M, int64_t N, int64_t K,
-                 int a_storage) {
+int launch_tn_ws(cognn_ctx* ctx, u64* Z, const u64* E0, const u64* E1, const u64* F, const u64* F1, u64 keyA, u64 keyB, int p, int64_t M,
+                 int64_t N, int64_t K, int a_storage) {
     const int nst = (int)((K + 15) / 16);
     const int nmb = (int)((M + 63) / 64);
     int splits = std::max(1, std::min(nst, (256 + nmb - 1) / nmb));      // one workgroup per CU: the pipeline prologue is paid once
@@ -777,8 +779,8 @@ int launch_tn_ws(cognn_ctx* ctx, u64* Z, const u64* E0, const u64* E1, const u64
 #define CG_TN_LAUNCH(D)                                                                                                            \
     do {                                                                                                                            \
         CG_HIP(hipFuncSetAttribute((const void*)beaver_gemm_tn_ws_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        hipLaunchKernelGGL(beaver_gemm_tn_ws_kernel<D>, dim3((unsigned)nmb, (unsigned)splits), dim3(512), lds, ctx->stream, Z, E0, E1, F, keyA, \
-                           keyB, p, (int)M, (int)N, (int)K, sps, a_storage);                                                        \
+        hipLaunchKernelGGL(beaver_gemm_tn_ws_kernel<D>, dim3((unsigned)nmb, (unsigned)splits), dim3(512), lds, ctx->stream, Z, E0, E1, F, F1,   \
+                           keyA, keyB, p, (int)M, (int)N, (int)K, sps, a_storage);                                                  \
     } while (0)
 #ifdef COGNN_GEMM_ABLATION
     static const int dbg = getenv("COGNN_GEMM_DBG") ? atoi(getenv("COGNN_GEMM_DBG")) : 0;
@@ -926,12 +928,15 @@ int cognn_dealer_gemm_c1_u64(cognn_ctx* ctx, uint64_t* C1, const cognn_keys* key
 }  // extern "C"
 
 namespace {
+__global__ __launch_bounds__(256) void add_inplace_kernel(u64* out, const u64* __restrict__ a, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) out[i] += a[i];
+}
 __global__ __launch_bounds__(256) void add_cp_kernel(u64* Z, const u64* c1, u64 keyC0, int p, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
         Z[i] += (p == 0) ? cognn_prng(keyC0, (u64)i) : c1[i];
 }
-int beaver_close_impl(cognn_ctx* ctx, uint64_t* Z, const uint64_t* E, const uint64_t* E1, const uint64_t* F, const uint64_t* c1,
-                      const cognn_keys* keys, int p, int64_t M, int64_t N, int64_t K, int transA, uint64_t* scratch, bool raw);
+int beaver_close_impl(cognn_ctx* ctx, uint64_t* Z, const uint64_t* E, const uint64_t* E1, const uint64_t* F, const uint64_t* F1,
+                      const uint64_t* c1, const cognn_keys* keys, int p, int64_t M, int64_t N, int64_t K, int transA, uint64_t* scratch, bool raw);
 }  // namespace
 
 extern "C" {
@@ -940,7 +945,7 @@ int cognn_beaver_gemm_close_u64(cognn_ctx* ctx, uint64_t* Z, const uint64_t* E, 
                                 const cognn_keys* keys, int p, int64_t M, int64_t N, int64_t K, int transA, uint64_t* scratch) {
     CG_REQUIRE(ctx && Z && E && F && keys && scratch && (p == 0 || p == 1), "cognn_beaver_gemm_close_u64: bad arguments");
     CG_REQUIRE(p == 0 || c1, "cognn_beaver_gemm_close_u64: p=1 needs the dealer share c1");
-    return beaver_close_impl(ctx, Z, E, E1, F, c1, keys, p, M, N, K, transA, scratch, false);
+    return beaver_close_impl(ctx, Z, E, E1, F, nullptr, c1, keys, p, M, N, K, transA, scratch, false);
 }
 
 int cognn_beaver_gemm_fusable(int64_t M, int64_t N, int64_t K, int transA) {
@@ -951,20 +956,28 @@ int cognn_beaver_gemm_fusable(int64_t M, int64_t N, int64_t K, int transA) {
 int cognn_beaver_gemm_close_raw_u64(cognn_ctx* ctx, uint64_t* Z, const uint64_t* E, const uint64_t* E1, const uint64_t* F,
                                     const cognn_keys* keys, int p, int64_t M, int64_t N, int64_t K, uint64_t* scratch) {
     CG_REQUIRE(ctx && Z && E && F && keys && scratch && (p == 0 || p == 1), "cognn_beaver_gemm_close_raw_u64: bad arguments");
-    return beaver_close_impl(ctx, Z, E, E1, F, nullptr, keys, p, M, N, K, 0, scratch, true);
+    return beaver_close_impl(ctx, Z, E, E1, F, nullptr, nullptr, keys, p, M, N, K, 0, scratch, true);
+}
+
+int cognn_beaver_gemm_close2_u64(cognn_ctx* ctx, uint64_t* Z, const uint64_t* E0, const uint64_t* E1, const uint64_t* F0, const uint64_t* F1,
+                                 const uint64_t* c1, const cognn_keys* keys, int p, int64_t M, int64_t N, int64_t K, int transA,
+                                 uint64_t* scratch, int raw) {
+    CG_REQUIRE(ctx && Z && E0 && F0 && keys && scratch && (p == 0 || p == 1), "cognn_beaver_gemm_close2_u64: bad arguments");
+    CG_REQUIRE(raw || p == 0 || c1, "cognn_beaver_gemm_close2_u64: p=1 needs the dealer share c1");
+    return beaver_close_impl(ctx, Z, E0, E1, F0, F1, raw ? nullptr : c1, keys, p, M, N, K, raw ? 0 : transA, scratch, raw != 0);
 }
 
 }  // extern "C"
 
 namespace {
-int beaver_close_impl(cognn_ctx* ctx, uint64_t* Z, const uint64_t* E, const uint64_t* E1, const uint64_t* F, const uint64_t* c1,
-                      const cognn_keys* keys, int p, int64_t M, int64_t N, int64_t K, int transA, uint64_t* scratch, bool raw) {
+int beaver_close_impl(cognn_ctx* ctx, uint64_t* Z, const uint64_t* E, const uint64_t* E1, const uint64_t* F, const uint64_t* F1,
+                      const uint64_t* c1, const cognn_keys* keys, int p, int64_t M, int64_t N, int64_t K, int transA, uint64_t* scratch, bool raw) {
     int rc;
     if (cognn_beaver_gemm_fusable(M, N, K, transA)) {
         unsigned char* planes = (unsigned char*)scratch;           // B limb planes, 16 KiB per K step, in the (MxK + KxN)-word scratch
         const int nst = (int)((K + 15) / 16);
         hipLaunchKernelGGL(prep_b_planes_ws_kernel, dim3((unsigned)std::min(nst * kFusedBN * 8 / 256 + 1, 1024)), dim3(256), 0, ctx->stream,
-                           planes, (const u64*)F, keys->k[p == 0 ? COGNN_SL_B0 : COGNN_SL_B1], p, (int)K, (int)N, nst);
+                           planes, (const u64*)F, (const u64*)F1, keys->k[p == 0 ? COGNN_SL_B0 : COGNN_SL_B1], p, (int)K, (int)N, nst);
         CG_LAUNCH_CHECK();
         const int cn = N <= 32 ? 1 : 2, bm = cn == 2 ? 64 : 128;
         const size_t lds = 3 * ((size_t)(8 * 2 * bm * 16) + (size_t)kNnBStage);
@@ -1010,8 +1023,8 @@ int beaver_close_impl(cognn_ctx* ctx, uint64_t* Z, const uint64_t* E, const uint
         // Z <- C_p, then one split-K launch adds E.(B_p + pF) + A_p.F
         if (p == 0) { if ((rc = fill(ctx, (u64*)Z, keys->k[COGNN_SL_C0], 0, M, N, 0, 0, nullptr))) return rc; }
         else CG_HIP(hipMemcpyAsync(Z, c1, (size_t)M * N * 8, hipMemcpyDeviceToDevice, ctx->stream));
-        return launch_tn_ws(ctx, (u64*)Z, (const u64*)E, (const u64*)E1, (const u64*)F, keys->k[p == 0 ? COGNN_SL_A0 : COGNN_SL_A1],
-                            keys->k[p == 0 ? COGNN_SL_B0 : COGNN_SL_B1], p, M, N, K, transA == 2);
+        return launch_tn_ws(ctx, (u64*)Z, (const u64*)E, (const u64*)E1, (const u64*)F, (const u64*)F1,
+                            keys->k[p == 0 ? COGNN_SL_A0 : COGNN_SL_A1], keys->k[p == 0 ? COGNN_SL_B0 : COGNN_SL_B1], p, M, N, K, transA == 2);
     }
     u64* Ap = (u64*)scratch;
     u64* Bp = Ap + (size_t)M * K;
@@ -1020,7 +1033,14 @@ int beaver_close_impl(cognn_ctx* ctx, uint64_t* Z, const uint64_t* E, const uint
     if ((rc = fill(ctx, Bp, keys->k[p == 0 ? COGNN_SL_B0 : COGNN_SL_B1], 0, K, N, 0, 0, p == 1 ? (const u64*)F : nullptr))) return rc;
     if (p == 0) { if ((rc = fill(ctx, (u64*)Z, keys->k[COGNN_SL_C0], 0, M, N, 0, 0, nullptr))) return rc; }
     else CG_HIP(hipMemcpyAsync(Z, c1, (size_t)M * N * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    if (p == 1 && F1 && K * N > 0) {                               // F given as two shares: B_1 + F0 + F1
+        const int64_t n = K * N;
+        hipLaunchKernelGGL(add_inplace_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 8192)), dim3(256), 0, ctx->stream, Bp,
+                           (const u64*)F1, n);
+        CG_LAUNCH_CHECK();
+    }
     if ((rc = gemm_dispatch(ctx, (u64*)Z, (const u64*)E, (const u64*)E1, Bp, M, N, K, transA, 1))) return rc;
-    return gemm_dispatch(ctx, (u64*)Z, Ap, nullptr, (const u64*)F, M, N, K, transA, 1);
+    if ((rc = gemm_dispatch(ctx, (u64*)Z, Ap, nullptr, (const u64*)F, M, N, K, transA, 1))) return rc;
+    return F1 ? gemm_dispatch(ctx, (u64*)Z, Ap, nullptr, (const u64*)F1, M, N, K, transA, 1) : 0;   // A_p.(F0 + F1) by linearity
 }
 }  // namespace

@@ -295,11 +295,7 @@ void gemm_stage(cognn_engine* E, int64_t it, XFn X, WFn Wm, SpecFn spec, DstFn d
     } else {
         exchange_ob2(E, 0, e0, 1, e1);
     }
-    for (size_t i = 0; i < E->sides.size(); ++i) {
-        Side& s = E->sides[i];
-        BE(cognn_add_u64(E->ctx, s.fsum, s.ob[1], s.ib[1], e1[i]));
-    }
-    std::vector<u64*> z;
+    std::vector<u64*> z;                                    // (F = F0 + F1 is summed inside the product kernels)
     GemmSpec g0 = spec(E->sides[0]);
     bool all_raw = true;
     for (auto& s : E->sides) { GemmSpec g = spec(s); all_raw = all_raw && E->be->cognn_beaver_gemm_fusable(g.M, g.N, g.K, g.transA); }
@@ -321,12 +317,9 @@ void gemm_stage(cognn_engine* E, int64_t it, XFn X, WFn Wm, SpecFn spec, DstFn d
             c1 = f->second;
         }
         if (E->timing) BE(cognn_timer_begin(E->ctx, T_GEMM));
-        if (all_raw) {
-            // fused single-launch product without C_p; C_p joins in the truncation opening below
-            BE(cognn_beaver_gemm_close_raw_u64(E->ctx, s.zbuf, e_own, e_peer, s.fsum, &k, s.p, g.M, g.N, g.K, s.scratch));
-        } else {
-            BE(cognn_beaver_gemm_close_u64(E->ctx, s.zbuf, e_own, e_peer, s.fsum, c1, &k, s.p, g.M, g.N, g.K, g.transA, s.scratch));
-        }
+        // all_raw: fused single-launch product without C_p; C_p joins in the truncation opening below
+        BE(cognn_beaver_gemm_close2_u64(E->ctx, s.zbuf, e_own, e_peer, s.ob[1], s.ib[1], c1, &k, s.p, g.M, g.N, g.K, g.transA, s.scratch,
+                                        all_raw ? 1 : 0));
         if (E->timing) { BE(cognn_timer_end(E->ctx, T_GEMM)); E->algo[T_GEMM] += 2.0 * 36 * 2 * (double)g.M * g.K * g.N; }
         if (all_raw) {
             cognn_keys tk = keys(E, s.owner, it, g.top);

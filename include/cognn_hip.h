@@ -105,6 +105,12 @@ int cognn_beaver_gemm_fusable(int64_t M, int64_t N, int64_t K, int transA);
 int cognn_beaver_gemm_close_raw_u64(cognn_ctx*, uint64_t* Z, const uint64_t* E0, const uint64_t* E1, const uint64_t* F,
                                     const cognn_keys* keys, int p, int64_t M, int64_t N, int64_t K, uint64_t* scratch);
 
+/* Both of the above with the opened F given as its two shares (F = F0 + F1, summed on the fly like E0 + E1; F1 may be
+ * NULL): saves the pass that would form the sum.  raw != 0: without C_p (c1 unused; fusable shapes only). */
+int cognn_beaver_gemm_close2_u64(cognn_ctx*, uint64_t* Z, const uint64_t* E0, const uint64_t* E1, const uint64_t* F0, const uint64_t* F1,
+                                 const uint64_t* c1, const cognn_keys* keys, int p, int64_t M, int64_t N, int64_t K, int transA,
+                                 uint64_t* scratch, int raw);
+
 /* ---- truncation by 2^16 (implicit in every sci:: fixed-point op) ------------------------- */
 /* c_p = mul * x_p + r_p (+2^61 if p==0) */
 int cognn_trunc_open_u64(cognn_ctx*, uint64_t* c, const uint64_t* x, uint64_t mul, const cognn_keys* keys, int p, int64_t n);

@@ -214,6 +214,14 @@ int cognn_beaver_gemm_close_raw_u64(cognn_ctx* c, uint64_t* Z, const uint64_t* E
     cognn_ring_gemm2_u64(c, Z, E, E1, Bp, M, N, K, 0, 0);
     return cognn_ring_gemm_u64(c, Z, Ap, F, M, N, K, 0, 1);
 }
+int cognn_beaver_gemm_close2_u64(cognn_ctx* c, uint64_t* Z, const uint64_t* E0, const uint64_t* E1, const uint64_t* F0, const uint64_t* F1,
+                                 const uint64_t* c1, const cognn_keys* keys, int p, int64_t M, int64_t N, int64_t K, int transA,
+                                 uint64_t* scratch, int raw) {
+    std::vector<u64> f((size_t)(K * N));
+    for (int64_t i = 0; i < K * N; ++i) f[i] = F0[i] + (F1 ? F1[i] : 0);
+    return raw ? cognn_beaver_gemm_close_raw_u64(c, Z, E0, E1, f.data(), keys, p, M, N, K, scratch)
+               : cognn_beaver_gemm_close_u64(c, Z, E0, E1, f.data(), c1, keys, p, M, N, K, transA, scratch);
+}
 int cognn_trunc_open_add_u64(cognn_ctx*, uint64_t* c, const uint64_t* x, const uint64_t* c1, const cognn_keys* gkeys,
                              const cognn_keys* tkeys, int p, int64_t n) {
     const cognn_opkeys tk = K(tkeys);

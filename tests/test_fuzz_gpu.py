@@ -115,7 +115,12 @@ def test_fuzz_gemm(libs, seed):
     for p in (0, 1):
         both(libs, "cognn_beaver_gemm_close_u64", [O((M, N)), O(sa.shape, check=False)],
              [("out", 0), A, E1 if seed % 2 else None, B, cc1 if p == 1 else None, ctypes.byref(k), p, M, N, K, tA, ("out", 1)])
+        B2 = rand_u64(rng, (K, N))                            # F given as two shares
+        both(libs, "cognn_beaver_gemm_close2_u64", [O((M, N)), O(sa.shape, check=False)],
+             [("out", 0), A, E1, B, B2 if seed % 3 else None, cc1 if p == 1 else None, ctypes.byref(k), p, M, N, K, tA, ("out", 1), 0])
         if ctx.lib.cognn_beaver_gemm_fusable(M, N, K, tA):
+            both(libs, "cognn_beaver_gemm_close2_u64", [O((M, N)), O(sa.shape, check=False)],
+                 [("out", 0), A, E1, B, B2, None, ctypes.byref(k), p, M, N, K, tA, ("out", 1), 1])
             both(libs, "cognn_beaver_gemm_close_raw_u64", [O((M, N)), O(sa.shape, check=False)],
                  [("out", 0), A, E1, B, ctypes.byref(k), p, M, N, K, ("out", 1)])
 
