@@ -250,7 +250,13 @@ cognn_keys gemm_keys(cognn_engine* E, Side& s, int64_t it, const GemmSpec& g) {
 
 // closing step of a truncation; open_next (optional) returns the mask key of the op that consumes dst(side): the close then
 // also writes that op's opening E = dst - mask into ob[0] (one pass less, see cognn_trunc_close_open_u64)
-using OpenNext = std::function<u64(Side&)>;
+struct OpenNext {
+    std::function<u64(Side&)> key;     // empty: plain close
+    int ob = 0;                        // outbox that receives the opening (0: left / element-wise operand, 1: right GEMM operand)
+    OpenNext() {}
+    OpenNext(std::function<u64(Side&)> k, int o = 0) : key(std::move(k)), ob(o) {}
+    explicit operator bool() const { return (bool)key; }
+};
 template <class DstFn>
 void trunc_close_all(cognn_engine* E, int64_t it, int top, DstFn dst, const std::vector<int64_t>& elems, const OpenNext& open_next) {
     for (size_t i = 0; i < E->sides.size(); ++i) {
@@ -258,7 +264,7 @@ void trunc_close_all(cognn_engine* E, int64_t it, int top, DstFn dst, const std:
         cognn_keys tk = keys(E, s.owner, it, top);
         const u64* c0 = s.p == 0 ? s.ob[2] : nullptr;
         const u64* c1 = s.p == 0 ? s.ib[2] : nullptr;
-        if (open_next) BE(cognn_trunc_close_open_u64(E->ctx, dst(s), s.ob[0], c0, c1, &tk, s.p, open_next(s), elems[i]));
+        if (open_next) BE(cognn_trunc_close_open_u64(E->ctx, dst(s), s.ob[open_next.ob], c0, c1, &tk, s.p, open_next.key(s), elems[i]));
         else BE(cognn_trunc_close_u64(E->ctx, dst(s), c0, c1, &tk, s.p, 0, elems[i]));
     }
 }
@@ -266,7 +272,8 @@ void trunc_close_all(cognn_engine* E, int64_t it, int top, DstFn dst, const std:
 // Beaver GEMM for every side: X(side), Wm(side) -> truncated product written to dst(side)
 template <class XFn, class WFn, class SpecFn, class DstFn>
 void gemm_stage(cognn_engine* E, int64_t it, XFn X, WFn Wm, SpecFn spec, DstFn dst, bool x_opened = false,
-                const OpenNext& open_next = nullptr) {
+                const OpenNext& open_next = OpenNext(), bool w_opened = false) {
+    // w_opened: ob[1] already holds F_p = W_p - B_p (written by the truncation close that produced W)
     std::vector<int64_t> e0, e1, eo;
     const bool feature = spec(E->sides[0]).feature != 0;
     const int xsrc = x_opened ? X_H1E_FRESH : spec(E->sides[0]).xsrc;
@@ -276,7 +283,7 @@ void gemm_stage(cognn_engine* E, int64_t it, XFn X, WFn Wm, SpecFn spec, DstFn d
         cognn_keys k = gkeys(s, g);
         if (xsrc == X_OPEN_HERE && !feature)
             BE(cognn_mask_open_u64(E->ctx, s.ob[0], X(s), k.k[s.p == 0 ? COGNN_SL_A0 : COGNN_SL_A1], g.M, g.K, g.transA));
-        BE(cognn_mask_open_u64(E->ctx, s.ob[1], Wm(s), k.k[s.p == 0 ? COGNN_SL_B0 : COGNN_SL_B1], g.K, g.N, 0));
+        if (!w_opened) BE(cognn_mask_open_u64(E->ctx, s.ob[1], Wm(s), k.k[s.p == 0 ? COGNN_SL_B0 : COGNN_SL_B1], g.K, g.N, 0));
         e0.push_back(g.M * g.K); e1.push_back(g.K * g.N); eo.push_back(g.M * g.N);
     }
     if (feature || xsrc == X_H1E_REUSE) {
@@ -346,7 +353,7 @@ void gemm_stage(cognn_engine* E, int64_t it, XFn X, WFn Wm, SpecFn spec, DstFn d
 enum { E_FROM_X = 0, E_IN_X = 1, E_IN_OB0 = 2 };
 template <class XFn, class DstFn>
 void rowscale_stage(cognn_engine* E, int64_t it, int op, int top, int F, XFn X, DstFn dst, int e_mode = E_FROM_X,
-                    const OpenNext& open_next = nullptr) {
+                    const OpenNext& open_next = OpenNext()) {
     // e_mode: E_FROM_X  open E_p = X_p - a_p here;
     //         E_IN_X    X(side) already holds E_p (written by the gather epilogue);
     //         E_IN_OB0  ob[0] already holds E_p (written by the truncation close that produced X)
@@ -645,7 +652,7 @@ void weight_update_chain(cognn_engine* E, int64_t it, int layer) {
 
 void run_iteration(cognn_engine* E, int64_t it) {
     const IterInfo I = iter_info(E, it);
-    bool relu_opened = false;
+    bool relu_opened = false, wgrad_w_opened = false;
     if (I.e == 0) {                                        // ss_...h:695, 938: back to the input features
         for (auto& s : E->sides) { s.cur = s.feat; s.curF = E->in(); }
     }
@@ -664,7 +671,7 @@ void run_iteration(cognn_engine* E, int64_t it) {
             }
             const bool scale_follows = I.e != 0;
             // the truncation close of the product also opens the row scale that consumes it
-            OpenNext open_scale = [&](Side& s) { return keys(E, s.owner, it, COGNN_OP_PS_SCALE).k[s.p == 0 ? COGNN_SL_A0 : COGNN_SL_A1]; };
+            OpenNext open_scale([&](Side& s) { return keys(E, s.owner, it, COGNN_OP_PS_SCALE).k[s.p == 0 ? COGNN_SL_A0 : COGNN_SL_A1]; });
             gemm_stage(E, it, [&](Side& s) { return s.cur; }, [&](Side& s) { return s.W[I.layer]; },
                        [&](Side& s) { return prescatter_spec(E, s, I.layer); },
                        [&](Side& s) { return scale_follows ? s.buf[1] : table_seg(E, s, F); }, x_opened,
@@ -684,9 +691,13 @@ void run_iteration(cognn_engine* E, int64_t it) {
         if (gscale) {
             // a hidden forward layer feeds the ReLU next: the close of this scale already opens it
             relu_opened = I.fwd && I.e != I.f - 1;
-            OpenNext open_relu = [&](Side& s) { return keys(E, s.owner, it, COGNN_OP_AP_RELU).k[s.p == 0 ? COGNN_SL_A0 : COGNN_SL_A1]; };
+            // ... and in a backward iteration the weight-gradient product d = h_t^T . in is next: its right operand is this result
+            wgrad_w_opened = !I.fwd;
+            OpenNext open_relu([&](Side& s) { return keys(E, s.owner, it, COGNN_OP_AP_RELU).k[s.p == 0 ? COGNN_SL_A0 : COGNN_SL_A1]; });
+            OpenNext open_wgrad([&](Side& s) { return gemm_keys(E, s, it, wgrad_spec(E, s, I.layer, it)).k[s.p == 0 ? COGNN_SL_B0 : COGNN_SL_B1]; }, 1);
             rowscale_stage(E, it, COGNN_OP_GA_SCALE, COGNN_OP_GA_SCALE_TRUNC, F, [&](Side& s) { return s.cur; },
-                           [&](Side& s) { return s.buf[1]; }, fuse_open ? E_IN_X : E_FROM_X, relu_opened ? open_relu : OpenNext());
+                           [&](Side& s) { return s.buf[1]; }, fuse_open ? E_IN_X : E_FROM_X,
+                           relu_opened ? open_relu : wgrad_w_opened ? open_wgrad : OpenNext());
             for (auto& s : E->sides) s.cur = s.buf[1];
         }
     }
@@ -716,7 +727,7 @@ void run_iteration(cognn_engine* E, int64_t it) {
     // d = h_t^T . in ; scale ; W -= lr d ; out = g  (gcn.h:671-684, 710-736)
     gemm_stage(E, it, [&](Side& s) { return I.layer == 0 ? s.feat : s.h1; }, [&](Side& s) { return s.cur; },
                [&](Side& s) { return wgrad_spec(E, s, I.layer, it); },
-               [&](Side& s) { return s.small[0]; });
+               [&](Side& s) { return s.small[0]; }, false, OpenNext(), wgrad_w_opened);
     weight_update_chain(E, it, I.layer);
     for (auto& s : E->sides) {
         if (I.layer == I.f - 1) { s.cur = s.g; s.curF = E->hid(); }
