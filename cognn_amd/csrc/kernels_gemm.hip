@@ -479,25 +479,19 @@ void beaver_gemm_ws_kernel(u64* Z, const u64* __restrict__ E0, const u64* __rest
 }
 
 // ------------------------------------------------------------------------------------------
-// TN products (weight gradients d = h_t^T . in, gcn.h:671,710): logical A [M x K] is stored [K x M], K = #vertices is
-// huge, the output [M x N] tiny.  Split-K over workgroups, 128 x 64 output block per workgroup (8 waves), both operands
-// streamed from HBM and limb-split per 32-deep K step, uint64 atomics for the partial outputs (integer adds commute,
-// so the result is exact and order-independent).
-//   BEAVER: Z += [E | A_p] . [B_p + p*F ; F] with E = E0+E1 and F from memory, A_p / B_p from their PRNG streams
-//           (both segments share the F tile of the step: 72 MFMAs per wave per step).
-//   plain : Z += (A1 + A2)^T-stored . B.
+// Plain TN product Z += (A1 + A2)^T-stored . B (dealer's offline C1 of a weight-gradient triple): logical A [M x K] is stored
+// [K x M], K = #vertices is huge, the output [M x N] tiny.  Split-K over workgroups, 128 x 64 output block per workgroup
+// (8 waves), both operands streamed from HBM and limb-split per 32-deep K step, uint64 atomics for the partial outputs
+// (integer adds commute, so the result is exact and order-independent).  The online Beaver close of the same shapes is
+// beaver_gemm_tn_ws_kernel below.
 // ------------------------------------------------------------------------------------------
-template <bool BEAVER>
 __global__ __launch_bounds__(512) void ring_gemm_tn_kernel(u64* Z, const u64* __restrict__ E0, const u64* __restrict__ E1,
-                                                           const u64* __restrict__ F, u64 keyA, u64 keyB, int p, int M, int N,
-                                                           int K, int steps_per_split) {
+                                                           const u64* __restrict__ F, int M, int N, int K, int steps_per_split) {
     constexpr int BM = 128;
     constexpr int kATile = 8 * 2 * BM * 16;                 // 32768: [plane][k-half][row][16]
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* sA0 = smem;                              // E tile
-    // smem + kATile: mask tile (BEAVER), addressed as sA0 + kATile
-    unsigned char* sB0 = smem + 2 * kATile;                 // B' planes [plane][col][48]
-    unsigned char* sB1 = sB0 + kBStage;                     // F planes (BEAVER)
+    unsigned char* sA0 = smem;
+    unsigned char* sB0 = smem + kATile;                     // B planes [plane][col][48]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -505,10 +499,8 @@ __global__ __launch_bounds__(512) void ring_gemm_tn_kernel(u64* Z, const u64* __
     const int nkt = (K + kKStep - 1) / kKStep;
     const int kt0 = blockIdx.y * steps_per_split;
     const int kt1 = min(nkt, kt0 + steps_per_split);
-    // A-side task: column m of the storage (= logical row), 8 consecutive k
-    const int am = tid & 127, akq = tid >> 7;               // akq in 0..3
-    // B-side task: column n, 4 consecutive k
-    const int bn = tid & 63, bkq = tid >> 6;                // bkq in 0..7
+    const int am = tid & 127, akq = tid >> 7;               // A-side task: column m of the storage (= logical row), 8 consecutive k
+    const int bn = tid & 63, bkq = tid >> 6;                // B-side task: column n, 4 consecutive k
 
     v16i acc[8];
 #pragma unroll
@@ -537,60 +529,31 @@ __global__ __launch_bounds__(512) void ring_gemm_tn_kernel(u64* Z, const u64* __
 
     if (kt0 < kt1) load_step(kt0);
     for (int kt = kt0; kt < kt1; ++kt) {
-        // ---- produce the step's tiles ----
         {
             u64 v[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = ea[j] + eb[j];
-            unsigned char* dst = (akq >> 1) * (BM * 16) + am * 16 + (akq & 1) * 8 + sA0;
-            split8_store<128>(v, dst);
-            if (BEAVER) {
-                const int k = kt * kKStep + akq * 8;
-                const int m = m0 + am;
-                u64 x = keyA + ((u64)m * (u64)K + (u64)k + 1ull) * COGNN_GAMMA;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) { v[j] = (m < M && k + j < K) ? cognn_mix64(x) : 0ull; x += COGNN_GAMMA; }
-                split8_store<128>(v, dst + kATile);
-            }
-            const int kb = kt * kKStep + bkq * 4;
-            u64 w[4];
+            split8_store<128>(v, (akq >> 1) * (BM * 16) + am * 16 + (akq & 1) * 8 + sA0);
             uint32_t pl[8];
-            if (BEAVER) {
+            split4(fv, pl);
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    w[j] = (bn < N && kb + j < K) ? cognn_prng(keyB, (u64)(kb + j) * (u64)N + (u64)bn) + (p == 1 ? fv[j] : 0ull) : 0ull;
-                split4(w, pl);
-#pragma unroll
-                for (int i = 0; i < 8; ++i) *reinterpret_cast<uint32_t*>(sB0 + i * (kFusedBN * kBRow) + bn * kBRow + bkq * 4) = pl[i];
-                split4(fv, pl);
-#pragma unroll
-                for (int i = 0; i < 8; ++i) *reinterpret_cast<uint32_t*>(sB1 + i * (kFusedBN * kBRow) + bn * kBRow + bkq * 4) = pl[i];
-            } else {
-                split4(fv, pl);
-#pragma unroll
-                for (int i = 0; i < 8; ++i) *reinterpret_cast<uint32_t*>(sB0 + i * (kFusedBN * kBRow) + bn * kBRow + bkq * 4) = pl[i];
-            }
+            for (int i = 0; i < 8; ++i) *reinterpret_cast<uint32_t*>(sB0 + i * (kFusedBN * kBRow) + bn * kBRow + bkq * 4) = pl[i];
         }
         if (kt + 1 < kt1) load_step(kt + 1);                // in flight during the MFMAs
         __syncthreads();
-        // ---- MFMAs ----
         const unsigned char* pa = sA0 + (lane >> 5) * (BM * 16) + (wm * 32 + (lane & 31)) * 16;
         const unsigned char* pb = sB0 + (wn * 32 + (lane & 31)) * kBRow + (lane >> 5) * 16;
+        v4i bf[8];
 #pragma unroll
-        for (int seg = 0; seg < (BEAVER ? 2 : 1); ++seg) {
-            v4i bf[8];
+        for (int i = 0; i < 8; ++i) bf[i] = *reinterpret_cast<const v4i*>(pb + i * (kFusedBN * kBRow));
 #pragma unroll
-            for (int i = 0; i < 8; ++i) bf[i] = *reinterpret_cast<const v4i*>(pb + seg * kBStage + i * (kFusedBN * kBRow));
+        for (int i = 0; i < 8; ++i) {
+            const v4i af = *reinterpret_cast<const v4i*>(pa + i * (2 * BM * 16));
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const v4i af = *reinterpret_cast<const v4i*>(pa + seg * kATile + i * (2 * BM * 16));
-#pragma unroll
-                for (int j = 0; j + i < 8; ++j) acc[i + j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af, bf[j], acc[i + j], 0, 0, 0);
-            }
+            for (int j = 0; j + i < 8; ++j) acc[i + j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af, bf[j], acc[i + j], 0, 0, 0);
         }
         __syncthreads();                                    // tiles are single-buffered
     }
-    // ---- partial output -> atomics ----
     const int col = wn * 32 + (lane & 31);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -798,18 +761,17 @@ int launch_tn_ws(cognn_ctx* ctx, u64* Z, const u64* E0, const u64* E1, const u64
     return 0;
 }
 
-// launches the TN kernel on Z (which already holds the value to accumulate onto)
-template <bool BEAVER>
-int launch_tn(cognn_ctx* ctx, u64* Z, const u64* E0, const u64* E1, const u64* F, u64 keyA, u64 keyB, int p, int64_t M, int64_t N, int64_t K) {
+// launches the plain TN kernel on Z (which already holds the value to accumulate onto)
+int launch_tn(cognn_ctx* ctx, u64* Z, const u64* A1, const u64* A2, const u64* B, int64_t M, int64_t N, int64_t K) {
     const int nkt = (int)((K + kKStep - 1) / kKStep);
     const int nmb = (int)((M + 127) / 128);
     int splits = std::max(1, std::min(nkt, (512 + nmb - 1) / nmb));
     const int sps = (nkt + splits - 1) / splits;
     splits = (nkt + sps - 1) / sps;
-    const size_t lds = 2 * (size_t)(8 * 2 * 128 * 16) + 2 * (size_t)kBStage;
-    CG_HIP(hipFuncSetAttribute((const void*)ring_gemm_tn_kernel<BEAVER>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(ring_gemm_tn_kernel<BEAVER>, dim3((unsigned)nmb, (unsigned)splits), dim3(512), lds, ctx->stream, Z, E0, E1, F, keyA,
-                       keyB, p, (int)M, (int)N, (int)K, sps);
+    const size_t lds = (size_t)(8 * 2 * 128 * 16) + (size_t)kBStage;
+    CG_HIP(hipFuncSetAttribute((const void*)ring_gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(ring_gemm_tn_kernel, dim3((unsigned)nmb, (unsigned)splits), dim3(512), lds, ctx->stream, Z, A1, A2, B, (int)M, (int)N,
+                       (int)K, sps);
     CG_LAUNCH_CHECK();
     return 0;
 }
@@ -870,7 +832,7 @@ int gemm_dispatch(cognn_ctx* ctx, u64* C, const u64* A, const u64* A2, const u64
     }
     if (transA && N <= kFusedBN && K >= 256 && M * N <= (1ll << 22)) {
         if (!accumulate) CG_HIP(hipMemsetAsync(C, 0, (size_t)M * N * 8, ctx->stream));
-        return launch_tn<false>(ctx, C, A, A2, B, 0, 0, 0, M, N, K);
+        return launch_tn(ctx, C, A, A2, B, M, N, K);
     }
     // generic path
     int kchunk = (int)K, splits = 1;

@@ -61,7 +61,6 @@ struct Side {
     u64* ob[3] = {nullptr, nullptr, nullptr};      // outboxes: 0/1 = Beaver openings, 2 = truncation / product opening
     u64* ib_store[3] = {nullptr, nullptr, nullptr};
     u64* ib[3] = {nullptr, nullptr, nullptr};      // peer's outboxes (aliases when the peer is on this rank)
-    u64* fsum = nullptr;                           // opened F of a Beaver GEMM (small)
     u64* scratch = nullptr;
     u64* zbuf = nullptr;           // untruncated GEMM output
     u64* small[3] = {nullptr, nullptr, nullptr};   // [in x hid]-sized temporaries for the weight chain
@@ -922,7 +921,6 @@ void alloc_sides(cognn_engine* E) {
         s.relu_mask = dalloc<uint8_t>(E, n * hid);
         for (int j = 0; j < 2; ++j) s.buf[j] = dalloc<u64>(E, n * fm);
         for (int j = 0; j < 3; ++j) s.ob[j] = dalloc<u64>(E, big);
-        s.fsum = dalloc<u64>(E, std::max<size_t>({(size_t)in * hid, n * (size_t)fm, (size_t)hid * lab}));
         for (int j = 0; j < 3; ++j) s.small[j] = dalloc<u64>(E, (size_t)in * hid + (size_t)hid * lab);
         s.scratch = dalloc<u64>(E, big + std::max<size_t>({(size_t)in * hid, n * (size_t)fm, (size_t)hid * lab}));
         s.zbuf = dalloc<u64>(E, std::max<size_t>({(size_t)in * hid, n * (size_t)fm, (size_t)hid * lab}));
