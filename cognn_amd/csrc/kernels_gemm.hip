@@ -967,6 +967,7 @@ int beaver_close_impl(cognn_ctx* ctx, uint64_t* Z, const uint64_t* E, const uint
             else CG_WS_LAUNCH(0, false, false, 2);
         } else {
             if (full && nst == 4) CG_WS_LAUNCH(4, true, true, 1);
+            else if (full && nst == 8) CG_WS_LAUNCH(8, true, true, 1);
             else if (full) CG_WS_LAUNCH(0, true, true, 1);
             else if (kal) CG_WS_LAUNCH(0, false, true, 1);
             else CG_WS_LAUNCH(0, false, false, 1);
