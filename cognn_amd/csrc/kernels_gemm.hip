@@ -289,13 +289,16 @@ __global__ __launch_bounds__(256) void prep_b_planes_ws_kernel(unsigned char* pl
 // the MFMAs of tile t from fragments already in registers and pre-read the first fragments of tile t+1; one barrier per
 // iteration.  (A barrier-free ring with per-wave progress counters in LDS was measured and is slower: the polling costs more
 // than the decoupling gains.)
-template <int NST, bool FULL, bool KALIGNED, int CN, int DBG = 0>   // DBG (timing experiments only, results wrong): 1 no E loads, 2 no PRNG,
+template <int NST, bool FULL, bool KALIGNED, int CN, int DBG = 0, bool SPLITK = false>   // DBG (timing experiments only, results wrong): 1 no E loads, 2 no PRNG,
                                                        // 4 no MFMA, 8 no limb split / LDS writes, 16 no B copy.  NST: K steps when known
                                                        // at compile time (0: run-time); FULL: M % BM == 0 and K % 16 == 0 (no edge
-                                                       // masks); KALIGNED: K % 4 == 0 (16-byte loads)
+                                                       // masks); KALIGNED: K % 4 == 0 (16-byte loads).  SPLITK (few row blocks, long K:
+                                                       // the dataset-sized graphs): blockIdx.y owns `ksteps` K steps of row block
+                                                       // blockIdx.x and adds its partial block into the zero-initialised Z with
+                                                       // uint64 atomics (exact: integer adds commute)
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void beaver_gemm_ws_kernel(u64* Z, const u64* __restrict__ E0, const u64* __restrict__ E1, const unsigned char* __restrict__ planes,
-                           u64 keyA, int M, int N, int K, int nst_rt) {
+                           u64 keyA, int M, int N, int K, int nst_rt, int ksteps) {
     constexpr int BM = CN == 2 ? 64 : 128;
     constexpr int R = BM / 64;                              // rows per producer thread
     constexpr int S = 3;                                    // LDS slots (tile t lives in slot t % S)
@@ -309,8 +312,14 @@ void beaver_gemm_ws_kernel(u64* Z, const u64* __restrict__ E0, const u64* __rest
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nmb = (M + BM - 1) / BM;
     const int my_blocks = (nmb - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
-    const int total = my_blocks * nst;
-    if (total == 0) return;
+    const int st0 = SPLITK ? (int)blockIdx.y * ksteps : 0;
+    const int total = SPLITK ? min(nst, st0 + ksteps) - st0 : my_blocks * nst;
+    if (total <= 0) return;
+    // tile t of this workgroup -> (row block, K step)
+#define CG_WS_MB(t_) (SPLITK ? (int)blockIdx.x : (int)blockIdx.x + ((t_) / nst) * (int)gridDim.x)
+#define CG_WS_ST(t_) (SPLITK ? st0 + (t_) : (t_) % nst)
+#define CG_WS_FIRST(t_) (SPLITK ? (t_) == 0 : ((t_) % nst) == 0)
+#define CG_WS_LAST(t_) (SPLITK ? (t_) == total - 1 : ((t_) % nst) == nst - 1)
 
     if (wave < 4) {
         // ================= consumers =================
@@ -338,7 +347,7 @@ void beaver_gemm_ws_kernel(u64* Z, const u64* __restrict__ E0, const u64* __rest
             _Pragma("unroll") for (int i = 1; i < 8; ++i) af_[i] = *reinterpret_cast<const v4i*>(pa_ + i * kPlane);       \
             _Pragma("unroll") for (int i = 0; i < 8; ++i) bfn_[i] = *reinterpret_cast<const v4i*>(pb0 + sn * kNnBStage + i * kBPlane); \
             afn0_ = *reinterpret_cast<const v4i*>(pa0 + sn * kAStage);                                                    \
-            if (((t_) % nst) == 0) {     /* first step of a block: accumulators start from the inline-constant zero */   \
+            if (CG_WS_FIRST(t_)) {       /* first step of a block: accumulators start from the inline-constant zero */   \
                 _Pragma("unroll") for (int j = 0; j < 8; ++j) acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af_[0], bf_[j], zero16, 0, 0, 0); \
             } else {                                                                                                      \
                 _Pragma("unroll") for (int j = 0; j < 8; ++j) acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af_[0], bf_[j], acc[j], 0, 0, 0); \
@@ -348,8 +357,8 @@ void beaver_gemm_ws_kernel(u64* Z, const u64* __restrict__ E0, const u64* __rest
                     acc[i + j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af_[i], bf_[j], acc[i + j], 0, 0, 0);              \
             }                                                                                                             \
         }                                                                                                                 \
-        if (!(DBG & 32) && ((t_) % nst) == nst - 1) {                                                                     \
-            const int mb_ = blockIdx.x + ((t_) / nst) * gridDim.x;                                                        \
+        if (!(DBG & 32) && CG_WS_LAST(t_)) {                                                                              \
+            const int mb_ = CG_WS_MB(t_);                                                                                 \
             const int col_ = wn * 32 + (lane & 31);                                                                       \
             _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                              \
                 const int row_ = mb_ * BM + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);                           \
@@ -357,7 +366,10 @@ void beaver_gemm_ws_kernel(u64* Z, const u64* __restrict__ E0, const u64* __rest
                                      ((uint32_t)acc[7][r] << 24);                                                         \
                 const long long lo_ = (long long)acc[0][r] + (long long)acc[1][r] * 256 + (long long)acc[2][r] * 65536 +  \
                                       (long long)acc[3][r] * 16777216;                                                    \
-                if ((FULL || row_ < M) && col_ < N) Z[(size_t)row_ * N + col_] = (u64)lo_ + ((u64)hi_ << 32);             \
+                if ((FULL || row_ < M) && col_ < N) {                                                                     \
+                    if (SPLITK) atomicAdd((unsigned long long*)&Z[(size_t)row_ * N + col_], (u64)lo_ + ((u64)hi_ << 32));  \
+                    else Z[(size_t)row_ * N + col_] = (u64)lo_ + ((u64)hi_ << 32);                                        \
+                }                                                                                                         \
             }                                                                                                             \
         }                                                                                                                 \
         sc = sn; sn = (sn == S - 1) ? 0 : sn + 1;                                                                         \
@@ -378,7 +390,7 @@ void beaver_gemm_ws_kernel(u64* Z, const u64* __restrict__ E0, const u64* __rest
 #define CG_WS_LOAD_B(t_, x0_, x1_, x2_, x3_)                                                                               \
     do {                                                                                                                  \
         if (!(DBG & 16)) {                                                                                                \
-            const u64x2* bp_ = reinterpret_cast<const u64x2*>(planes + (size_t)(min((t_), total - 1) % nst) * kNnBStage) + ptid; \
+            const u64x2* bp_ = reinterpret_cast<const u64x2*>(planes + (size_t)CG_WS_ST(min((t_), total - 1)) * kNnBStage) + ptid; \
             x0_ = bp_[0]; x1_ = bp_[256]; x2_ = bp_[512]; x3_ = bp_[768];                                                  \
         }                                                                                                                 \
     } while (0)
@@ -392,7 +404,7 @@ void beaver_gemm_ws_kernel(u64* Z, const u64* __restrict__ E0, const u64* __rest
 #define CG_WS_LOAD_TILE(t_, s0_, s1_)                                                                                      \
     do {                                                                                                                  \
         const int tt_ = min((t_), total - 1);                                                                             \
-        const int mb_ = blockIdx.x + (tt_ / nst) * gridDim.x, k_ = (tt_ % nst) * 16 + q * 4;                              \
+        const int mb_ = CG_WS_MB(tt_), k_ = CG_WS_ST(tt_) * 16 + q * 4;                                                   \
         _Pragma("unroll") for (int r = 0; r < R; ++r) {                                                                   \
             const int m_ = FULL ? mb_ * BM + trow + 64 * r : min(mb_ * BM + trow + 64 * r, M - 1);                        \
             if (DBG & 1) {                                                                                                \
@@ -413,7 +425,7 @@ void beaver_gemm_ws_kernel(u64* Z, const u64* __restrict__ E0, const u64* __rest
     } while (0)
 #define CG_WS_PRODUCE(t_, slot_, s0_, s1_)                                                                                 \
     do {                                                                                                                  \
-        const int mb_ = blockIdx.x + ((t_) / nst) * gridDim.x, k_ = ((t_) % nst) * 16 + q * 4;                            \
+        const int mb_ = CG_WS_MB(t_), k_ = CG_WS_ST(t_) * 16 + q * 4;                                                     \
         unsigned char* dst_ = sA + (slot_) * kAStage + q * 4;                                                             \
         _Pragma("unroll") for (int r = 0; r < R; ++r) {                                                                   \
             const int m_ = mb_ * BM + trow + 64 * r;                                                                      \
@@ -476,6 +488,10 @@ void beaver_gemm_ws_kernel(u64* Z, const u64* __restrict__ E0, const u64* __rest
 #undef CG_WS_LOAD_B
 #undef CG_WS_STORE_B
     }
+#undef CG_WS_MB
+#undef CG_WS_ST
+#undef CG_WS_FIRST
+#undef CG_WS_LAST
 }
 
 // ------------------------------------------------------------------------------------------
@@ -948,11 +964,22 @@ int beaver_close_impl(cognn_ctx* ctx, uint64_t* Z, const uint64_t* E, const uint
 #define CG_WS_LAUNCH(...)                                                                                                          \
     do {                                                                                                                            \
         CG_HIP(hipFuncSetAttribute((const void*)beaver_gemm_ws_kernel<__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        hipLaunchKernelGGL((beaver_gemm_ws_kernel<__VA_ARGS__>), dim3((unsigned)std::min(nmb, 256)), dim3(512), lds, ctx->stream,   \
-                       (u64*)Z, (const u64*)E, (const u64*)E1, planes, keys->k[p == 0 ? COGNN_SL_A0 : COGNN_SL_A1], (int)M,    \
-                       (int)N, (int)K, nst);                                                                                    \
+        hipLaunchKernelGGL((beaver_gemm_ws_kernel<__VA_ARGS__>), dim3((unsigned)std::min(nmb, 256), (unsigned)ksplits), dim3(512), lds,    \
+                           ctx->stream, (u64*)Z, (const u64*)E, (const u64*)E1, planes, keys->k[p == 0 ? COGNN_SL_A0 : COGNN_SL_A1],       \
+                           (int)M, (int)N, (int)K, nst, ksteps);                                                                    \
     } while (0)
-        if (cn == 2) {
+        // few row blocks and a long K (dataset-sized graphs: 1354 x 1433 for Cora): split K over workgroups to fill the chip
+        int ksplits = 1, ksteps = nst;
+        if (nmb <= 64 && nst >= 8) {
+            ksplits = std::min(nst / 4, (256 + nmb - 1) / nmb);
+            ksteps = (nst + ksplits - 1) / ksplits;
+            ksplits = (nst + ksteps - 1) / ksteps;
+        }
+        if (ksplits > 1) CG_HIP(hipMemsetAsync(Z, 0, (size_t)M * N * 8, ctx->stream));
+        if (ksplits > 1) {
+            if (cn == 2) { if (kal) CG_WS_LAUNCH(0, false, true, 2, 0, true); else CG_WS_LAUNCH(0, false, false, 2, 0, true); }
+            else { if (kal) CG_WS_LAUNCH(0, false, true, 1, 0, true); else CG_WS_LAUNCH(0, false, false, 1, 0, true); }
+        } else if (cn == 2) {
 #ifdef COGNN_GEMM_ABLATION   // timing experiments only (`make ABLATION=1`, tools/abl_gemm.sh): these variants compute wrong results
             static const int dbg = getenv("COGNN_GEMM_DBG") ? atoi(getenv("COGNN_GEMM_DBG")) : 0;
             if (full && nst == 8 && dbg == 1) CG_WS_LAUNCH(8, true, true, 2, 1);
