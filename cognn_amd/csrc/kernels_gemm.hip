@@ -1,15 +1,17 @@
 // Ring GEMM on uint64 shares (mod 2^64): the local arithmetic of sci::twoPartyGCNMatMul
-// (optimize-gcn/gcn.h:233,665,671,710) under Beaver triples (DESIGN.md §3.4, §5.2).
+// (optimize-gcn/gcn.h:233,665,671,710) under Beaver triples (DESIGN.md §3.5, §5).
 //
-// Fast path (NN, tall-skinny A): v_mfma_i32_32x32x32_i8 on a signed 8-bit limb decomposition.
+// All fast paths use v_mfma_i32_32x32x32_i8 on a signed 8-bit limb decomposition:
 //   x = sum_i d_i 2^(8i) (mod 2^64), d_i in [-128,127]:  d = ((x + 0x80..80) ^ 0x80..80) bytes.
 //   C = sum_{s=0..7} 2^(8s) P_s,  P_s = sum_{i+j=s} A_i . B_j   (36 limb-pair products, int32
 //   accumulators, products with i+j > 7 vanish mod 2^64).
-// A workgroup of 8 waves owns 128 (BN=64) or 256 (BN=32) rows; B's limb planes live in LDS for
-// the whole kernel, A tiles are streamed HBM -> registers -> (limb split) -> LDS -> MFMA with a
-// two-stage LDS ring and one barrier per 32-deep K step; the next tile's global loads are issued
-// before the current tile's MFMAs.
-// Generic path: a split-K VALU kernel for every other shape (transposed A, tiny M, huge K).
+// Kernels in this file:
+//   beaver_gemm_ws_kernel      online Beaver close, NN, N <= 64: wave-specialised (4 MFMA consumer + 4 producer waves),
+//                              persistent over row blocks or split-K for few row blocks;
+//   beaver_gemm_tn_ws_kernel   online Beaver close of the weight-gradient products (A stored transposed, K = #vertices);
+//   ring_gemm_mfma_kernel      one plain product per launch (dealer's offline C1, NN), B planes resident in LDS;
+//   ring_gemm_tn_kernel        plain TN product (dealer's offline C1 of the weight gradients), split-K with atomics;
+//   ring_gemm_simple_kernel    split-K VALU kernel for every other shape (tiny M, N > 64, huge K).
 #include "common.h"
 #include <algorithm>
 #include <cstdlib>
