@@ -138,9 +138,17 @@ def main():
             raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run (WORLD_SIZE=%d)" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the engine has no CPU fallback")
+    # COGNN_BENCH_BACKEND=gloo: rehearsal of the N > 1 path on a box with fewer GPUs than ranks (ranks share the devices round
+    # robin, messages are staged through host memory); the real multi-GPU run uses RCCL ("nccl")
+    backend = os.environ.get("COGNN_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     from cognn_amd.engine import Engine, GnnParam
     wl = WORKLOADS[args.workload]
@@ -159,7 +167,7 @@ def main():
     eng = Engine(k, src, dst, part, param, seed=0xC06A11, variant=variant, rank=rank, world=world, device=local_rank)
     if world > 1:
         from cognn_amd import dist as cdist
-        eng.set_exchange(cdist.make_exchange(torch.device("cuda", local_rank)))
+        eng.set_exchange(cdist.make_exchange(torch.device("cuda", local_rank), host_staged=(backend != "nccl")))
     for P in eng.hosted:                      # Bernoulli(0.01) bag-of-words features, uniform labels
         vids = eng.party_vids(P)
         rng = np.random.default_rng(0xC06A12 + P)
@@ -186,7 +194,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     n_agg, ms_agg, bytes_agg = eng.timing(0)
@@ -212,7 +220,7 @@ def main():
         "config": {"workload": "%d-party %s pass (GAS iterations 0-%d) on a synthetic %d-vertex/%d-edge global graph, "
                                "partition vid %% %d, input_dim=%d hidden_dim=%d num_labels=%d, %d part%s per GPU"
                                % (k, variant, iters - 1, V, 2 * Eu, k, in_dim, hid, lab, k // world, "y" if k // world == 1 else "ies"),
-                   "name": args.workload, "parties": k, "exchange": "in-device" if world == 1 else "rccl-p2p"},
+                   "name": args.workload, "parties": k, "exchange": "in-device" if world == 1 else ("rccl-p2p" if backend == "nccl" else backend + "-host-staged")},
         "epoch_time_s": dt / args.steps,
         "edges_feat_per_s_per_party": value / k,
         "offline_ms": offline_ms, "setup_s": setup_s,
