@@ -12,6 +12,7 @@ from gpu_util import dev, dev_empty, host, ptr, rand_u64, U64
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SCALE = int(os.environ.get("COGNN_FUZZ_SCALE", "1"))        # soak runs: COGNN_FUZZ_SCALE=20 multiplies the number of seeds
 
 
 @pytest.fixture(scope="module")
@@ -70,7 +71,7 @@ def O(shape, dtype=U64, init=None, check=True):
     return (np.zeros(shape, dtype=dtype), init, check)
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(24 * SCALE))
 def test_fuzz_gather(libs, seed):
     rng = np.random.default_rng(1000 + seed)
     rows = int(rng.integers(1, 700)); table_rows = int(rng.integers(1, 900))
@@ -93,7 +94,7 @@ def test_fuzz_gather(libs, seed):
     both(libs, "cognn_scatter_add_rows_u64", [O((rows, F), init=base)], [("out", 0), part, idx, len(idx), F])
 
 
-@pytest.mark.parametrize("seed", range(40))
+@pytest.mark.parametrize("seed", range(40 * SCALE))
 def test_fuzz_gemm(libs, seed):
     rng = np.random.default_rng(2000 + seed)
     M = int(rng.choice([1, 5, 63, 64, 255, 256, 257, 300, 1000, 2048, 4097]))
@@ -125,7 +126,7 @@ def test_fuzz_gemm(libs, seed):
                  [("out", 0), A, E1, B, ctypes.byref(k), p, M, N, K, ("out", 1)])
 
 
-@pytest.mark.parametrize("seed", range(16))
+@pytest.mark.parametrize("seed", range(16 * SCALE))
 def test_fuzz_elementwise(libs, seed):
     rng = np.random.default_rng(3000 + seed)
     rows = int(rng.integers(1, 400)); F = int(rng.choice([1, 2, 5, 16, 33, 64]))
@@ -158,7 +159,7 @@ def test_fuzz_elementwise(libs, seed):
     both(libs, "cognn_prng_fill_u64", [O(n)], [("out", 0), ctypes.c_uint64(5 + seed), n])
 
 
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", range(6 * SCALE))
 def test_fuzz_softmax(libs, seed):
     rng = np.random.default_rng(4000 + seed)
     rows = int(rng.integers(1, 500)); L = int(rng.choice([2, 3, 7, 16, 33, 40])); train = int(rng.integers(0, rows + 1))
