@@ -40,6 +40,8 @@ _SIGNATURES = {
     "cognn_ctx_create_private": (_I, [_I, ctypes.POINTER(_P)]),
     "cognn_ctx_destroy": (_I, [_P]),
     "cognn_ctx_sync": (_I, [_P]),
+    "cognn_batch_begin": (_I, [_P]),
+    "cognn_batch_end": (_I, [_P]),
     "cognn_malloc": (_I, [_P, ctypes.POINTER(_P), ctypes.c_size_t]),
     "cognn_free": (_I, [_P, _P]),
     "cognn_memcpy_h2d": (_I, [_P, _P, _P, ctypes.c_size_t]),

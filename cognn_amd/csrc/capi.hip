@@ -49,9 +49,19 @@ int cognn_ctx_destroy(cognn_ctx* ctx) {
     return 0;
 }
 int cognn_ctx_sync(cognn_ctx* ctx) {
+    { const int rc_flush_ = cg_flush(ctx); if (rc_flush_) return rc_flush_; }
     CG_REQUIRE(ctx, "cognn_ctx_sync: null ctx");
     CG_HIP(hipStreamSynchronize(ctx->stream));
     return 0;
+}
+int cognn_batch_begin(cognn_ctx* ctx) {
+    CG_REQUIRE(ctx, "cognn_batch_begin: null context");
+    ++ctx->batch_depth;
+    return 0;
+}
+int cognn_batch_end(cognn_ctx* ctx) {
+    CG_REQUIRE(ctx && ctx->batch_depth > 0, "cognn_batch_end: no open batch");
+    return --ctx->batch_depth == 0 ? cg_flush(ctx) : 0;
 }
 int cognn_malloc(cognn_ctx* ctx, void** ptr, size_t bytes) {
     CG_REQUIRE(ctx && ptr, "cognn_malloc: null argument");
@@ -65,26 +75,31 @@ int cognn_free(cognn_ctx* ctx, void* ptr) {
     return 0;
 }
 int cognn_memcpy_h2d(cognn_ctx* ctx, void* dst, const void* src, size_t bytes) {
+    { const int rc_flush_ = cg_flush(ctx); if (rc_flush_) return rc_flush_; }
     CG_REQUIRE(ctx, "cognn_memcpy_h2d: null ctx");
     if (bytes) { CG_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream)); CG_HIP(hipStreamSynchronize(ctx->stream)); }
     return 0;
 }
 int cognn_memcpy_d2h(cognn_ctx* ctx, void* dst, const void* src, size_t bytes) {
+    { const int rc_flush_ = cg_flush(ctx); if (rc_flush_) return rc_flush_; }
     CG_REQUIRE(ctx, "cognn_memcpy_d2h: null ctx");
     if (bytes) { CG_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream)); CG_HIP(hipStreamSynchronize(ctx->stream)); }
     return 0;
 }
 int cognn_memcpy_d2d(cognn_ctx* ctx, void* dst, const void* src, size_t bytes) {
+    { const int rc_flush_ = cg_flush(ctx); if (rc_flush_) return rc_flush_; }
     CG_REQUIRE(ctx, "cognn_memcpy_d2d: null ctx");
     if (bytes) CG_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
     return 0;
 }
 int cognn_memset0(cognn_ctx* ctx, void* dst, size_t bytes) {
+    { const int rc_flush_ = cg_flush(ctx); if (rc_flush_) return rc_flush_; }
     CG_REQUIRE(ctx, "cognn_memset0: null ctx");
     if (bytes) CG_HIP(hipMemsetAsync(dst, 0, bytes, ctx->stream));
     return 0;
 }
 int cognn_timer_begin(cognn_ctx* ctx, int kind) {
+    { const int rc_flush_ = cg_flush(ctx); if (rc_flush_) return rc_flush_; }
     CG_REQUIRE(ctx && kind >= 0 && kind < 8, "cognn_timer_begin: bad arguments");
     hipEvent_t ev;
     CG_HIP(hipEventCreate(&ev));
@@ -93,6 +108,7 @@ int cognn_timer_begin(cognn_ctx* ctx, int kind) {
     return 0;
 }
 int cognn_timer_end(cognn_ctx* ctx, int kind) {
+    { const int rc_flush_ = cg_flush(ctx); if (rc_flush_) return rc_flush_; }
     CG_REQUIRE(ctx && kind >= 0 && kind < 8 && !ctx->open_begin[kind].empty(), "cognn_timer_end: no open timer");
     hipEvent_t ev;
     CG_HIP(hipEventCreate(&ev));

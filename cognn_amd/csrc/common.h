@@ -8,13 +8,24 @@
 
 #include <vector>
 struct cognn_timer_pair { hipEvent_t b, e; };
+struct cognn_ctx;
+// Element-wise launches of one kind queued between cognn_batch_begin / cognn_batch_end (kernels_elementwise.hip): the
+// descriptors of up to kBatchMax calls are passed by value to ONE launch.
+struct cognn_pending_batch {
+    int (*flush)(cognn_ctx*) = nullptr;        // launcher of the queued functor type (nullptr: nothing queued)
+    alignas(16) unsigned char storage[4096];
+};
 struct cognn_ctx {
     int device;
     hipStream_t stream;
     bool own_stream;
     std::vector<cognn_timer_pair> timers[8];   // per kind
     std::vector<hipEvent_t> open_begin[8];
+    int batch_depth = 0;
+    cognn_pending_batch pending;
 };
+// launches whatever is queued (every non-element-wise entry point calls it first, so stream order is preserved)
+static inline int cg_flush(cognn_ctx* ctx) { return (ctx && ctx->pending.flush) ? ctx->pending.flush(ctx) : 0; }
 
 int cognn_set_error(const char* fmt, ...);
 

@@ -52,12 +52,59 @@ __global__ __launch_bounds__(kThreads) void ew_kernel(int64_t n, F f) {
     if (i + 1 < n) f(i, 2);
     else if (i < n) f(i, 1);
 }
+// Batched form: the same functor type for several independent tensors (the sides of one protocol phase) in ONE launch.
+// The descriptors travel by value in the kernel arguments; a workgroup finds its segment by a short uniform scan.
+constexpr int kBatchMax = 8;
+template <class F>
+struct EwBatch {
+    F f[kBatchMax];
+    int64_t n[kBatchMax];
+    unsigned blk_end[kBatchMax];               // exclusive prefix of workgroup counts
+    int count;
+};
+template <class F>
+__global__ __launch_bounds__(kThreads) void ew_batch_kernel(EwBatch<F> b) {
+    const unsigned blk = blockIdx.x;
+    int seg = 0;
+    while (seg < b.count - 1 && blk >= b.blk_end[seg]) ++seg;
+    const unsigned blk0 = seg ? b.blk_end[seg - 1] : 0u;
+    const int64_t n = b.n[seg];
+    const int64_t i = 2 * ((int64_t)(blk - blk0) * kThreads + threadIdx.x);
+    if (i + 1 < n) b.f[seg](i, 2);
+    else if (i < n) b.f[seg](i, 1);
+}
+template <class F>
+int flush_ew(cognn_ctx* ctx) {
+    static_assert(sizeof(EwBatch<F>) <= sizeof(ctx->pending.storage), "batch descriptor does not fit the pending buffer");
+    EwBatch<F>* b = reinterpret_cast<EwBatch<F>*>(ctx->pending.storage);
+    ctx->pending.flush = nullptr;
+    if (b->count <= 0) return 0;
+    const unsigned blocks = b->blk_end[b->count - 1];
+    if (b->count == 1) hipLaunchKernelGGL(ew_kernel<F>, dim3(blocks), dim3(kThreads), 0, ctx->stream, b->n[0], b->f[0]);
+    else hipLaunchKernelGGL(ew_batch_kernel<F>, dim3(blocks), dim3(kThreads), 0, ctx->stream, *b);
+    b->count = 0;
+    CG_LAUNCH_CHECK();
+    return 0;
+}
 template <class F>
 int launch_ew(cognn_ctx* ctx, int64_t n, F f) {
     if (n <= 0) return 0;
-    int64_t pairs = (n + 1) / 2;
-    dim3 grid((unsigned)((pairs + kThreads - 1) / kThreads));
-    hipLaunchKernelGGL(ew_kernel<F>, grid, dim3(kThreads), 0, ctx->stream, n, f);
+    const int64_t pairs = (n + 1) / 2;
+    const unsigned blocks = (unsigned)((pairs + kThreads - 1) / kThreads);
+    if (ctx->batch_depth > 0) {
+        int rc;
+        if (ctx->pending.flush && ctx->pending.flush != &flush_ew<F>) { if ((rc = ctx->pending.flush(ctx))) return rc; }
+        EwBatch<F>* b = reinterpret_cast<EwBatch<F>*>(ctx->pending.storage);
+        if (!ctx->pending.flush) { b->count = 0; ctx->pending.flush = &flush_ew<F>; }
+        const unsigned base = b->count ? b->blk_end[b->count - 1] : 0u;
+        if ((uint64_t)base + blocks > 0x7fffffffull) { if ((rc = flush_ew<F>(ctx))) return rc; return launch_ew(ctx, n, f); }
+        b->f[b->count] = f; b->n[b->count] = n; b->blk_end[b->count] = base + blocks;
+        if (++b->count == kBatchMax) return flush_ew<F>(ctx);
+        return 0;
+    }
+    int rc;
+    if ((rc = cg_flush(ctx))) return rc;
+    hipLaunchKernelGGL(ew_kernel<F>, dim3(blocks), dim3(kThreads), 0, ctx->stream, n, f);
     CG_LAUNCH_CHECK();
     return 0;
 }
@@ -469,6 +516,7 @@ int cognn_mask_select_u64(cognn_ctx* ctx, uint64_t* out, const uint64_t* in, con
 }
 int cognn_softmax_u64(cognn_ctx* ctx, uint64_t* p_out, uint64_t* d_out, uint64_t* pfx_out, const uint64_t* z0, const uint64_t* z1,
                       const int32_t* labels, const cognn_keys* keys, int p, int64_t rows, int64_t L, int64_t train_rows) {
+    { const int rc_flush_ = cg_flush(ctx); if (rc_flush_) return rc_flush_; }
     CG_REQUIRE(ctx && d_out && keys && (p == 0 || p == 1), "cognn_softmax_u64: bad arguments");
     CG_REQUIRE(p == 1 || (z0 && z1 && labels), "cognn_softmax_u64: owner side needs z0, z1, labels");
     CG_REQUIRE(L > 0 && L <= 64, "cognn_softmax_u64: unsupported label count %lld (max 64)", (long long)L);
@@ -487,6 +535,7 @@ int cognn_softmax_u64(cognn_ctx* ctx, uint64_t* p_out, uint64_t* d_out, uint64_t
 }
 int cognn_metrics_q16(cognn_ctx* ctx, const uint64_t* pfx, const int32_t* labels, const uint8_t* border,
                       int64_t rows, int64_t L, int64_t train_rows, int64_t val_rows, int64_t* counts6, double* loss) {
+    { const int rc_flush_ = cg_flush(ctx); if (rc_flush_) return rc_flush_; }
     CG_REQUIRE(ctx && pfx && labels && counts6 && loss, "cognn_metrics_q16: bad arguments");
     CG_HIP(hipMemsetAsync(counts6, 0, 6 * sizeof(int64_t), ctx->stream));
     CG_HIP(hipMemsetAsync(loss, 0, sizeof(double), ctx->stream));
@@ -506,6 +555,7 @@ int cognn_metrics_q16(cognn_ctx* ctx, const uint64_t* pfx, const int32_t* labels
 }
 
 int cognn_transpose_u64(cognn_ctx* ctx, uint64_t* out, const uint64_t* in, int64_t rows, int64_t cols) {
+    { const int rc_flush_ = cg_flush(ctx); if (rc_flush_) return rc_flush_; }
     CG_REQUIRE(ctx && out && in && out != in, "cognn_transpose_u64: bad arguments");
     if (rows * cols <= 0) return 0;
     hipLaunchKernelGGL(transpose_kernel, dim3(cg_div_up(rows * cols, kThreads)), dim3(kThreads), 0, ctx->stream, (u64*)out,

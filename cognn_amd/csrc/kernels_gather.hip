@@ -189,6 +189,7 @@ static int gather_impl(cognn_ctx* ctx, uint64_t* out, const uint64_t* base, cons
 
 int cognn_gather_csr_u64(cognn_ctx* ctx, uint64_t* out, const uint64_t* base, const uint64_t* table,
                          const uint32_t* rowptr, const uint32_t* col, int64_t n_rows, int64_t F) {
+    { const int rc_flush_ = cg_flush(ctx); if (rc_flush_) return rc_flush_; }
     OpenSegs segs;
     segs.n = 0;
     return gather_impl(ctx, out, base, table, rowptr, col, n_rows, F, segs);
@@ -197,6 +198,7 @@ int cognn_gather_csr_u64(cognn_ctx* ctx, uint64_t* out, const uint64_t* base, co
 int cognn_gather_csr_open_u64(cognn_ctx* ctx, uint64_t* out, const uint64_t* base, const uint64_t* table,
                               const uint32_t* rowptr, const uint32_t* col, int64_t n_rows, int64_t F,
                               int32_t nseg, const int64_t* seg_begin, const int64_t* seg_end, const uint64_t* seg_key) {
+    { const int rc_flush_ = cg_flush(ctx); if (rc_flush_) return rc_flush_; }
     CG_REQUIRE(nseg >= 0 && nseg <= 32 && (nseg == 0 || (seg_begin && seg_end && seg_key)), "cognn_gather_csr_open_u64: bad segment list");
     OpenSegs segs;
     segs.n = nseg;
@@ -217,6 +219,7 @@ static int gather_impl(cognn_ctx* ctx, uint64_t* out, const uint64_t* base, cons
 
 int cognn_scatter_add_rows_u64(cognn_ctx* ctx, uint64_t* v, const uint64_t* partial, const uint32_t* row_index,
                                int64_t n_partial, int64_t F) {
+    { const int rc_flush_ = cg_flush(ctx); if (rc_flush_) return rc_flush_; }
     CG_REQUIRE(ctx && v && (n_partial == 0 || (partial && row_index)), "cognn_scatter_add_rows_u64: null argument");
     CG_REQUIRE(n_partial >= 0 && n_partial < (1ll << 31) && F > 0 && F < (1 << 20), "cognn_scatter_add_rows_u64: bad shape");
     if (n_partial == 0) return 0;

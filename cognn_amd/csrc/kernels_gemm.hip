@@ -874,6 +874,7 @@ extern "C" {
 
 int cognn_ring_gemm_u64(cognn_ctx* ctx, uint64_t* C, const uint64_t* A, const uint64_t* B,
                         int64_t M, int64_t N, int64_t K, int transA, int accumulate) {
+    { const int rc_flush_ = cg_flush(ctx); if (rc_flush_) return rc_flush_; }
     CG_REQUIRE(ctx && C && A && B, "cognn_ring_gemm_u64: null argument");
     CG_REQUIRE(M >= 0 && N >= 0 && K >= 0 && M < (1ll << 31) && N < (1ll << 31) && K < (1ll << 31), "cognn_ring_gemm_u64: bad shape");
     CG_REQUIRE(cg_aligned16(A) && cg_aligned16(B) && cg_aligned16(C), "cognn_ring_gemm_u64: operands must be 16-byte aligned");
@@ -882,6 +883,7 @@ int cognn_ring_gemm_u64(cognn_ctx* ctx, uint64_t* C, const uint64_t* A, const ui
 
 int cognn_ring_gemm2_u64(cognn_ctx* ctx, uint64_t* C, const uint64_t* A1, const uint64_t* A2, const uint64_t* B,
                          int64_t M, int64_t N, int64_t K, int transA, int accumulate) {
+    { const int rc_flush_ = cg_flush(ctx); if (rc_flush_) return rc_flush_; }
     CG_REQUIRE(ctx && C && A1 && B, "cognn_ring_gemm2_u64: null argument");
     CG_REQUIRE(M >= 0 && N >= 0 && K >= 0 && M < (1ll << 31) && N < (1ll << 31) && K < (1ll << 31), "cognn_ring_gemm2_u64: bad shape");
     CG_REQUIRE(cg_aligned16(A1) && cg_aligned16(B) && cg_aligned16(C) && (A2 == nullptr || cg_aligned16(A2)),
@@ -891,6 +893,7 @@ int cognn_ring_gemm2_u64(cognn_ctx* ctx, uint64_t* C, const uint64_t* A1, const 
 
 int cognn_dealer_gemm_c1_u64(cognn_ctx* ctx, uint64_t* C1, const cognn_keys* keys, int64_t M, int64_t N, int64_t K,
                              int transA, uint64_t* scratchA, uint64_t* scratchB) {
+    { const int rc_flush_ = cg_flush(ctx); if (rc_flush_) return rc_flush_; }
     CG_REQUIRE(ctx && C1 && keys && scratchA && scratchB, "cognn_dealer_gemm_c1_u64: null argument");
     int rc;
     if ((rc = fill(ctx, (u64*)scratchA, keys->k[COGNN_SL_A0], keys->k[COGNN_SL_A1], M, K, transA, 1, nullptr))) return rc;
@@ -923,6 +926,7 @@ extern "C" {
 
 int cognn_beaver_gemm_close_u64(cognn_ctx* ctx, uint64_t* Z, const uint64_t* E, const uint64_t* E1, const uint64_t* F, const uint64_t* c1,
                                 const cognn_keys* keys, int p, int64_t M, int64_t N, int64_t K, int transA, uint64_t* scratch) {
+    { const int rc_flush_ = cg_flush(ctx); if (rc_flush_) return rc_flush_; }
     CG_REQUIRE(ctx && Z && E && F && keys && scratch && (p == 0 || p == 1), "cognn_beaver_gemm_close_u64: bad arguments");
     CG_REQUIRE(p == 0 || c1, "cognn_beaver_gemm_close_u64: p=1 needs the dealer share c1");
     return beaver_close_impl(ctx, Z, E, E1, F, nullptr, c1, keys, p, M, N, K, transA, scratch, false);
@@ -935,6 +939,7 @@ int cognn_beaver_gemm_fusable(int64_t M, int64_t N, int64_t K, int transA) {
 
 int cognn_beaver_gemm_close_raw_u64(cognn_ctx* ctx, uint64_t* Z, const uint64_t* E, const uint64_t* E1, const uint64_t* F,
                                     const cognn_keys* keys, int p, int64_t M, int64_t N, int64_t K, uint64_t* scratch) {
+    { const int rc_flush_ = cg_flush(ctx); if (rc_flush_) return rc_flush_; }
     CG_REQUIRE(ctx && Z && E && F && keys && scratch && (p == 0 || p == 1), "cognn_beaver_gemm_close_raw_u64: bad arguments");
     return beaver_close_impl(ctx, Z, E, E1, F, nullptr, nullptr, keys, p, M, N, K, 0, scratch, true);
 }
@@ -942,6 +947,7 @@ int cognn_beaver_gemm_close_raw_u64(cognn_ctx* ctx, uint64_t* Z, const uint64_t*
 int cognn_beaver_gemm_close2_u64(cognn_ctx* ctx, uint64_t* Z, const uint64_t* E0, const uint64_t* E1, const uint64_t* F0, const uint64_t* F1,
                                  const uint64_t* c1, const cognn_keys* keys, int p, int64_t M, int64_t N, int64_t K, int transA,
                                  uint64_t* scratch, int raw) {
+    { const int rc_flush_ = cg_flush(ctx); if (rc_flush_) return rc_flush_; }
     CG_REQUIRE(ctx && Z && E0 && F0 && keys && scratch && (p == 0 || p == 1), "cognn_beaver_gemm_close2_u64: bad arguments");
     CG_REQUIRE(raw || p == 0 || c1, "cognn_beaver_gemm_close2_u64: p=1 needs the dealer share c1");
     return beaver_close_impl(ctx, Z, E0, E1, F0, F1, raw ? nullptr : c1, keys, p, M, N, K, raw ? 0 : transA, scratch, raw != 0);

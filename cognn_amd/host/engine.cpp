@@ -123,6 +123,17 @@ namespace {
     do {                                                                           \
         if ((E->be->call) != 0) throw EngineError(std::string(E->be->cognn_last_error())); \
     } while (0)
+// Queues the element-wise launches issued while it is alive (same kind, independent tensors: the sides of one phase) into
+// shared launches - see cognn_batch_begin in include/cognn_hip.h.  Only around loops whose iterations do not depend on each other.
+struct Batch {
+    cognn_engine* E;
+    explicit Batch(cognn_engine* e);
+    ~Batch();
+    Batch(const Batch&) = delete;
+    Batch& operator=(const Batch&) = delete;
+};
+Batch::Batch(cognn_engine* e) : E(e) { BE(cognn_batch_begin(E->ctx)); }
+Batch::~Batch() { E->be->cognn_batch_end(E->ctx); }         // a failure here resurfaces at the next call (sticky HIP error)
 
 template <class T>
 T* dalloc(cognn_engine* E, size_t count) {
@@ -221,12 +232,16 @@ enum { X_OPEN_HERE = 0, X_H1E_FRESH = 1, X_H1E_REUSE = 2 };
 template <class DstFn>
 void trunc_stage(cognn_engine* E, int64_t it, int op, u64 mul, const std::vector<u64*>& x, const std::vector<int64_t>& elems,
                  DstFn dst, int mode, u64 owner_override = ~0ull) {
-    for (size_t i = 0; i < E->sides.size(); ++i) {
-        Side& s = E->sides[i];
-        cognn_keys k = keys(E, owner_override == ~0ull ? (u64)s.owner : owner_override, it, op);
-        BE(cognn_trunc_open_u64(E->ctx, s.ob[2], x[i], mul, &k, s.p, elems[i]));
+    {
+        Batch batch(E);
+        for (size_t i = 0; i < E->sides.size(); ++i) {
+            Side& s = E->sides[i];
+            cognn_keys k = keys(E, owner_override == ~0ull ? (u64)s.owner : owner_override, it, op);
+            BE(cognn_trunc_open_u64(E->ctx, s.ob[2], x[i], mul, &k, s.p, elems[i]));
+        }
     }
     exchange_ob(E, 2, elems);
+    Batch batch(E);
     for (size_t i = 0; i < E->sides.size(); ++i) {
         Side& s = E->sides[i];
         cognn_keys k = keys(E, owner_override == ~0ull ? (u64)s.owner : owner_override, it, op);
@@ -258,6 +273,7 @@ struct OpenNext {
 };
 template <class DstFn>
 void trunc_close_all(cognn_engine* E, int64_t it, int top, DstFn dst, const std::vector<int64_t>& elems, const OpenNext& open_next) {
+    Batch batch(E);
     for (size_t i = 0; i < E->sides.size(); ++i) {
         Side& s = E->sides[i];
         cognn_keys tk = keys(E, s.owner, it, top);
@@ -277,13 +293,16 @@ void gemm_stage(cognn_engine* E, int64_t it, XFn X, WFn Wm, SpecFn spec, DstFn d
     const bool feature = spec(E->sides[0]).feature != 0;
     const int xsrc = x_opened ? X_H1E_FRESH : spec(E->sides[0]).xsrc;
     auto gkeys = [&](Side& s, const GemmSpec& g) { return gemm_keys(E, s, it, g); };
-    for (auto& s : E->sides) {
-        GemmSpec g = spec(s);
-        cognn_keys k = gkeys(s, g);
-        if (xsrc == X_OPEN_HERE && !feature)
-            BE(cognn_mask_open_u64(E->ctx, s.ob[0], X(s), k.k[s.p == 0 ? COGNN_SL_A0 : COGNN_SL_A1], g.M, g.K, g.transA));
-        if (!w_opened) BE(cognn_mask_open_u64(E->ctx, s.ob[1], Wm(s), k.k[s.p == 0 ? COGNN_SL_B0 : COGNN_SL_B1], g.K, g.N, 0));
-        e0.push_back(g.M * g.K); e1.push_back(g.K * g.N); eo.push_back(g.M * g.N);
+    {
+        Batch batch(E);
+        for (auto& s : E->sides) {
+            GemmSpec g = spec(s);
+            cognn_keys k = gkeys(s, g);
+            if (xsrc == X_OPEN_HERE && !feature)
+                BE(cognn_mask_open_u64(E->ctx, s.ob[0], X(s), k.k[s.p == 0 ? COGNN_SL_A0 : COGNN_SL_A1], g.M, g.K, g.transA));
+            if (!w_opened) BE(cognn_mask_open_u64(E->ctx, s.ob[1], Wm(s), k.k[s.p == 0 ? COGNN_SL_B0 : COGNN_SL_B1], g.K, g.N, 0));
+            e0.push_back(g.M * g.K); e1.push_back(g.K * g.N); eo.push_back(g.M * g.N);
+        }
     }
     if (feature || xsrc == X_H1E_REUSE) {
         exchange_ob(E, 1, e1);                              // the opening of X was exchanged earlier (start() / two iterations ago)
@@ -335,10 +354,13 @@ void gemm_stage(cognn_engine* E, int64_t it, XFn X, WFn Wm, SpecFn spec, DstFn d
     }
     // all GEMMs of one stage share the truncation op id
     if (!all_raw) {
-        for (size_t i = 0; i < E->sides.size(); ++i) {
-            Side& s = E->sides[i];
-            cognn_keys tk = keys(E, s.owner, it, g0.top);
-            BE(cognn_trunc_open_u64(E->ctx, s.ob[2], z[i], 1, &tk, s.p, eo[i]));
+        {
+            Batch batch(E);
+            for (size_t i = 0; i < E->sides.size(); ++i) {
+                Side& s = E->sides[i];
+                cognn_keys tk = keys(E, s.owner, it, g0.top);
+                BE(cognn_trunc_open_u64(E->ctx, s.ob[2], z[i], 1, &tk, s.p, eo[i]));
+            }
         }
         exchange_ob(E, 2, eo);
         trunc_close_all(E, it, g0.top, dst, eo, open_next);
@@ -358,10 +380,13 @@ void rowscale_stage(cognn_engine* E, int64_t it, int op, int top, int F, XFn X, 
     //         E_IN_OB0  ob[0] already holds E_p (written by the truncation close that produced X)
     const bool e_opened = e_mode == E_IN_X;
     std::vector<int64_t> eF, e1;
-    for (auto& s : E->sides) {
-        cognn_keys k = keys(E, s.owner, it, op);
-        BE(cognn_rowscale_open_u64(E->ctx, e_mode == E_FROM_X ? s.ob[0] : nullptr, s.ob[1], X(s), s.svec, &k, s.p, s.n, F));
-        eF.push_back((int64_t)s.n * F); e1.push_back(s.n);
+    {
+        Batch batch(E);
+        for (auto& s : E->sides) {
+            cognn_keys k = keys(E, s.owner, it, op);
+            BE(cognn_rowscale_open_u64(E->ctx, e_mode == E_FROM_X ? s.ob[0] : nullptr, s.ob[1], X(s), s.svec, &k, s.p, s.n, F));
+            eF.push_back((int64_t)s.n * F); e1.push_back(s.n);
+        }
     }
     if (e_opened) {
         XList xl;
@@ -377,11 +402,14 @@ void rowscale_stage(cognn_engine* E, int64_t it, int op, int top, int F, XFn X, 
     } else {
         exchange_ob2(E, 0, eF, 1, e1);
     }
-    for (auto& s : E->sides) {                              // the opened sums E0+E1, G0+G1 are formed inside the kernel
-        cognn_keys k = keys(E, s.owner, it, op), tk = keys(E, s.owner, it, top);
-        const u64* e_own = e_opened ? X(s) : s.ob[0];
-        const u64* e_peer = e_opened ? (s.peer ? X(*s.peer) : s.ib[0]) : s.ib[0];
-        BE(cognn_rowscale_close_u64(E->ctx, s.ob[2], e_own, e_peer, s.ob[1], s.ib[1], &k, &tk, s.p, s.n, F));
+    {
+        Batch batch(E);
+        for (auto& s : E->sides) {                          // the opened sums E0+E1, G0+G1 are formed inside the kernel
+            cognn_keys k = keys(E, s.owner, it, op), tk = keys(E, s.owner, it, top);
+            const u64* e_own = e_opened ? X(s) : s.ob[0];
+            const u64* e_peer = e_opened ? (s.peer ? X(*s.peer) : s.ib[0]) : s.ib[0];
+            BE(cognn_rowscale_close_u64(E->ctx, s.ob[2], e_own, e_peer, s.ob[1], s.ib[1], &k, &tk, s.p, s.n, F));
+        }
     }
     exchange_ob(E, 2, eF);
     trunc_close_all(E, it, top, dst, eF, open_next);
@@ -391,27 +419,36 @@ void relu_stage(cognn_engine* E, int64_t it, bool e_opened) {
     // e_opened: ob[0] already holds E = z - a (written by the truncation close that produced z)
     const int F = E->hid();
     std::vector<int64_t> eF;
-    for (auto& s : E->sides) {
-        cognn_keys k = keys(E, s.owner, it, COGNN_OP_AP_RELU);
-        // only E = z - a is opened online: g = t - b is input-independent and published by the dealer offline
-        if (!e_opened) BE(cognn_relu_open_u64(E->ctx, s.ob[0], nullptr, s.cur, &k, s.p, (int64_t)s.n * F));
-        eF.push_back((int64_t)s.n * F);
+    {
+        Batch batch(E);
+        for (auto& s : E->sides) {
+            cognn_keys k = keys(E, s.owner, it, COGNN_OP_AP_RELU);
+            // only E = z - a is opened online: g = t - b is input-independent and published by the dealer offline
+            if (!e_opened) BE(cognn_relu_open_u64(E->ctx, s.ob[0], nullptr, s.cur, &k, s.p, (int64_t)s.n * F));
+            eF.push_back((int64_t)s.n * F);
+        }
     }
     exchange_ob(E, 0, eF);
-    for (size_t i = 0; i < E->sides.size(); ++i) {
-        Side& s = E->sides[i];
-        cognn_keys k = keys(E, s.owner, it, COGNN_OP_AP_RELU);
-        BE(cognn_relu_mul_u64(E->ctx, s.ob[2], s.ob[0], s.ib[0], nullptr, nullptr, &k, s.p, eF[i]));
+    {
+        Batch batch(E);
+        for (size_t i = 0; i < E->sides.size(); ++i) {
+            Side& s = E->sides[i];
+            cognn_keys k = keys(E, s.owner, it, COGNN_OP_AP_RELU);
+            BE(cognn_relu_mul_u64(E->ctx, s.ob[2], s.ob[0], s.ib[0], nullptr, nullptr, &k, s.p, eF[i]));
+        }
     }
     exchange_ob(E, 2, eF);
     // H is the next iteration's PreScatter GEMM input (layer 1): write it straight into its h_t slot and emit the
     // Beaver opening E_p = H_p - A_p of that product in the same pass (gcn.h:230-239 of iteration it+1)
-    for (size_t i = 0; i < E->sides.size(); ++i) {
-        Side& s = E->sides[i];
-        cognn_keys nk = keys(E, s.owner, it + 1, COGNN_OP_PS_GEMM);
-        BE(cognn_relu_close_open_u64(E->ctx, s.h1, s.h1E, s.relu_mask, s.cur, s.ob[2], s.ib[2],
-                                     nk.k[s.p == 0 ? COGNN_SL_A0 : COGNN_SL_A1], eF[i]));
-        s.cur = s.h1;
+    {
+        Batch batch(E);
+        for (size_t i = 0; i < E->sides.size(); ++i) {
+            Side& s = E->sides[i];
+            cognn_keys nk = keys(E, s.owner, it + 1, COGNN_OP_PS_GEMM);
+            BE(cognn_relu_close_open_u64(E->ctx, s.h1, s.h1E, s.relu_mask, s.cur, s.ob[2], s.ib[2],
+                                         nk.k[s.p == 0 ? COGNN_SL_A0 : COGNN_SL_A1], eF[i]));
+            s.cur = s.h1;
+        }
     }
     E->gemm_x_opened_for = it + 1;
 }
@@ -627,18 +664,24 @@ void weight_update_chain(cognn_engine* E, int64_t it, int layer) {
     std::vector<int64_t> el;
     for (auto& s : E->sides) { d.push_back(s.small[0]); d2.push_back(s.small[1]); el.push_back(elems); }
     // gradient scale: per-owner constant, so the stage runs per side with its own multiplier
-    for (size_t i = 0; i < E->sides.size(); ++i) {
-        Side& s = E->sides[i];
-        const int64_t train = (int64_t)((double)s.n * E->cfg.train_ratio);
-        const u64 gs = train > 0 ? fx_trunc(1.0 / (double)train) : 0;
-        cognn_keys k = keys(E, s.owner, it, COGNN_OP_AP_GSCALE_TRUNC);
-        BE(cognn_trunc_open_u64(E->ctx, s.ob[2], d[i], gs, &k, s.p, elems));
+    {
+        Batch batch(E);
+        for (size_t i = 0; i < E->sides.size(); ++i) {
+            Side& s = E->sides[i];
+            const int64_t train = (int64_t)((double)s.n * E->cfg.train_ratio);
+            const u64 gs = train > 0 ? fx_trunc(1.0 / (double)train) : 0;
+            cognn_keys k = keys(E, s.owner, it, COGNN_OP_AP_GSCALE_TRUNC);
+            BE(cognn_trunc_open_u64(E->ctx, s.ob[2], d[i], gs, &k, s.p, elems));
+        }
     }
     exchange_ob(E, 2, el);
-    for (size_t i = 0; i < E->sides.size(); ++i) {
-        Side& s = E->sides[i];
-        cognn_keys k = keys(E, s.owner, it, COGNN_OP_AP_GSCALE_TRUNC);
-        BE(cognn_trunc_close_u64(E->ctx, d2[i], s.p == 0 ? s.ob[2] : nullptr, s.p == 0 ? s.ib[2] : nullptr, &k, s.p, 0, elems));
+    {
+        Batch batch(E);
+        for (size_t i = 0; i < E->sides.size(); ++i) {
+            Side& s = E->sides[i];
+            cognn_keys k = keys(E, s.owner, it, COGNN_OP_AP_GSCALE_TRUNC);
+            BE(cognn_trunc_close_u64(E->ctx, d2[i], s.p == 0 ? s.ob[2] : nullptr, s.p == 0 ? s.ib[2] : nullptr, &k, s.p, 0, elems));
+        }
     }
     const u64 lr = fx_trunc(E->cfg.learning_rate);
     trunc_stage(E, it, COGNN_OP_AP_LR_TRUNC, lr, d2, el, [&](Side& s) { return s.W[layer]; }, 1);
@@ -715,6 +758,7 @@ void run_iteration(cognn_engine* E, int64_t it) {
                        [&](Side& s) { return GemmSpec{s.n, E->hid(), E->lab(), 0, COGNN_OP_AP_GEMM, COGNN_OP_AP_GEMM_TRUNC}; },
                        [&](Side& s) { return s.g; });
         } else {                                           // out = in * 1[z>0]  (gcn.h:702-708; g' skipped for layer 0)
+            Batch batch(E);
             for (auto& s : E->sides) {
                 u64* dstb = (s.cur == s.buf[1]) ? s.buf[0] : s.buf[1];
                 BE(cognn_mask_select_u64(E->ctx, dstb, s.cur, s.relu_mask, (int64_t)s.n * E->hid()));

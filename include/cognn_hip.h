@@ -40,6 +40,12 @@ int cognn_ctx_create(int device, void* stream, cognn_ctx** out);
 int cognn_ctx_create_private(int device, cognn_ctx** out);
 int cognn_ctx_destroy(cognn_ctx* ctx);
 int cognn_ctx_sync(cognn_ctx* ctx);
+/* Launch batching: between begin and end, consecutive element-wise calls of the SAME kind (trunc / rowscale / relu /
+ * mask / add ...) are queued and issued as one launch of up to 8 tensors.  The caller guarantees that the queued calls are
+ * independent of each other (the sides of one protocol phase); any other entry point, a different kind of call, or end()
+ * launches what is queued first, so stream order is otherwise preserved.  Nestable. */
+int cognn_batch_begin(cognn_ctx*);
+int cognn_batch_end(cognn_ctx*);
 int cognn_malloc(cognn_ctx* ctx, void** ptr, size_t bytes);
 int cognn_free(cognn_ctx* ctx, void* ptr);
 int cognn_memcpy_h2d(cognn_ctx* ctx, void* dst, const void* src, size_t bytes);
