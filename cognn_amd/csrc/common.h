@@ -13,7 +13,7 @@ struct cognn_ctx;
 // descriptors of up to kBatchMax calls are passed by value to ONE launch.
 struct cognn_pending_batch {
     int (*flush)(cognn_ctx*) = nullptr;        // launcher of the queued functor type (nullptr: nothing queued)
-    alignas(16) unsigned char storage[4096];
+    alignas(16) unsigned char storage[8192];
 };
 struct cognn_ctx {
     int device;

@@ -54,7 +54,7 @@ __global__ __launch_bounds__(kThreads) void ew_kernel(int64_t n, F f) {
 }
 // Batched form: the same functor type for several independent tensors (the sides of one protocol phase) in ONE launch.
 // The descriptors travel by value in the kernel arguments; a workgroup finds its segment by a short uniform scan.
-constexpr int kBatchMax = 8;
+constexpr int kBatchMax = 16;
 template <class F>
 struct EwBatch {
     F f[kBatchMax];

@@ -41,7 +41,7 @@ int cognn_ctx_create_private(int device, cognn_ctx** out);
 int cognn_ctx_destroy(cognn_ctx* ctx);
 int cognn_ctx_sync(cognn_ctx* ctx);
 /* Launch batching: between begin and end, consecutive element-wise calls of the SAME kind (trunc / rowscale / relu /
- * mask / add ...) are queued and issued as one launch of up to 8 tensors.  The caller guarantees that the queued calls are
+ * mask / add ...) are queued and issued as one launch of up to 16 tensors.  The caller guarantees that the queued calls are
  * independent of each other (the sides of one protocol phase); any other entry point, a different kind of call, or end()
  * launches what is queued first, so stream order is otherwise preserved.  Nestable. */
 int cognn_batch_begin(cognn_ctx*);
