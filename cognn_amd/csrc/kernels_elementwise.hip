@@ -368,7 +368,7 @@ template <int G>
 __global__ __launch_bounds__(kThreads) void metrics_kernel(const u64* pfx, const int32_t* labels, const uint8_t* border,
                                                             int64_t rows, int L, int64_t train_rows, int64_t val_rows,
                                                             unsigned long long* counts, double* loss) {
-    // grid-stride over rows; per-thread partial counts -> LDS -> one set of global atomics per workgroup
+    // grid-stride over row groups; per-thread partial counts -> LDS -> one set of global atomics per workgroup
     __shared__ unsigned long long s_cnt[5];
     __shared__ double s_loss;
     if (threadIdx.x < 5) s_cnt[threadIdx.x] = 0;
@@ -377,37 +377,43 @@ __global__ __launch_bounds__(kThreads) void metrics_kernel(const u64* pfx, const
     const int j = threadIdx.x % G;
     unsigned int c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0;
     double ls = 0.0;
-    const int64_t rows_per_pass = (int64_t)gridDim.x * (kThreads / G);
-    // all G lanes of a group share r, so the loop condition is uniform inside every shuffle group
-    for (int64_t r = (int64_t)blockIdx.x * (kThreads / G) + threadIdx.x / G; r < rows; r += rows_per_pass) {
-        const bool valid = r < rows && j < L;
-        u64 bv = valid ? pfx[r * L + j] : 0ull;
-        int bj = valid ? j : (1 << 20);
+    // A group of G lanes owns G consecutive rows per pass: the argmax of each row is a G-lane shuffle reduction (lane 0 ends up
+    // with the row's result), then lane i takes over row i's log() so that the double-precision log runs on all lanes
+    const int64_t groups = (int64_t)gridDim.x * (kThreads / G);
+    const int64_t gid = (int64_t)blockIdx.x * (kThreads / G) + threadIdx.x / G;
+    for (int64_t rb = gid * G; rb < rows; rb += groups * G) {          // uniform inside every shuffle group
+        double my_pl = 1.0;                                            // log(1) = 0 for rows beyond the end
+        for (int i = 0; i < G; ++i) {
+            const int64_t r = rb + i;
+            const bool valid = r < rows && j < L;
+            u64 bv = valid ? pfx[r * L + j] : 0ull;
+            int bj = valid ? j : (1 << 20);
 #pragma unroll
-        for (int o = G / 2; o > 0; o >>= 1) {              // argmax, first maximum wins ties
-            u64 ov = __shfl_xor(bv, o, G);
-            int oj = __shfl_xor(bj, o, G);
-            if (ov > bv || (ov == bv && oj < bj)) { bv = ov; bj = oj; }
+            for (int o = G / 2; o > 0; o >>= 1) {          // argmax, first maximum wins ties
+                u64 ov = __shfl_xor(bv, o, G);
+                int oj = __shfl_xor(bj, o, G);
+                if (ov > bv || (ov == bv && oj < bj)) { bv = ov; bj = oj; }
+            }
+            // after the butterfly every lane holds the row's argmax: lane i keeps the bookkeeping of row i
+            if (j == i && r < rows) {
+                const int lab = labels[r];
+                const bool ok = bj == lab;
+                const bool b = border ? border[r] != 0 : false;
+                const bool tr = r < train_rows, te = r >= train_rows + val_rows;
+                c0 += ok; c1 += ok && tr; c2 += ok && tr && b; c3 += ok && te; c4 += ok && te && b;
+                my_pl = (double)pfx[r * L + lab] / (double)COGNN_FX_ONE;
+                if (my_pl == 0.0) my_pl = 0.001;           /* gcn.h:613-615 */
+            }
         }
-        if (r < rows && j == 0) {
-            const int lab = labels[r];
-            const bool ok = bj == lab;
-            const bool b = border ? border[r] != 0 : false;
-            const bool tr = r < train_rows, te = r >= train_rows + val_rows;
-            c0 += ok; c1 += ok && tr; c2 += ok && tr && b; c3 += ok && te; c4 += ok && te && b;
-            double pl = (double)pfx[r * L + lab] / (double)COGNN_FX_ONE;
-            if (pl == 0.0) pl = 0.001;                     /* gcn.h:613-615 */
-            ls += -log(pl);
-        }
+        ls += -log(my_pl);
     }
-    if (j == 0) {
-        if (c0) atomicAdd(&s_cnt[0], (unsigned long long)c0);
-        if (c1) atomicAdd(&s_cnt[1], (unsigned long long)c1);
-        if (c2) atomicAdd(&s_cnt[2], (unsigned long long)c2);
-        if (c3) atomicAdd(&s_cnt[3], (unsigned long long)c3);
-        if (c4) atomicAdd(&s_cnt[4], (unsigned long long)c4);
-        if (ls != 0.0) atomicAdd(&s_loss, ls);
-    }
+    // per-thread partials -> LDS
+    if (c0) atomicAdd(&s_cnt[0], (unsigned long long)c0);
+    if (c1) atomicAdd(&s_cnt[1], (unsigned long long)c1);
+    if (c2) atomicAdd(&s_cnt[2], (unsigned long long)c2);
+    if (c3) atomicAdd(&s_cnt[3], (unsigned long long)c3);
+    if (c4) atomicAdd(&s_cnt[4], (unsigned long long)c4);
+    if (ls != 0.0) atomicAdd(&s_loss, ls);
     __syncthreads();
     if (threadIdx.x < 5 && s_cnt[threadIdx.x]) atomicAdd(&counts[threadIdx.x], s_cnt[threadIdx.x]);
     if (threadIdx.x == 0) atomicAdd(loss, s_loss);
@@ -545,7 +551,7 @@ int cognn_metrics_q16(cognn_ctx* ctx, const uint64_t* pfx, const int32_t* labels
     while (G < L) G <<= 1;
 #define CG_MT_CASE(g)                                                                                                     \
     case g:                                                                                                                \
-        hipLaunchKernelGGL(metrics_kernel<g>, dim3(std::min(cg_div_up(rows * g, kThreads), 512)), dim3(kThreads), 0, ctx->stream, (const u64*)pfx, \
+        hipLaunchKernelGGL(metrics_kernel<g>, dim3(std::min(cg_div_up(rows, kThreads), 512)), dim3(kThreads), 0, ctx->stream, (const u64*)pfx, \
                            labels, border, rows, (int)L, train_rows, val_rows, (unsigned long long*)counts6, loss);       \
         break;
     switch (G) { CG_MT_CASE(1) CG_MT_CASE(2) CG_MT_CASE(4) CG_MT_CASE(8) CG_MT_CASE(16) CG_MT_CASE(32) CG_MT_CASE(64) }
