@@ -52,7 +52,7 @@ def test_cli_runs_reference_formats_and_matches_oracle(tmp_path):
     cmd = [BIN, "-t", str(k), "-g", str(k), "-i", "1", "-m", "12", "-p", "1", "-s", setting, "-r", "1",
            str(tmp_path / "edges.txt"), str(tmp_path / "vertices.txt"), str(tmp_path / "part.txt"), str(tmp_path / "out.txt"),
            str(tmp_path / "config.txt")]
-    res = subprocess.run(cmd, capture_output=True, text=True, timeout=120)
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=120, cwd=tmp_path)     # preprocess/<setting>/ lands in cwd
     assert res.returncode == 0, res.stderr
     out = res.stdout
     assert len(re.findall(r"::iteration took [0-9.]+ seconds", out)) == 12
@@ -101,7 +101,7 @@ def test_gpu_binary_matches_oracle(tmp_path):
     cmd = [exe, "-t", str(k), "-g", str(k), "-i", "0", "-m", "6", "-s", "gpu-harness", "-r", "1", "-n", "1",
            str(tmp_path / "edges.txt"), str(tmp_path / "vertices.txt"), str(tmp_path / "part.txt"), str(tmp_path / "out.txt"),
            str(tmp_path / "config.txt")]
-    res = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=tmp_path)
     assert res.returncode == 0, res.stderr
     p = co.GnnParam(num_labels=lab, input_dim=in_dim, hidden_dim=hid, num_samples=V, learning_rate=0.5)
     o = co.OracleEngine(k, src, dst, [v % k for v in range(V)], feats, labels, p, seed=_fnv1a("gpu-harness"))
