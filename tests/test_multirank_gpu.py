@@ -26,3 +26,17 @@ def test_eight_parties_two_ranks_wide_rows_hip(tmp_path):
     cfg = dict(BASE, k=8, V=4096, Eu=16384, hid=16, lab=8, variant="optimize-gcn-inference", iters=2, backend="hip")
     cfg["in"] = 32
     _check(cfg, 2, tmp_path)
+
+
+def test_four_parties_two_ranks_training_wide_rows_hip(tmp_path):
+    # one training epoch at kernel-relevant widths: wave-specialised NN / TN Beaver products, batched element-wise launches,
+    # mask/opening reuse of both weight gradients, all across a rank boundary
+    cfg = dict(BASE, k=4, V=2048, Eu=8192, hid=64, lab=16, variant="optimize-gcn", iters=6, backend="hip")
+    cfg["in"] = 128
+    _check(cfg, 2, tmp_path)
+
+
+def test_four_parties_four_ranks_training_hip(tmp_path):
+    cfg = dict(BASE, k=4, V=600, Eu=2000, hid=16, lab=7, variant="optimize-gcn", iters=12, backend="hip")
+    cfg["in"] = 33
+    _check(cfg, 4, tmp_path)
