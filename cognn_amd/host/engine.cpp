@@ -97,7 +97,10 @@ struct cognn_engine {
     u64* aggOut = nullptr;
     uint32_t *agg_rowptr = nullptr, *agg_col = nullptr, *part_rowptr = nullptr, *part_col = nullptr;
     int64_t aggEdges = 0, partEdges = 0;
-    struct Seg { int src_party, dst_owner; int64_t rows, inbox_off, out_off; int src_rank, dst_rank; };
+    // One partial-sum segment per (source rank, destination owner g): row i = sum over ALL parties Q hosted by the source rank
+    // of Q's own-share rows over the edges Q -> rows_vid[i] (pre-summed on the sender: one row per destination vertex however
+    // many of the sender's parties reach it).
+    struct Seg { int dst_owner; int64_t rows, inbox_off, out_off; int src_rank, dst_rank; std::vector<uint64_t> rows_vid; };
     std::vector<Seg> segs;         // partial-sum segments this rank sends or receives
     std::vector<std::vector<double>> hostFeat;
     std::vector<std::vector<int32_t>> hostLabels;
@@ -837,36 +840,42 @@ void build_layout(cognn_engine* E) {
     even();
     E->aggRows = off;
     for (int o = 0; o < k; ++o) if (E->B_off[o] < 0) { even(); E->B_off[o] = off; off += nrows(o); }
-    // partial-sum segments: (Q -> g) goes from rank(Q) to rank(co(g)); receiver-side order: source rank, then g, then Q
+    // partial-sum segments: (source rank -> g) goes to rank(co(g)); receiver-side order: source rank, then g
     E->segs.clear();
     const int64_t inbox0 = off;
-    auto seg_rows = [&](int Q, int g) { return (int64_t)G.party[Q].out[g].rows_vid.size(); };
+    auto seg_vids = [&](int sr, int g) {                    // distinct destination vertices of g reached from any party of rank sr
+        std::vector<uint64_t> v;
+        for (int Q = sr * E->m; Q < (sr + 1) * E->m; ++Q) {
+            if (Q == g) continue;
+            const auto& rv = G.party[Q].out[g].rows_vid;
+            v.insert(v.end(), rv.begin(), rv.end());
+        }
+        std::sort(v.begin(), v.end());
+        v.erase(std::unique(v.begin(), v.end()), v.end());
+        return v;
+    };
     std::vector<int> src_order;
     for (int r = 0; r < E->world; ++r) if (r != E->rank) src_order.push_back(r);
     src_order.push_back(E->rank);                          // own-rank segments last, adjacent to the outbox
     for (int sr : src_order) {
         if (sr == E->rank) { even(); E->inboxLocalOff = off; continue; }   // same-rank producers: read in place, see build_csrs
-        for (int g : E->cohosted)
-            for (int Q = 0; Q < k; ++Q) {
-                if (Q == g || E->rank_of(Q) != sr) continue;
-                cognn_engine::Seg sg{Q, g, seg_rows(Q, g), off, -1, sr, E->rank};
-                E->segs.push_back(sg);
-                off += sg.rows;
-            }
+        for (int g : E->cohosted) {
+            cognn_engine::Seg sg{g, 0, off, -1, sr, E->rank, seg_vids(sr, g)};
+            sg.rows = (int64_t)sg.rows_vid.size();
+            off += sg.rows;
+            E->segs.push_back(std::move(sg));
+        }
     }
     E->inboxRows = off - inbox0;
-    // outbox: segments of hosted parties for owners co-hosted elsewhere, grouped by destination rank in the
-    // receiver's order (g of that rank's cohosted list, then Q)
+    // outbox: one segment per owner co-hosted elsewhere, grouped by destination rank in the receiver's order (its cohosted list)
     for (int dr = 0; dr < E->world; ++dr) {
         if (dr == E->rank) continue;
         for (int P = dr * E->m; P < (dr + 1) * E->m; ++P) {
             const int g = (P + k - 1) % k;                 // owner whose co-party P lives on rank dr
-            for (int Q : E->hosted) {
-                if (Q == g) continue;
-                cognn_engine::Seg sg{Q, g, seg_rows(Q, g), -1, off, E->rank, dr};
-                E->segs.push_back(sg);
-                off += sg.rows;
-            }
+            cognn_engine::Seg sg{g, 0, -1, off, E->rank, dr, seg_vids(E->rank, g)};
+            sg.rows = (int64_t)sg.rows_vid.size();
+            off += sg.rows;
+            E->segs.push_back(std::move(sg));
         }
     }
     E->tableRows = off;
@@ -884,12 +893,18 @@ void build_csrs(cognn_engine* E) {
     int64_t expect = E->inboxLocalOff;
     for (auto* sg : produced) {
         if (sg->out_off != expect) throw EngineError("engine: partial segment layout is not contiguous");
-        const cognn::EdgeBlock& blk = G.party[sg->src_party].out[sg->dst_owner];
-        const int64_t abase = E->A_off[sg->src_party];
-        for (size_t r = 0; r + 1 < blk.rowptr.size(); ++r) {
-            for (uint32_t q = blk.rowptr[r]; q < blk.rowptr[r + 1]; ++q) pcol.push_back((uint32_t)(abase + blk.col[q]));
-            prp.push_back((uint32_t)pcol.size());
+        // per destination vertex: the source rows of every hosted party's edges into it
+        std::vector<std::vector<uint32_t>> rows((size_t)sg->rows);
+        for (int Q : E->hosted) {
+            if (Q == sg->dst_owner) continue;
+            const cognn::EdgeBlock& blk = G.party[Q].out[sg->dst_owner];
+            const int64_t abase = E->A_off[Q];
+            for (size_t r = 0; r + 1 < blk.rowptr.size(); ++r) {
+                const size_t idx = (size_t)(std::lower_bound(sg->rows_vid.begin(), sg->rows_vid.end(), blk.rows_vid[r]) - sg->rows_vid.begin());
+                for (uint32_t q = blk.rowptr[r]; q < blk.rowptr[r + 1]; ++q) rows[idx].push_back((uint32_t)(abase + blk.col[q]));
+            }
         }
+        for (auto& l : rows) { pcol.insert(pcol.end(), l.begin(), l.end()); prp.push_back((uint32_t)pcol.size()); }
         expect += sg->rows;
     }
     E->partEdges = (int64_t)pcol.size();
@@ -929,9 +944,8 @@ void build_csrs(cognn_engine* E) {
         }
     for (auto& sg : E->segs) {                              // partial rows received from other ranks
         if (sg.dst_rank != E->rank) continue;
-        const cognn::EdgeBlock& blk = G.party[sg.src_party].out[sg.dst_owner];
         const int64_t rbase = E->B_off[sg.dst_owner];
-        for (size_t r = 0; r < blk.rows_vid.size(); ++r) lists[rbase + G.row_of_vid[blk.rows_vid[r]]].push_back((uint32_t)(sg.inbox_off + r));
+        for (size_t r = 0; r < sg.rows_vid.size(); ++r) lists[rbase + G.row_of_vid[sg.rows_vid[r]]].push_back((uint32_t)(sg.inbox_off + r));
     }
     std::vector<uint32_t> arp{0}, acol;
     for (auto& l : lists) { acol.insert(acol.end(), l.begin(), l.end()); arp.push_back((uint32_t)acol.size()); }
