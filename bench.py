@@ -167,7 +167,7 @@ def main():
     eng = Engine(k, src, dst, part, param, seed=0xC06A11, variant=variant, rank=rank, world=world, device=local_rank)
     if world > 1:
         from cognn_amd import dist as cdist
-        eng.set_exchange(cdist.make_exchange(torch.device("cuda", local_rank), host_staged=(backend != "nccl")))
+        eng.set_exchange(cdist.make_exchange_async(torch.device("cuda", local_rank), host_staged=(backend != "nccl")))
     for P in eng.hosted:                      # Bernoulli(0.01) bag-of-words features, uniform labels
         vids = eng.party_vids(P)
         rng = np.random.default_rng(0xC06A12 + P)

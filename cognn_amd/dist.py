@@ -8,7 +8,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-from .engine_api import EXCHANGE_FN
+from .engine_api import EXCHANGE_FN, EXCHANGE_WAIT_FN
 
 
 class _DevBuf:
@@ -71,3 +71,56 @@ def make_exchange(device, group=None, host_staged=False):
             return 1
 
     return EXCHANGE_FN(_exchange)
+
+
+def make_exchange_async(device, group=None, host_staged=False):
+    """(begin, wait) callbacks for cognn_engine_set_exchange_async(): begin enqueues a round and returns, wait completes every
+    enqueued round - the engine runs the kernels of the sides whose peer is local in between.  With RCCL the p2p group runs on
+    the communicator's stream (ordered after the kernels already launched), wait makes the engine's stream wait for it."""
+    cache = {}
+    inflight = []                                       # (works, [(device tensor, host tensor)] to copy back)
+
+    def _build(xfers, n):
+        ops, pre, post = [], [], []
+        for i in range(n):
+            x = xfers[i]
+            t = _wrap(x.ptr, x.bytes, device)
+            if host_staged and device.type == "cuda":
+                h = torch.empty(x.bytes, dtype=torch.uint8)
+                (pre if x.is_send else post).append((t, h))
+                ops.append(dist.P2POp(dist.isend if x.is_send else dist.irecv, h, x.peer, group))
+            else:
+                ops.append(dist.P2POp(dist.isend if x.is_send else dist.irecv, t, x.peer, group))
+        return ops, pre, post
+
+    def _begin(user, xfers, n):
+        try:
+            if n <= 0:
+                return 0
+            key = tuple((xfers[i].ptr, xfers[i].bytes, xfers[i].peer, xfers[i].is_send) for i in range(n))
+            ent = cache.get(key)
+            if ent is None:
+                ent = cache[key] = _build(xfers, n)
+            ops, pre, post = ent
+            for t, h in pre:
+                h.copy_(t)                                  # device -> host of what is already enqueued on the engine's stream
+            inflight.append((dist.batch_isend_irecv(ops), post))
+            return 0
+        except Exception as ex:  # noqa: BLE001 - the C caller only understands a status code
+            print("cognn exchange (begin) failed: %r" % (ex,), flush=True)
+            return 1
+
+    def _wait(user):
+        try:
+            while inflight:
+                works, post = inflight.pop(0)
+                for w in works:
+                    w.wait()
+                for t, h in post:
+                    t.copy_(h)
+            return 0
+        except Exception as ex:  # noqa: BLE001
+            print("cognn exchange (wait) failed: %r" % (ex,), flush=True)
+            return 1
+
+    return EXCHANGE_FN(_begin), EXCHANGE_WAIT_FN(_wait)

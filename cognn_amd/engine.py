@@ -103,8 +103,12 @@ class Engine:
         _check(self.lib.cognn_engine_set_weights(self.h, a.ctypes.data, b.ctypes.data))
 
     def set_exchange(self, fn):
-        self._keep.append(fn)
-        _check(self.lib.cognn_engine_set_exchange(self.h, fn, None))
+        """fn: the callback of cognn_amd.dist.make_exchange, or the (begin, wait) pair of make_exchange_async."""
+        self._xfn = fn                                     # keep the ctypes callbacks alive
+        if isinstance(fn, tuple):
+            _check(self.lib.cognn_engine_set_exchange_async(self.h, fn[0], fn[1], None))
+        else:
+            _check(self.lib.cognn_engine_set_exchange(self.h, fn, None))
 
     def start(self):
         _check(self.lib.cognn_engine_start(self.h))

@@ -20,12 +20,14 @@ class Xfer(ctypes.Structure):
 
 
 EXCHANGE_FN = ctypes.CFUNCTYPE(ctypes.c_int, _P, ctypes.POINTER(Xfer), _I)
+EXCHANGE_WAIT_FN = ctypes.CFUNCTYPE(ctypes.c_int, _P)
 
 _SIGNATURES = {
     "cognn_engine_last_error": (ctypes.c_char_p, []),
     "cognn_engine_create": (ctypes.c_int, [ctypes.POINTER(EngineConfig), _L, _L, _P, _P, _P, ctypes.POINTER(_P)]),
     "cognn_engine_destroy": (ctypes.c_int, [_P]),
     "cognn_engine_set_exchange": (ctypes.c_int, [_P, EXCHANGE_FN, _P]),
+    "cognn_engine_set_exchange_async": (ctypes.c_int, [_P, EXCHANGE_FN, EXCHANGE_WAIT_FN, _P]),
     "cognn_engine_party_rows": (ctypes.c_int, [_P, _I, ctypes.POINTER(_L)]),
     "cognn_engine_party_vids": (ctypes.c_int, [_P, _I, _P]),
     "cognn_engine_party_degrees": (ctypes.c_int, [_P, _I, _P, _P, _P]),

@@ -86,7 +86,9 @@ struct cognn_engine {
     std::vector<Side> sides;
     std::vector<void*> allocs;
     cognn_exchange_fn xfn = nullptr;
+    cognn_exchange_wait_fn xwait = nullptr;   // set: xfn only enqueues the round, xwait completes it (asynchronous exchange)
     void* xuser = nullptr;
+    bool xpending = false;                     // an enqueued round has not been waited for yet
     bool started = false, timing = false;
     int64_t gemm_x_opened_for = -1;    // iteration whose PreScatter GEMM input was already opened by the previous ReLU close
     // share table of the current message-passing round
@@ -181,10 +183,24 @@ struct XList {
     void send(int peer, void* p, int64_t bytes) { if (bytes > 0) v.push_back(cognn_xfer{peer, 1, p, bytes}); }
     void recv(int peer, void* p, int64_t bytes) { if (bytes > 0) v.push_back(cognn_xfer{peer, 0, p, bytes}); }
 };
+// completes the round that is still in flight (asynchronous exchange); a no-op otherwise
+void exchange_wait(cognn_engine* E) {
+    if (!E->xpending) return;
+    E->xpending = false;
+    if (E->xwait(E->xuser) != 0) throw EngineError("engine: exchange wait function failed");
+}
+// starts a round.  With a wait function registered the call only enqueues the messages; whoever consumes received data - or
+// overwrites a buffer that is being sent - calls exchange_wait first (for_sides does, before it touches a side whose peer is remote).
 void run_exchange(cognn_engine* E, XList& xl) {
+    exchange_wait(E);
     if (xl.v.empty()) return;
     if (!E->xfn) throw EngineError("engine: world > 1 needs an exchange function (cognn_engine_set_exchange)");
     if (E->xfn(E->xuser, xl.v.data(), (int32_t)xl.v.size()) != 0) throw EngineError("engine: exchange function failed");
+    if (E->xwait) E->xpending = true;
+}
+void run_exchange_sync(cognn_engine* E, XList& xl) {
+    run_exchange(E, xl);
+    exchange_wait(E);
 }
 // pairwise swap of outbox j (elems u64 each) between the two sides of every owner
 void exchange_ob(cognn_engine* E, int j, const std::vector<int64_t>& elems) {
@@ -231,25 +247,38 @@ struct GemmSpec {            // logical Z[MxN] = X[MxK] . Wm[KxN]
 };
 enum { X_OPEN_HERE = 0, X_H1E_FRESH = 1, X_H1E_REUSE = 2 };
 
+// Runs fn(side, index) for every hosted side: first the sides whose peer lives on this rank, then - once the exchange round
+// that may still be in flight has completed - the sides whose peer is remote.  With an asynchronous exchange the interior
+// sides' kernels overlap the boundary sides' messages.  batched: the calls are independent element-wise launches of one
+// kind (see Batch).
+template <class Fn>
+void for_sides(cognn_engine* E, bool batched, Fn fn) {
+    for (int pass = 0; pass < 2; ++pass) {
+        if (pass == 1) exchange_wait(E);
+        if (batched) {
+            Batch batch(E);
+            for (size_t i = 0; i < E->sides.size(); ++i)
+                if ((E->sides[i].peer != nullptr) == (pass == 0)) fn(E->sides[i], i);
+        } else {
+            for (size_t i = 0; i < E->sides.size(); ++i)
+                if ((E->sides[i].peer != nullptr) == (pass == 0)) fn(E->sides[i], i);
+        }
+    }
+}
+
 // truncation of every side's `x` (elems) scaled by `mul`; result written/applied to dst(side)
 template <class DstFn>
 void trunc_stage(cognn_engine* E, int64_t it, int op, u64 mul, const std::vector<u64*>& x, const std::vector<int64_t>& elems,
                  DstFn dst, int mode, u64 owner_override = ~0ull) {
-    {
-        Batch batch(E);
-        for (size_t i = 0; i < E->sides.size(); ++i) {
-            Side& s = E->sides[i];
-            cognn_keys k = keys(E, owner_override == ~0ull ? (u64)s.owner : owner_override, it, op);
-            BE(cognn_trunc_open_u64(E->ctx, s.ob[2], x[i], mul, &k, s.p, elems[i]));
-        }
-    }
+    for_sides(E, true, [&](Side& s, size_t i) {
+        cognn_keys k = keys(E, owner_override == ~0ull ? (u64)s.owner : owner_override, it, op);
+        BE(cognn_trunc_open_u64(E->ctx, s.ob[2], x[i], mul, &k, s.p, elems[i]));
+    });
     exchange_ob(E, 2, elems);
-    Batch batch(E);
-    for (size_t i = 0; i < E->sides.size(); ++i) {
-        Side& s = E->sides[i];
+    for_sides(E, true, [&](Side& s, size_t i) {
         cognn_keys k = keys(E, owner_override == ~0ull ? (u64)s.owner : owner_override, it, op);
         BE(cognn_trunc_close_u64(E->ctx, dst(s), s.p == 0 ? s.ob[2] : nullptr, s.p == 0 ? s.ib[2] : nullptr, &k, s.p, mode, elems[i]));
-    }
+    });
 }
 
 // dealer streams of a Beaver product: its own (owner, iteration, op) streams, except that a reused operand keeps the A streams
@@ -276,15 +305,13 @@ struct OpenNext {
 };
 template <class DstFn>
 void trunc_close_all(cognn_engine* E, int64_t it, int top, DstFn dst, const std::vector<int64_t>& elems, const OpenNext& open_next) {
-    Batch batch(E);
-    for (size_t i = 0; i < E->sides.size(); ++i) {
-        Side& s = E->sides[i];
+    for_sides(E, true, [&](Side& s, size_t i) {
         cognn_keys tk = keys(E, s.owner, it, top);
         const u64* c0 = s.p == 0 ? s.ob[2] : nullptr;
         const u64* c1 = s.p == 0 ? s.ib[2] : nullptr;
         if (open_next) BE(cognn_trunc_close_open_u64(E->ctx, dst(s), s.ob[open_next.ob], c0, c1, &tk, s.p, open_next.key(s), elems[i]));
         else BE(cognn_trunc_close_u64(E->ctx, dst(s), c0, c1, &tk, s.p, 0, elems[i]));
-    }
+    });
 }
 
 // Beaver GEMM for every side: X(side), Wm(side) -> truncated product written to dst(side)
@@ -292,26 +319,24 @@ template <class XFn, class WFn, class SpecFn, class DstFn>
 void gemm_stage(cognn_engine* E, int64_t it, XFn X, WFn Wm, SpecFn spec, DstFn dst, bool x_opened = false,
                 const OpenNext& open_next = OpenNext(), bool w_opened = false) {
     // w_opened: ob[1] already holds F_p = W_p - B_p (written by the truncation close that produced W)
-    std::vector<int64_t> e0, e1, eo;
+    const size_t ns = E->sides.size();
+    std::vector<int64_t> e0(ns), e1(ns), eo(ns);
     const bool feature = spec(E->sides[0]).feature != 0;
     const int xsrc = x_opened ? X_H1E_FRESH : spec(E->sides[0]).xsrc;
     auto gkeys = [&](Side& s, const GemmSpec& g) { return gemm_keys(E, s, it, g); };
-    {
-        Batch batch(E);
-        for (auto& s : E->sides) {
-            GemmSpec g = spec(s);
-            cognn_keys k = gkeys(s, g);
-            if (xsrc == X_OPEN_HERE && !feature)
-                BE(cognn_mask_open_u64(E->ctx, s.ob[0], X(s), k.k[s.p == 0 ? COGNN_SL_A0 : COGNN_SL_A1], g.M, g.K, g.transA));
-            if (!w_opened) BE(cognn_mask_open_u64(E->ctx, s.ob[1], Wm(s), k.k[s.p == 0 ? COGNN_SL_B0 : COGNN_SL_B1], g.K, g.N, 0));
-            e0.push_back(g.M * g.K); e1.push_back(g.K * g.N); eo.push_back(g.M * g.N);
-        }
-    }
+    for_sides(E, true, [&](Side& s, size_t i) {
+        GemmSpec g = spec(s);
+        cognn_keys k = gkeys(s, g);
+        if (xsrc == X_OPEN_HERE && !feature)
+            BE(cognn_mask_open_u64(E->ctx, s.ob[0], X(s), k.k[s.p == 0 ? COGNN_SL_A0 : COGNN_SL_A1], g.M, g.K, g.transA));
+        if (!w_opened) BE(cognn_mask_open_u64(E->ctx, s.ob[1], Wm(s), k.k[s.p == 0 ? COGNN_SL_B0 : COGNN_SL_B1], g.K, g.N, 0));
+        e0[i] = g.M * g.K; e1[i] = g.K * g.N; eo[i] = g.M * g.N;
+    });
     if (feature || xsrc == X_H1E_REUSE) {
         exchange_ob(E, 1, e1);                              // the opening of X was exchanged earlier (start() / two iterations ago)
     } else if (xsrc == X_H1E_FRESH) {
         XList xl;                                           // the ReLU close left E_p in h1E: it travels with the W opening
-        for (size_t i = 0; i < E->sides.size(); ++i) {
+        for (size_t i = 0; i < ns; ++i) {
             Side& s = E->sides[i];
             if (s.peer) continue;
             xl.send(s.peer_rank, s.h1E, e0[i] * 8);
@@ -323,12 +348,11 @@ void gemm_stage(cognn_engine* E, int64_t it, XFn X, WFn Wm, SpecFn spec, DstFn d
     } else {
         exchange_ob2(E, 0, e0, 1, e1);
     }
-    std::vector<u64*> z;                                    // (F = F0 + F1 is summed inside the product kernels)
+    std::vector<u64*> z(ns);                                // (F = F0 + F1 is summed inside the product kernels)
     GemmSpec g0 = spec(E->sides[0]);
     bool all_raw = true;
     for (auto& s : E->sides) { GemmSpec g = spec(s); all_raw = all_raw && E->be->cognn_beaver_gemm_fusable(g.M, g.N, g.K, g.transA); }
-    for (size_t i = 0; i < E->sides.size(); ++i) {
-        Side& s = E->sides[i];
+    for_sides(E, false, [&](Side& s, size_t i) {
         GemmSpec g = spec(s);
         cognn_keys k = gkeys(s, g);
         const u64* e_own = feature ? s.featSum : xsrc != X_OPEN_HERE ? s.h1E : s.ob[0];   // featSum is already the sum of both shares
@@ -353,21 +377,14 @@ void gemm_stage(cognn_engine* E, int64_t it, XFn X, WFn Wm, SpecFn spec, DstFn d
             cognn_keys tk = keys(E, s.owner, it, g.top);
             BE(cognn_trunc_open_add_u64(E->ctx, s.ob[2], s.zbuf, c1, &k, &tk, s.p, eo[i]));
         }
-        z.push_back(s.zbuf);
-    }
+        z[i] = s.zbuf;
+    });
     // all GEMMs of one stage share the truncation op id
     if (!all_raw) {
-        {
-            Batch batch(E);
-            for (size_t i = 0; i < E->sides.size(); ++i) {
-                Side& s = E->sides[i];
-                cognn_keys tk = keys(E, s.owner, it, g0.top);
-                BE(cognn_trunc_open_u64(E->ctx, s.ob[2], z[i], 1, &tk, s.p, eo[i]));
-            }
-        }
-        exchange_ob(E, 2, eo);
-        trunc_close_all(E, it, g0.top, dst, eo, open_next);
-        return;
+        for_sides(E, true, [&](Side& s, size_t i) {
+            cognn_keys tk = keys(E, s.owner, it, g0.top);
+            BE(cognn_trunc_open_u64(E->ctx, s.ob[2], z[i], 1, &tk, s.p, eo[i]));
+        });
     }
     exchange_ob(E, 2, eo);
     trunc_close_all(E, it, g0.top, dst, eo, open_next);
@@ -382,18 +399,16 @@ void rowscale_stage(cognn_engine* E, int64_t it, int op, int top, int F, XFn X, 
     //         E_IN_X    X(side) already holds E_p (written by the gather epilogue);
     //         E_IN_OB0  ob[0] already holds E_p (written by the truncation close that produced X)
     const bool e_opened = e_mode == E_IN_X;
-    std::vector<int64_t> eF, e1;
-    {
-        Batch batch(E);
-        for (auto& s : E->sides) {
-            cognn_keys k = keys(E, s.owner, it, op);
-            BE(cognn_rowscale_open_u64(E->ctx, e_mode == E_FROM_X ? s.ob[0] : nullptr, s.ob[1], X(s), s.svec, &k, s.p, s.n, F));
-            eF.push_back((int64_t)s.n * F); e1.push_back(s.n);
-        }
-    }
+    const size_t ns = E->sides.size();
+    std::vector<int64_t> eF(ns), e1(ns);
+    for_sides(E, true, [&](Side& s, size_t i) {
+        cognn_keys k = keys(E, s.owner, it, op);
+        BE(cognn_rowscale_open_u64(E->ctx, e_mode == E_FROM_X ? s.ob[0] : nullptr, s.ob[1], X(s), s.svec, &k, s.p, s.n, F));
+        eF[i] = (int64_t)s.n * F; e1[i] = s.n;
+    });
     if (e_opened) {
         XList xl;
-        for (size_t i = 0; i < E->sides.size(); ++i) {
+        for (size_t i = 0; i < ns; ++i) {
             Side& s = E->sides[i];
             if (s.peer) continue;
             xl.send(s.peer_rank, X(s), eF[i] * 8);
@@ -405,15 +420,12 @@ void rowscale_stage(cognn_engine* E, int64_t it, int op, int top, int F, XFn X, 
     } else {
         exchange_ob2(E, 0, eF, 1, e1);
     }
-    {
-        Batch batch(E);
-        for (auto& s : E->sides) {                          // the opened sums E0+E1, G0+G1 are formed inside the kernel
-            cognn_keys k = keys(E, s.owner, it, op), tk = keys(E, s.owner, it, top);
-            const u64* e_own = e_opened ? X(s) : s.ob[0];
-            const u64* e_peer = e_opened ? (s.peer ? X(*s.peer) : s.ib[0]) : s.ib[0];
-            BE(cognn_rowscale_close_u64(E->ctx, s.ob[2], e_own, e_peer, s.ob[1], s.ib[1], &k, &tk, s.p, s.n, F));
-        }
-    }
+    for_sides(E, true, [&](Side& s, size_t) {               // the opened sums E0+E1, G0+G1 are formed inside the kernel
+        cognn_keys k = keys(E, s.owner, it, op), tk = keys(E, s.owner, it, top);
+        const u64* e_own = e_opened ? X(s) : s.ob[0];
+        const u64* e_peer = e_opened ? (s.peer ? X(*s.peer) : s.ib[0]) : s.ib[0];
+        BE(cognn_rowscale_close_u64(E->ctx, s.ob[2], e_own, e_peer, s.ob[1], s.ib[1], &k, &tk, s.p, s.n, F));
+    });
     exchange_ob(E, 2, eF);
     trunc_close_all(E, it, top, dst, eF, open_next);
 }
@@ -421,38 +433,27 @@ void rowscale_stage(cognn_engine* E, int64_t it, int op, int top, int F, XFn X, 
 void relu_stage(cognn_engine* E, int64_t it, bool e_opened) {
     // e_opened: ob[0] already holds E = z - a (written by the truncation close that produced z)
     const int F = E->hid();
-    std::vector<int64_t> eF;
-    {
-        Batch batch(E);
-        for (auto& s : E->sides) {
-            cognn_keys k = keys(E, s.owner, it, COGNN_OP_AP_RELU);
-            // only E = z - a is opened online: g = t - b is input-independent and published by the dealer offline
-            if (!e_opened) BE(cognn_relu_open_u64(E->ctx, s.ob[0], nullptr, s.cur, &k, s.p, (int64_t)s.n * F));
-            eF.push_back((int64_t)s.n * F);
-        }
-    }
+    std::vector<int64_t> eF(E->sides.size());
+    for_sides(E, true, [&](Side& s, size_t i) {
+        cognn_keys k = keys(E, s.owner, it, COGNN_OP_AP_RELU);
+        // only E = z - a is opened online: g = t - b is input-independent and published by the dealer offline
+        if (!e_opened) BE(cognn_relu_open_u64(E->ctx, s.ob[0], nullptr, s.cur, &k, s.p, (int64_t)s.n * F));
+        eF[i] = (int64_t)s.n * F;
+    });
     exchange_ob(E, 0, eF);
-    {
-        Batch batch(E);
-        for (size_t i = 0; i < E->sides.size(); ++i) {
-            Side& s = E->sides[i];
-            cognn_keys k = keys(E, s.owner, it, COGNN_OP_AP_RELU);
-            BE(cognn_relu_mul_u64(E->ctx, s.ob[2], s.ob[0], s.ib[0], nullptr, nullptr, &k, s.p, eF[i]));
-        }
-    }
+    for_sides(E, true, [&](Side& s, size_t i) {
+        cognn_keys k = keys(E, s.owner, it, COGNN_OP_AP_RELU);
+        BE(cognn_relu_mul_u64(E->ctx, s.ob[2], s.ob[0], s.ib[0], nullptr, nullptr, &k, s.p, eF[i]));
+    });
     exchange_ob(E, 2, eF);
     // H is the next iteration's PreScatter GEMM input (layer 1): write it straight into its h_t slot and emit the
     // Beaver opening E_p = H_p - A_p of that product in the same pass (gcn.h:230-239 of iteration it+1)
-    {
-        Batch batch(E);
-        for (size_t i = 0; i < E->sides.size(); ++i) {
-            Side& s = E->sides[i];
-            cognn_keys nk = keys(E, s.owner, it + 1, COGNN_OP_PS_GEMM);
-            BE(cognn_relu_close_open_u64(E->ctx, s.h1, s.h1E, s.relu_mask, s.cur, s.ob[2], s.ib[2],
-                                         nk.k[s.p == 0 ? COGNN_SL_A0 : COGNN_SL_A1], eF[i]));
-            s.cur = s.h1;
-        }
-    }
+    for_sides(E, true, [&](Side& s, size_t i) {
+        cognn_keys nk = keys(E, s.owner, it + 1, COGNN_OP_PS_GEMM);
+        BE(cognn_relu_close_open_u64(E->ctx, s.h1, s.h1E, s.relu_mask, s.cur, s.ob[2], s.ib[2],
+                                     nk.k[s.p == 0 ? COGNN_SL_A0 : COGNN_SL_A1], eF[i]));
+        s.cur = s.h1;
+    });
     E->gemm_x_opened_for = it + 1;
 }
 
@@ -464,7 +465,7 @@ void softmax_stage(cognn_engine* E, int64_t it) {
         if (s.p == 1) xl.send(s.peer_rank, s.cur, (int64_t)s.n * L * 8);
         else xl.recv(s.peer_rank, s.ib[0], (int64_t)s.n * L * 8);
     }
-    run_exchange(E, xl);
+    run_exchange_sync(E, xl);
     for (auto& s : E->sides) {
         cognn_keys k = keys(E, s.owner, it, COGNN_OP_AP_SOFTMAX);
         const int64_t train = (int64_t)((double)s.n * E->cfg.train_ratio);      // gcn.h:560
@@ -508,7 +509,7 @@ void message_passing(cognn_engine* E, int F, int64_t it, bool open_scale) {
                 xl.recv(rc, seg, bytes);
             }
         }
-        run_exchange(E, xl);
+        run_exchange_sync(E, xl);
     }
     // partial sums of every hosted party for its remote destinations (ss_...h:827-835, 1063-1067)
     if (E->partRows > 0) {
@@ -525,7 +526,7 @@ void message_passing(cognn_engine* E, int F, int64_t it, bool open_scale) {
             if (sg.src_rank == E->rank && sg.dst_rank != E->rank) xl.send(sg.dst_rank, E->table + sg.out_off * F, sg.rows * F * 8);
             if (sg.dst_rank == E->rank && sg.src_rank != E->rank) xl.recv(sg.src_rank, E->table + sg.inbox_off * F, sg.rows * F * 8);
         }
-        run_exchange(E, xl);
+        run_exchange_sync(E, xl);
     }
     // aggregate: out = self + local in-edges + replica in-edges (owner rows) / + received partials (co rows)
     if (E->timing) BE(cognn_timer_begin(E->ctx, T_AGG));
@@ -582,7 +583,7 @@ void weight_average(cognn_engine* E, int64_t it, int layer) {
                 for (int r = 0; r < E->world; ++r)
                     if (r != E->rank) xl.recv(r, E->wa_recv[h] + (size_t)r * elems, (int64_t)bytes);
         }
-        run_exchange(E, xl);
+        run_exchange_sync(E, xl);
     }
     for (int h = 0; h < 2; ++h)
         if (E->rank == holder[h])
@@ -599,7 +600,7 @@ void weight_average(cognn_engine* E, int64_t it, int layer) {
             XList xl;
             if (E->rank == r1) xl.send(r0, c1, (int64_t)bytes);
             if (E->rank == r0) xl.recv(r1, c1, (int64_t)bytes);
-            run_exchange(E, xl);
+            run_exchange_sync(E, xl);
         }
         if (E->rank == r0) BE(cognn_trunc_close_u64(E->ctx, part[0], c0, c1, &tk, 0, 0, elems));
         if (E->rank == r1) BE(cognn_trunc_close_u64(E->ctx, part[1], nullptr, nullptr, &tk, 1, 0, elems));
@@ -615,7 +616,7 @@ void weight_average(cognn_engine* E, int64_t it, int layer) {
                 xl.recv(holder[h], avg[h], (int64_t)bytes);
             }
         }
-        run_exchange(E, xl);
+        run_exchange_sync(E, xl);
     }
     for (auto& s : E->sides) {                             // owner 0 keeps (s0, s1); owners >= 1 keep (s1, s0)
         const int which = (s.owner == 0) ? s.p : 1 - s.p;
@@ -667,25 +668,17 @@ void weight_update_chain(cognn_engine* E, int64_t it, int layer) {
     std::vector<int64_t> el;
     for (auto& s : E->sides) { d.push_back(s.small[0]); d2.push_back(s.small[1]); el.push_back(elems); }
     // gradient scale: per-owner constant, so the stage runs per side with its own multiplier
-    {
-        Batch batch(E);
-        for (size_t i = 0; i < E->sides.size(); ++i) {
-            Side& s = E->sides[i];
-            const int64_t train = (int64_t)((double)s.n * E->cfg.train_ratio);
-            const u64 gs = train > 0 ? fx_trunc(1.0 / (double)train) : 0;
-            cognn_keys k = keys(E, s.owner, it, COGNN_OP_AP_GSCALE_TRUNC);
-            BE(cognn_trunc_open_u64(E->ctx, s.ob[2], d[i], gs, &k, s.p, elems));
-        }
-    }
+    for_sides(E, true, [&](Side& s, size_t i) {
+        const int64_t train = (int64_t)((double)s.n * E->cfg.train_ratio);
+        const u64 gs = train > 0 ? fx_trunc(1.0 / (double)train) : 0;
+        cognn_keys k = keys(E, s.owner, it, COGNN_OP_AP_GSCALE_TRUNC);
+        BE(cognn_trunc_open_u64(E->ctx, s.ob[2], d[i], gs, &k, s.p, elems));
+    });
     exchange_ob(E, 2, el);
-    {
-        Batch batch(E);
-        for (size_t i = 0; i < E->sides.size(); ++i) {
-            Side& s = E->sides[i];
-            cognn_keys k = keys(E, s.owner, it, COGNN_OP_AP_GSCALE_TRUNC);
-            BE(cognn_trunc_close_u64(E->ctx, d2[i], s.p == 0 ? s.ob[2] : nullptr, s.p == 0 ? s.ib[2] : nullptr, &k, s.p, 0, elems));
-        }
-    }
+    for_sides(E, true, [&](Side& s, size_t i) {
+        cognn_keys k = keys(E, s.owner, it, COGNN_OP_AP_GSCALE_TRUNC);
+        BE(cognn_trunc_close_u64(E->ctx, d2[i], s.p == 0 ? s.ob[2] : nullptr, s.p == 0 ? s.ib[2] : nullptr, &k, s.p, 0, elems));
+    });
     const u64 lr = fx_trunc(E->cfg.learning_rate);
     trunc_stage(E, it, COGNN_OP_AP_LR_TRUNC, lr, d2, el, [&](Side& s) { return s.W[layer]; }, 1);
     if (E->cfg.variant == COGNN_VARIANT_OPTIMIZE_GCN_INFERENCE) {   // optimize-gcn-inference/gcn.h:680-681,732-733
@@ -780,6 +773,7 @@ void run_iteration(cognn_engine* E, int64_t it) {
         else { s.curF = 0; }                               // vertexInterData["g"] is empty for the first layer
     }
     weight_average(E, it, I.layer);
+    exchange_wait(E);
 }
 
 // dealer phase: product shares of every Beaver GEMM in [it0,it1)
@@ -1058,7 +1052,7 @@ void start(cognn_engine* E) {
             xl.send(s.peer_rank, s.featE, (int64_t)s.n * in * 8);
             xl.recv(s.peer_rank, s.featE_peer, (int64_t)s.n * in * 8);
         }
-        run_exchange(E, xl);
+        run_exchange_sync(E, xl);
     }
     // E = E_0 + E_1 is constant over the whole run: sum it once (in place; a co-located pair shares the owner side's copy, so
     // its two GEMMs read the same 8*n*in bytes)
@@ -1129,7 +1123,14 @@ int cognn_engine_destroy(cognn_engine* E) {
 }
 
 int cognn_engine_set_exchange(cognn_engine* E, cognn_exchange_fn fn, void* user) {
-    return guard([&] { if (!E) throw EngineError("null engine"); E->xfn = fn; E->xuser = user; });
+    return guard([&] { if (!E) throw EngineError("null engine"); E->xfn = fn; E->xwait = nullptr; E->xuser = user; });
+}
+int cognn_engine_set_exchange_async(cognn_engine* E, cognn_exchange_fn begin_fn, cognn_exchange_wait_fn wait_fn, void* user) {
+    return guard([&] {
+        if (!E) throw EngineError("null engine");
+        if (!begin_fn || !wait_fn) throw EngineError("cognn_engine_set_exchange_async: both functions are required");
+        E->xfn = begin_fn; E->xwait = wait_fn; E->xuser = user;
+    });
 }
 
 int cognn_engine_party_rows(cognn_engine* E, int32_t party, int64_t* rows) {

@@ -105,7 +105,7 @@ def main(argv=None):
                  device=local_rank if on_gpu else 0, stream=None if on_gpu else 0, undirected=a.u)
     if world > 1:
         from . import dist as cdist
-        eng.set_exchange(cdist.make_exchange(torch.device("cuda", local_rank) if on_gpu else torch.device("cpu")))
+        eng.set_exchange(cdist.make_exchange_async(torch.device("cuda", local_rank) if on_gpu else torch.device("cpu")))
     vids = {p: eng.party_vids(p) for p in eng.hosted}
     wanted = set(int(v) for p in eng.hosted for v in vids[p])
     rows = read_vertex_rows(vertex, wanted, gp.input_dim)

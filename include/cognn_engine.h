@@ -47,12 +47,18 @@ typedef struct {
 /* must perform all transfers of the list as one p2p group, ordered after previously enqueued work of
  * the engine's stream and complete (stream-ordered) before returning control for later kernels */
 typedef int (*cognn_exchange_fn)(void* user, const cognn_xfer* xfers, int32_t n);
+/* Asynchronous form: with a wait function registered, cognn_exchange_fn only ENQUEUES the round (ordered after the work
+ * already enqueued on the engine's stream) and returns; cognn_exchange_wait_fn makes later work of the engine's stream wait
+ * for every enqueued round.  The engine then runs the kernels of the sides whose peer is on the same rank between the two
+ * calls, so their compute overlaps the messages of the sides whose peer is remote.  At most one round is in flight. */
+typedef int (*cognn_exchange_wait_fn)(void* user);
 
 const char* cognn_engine_last_error(void);
 int cognn_engine_create(const cognn_engine_config* cfg, int64_t num_vertices, int64_t num_edges,
                         const int64_t* src, const int64_t* dst, const int32_t* part, cognn_engine** out);
 int cognn_engine_destroy(cognn_engine* e);
 int cognn_engine_set_exchange(cognn_engine* e, cognn_exchange_fn fn, void* user);
+int cognn_engine_set_exchange_async(cognn_engine* e, cognn_exchange_fn begin_fn, cognn_exchange_wait_fn wait_fn, void* user);
 /* rows (local vertices) of a party and their vids in row order (localVertexPos, ss_...h:474) */
 int cognn_engine_party_rows(cognn_engine* e, int32_t party, int64_t* rows);
 int cognn_engine_party_vids(cognn_engine* e, int32_t party, int64_t* vids);

@@ -30,7 +30,9 @@ def main():
     feats, labels = co.synth_features(V, cfg["in"], cfg["lab"], cfg["gseed"] + 1, density=0.2)
     gp = GnnParam(num_labels=cfg["lab"], input_dim=cfg["in"], hidden_dim=cfg["hid"], num_samples=V, learning_rate=0.5)
     eng = Engine(k, src, dst, part, gp, seed=cfg["seed"], variant=cfg["variant"], rank=rank, world=world, stream=0)
-    eng.set_exchange(cdist.make_exchange(torch.device("cuda", 0), host_staged=True) if hip else cdist.make_exchange(torch.device("cpu")))
+    # asynchronous exchange (begin / wait) unless the case asks for the blocking callback
+    mk = cdist.make_exchange if cfg.get("blocking_exchange") else cdist.make_exchange_async
+    eng.set_exchange(mk(torch.device("cuda", 0), host_staged=True) if hip else mk(torch.device("cpu")))
     eng.set_global_data(feats, labels)
     eng.start()
     out = {}

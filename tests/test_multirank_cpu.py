@@ -76,6 +76,10 @@ def test_four_parties_two_ranks_training(tmp_path):
     _check(dict(BASE, k=4), 2, tmp_path)
 
 
+def test_four_parties_two_ranks_training_blocking_exchange(tmp_path):
+    _check(dict(BASE, k=4, blocking_exchange=True), 2, tmp_path)
+
+
 def test_three_parties_three_ranks_training(tmp_path):
     _check(dict(BASE, k=3), 3, tmp_path)
 
