@@ -509,7 +509,7 @@ void message_passing(cognn_engine* E, int F, int64_t it, bool open_scale) {
                 xl.recv(rc, seg, bytes);
             }
         }
-        run_exchange_sync(E, xl);
+        run_exchange(E, xl);                                // in flight during the partial-sum launch below (it reads own-share rows only)
     }
     // partial sums of every hosted party for its remote destinations (ss_...h:827-835, 1063-1067)
     if (E->partRows > 0) {
