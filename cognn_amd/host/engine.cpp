@@ -1244,6 +1244,7 @@ int cognn_engine_run(cognn_engine* E, int64_t it0, int64_t it1) {
         for (int64_t it = it0; it < it1; ++it) {
             auto t0 = std::chrono::high_resolution_clock::now();
             run_iteration(E, it);
+            exchange_wait(E);                               // nothing stays in flight across iterations / API calls
             if (E->cfg.verbose) {
                 BE(cognn_ctx_sync(E->ctx));
                 const double sec = std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - t0).count();
