@@ -109,7 +109,8 @@ struct cognn_engine {
     std::vector<double> w0, w1;
     double algo[3] = {0, 0, 0};
     u64* wa[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // weight-averaging temporaries
-    u64* wa_recv[2] = {nullptr, nullptr};                                    // [world x elems] each
+    u64* wa_recv[2] = {nullptr, nullptr};                                    // [world x wa_stride] each
+    size_t wa_stride = 0;                                                     // even element count: every rank's slot is 16-byte aligned
 
     int in() const { return cfg.input_dim; }
     int hid() const { return cfg.hidden_dim; }
@@ -581,14 +582,14 @@ void weight_average(cognn_engine* E, int64_t it, int layer) {
             if (E->rank != holder[h]) xl.send(holder[h], part[h], (int64_t)bytes);
             else
                 for (int r = 0; r < E->world; ++r)
-                    if (r != E->rank) xl.recv(r, E->wa_recv[h] + (size_t)r * elems, (int64_t)bytes);
+                    if (r != E->rank) xl.recv(r, E->wa_recv[h] + (size_t)r * E->wa_stride, (int64_t)bytes);
         }
         run_exchange_sync(E, xl);
     }
     for (int h = 0; h < 2; ++h)
         if (E->rank == holder[h])
             for (int r = 0; r < E->world; ++r)
-                if (r != E->rank) BE(cognn_add_u64(E->ctx, part[h], part[h], E->wa_recv[h] + (size_t)r * elems, elems));
+                if (r != E->rank) BE(cognn_add_u64(E->ctx, part[h], part[h], E->wa_recv[h] + (size_t)r * E->wa_stride, elems));
     if (E->cfg.variant == COGNN_VARIANT_OPTIMIZE_GCN) {    // twoPartyGCNMatrixScale between parties 0 and 1
         cognn_keys tk = keys(E, COGNN_OWNER_WAVG, it, COGNN_OP_WAVG_TRUNC);
         const u64 ws = fx_trunc(1.0 / k);
@@ -957,7 +958,8 @@ void alloc_sides(cognn_engine* E) {
     {
         const size_t welems = std::max((size_t)in * hid, (size_t)hid * lab);
         for (int j = 0; j < 6; ++j) E->wa[j] = dalloc<u64>(E, welems);
-        for (int j = 0; j < 2; ++j) E->wa_recv[j] = dalloc<u64>(E, welems * (size_t)E->world);
+        E->wa_stride = (welems + 1) & ~(size_t)1;
+        for (int j = 0; j < 2; ++j) E->wa_recv[j] = dalloc<u64>(E, E->wa_stride * (size_t)E->world);
     }
     for (auto& s : E->sides) {
         const size_t n = (size_t)s.n;

@@ -2,6 +2,9 @@
 cuda:0), messages travel as host copies over gloo (cognn_amd/dist.py host_staged) because two RCCL ranks cannot share a
 device.  Exercises what the CPU multi-rank tests cannot: the rank-aware share-table layout, the partial-sum launch and the
 inbox/outbox segments with the HIP kernels.  Every rank's shares are compared bit for bit with the oracle."""
+import os
+
+import numpy as np
 import pytest
 
 from test_multirank_cpu import BASE, _check
@@ -40,3 +43,16 @@ def test_four_parties_four_ranks_training_hip(tmp_path):
     cfg = dict(BASE, k=4, V=600, Eu=2000, hid=16, lab=7, variant="optimize-gcn", iters=12, backend="hip")
     cfg["in"] = 33
     _check(cfg, 4, tmp_path)
+
+
+@pytest.mark.parametrize("seed", range(3 * int(os.environ.get("COGNN_FUZZ_SCALE", "1"))))
+def test_multirank_random_configuration_hip(tmp_path, seed):
+    rng = np.random.default_rng(9000 + seed)
+    world = int(rng.choice([2, 3, 4]))
+    k = world * int(rng.integers(1, 3))
+    V = int(rng.integers(k, 400))
+    cfg = dict(BASE, k=k, V=V, Eu=int(min(V * (V - 1) // 2, rng.integers(1, 4 * V + 1))), gseed=int(rng.integers(1, 1000)),
+               seed=int(rng.integers(1, 1 << 30)), hid=int(rng.choice([3, 8, 16, 33])), lab=int(rng.choice([2, 5, 16])),
+               variant="optimize-gcn" if seed % 2 else "optimize-gcn-inference", iters=6 if seed % 2 else 2, backend="hip")
+    cfg["in"] = int(rng.choice([5, 16, 40]))
+    _check(cfg, world, tmp_path)
