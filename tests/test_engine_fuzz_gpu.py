@@ -18,6 +18,9 @@ def test_engine_random_configuration(seed):
     rng = np.random.default_rng(7000 + seed)
     k = int(rng.integers(2, 6))
     V = int(rng.integers(k, 260))
+    if seed % 5 == 0:                                                     # enough rows per party for the MFMA product kernels (M >= 256)
+        k = int(rng.integers(2, 4))
+        V = int(rng.integers(600, 3000))
     max_pairs = V * (V - 1) // 2
     Eu = int(min(max_pairs, rng.integers(0, 4 * V + 1)))
     in_dim = int(rng.choice([3, 8, 17, 32, 50, 129]))
