@@ -811,17 +811,31 @@ class PlainEngine:
         deg = np.asarray(self.o.states[P].localVertexInDeg, dtype=np.float64)
         return np.where(deg == 0, 0.0, np.power(deg + 1.0, -0.5))
 
+    def _adjacency(self):
+        """Global (all parties' rows stacked) 0/1 adjacency of the real edges: built once from the same preprocess arrays the
+        share engine uses (dummy self sources dropped), as a scipy CSR so that long runs stay fast."""
+        if getattr(self, "_adj", None) is None:
+            import scipy.sparse as sp
+            off = np.cumsum([0] + [len(self.o.states[P].localVertexPos) for P in range(self.k)])
+            rows, cols = [], []
+            for P in range(self.k):
+                gs = self.o.states[P]
+                for i in range(self.k):
+                    for s, d in zip(gs.updateSrcVertexPos[i], gs.updateDstVertexPos[i]):
+                        if i == P and s == d and gs.isGatherDstVertexDummy[P][gs.reorderedIndex[d]]:
+                            continue                              # dummy self source
+                        (ps, rs), (pd, rd) = self.vid_row[s], self.vid_row[d]
+                        rows.append(off[pd] + rd); cols.append(off[ps] + rs)
+            n = int(off[-1])
+            self._adj = sp.csr_matrix((np.ones(len(rows)), (rows, cols)), shape=(n, n))
+            self._off = off
+        return self._adj, self._off
+
     def _aggregate(self):
-        newX = [x.copy() for x in self.X]
-        for P in range(self.k):
-            gs = self.o.states[P]
-            for i in range(self.k):
-                for s, d in zip(gs.updateSrcVertexPos[i], gs.updateDstVertexPos[i]):
-                    if i == P and s == d and gs.isGatherDstVertexDummy[P][gs.reorderedIndex[d]]:
-                        continue                              # dummy self source
-                    (ps, rs), (pd, rd) = self.vid_row[s], self.vid_row[d]
-                    newX[pd][rd] += self.X[ps][rs]
-        self.X = newX
+        A, off = self._adjacency()
+        allx = np.vstack(self.X)
+        allx = allx + A @ allx
+        self.X = [allx[off[P]:off[P + 1]] for P in range(self.k)]
 
     def iteration(self, it):
         o = self.o; g = o.param; ep = o.epoch_len(); f = o.fwd_layers(); e = it % ep
