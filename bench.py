@@ -166,15 +166,20 @@ def main():
     part = (np.arange(V) % k).astype(np.int32)
     param = GnnParam(num_labels=lab, input_dim=in_dim, hidden_dim=hid, num_samples=V, num_edges=len(src))
     eng = Engine(k, src, dst, part, param, seed=0xC06A11, variant=variant, rank=rank, world=world, device=local_rank)
+    xch = None
     if world > 1:
         from cognn_amd import dist as cdist
-        eng.set_exchange(cdist.make_exchange_async(torch.device("cuda", local_rank), host_staged=(backend != "nccl")))
+        if backend == "nccl":                 # the native transport: ncclSend/ncclRecv groups issued from C++ (include/cognn_exchange.h)
+            xch = cdist.attach_rccl(eng, local_rank)
+        else:                                 # rehearsal transport (gloo, host-staged)
+            eng.set_exchange(cdist.make_exchange_async(torch.device("cuda", local_rank), host_staged=True))
     for P in eng.hosted:                      # Bernoulli(0.01) bag-of-words features, uniform labels
         vids = eng.party_vids(P)
         rng = np.random.default_rng(0xC06A12 + P)
         eng.set_party_data(P, (rng.random((len(vids), in_dim)) < 0.01).astype(np.float64), rng.integers(0, lab, size=len(vids)))
     eng.start()
     t_off = time.perf_counter()
+    eng.retain_offline(True)                  # every step replays the same iterations: keep their dealt product shares
     eng.offline(0, iters)
     torch.cuda.synchronize()
     offline_ms = (time.perf_counter() - t_off) * 1e3
@@ -188,6 +193,7 @@ def main():
     for _ in range(args.warmup):
         eng.run(0, iters)
     eng.enable_timing(True)
+    x0 = xch.stats() if xch else None
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -198,6 +204,7 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    x1 = xch.stats() if xch else None
     n_agg, ms_agg, bytes_agg = eng.timing(0)
     n_part, ms_part, bytes_part = eng.timing(1)
     n_gemm, ms_gemm, ops_gemm = eng.timing(2)
@@ -237,6 +244,11 @@ def main():
                                           "frac_of_5000_TOPs": ((ops_gemm / 1e12) / (ms_gemm / 1e3) / 5000.0) if ms_gemm > 0 else None}},
         "graph": wlinfo,
     }
+    if xch:                                   # rank 0's share of the exchange: rounds and bytes per step (all ranks are symmetric up to the partition)
+        out["exchange"] = {"rounds_per_step": (x1["rounds"] - x0["rounds"]) / args.steps,
+                           "MB_sent_per_step": (x1["bytes_sent"] - x0["bytes_sent"]) / args.steps / 1e6,
+                           "MB_received_per_step": (x1["bytes_received"] - x0["bytes_received"]) / args.steps / 1e6,
+                           "transport": "native RCCL p2p groups on a communication stream (csrc/exchange_rccl.hip)"}
     if args.check and world == 1:
         a = eng.shares(0, 0); b = eng.shares(0, 1)
         with np.errstate(over="ignore"):
@@ -249,6 +261,8 @@ def main():
     if rank == 0:
         print(json.dumps(out))
     eng.close()
+    if xch:
+        xch.close()
     if world > 1:
         dist.destroy_process_group()
 

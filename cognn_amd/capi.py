@@ -92,12 +92,12 @@ def exported_names():
     return list(_SIGNATURES.keys())
 
 
-def load(path=None):
-    """Load libcognn_hip.so once and declare every entry point of the C ABI."""
+def load():
+    """Load libcognn_hip.so (LIB_PATH) once and declare every entry point of the C ABI."""
     global _lib
     if _lib is not None:
         return _lib
-    path = path or LIB_PATH
+    path = LIB_PATH
     try:
         # Load order matters: torch ships its own libamdhip64.so.7; importing it first makes this library bind to
         # the same HIP runtime instance instead of bringing a second one into the process (INTEGRATION.md §3).

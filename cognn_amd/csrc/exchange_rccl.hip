@@ -1,0 +1,229 @@
+// Native share exchange over RCCL (include/cognn_exchange.h): one p2p group per round on a communication stream, ordered with
+// the engine's compute stream by HIP events only.  Stands in for the reference's TCP mesh and message helpers
+// (include/engine.h:157-201, include/comm_sync.h:245-277).
+#include <arpa/inet.h>
+#include <errno.h>
+#include <netinet/in.h>
+#include <netinet/tcp.h>
+#include <rccl/rccl.h>
+#include <stdarg.h>
+#include <string.h>
+#include <sys/socket.h>
+#include <unistd.h>
+
+#include <chrono>
+#include <thread>
+
+#include "common.h"
+#include "../../include/cognn_exchange.h"
+
+static thread_local char g_xerr[1024] = "";
+static int xerr(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_xerr, sizeof(g_xerr), fmt, ap);
+    va_end(ap);
+    return 1;
+}
+#define X_HIP(expr)                                                                                            \
+    do {                                                                                                       \
+        hipError_t _e = (expr);                                                                                \
+        if (_e != hipSuccess) return xerr("%s:%d: %s failed: %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+    } while (0)
+#define X_NCCL(expr)                                                                                           \
+    do {                                                                                                       \
+        ncclResult_t _r = (expr);                                                                              \
+        if (_r != ncclSuccess) return xerr("%s:%d: %s failed: %s", __FILE__, __LINE__, #expr, ncclGetErrorString(_r)); \
+    } while (0)
+#define X_REQUIRE(cond, ...)                     \
+    do {                                         \
+        if (!(cond)) return xerr(__VA_ARGS__);   \
+    } while (0)
+
+struct cognn_rccl_exchange {
+    ncclComm_t comm = nullptr;
+    int rank = 0, world = 1, device = 0;
+    hipStream_t compute = nullptr;      // the engine's stream (not owned)
+    hipStream_t comm_stream = nullptr;  // owned
+    hipEvent_t ready = nullptr;         // compute -> comm: the round's send buffers are written
+    hipEvent_t done = nullptr;          // comm -> compute: the round's messages have arrived
+    int64_t rounds = 0, sent = 0, received = 0;
+    uint64_t* scratch = nullptr;        // barrier payload
+};
+
+extern "C" {
+
+const char* cognn_exchange_last_error(void) { return g_xerr; }
+
+int cognn_rccl_unique_id(void* id128) {
+    X_REQUIRE(id128, "cognn_rccl_unique_id: null argument");
+    static_assert(sizeof(ncclUniqueId) == COGNN_RCCL_ID_BYTES, "ncclUniqueId size");
+    ncclUniqueId id;
+    X_NCCL(ncclGetUniqueId(&id));
+    memcpy(id128, &id, sizeof(id));
+    return 0;
+}
+
+static int write_all(int fd, const void* p, size_t n) {
+    const char* c = (const char*)p;
+    while (n) {
+        ssize_t w = send(fd, c, n, MSG_NOSIGNAL);
+        if (w <= 0) { if (errno == EINTR) continue; return 1; }
+        c += w; n -= (size_t)w;
+    }
+    return 0;
+}
+static int read_all(int fd, void* p, size_t n) {
+    char* c = (char*)p;
+    while (n) {
+        ssize_t r = recv(fd, c, n, 0);
+        if (r <= 0) { if (r < 0 && errno == EINTR) continue; return 1; }
+        c += r; n -= (size_t)r;
+    }
+    return 0;
+}
+
+int cognn_rccl_rendezvous_tcp(const char* addr, int port, int rank, int world, double timeout_s, void* id128) {
+    X_REQUIRE(addr && id128 && world >= 1 && rank >= 0 && rank < world, "cognn_rccl_rendezvous_tcp: bad arguments");
+    if (port <= 0) port = 1712;                                     // the reference's base port (engine.h:171)
+    sockaddr_in sa;
+    memset(&sa, 0, sizeof(sa));
+    sa.sin_family = AF_INET;
+    sa.sin_port = htons((uint16_t)port);
+    X_REQUIRE(inet_pton(AF_INET, addr, &sa.sin_addr) == 1, "cognn_rccl_rendezvous_tcp: '%s' is not an IPv4 address", addr);
+    const auto deadline = std::chrono::steady_clock::now() + std::chrono::duration<double>(timeout_s);
+    if (rank == 0) {
+        if (cognn_rccl_unique_id(id128)) return 1;
+        if (world == 1) return 0;
+        int ls = socket(AF_INET, SOCK_STREAM, 0);
+        X_REQUIRE(ls >= 0, "cognn_rccl_rendezvous_tcp: socket: %s", strerror(errno));
+        int one = 1;
+        setsockopt(ls, SOL_SOCKET, SO_REUSEADDR, &one, sizeof(one));
+        if (bind(ls, (sockaddr*)&sa, sizeof(sa)) != 0 || listen(ls, world) != 0) {
+            const int e = errno; close(ls);
+            return xerr("cognn_rccl_rendezvous_tcp: cannot listen on %s:%d: %s", addr, port, strerror(e));
+        }
+        timeval tv; tv.tv_sec = 1; tv.tv_usec = 0;
+        setsockopt(ls, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof(tv));    // accept() wakes up once a second to check the deadline
+        for (int served = 0; served < world - 1;) {
+            int c = accept(ls, nullptr, nullptr);
+            if (c < 0) {
+                if (std::chrono::steady_clock::now() > deadline) { close(ls); return xerr("cognn_rccl_rendezvous_tcp: %d of %d ranks connected before the timeout", served, world - 1); }
+                continue;
+            }
+            int32_t peer = -1;
+            const int bad = read_all(c, &peer, sizeof(peer)) || peer <= 0 || peer >= world || write_all(c, id128, COGNN_RCCL_ID_BYTES);
+            close(c);
+            if (bad) { close(ls); return xerr("cognn_rccl_rendezvous_tcp: hand-shake with a client failed"); }
+            ++served;
+        }
+        close(ls);
+        return 0;
+    }
+    for (;;) {
+        int s = socket(AF_INET, SOCK_STREAM, 0);
+        X_REQUIRE(s >= 0, "cognn_rccl_rendezvous_tcp: socket: %s", strerror(errno));
+        if (connect(s, (sockaddr*)&sa, sizeof(sa)) == 0) {
+            int32_t me = rank;
+            const int bad = write_all(s, &me, sizeof(me)) || read_all(s, id128, COGNN_RCCL_ID_BYTES);
+            close(s);
+            X_REQUIRE(!bad, "cognn_rccl_rendezvous_tcp: hand-shake with rank 0 failed");
+            return 0;
+        }
+        close(s);
+        if (std::chrono::steady_clock::now() > deadline) return xerr("cognn_rccl_rendezvous_tcp: rank 0 at %s:%d not reachable: %s", addr, port, strerror(errno));
+        std::this_thread::sleep_for(std::chrono::milliseconds(50));
+    }
+}
+
+int cognn_rccl_exchange_create(const void* id128, int rank, int world, int device, void* compute_stream, cognn_rccl_exchange** out) {
+    X_REQUIRE(id128 && out && world >= 1 && rank >= 0 && rank < world, "cognn_rccl_exchange_create: bad arguments");
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    X_REQUIRE(e == hipSuccess && count > 0, "cognn_rccl_exchange_create: no HIP device available");
+    X_REQUIRE(device >= 0 && device < count, "cognn_rccl_exchange_create: device %d out of range (count %d)", device, count);
+    X_HIP(hipSetDevice(device));
+    cognn_rccl_exchange* x = new cognn_rccl_exchange();
+    x->rank = rank; x->world = world; x->device = device; x->compute = (hipStream_t)compute_stream;
+    ncclUniqueId id;
+    memcpy(&id, id128, sizeof(id));
+    ncclResult_t r = ncclCommInitRank(&x->comm, world, id, rank);
+    if (r != ncclSuccess) { delete x; return xerr("cognn_rccl_exchange_create: ncclCommInitRank failed: %s", ncclGetErrorString(r)); }
+    if (hipStreamCreateWithFlags(&x->comm_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&x->ready, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&x->done, hipEventDisableTiming) != hipSuccess || hipMalloc((void**)&x->scratch, 16) != hipSuccess) {
+        cognn_rccl_exchange_destroy(x);
+        return xerr("cognn_rccl_exchange_create: stream / event creation failed");
+    }
+    *out = x;
+    return 0;
+}
+
+int cognn_rccl_exchange_destroy(cognn_rccl_exchange* x) {
+    if (!x) return 0;
+    if (x->comm_stream) (void)hipStreamSynchronize(x->comm_stream);
+    if (x->comm) (void)ncclCommDestroy(x->comm);
+    if (x->ready) (void)hipEventDestroy(x->ready);
+    if (x->done) (void)hipEventDestroy(x->done);
+    if (x->comm_stream) (void)hipStreamDestroy(x->comm_stream);
+    if (x->scratch) (void)hipFree(x->scratch);
+    delete x;
+    return 0;
+}
+
+int cognn_rccl_exchange_begin(void* user, const cognn_xfer* xfers, int32_t n) {
+    cognn_rccl_exchange* x = (cognn_rccl_exchange*)user;
+    X_REQUIRE(x && (n == 0 || xfers), "cognn_rccl_exchange_begin: bad arguments");
+    for (int32_t i = 0; i < n; ++i)
+        X_REQUIRE(xfers[i].peer >= 0 && xfers[i].peer < x->world && xfers[i].ptr && xfers[i].bytes > 0,
+                  "cognn_rccl_exchange_begin: message %d is malformed (peer %d, %lld bytes)", i, xfers[i].peer, (long long)xfers[i].bytes);
+    // the messages may only leave once the kernels that write them have run ...
+    X_HIP(hipEventRecord(x->ready, x->compute));
+    X_HIP(hipStreamWaitEvent(x->comm_stream, x->ready, 0));
+    X_NCCL(ncclGroupStart());
+    for (int32_t i = 0; i < n; ++i) {
+        const cognn_xfer& t = xfers[i];
+        ncclResult_t r = t.is_send ? ncclSend(t.ptr, (size_t)t.bytes, ncclChar, t.peer, x->comm, x->comm_stream)
+                                   : ncclRecv(t.ptr, (size_t)t.bytes, ncclChar, t.peer, x->comm, x->comm_stream);
+        if (r != ncclSuccess) { (void)ncclGroupEnd(); return xerr("cognn_rccl_exchange_begin: %s failed: %s", t.is_send ? "ncclSend" : "ncclRecv", ncclGetErrorString(r)); }
+        (t.is_send ? x->sent : x->received) += t.bytes;
+    }
+    X_NCCL(ncclGroupEnd());
+    // ... and whoever consumes a received buffer (or overwrites a sent one) waits for this event on the compute stream
+    X_HIP(hipEventRecord(x->done, x->comm_stream));
+    ++x->rounds;
+    return 0;
+}
+
+int cognn_rccl_exchange_wait(void* user) {
+    cognn_rccl_exchange* x = (cognn_rccl_exchange*)user;
+    X_REQUIRE(x, "cognn_rccl_exchange_wait: null exchange");
+    X_HIP(hipStreamWaitEvent(x->compute, x->done, 0));
+    return 0;
+}
+
+int cognn_engine_set_exchange_rccl(cognn_engine* e, cognn_rccl_exchange* x) {
+    X_REQUIRE(e && x, "cognn_engine_set_exchange_rccl: null argument");
+    if (cognn_engine_set_exchange_async(e, cognn_rccl_exchange_begin, cognn_rccl_exchange_wait, x) != 0)
+        return xerr("cognn_engine_set_exchange_rccl: %s", cognn_engine_last_error());
+    return 0;
+}
+
+int cognn_rccl_exchange_stats(cognn_rccl_exchange* x, int64_t* rounds, int64_t* bytes_sent, int64_t* bytes_received) {
+    X_REQUIRE(x, "cognn_rccl_exchange_stats: null exchange");
+    if (rounds) *rounds = x->rounds;
+    if (bytes_sent) *bytes_sent = x->sent;
+    if (bytes_received) *bytes_received = x->received;
+    return 0;
+}
+
+int cognn_rccl_exchange_barrier(cognn_rccl_exchange* x) {
+    X_REQUIRE(x, "cognn_rccl_exchange_barrier: null exchange");
+    X_HIP(hipEventRecord(x->ready, x->compute));
+    X_HIP(hipStreamWaitEvent(x->comm_stream, x->ready, 0));
+    X_NCCL(ncclAllReduce(x->scratch, x->scratch + 1, 1, ncclUint64, ncclSum, x->comm, x->comm_stream));
+    X_HIP(hipStreamSynchronize(x->comm_stream));
+    return 0;
+}
+
+}  // extern "C"

@@ -1,14 +1,79 @@
-"""Share-exchange / Beaver-reveal rounds over torch.distributed (backend "nccl" = RCCL over xGMI on the
-GPU box, "gloo" in the CPU tests).  Replaces the reference's TCP paths (CommSync::send/recvShareVecVec,
-include/comm_sync.h:245-277; TaskComm; Engine's channel mesh, include/engine.h:157-201): one logical
-message = one p2p op on a flat uint64 buffer, all messages of a round issued as one p2p group."""
+"""Share-exchange transports for Python hosts.
+
+* `attach_rccl(engine, ...)` - the product path: the native RCCL transport of libcognn_hip.so (include/cognn_exchange.h,
+  csrc/exchange_rccl.hip).  Python only bootstraps it (the 128-byte communicator id travels over the existing
+  torch.distributed group, or over the library's own TCP rendezvous); every round afterwards is ncclSend/ncclRecv issued
+  from C++ on a communication stream - no interpreter in the loop.
+* `make_exchange[_async]` - the same rounds over torch.distributed p2p ops, kept as the TEST transport: "gloo" lets the
+  multi-rank engine logic run on CPU-only machines and lets several ranks share one GPU (host-staged), which RCCL cannot.
+
+Both replace the reference's TCP paths (CommSync::send/recvShareVecVec, include/comm_sync.h:245-277; TaskComm; Engine's
+channel mesh, include/engine.h:157-201): one logical message = one p2p op on a flat uint64 buffer, all messages of a
+round issued as one p2p group."""
 import ctypes
 
 import numpy as np
 import torch
 import torch.distributed as dist
 
-from .engine_api import EXCHANGE_FN, EXCHANGE_WAIT_FN
+from .engine_api import EXCHANGE_FN, EXCHANGE_WAIT_FN, RCCL_ID_BYTES
+
+
+class RcclExchange:
+    """Owner of a cognn_rccl_exchange handle."""
+
+    def __init__(self, lib, handle, rank, world):
+        self.lib = lib; self.h = handle; self.rank = rank; self.world = world
+
+    def stats(self):
+        r = ctypes.c_int64(); s = ctypes.c_int64(); v = ctypes.c_int64()
+        if self.lib.cognn_rccl_exchange_stats(self.h, ctypes.byref(r), ctypes.byref(s), ctypes.byref(v)) != 0:
+            raise RuntimeError(self.lib.cognn_exchange_last_error().decode())
+        return {"rounds": r.value, "bytes_sent": s.value, "bytes_received": v.value}
+
+    def barrier(self):
+        if self.lib.cognn_rccl_exchange_barrier(self.h) != 0:
+            raise RuntimeError(self.lib.cognn_exchange_last_error().decode())
+
+    def close(self):
+        if self.h:
+            self.lib.cognn_rccl_exchange_destroy(self.h)
+            self.h = None
+
+
+def create_rccl_exchange(rank, world, device_index, stream, group=None, tcp=None):
+    """Creates the native transport for this rank.  The communicator id comes from rank 0 through `group` (any
+    torch.distributed backend) or, with tcp=(addr, port), through the library's own rendezvous."""
+    from . import capi
+    lib = capi.load()
+    if not hasattr(lib, "cognn_rccl_exchange_create"):
+        raise capi.CognnError("this engine library was built without the RCCL transport")
+    ident = (ctypes.c_uint8 * RCCL_ID_BYTES)()
+    if tcp is not None:
+        if lib.cognn_rccl_rendezvous_tcp(tcp[0].encode(), int(tcp[1]), rank, world, 120.0, ident) != 0:
+            raise capi.CognnError(lib.cognn_exchange_last_error().decode())
+    else:
+        if rank == 0 and lib.cognn_rccl_unique_id(ident) != 0:
+            raise capi.CognnError(lib.cognn_exchange_last_error().decode())
+        if world > 1:
+            box = [bytes(ident) if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0, group=group)
+            ctypes.memmove(ident, box[0], RCCL_ID_BYTES)
+    h = ctypes.c_void_p()
+    if lib.cognn_rccl_exchange_create(ident, rank, world, device_index, ctypes.c_void_p(stream), ctypes.byref(h)) != 0:
+        raise capi.CognnError(lib.cognn_exchange_last_error().decode())
+    return RcclExchange(lib, h, rank, world)
+
+
+def attach_rccl(engine, device_index, stream=None, group=None, tcp=None):
+    """Gives `engine` the native RCCL transport (see module docstring); returns the RcclExchange (keep it alive)."""
+    if stream is None:
+        stream = torch.cuda.current_stream(device_index).cuda_stream
+    x = create_rccl_exchange(engine.rank, engine.world, device_index, stream, group=group, tcp=tcp)
+    if x.lib.cognn_engine_set_exchange_rccl(engine.h, x.h) != 0:
+        raise RuntimeError(x.lib.cognn_exchange_last_error().decode())
+    engine._xfn = x
+    return x
 
 
 class _DevBuf:

@@ -127,6 +127,24 @@ class Engine:
     def run(self, it0, it1):
         _check(self.lib.cognn_engine_run(self.h, it0, it1))
 
+    def sync(self):
+        _check(self.lib.cognn_engine_sync(self.h))
+
+    def retain_offline(self, on=True):
+        """Keep dealt product shares after use (replaying the same iterations, e.g. bench.py); default: release them."""
+        _check(self.lib.cognn_engine_set_option(self.h, 1, int(on)))
+
+    def phase_seconds(self):
+        """Device time per phase of the last iteration (engine created with verbose=True), see cognn_engine_get_phase_seconds."""
+        out = np.zeros(6, dtype=np.float64)
+        _check(self.lib.cognn_engine_get_phase_seconds(self.h, out.ctypes.data))
+        return dict(zip(["prescatter", "message_passing", "gather_scale", "apply", "weight_average", "rounds"], out.tolist()))
+
+    def memory(self):
+        n = ctypes.c_int64(); b = ctypes.c_int64()
+        _check(self.lib.cognn_engine_get_memory(self.h, ctypes.byref(n), ctypes.byref(b)))
+        return n.value, b.value
+
     def shares(self, owner, side):
         r = ctypes.c_int64(); c = ctypes.c_int64()
         _check(self.lib.cognn_engine_get_shares(self.h, owner, side, None, ctypes.byref(r), ctypes.byref(c)))

@@ -44,11 +44,31 @@ _SIGNATURES = {
     "cognn_engine_enable_timing": (ctypes.c_int, [_P, _I]),
     "cognn_engine_get_timing": (ctypes.c_int, [_P, _I, ctypes.POINTER(_L), ctypes.POINTER(_D), ctypes.POINTER(_D)]),
     "cognn_engine_get_workload": (ctypes.c_int, [_P, _P]),
+    "cognn_engine_sync": (ctypes.c_int, [_P]),
+    "cognn_engine_get_phase_seconds": (ctypes.c_int, [_P, _P]),
+    "cognn_engine_set_option": (ctypes.c_int, [_P, _I, _L]),
+    "cognn_engine_get_memory": (ctypes.c_int, [_P, ctypes.POINTER(_L), ctypes.POINTER(_L)]),
 }
 
 
+# include/cognn_exchange.h: the native RCCL transport (only in the HIP library)
+_EXCHANGE_SIGNATURES = {
+    "cognn_exchange_last_error": (ctypes.c_char_p, []),
+    "cognn_rccl_unique_id": (ctypes.c_int, [_P]),
+    "cognn_rccl_rendezvous_tcp": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, _D, _P]),
+    "cognn_rccl_exchange_create": (ctypes.c_int, [_P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P, ctypes.POINTER(_P)]),
+    "cognn_rccl_exchange_destroy": (ctypes.c_int, [_P]),
+    "cognn_rccl_exchange_begin": (ctypes.c_int, [_P, ctypes.POINTER(Xfer), _I]),
+    "cognn_rccl_exchange_wait": (ctypes.c_int, [_P]),
+    "cognn_engine_set_exchange_rccl": (ctypes.c_int, [_P, _P]),
+    "cognn_rccl_exchange_stats": (ctypes.c_int, [_P, ctypes.POINTER(_L), ctypes.POINTER(_L), ctypes.POINTER(_L)]),
+    "cognn_rccl_exchange_barrier": (ctypes.c_int, [_P]),
+}
+RCCL_ID_BYTES = 128
+
+
 def exported_names():
-    return list(_SIGNATURES.keys())
+    return list(_SIGNATURES.keys()) + list(_EXCHANGE_SIGNATURES.keys())
 
 
 def declare(lib):
@@ -56,3 +76,8 @@ def declare(lib):
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
+    for name, (res, args) in _EXCHANGE_SIGNATURES.items():
+        fn = getattr(lib, name, None)          # absent from a library built without the transport
+        if fn is not None:
+            fn.restype = res
+            fn.argtypes = args

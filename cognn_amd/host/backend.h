@@ -1,9 +1,9 @@
 // Arithmetic backend used by the host engine: exactly the entry points of include/cognn_hip.h as a
 // table of function pointers.  libcognn_hip.so binds it to the HIP implementations
-// (cognn_hip_backend(), backend_hip.cpp).  The engine source itself contains no device code, so the
-// tests can build the same engine.cpp against a plain-C++ stand-in (tests/cpu_backend/) to exercise the
-// multi-rank exchange logic on CPU with gloo; that stand-in is test infrastructure and is never linked
-// into the product library.
+// (cognn_default_backend(), backend_hip.cpp) - the only table the product library links.  The engine source itself
+// contains no device code, so the tests can build the same engine.cpp against a plain-C++ stand-in
+// (oracle/cpu_backend.cpp -> oracle/libcognn_engine_cpu.so) to exercise the multi-rank exchange logic on CPU with gloo;
+// that stand-in is test infrastructure and is never linked into the product library.
 #pragma once
 #include "../../include/cognn_hip.h"
 

@@ -37,11 +37,10 @@ struct EngineError : std::runtime_error {
     using std::runtime_error::runtime_error;
 };
 
-enum { T_AGG = 0, T_PART = 1, T_GEMM = 2 };
+enum { T_AGG = 0, T_PART = 1, T_GEMM = 2, T_PH_PRESCATTER = 3, T_PH_MP = 4, T_PH_GATHER = 5, T_PH_APPLY = 6, T_PH_WAVG = 7 };
 
 struct Side {
     int owner = 0, p = 0, n = 0;
-    std::map<std::pair<int64_t, int>, int64_t> c1_elems;   // size of every dealt product share
     int peer_rank = 0;
     Side* peer = nullptr;          // non-null when the other share-holder is hosted on this rank
     u64* feat = nullptr;           // [n x in] input-feature share (localVertexSvvBackup / remoteVertexSvvsBackup)
@@ -71,7 +70,8 @@ struct Side {
     int64_t* counts = nullptr;
     double* loss = nullptr;
     bool has_metrics = false;
-    std::map<std::pair<int64_t, int>, u64*> c1;   // dealer product shares, (iter, op) -> [M x N]
+    struct C1 { u64* ptr; int64_t elems; };
+    std::map<std::pair<int64_t, int>, C1> c1;     // dealt product shares not consumed yet, (iter, op) -> [M x N]
 };
 
 }  // namespace
@@ -85,6 +85,11 @@ struct cognn_engine {
     std::vector<int> hosted, cohosted;
     std::vector<Side> sides;
     std::vector<void*> allocs;
+    int64_t alloc_bytes = 0;
+    std::map<int64_t, std::vector<u64*>> c1_pool;   // released product-share buffers by element count, reused by later deals
+    bool retain_offline = false;                    // COGNN_OPT_RETAIN_OFFLINE
+    double phase_s[6] = {0, 0, 0, 0, 0, 0};         // cognn_engine_get_phase_seconds
+    int64_t rounds = 0;                             // exchange rounds started (all iterations)
     cognn_exchange_fn xfn = nullptr;
     cognn_exchange_wait_fn xwait = nullptr;   // set: xfn only enqueues the round, xwait completes it (asynchronous exchange)
     void* xuser = nullptr;
@@ -146,8 +151,29 @@ T* dalloc(cognn_engine* E, size_t count) {
     void* p = nullptr;
     BE(cognn_malloc(E->ctx, &p, std::max<size_t>(count, 2) * sizeof(T)));
     E->allocs.push_back(p);
+    E->alloc_bytes += (int64_t)(std::max<size_t>(count, 2) * sizeof(T));
     return (T*)p;
 }
+// product-share buffers are recycled: a consumed share goes back to the pool and serves a later deal of the same size
+// (everything runs on one stream, so reuse is ordered after the last reader)
+u64* c1_alloc(cognn_engine* E, int64_t elems) {
+    auto& v = E->c1_pool[elems];
+    if (!v.empty()) { u64* p = v.back(); v.pop_back(); return p; }
+    return dalloc<u64>(E, (size_t)elems);
+}
+void c1_release(cognn_engine* E, Side& s, std::pair<int64_t, int> key) {
+    auto f = s.c1.find(key);
+    if (f == s.c1.end() || E->retain_offline) return;
+    E->c1_pool[f->second.elems].push_back(f->second.ptr);
+    s.c1.erase(f);
+}
+// HIP-event bracket of one phase of an iteration (cfg.verbose)
+struct Phase {
+    cognn_engine* E; int kind; bool on;
+    Phase(cognn_engine* e, int k) : E(e), kind(k), on(e->cfg.verbose != 0) { if (on) BE(cognn_timer_begin(E->ctx, kind)); }
+    void end() { if (on) { on = false; BE(cognn_timer_end(E->ctx, kind)); } }
+    ~Phase() { if (on) E->be->cognn_timer_end(E->ctx, kind); }
+};
 template <class T>
 T* upload(cognn_engine* E, const std::vector<T>& v) {
     T* d = dalloc<T>(E, v.size());
@@ -197,6 +223,7 @@ void run_exchange(cognn_engine* E, XList& xl) {
     if (xl.v.empty()) return;
     if (!E->xfn) throw EngineError("engine: world > 1 needs an exchange function (cognn_engine_set_exchange)");
     if (E->xfn(E->xuser, xl.v.data(), (int32_t)xl.v.size()) != 0) throw EngineError("engine: exchange function failed");
+    ++E->rounds;
     if (E->xwait) E->xpending = true;
 }
 void run_exchange_sync(cognn_engine* E, XList& xl) {
@@ -362,12 +389,11 @@ void gemm_stage(cognn_engine* E, int64_t it, XFn X, WFn Wm, SpecFn spec, DstFn d
         if (s.p == 1) {
             auto f = s.c1.find({it, g.op});
             if (f == s.c1.end()) {                       // dealer product share not precomputed: do it now
-                u64* c = dalloc<u64>(E, (size_t)eo[i]);
+                u64* c = c1_alloc(E, eo[i]);
                 BE(cognn_dealer_gemm_c1_u64(E->ctx, c, &k, g.M, g.N, g.K, g.transA, s.scratch, s.scratch + g.M * g.K));
-                f = s.c1.emplace(std::make_pair(it, g.op), c).first;
-                s.c1_elems[{it, g.op}] = eo[i];
+                f = s.c1.emplace(std::make_pair(it, g.op), Side::C1{c, eo[i]}).first;
             }
-            c1 = f->second;
+            c1 = f->second.ptr;
         }
         if (E->timing) BE(cognn_timer_begin(E->ctx, T_GEMM));
         // all_raw: fused single-launch product without C_p; C_p joins in the truncation opening below
@@ -378,6 +404,7 @@ void gemm_stage(cognn_engine* E, int64_t it, XFn X, WFn Wm, SpecFn spec, DstFn d
             cognn_keys tk = keys(E, s.owner, it, g.top);
             BE(cognn_trunc_open_add_u64(E->ctx, s.ob[2], s.zbuf, c1, &k, &tk, s.p, eo[i]));
         }
+        if (s.p == 1) c1_release(E, s, {it, g.op});       // consumed: the buffer serves a later deal
         z[i] = s.zbuf;
     });
     // all GEMMs of one stage share the truncation op id
@@ -698,6 +725,7 @@ void run_iteration(cognn_engine* E, int64_t it) {
     if (!I.apply_only) {
         const int F = mp_width(E, I.e);
         // ---- PreScatterComp (gcn.h:198-255) ----
+        Phase ph_ps(E, T_PH_PRESCATTER);
         if (I.fwd) {
             bool x_opened = (I.layer == 1 && E->gemm_x_opened_for == it);   // H already sits in h_t[1], its opening in h1E
             if (I.layer == 1 && !x_opened) {               // (not reached in a normal run: the ReLU close of iteration it-1 does both)
@@ -722,11 +750,16 @@ void run_iteration(cognn_engine* E, int64_t it) {
             rowscale_stage(E, it, COGNN_OP_PS_SCALE, COGNN_OP_PS_SCALE_TRUNC, F, [&](Side& s) { return s.cur; },
                            [&](Side& s) { return table_seg(E, s, F); });
         }
+        ph_ps.end();
         // ---- Scatter / PreMerge / Gather ----
         const bool gscale = (it + 1) % I.ep != 0;          // gcn.h:470
         const bool fuse_open = gscale && E->sides.size() <= 32;
-        message_passing(E, F, it, fuse_open);
+        {
+            Phase ph_mp(E, T_PH_MP);
+            message_passing(E, F, it, fuse_open);
+        }
         relu_opened = false;
+        Phase ph_ga(E, T_PH_GATHER);
         if (gscale) {
             // a hidden forward layer feeds the ReLU next: the close of this scale already opens it
             relu_opened = I.fwd && I.e != I.f - 1;
@@ -741,6 +774,7 @@ void run_iteration(cognn_engine* E, int64_t it) {
         }
     }
     // ---- ApplyComp (gcn.h:515-811) ----
+    Phase ph_ap(E, T_PH_APPLY);
     if (I.fwd) {
         if (I.e != I.f - 1) relu_stage(E, it, relu_opened);
         else softmax_stage(E, it);
@@ -773,34 +807,47 @@ void run_iteration(cognn_engine* E, int64_t it) {
         if (I.layer == I.f - 1) { s.cur = s.g; s.curF = E->hid(); }
         else { s.curF = 0; }                               // vertexInterData["g"] is empty for the first layer
     }
+    ph_ap.end();
+    Phase ph_wa(E, T_PH_WAVG);
     weight_average(E, it, I.layer);
     exchange_wait(E);
 }
 
+// the Beaver product a side runs in GAS iteration `it` (at most one: PreScatter in forward iterations, Apply in backward ones)
+bool gemm_of_iteration(cognn_engine* E, Side& s, int64_t it, GemmSpec& g) {
+    const IterInfo I = iter_info(E, it);
+    if (!I.apply_only && I.fwd) { g = prescatter_spec(E, s, I.layer); return true; }
+    if (!I.fwd && (I.e - I.f) % 2 == 0 && I.layer == I.f - 1) {
+        g = GemmSpec{s.n, E->hid(), E->lab(), 0, COGNN_OP_AP_GEMM, COGNN_OP_AP_GEMM_TRUNC};
+        return true;
+    }
+    if (!I.fwd && (I.e - I.f) % 2 == 1) { g = wgrad_spec(E, s, I.layer, it); return true; }
+    return false;
+}
+
 // dealer phase: product shares of every Beaver GEMM in [it0,it1)
 void run_offline(cognn_engine* E, int64_t it0, int64_t it1) {
-    for (int64_t it = it0; it < it1; ++it) {
-        const IterInfo I = iter_info(E, it);
+    for (int64_t it = it0; it < it1; ++it)
         for (auto& s : E->sides) {
-            if (s.p != 1) continue;
             GemmSpec g;
-            bool have = false;
-            if (!I.apply_only && I.fwd) { g = prescatter_spec(E, s, I.layer); have = true; }
-            else if (!I.fwd && (I.e - I.f) % 2 == 0 && I.layer == I.f - 1) {
-                g = GemmSpec{s.n, E->hid(), E->lab(), 0, COGNN_OP_AP_GEMM, COGNN_OP_AP_GEMM_TRUNC}; have = true;
-            } else if (!I.fwd && (I.e - I.f) % 2 == 1) {
-                g = wgrad_spec(E, s, I.layer, it);
-                have = true;
-            }
-            if (!have || s.c1.count({it, g.op})) continue;
+            if (s.p != 1 || !gemm_of_iteration(E, s, it, g) || s.c1.count({it, g.op})) continue;
             cognn_keys k = gemm_keys(E, s, it, g);
-            u64* c = dalloc<u64>(E, (size_t)(g.M * g.N));
+            u64* c = c1_alloc(E, g.M * g.N);
             BE(cognn_dealer_gemm_c1_u64(E->ctx, c, &k, g.M, g.N, g.K, g.transA, s.scratch, s.scratch + g.M * g.K));
-            s.c1[{it, g.op}] = c;
-            s.c1_elems[{it, g.op}] = g.M * g.N;
+            s.c1[{it, g.op}] = Side::C1{c, g.M * g.N};
         }
-    }
 }
+
+// identifies the run a cached product share belongs to: parties, ranks, variant, dimensions, graph size, rows of the owner
+u64 run_fingerprint(cognn_engine* E, const Side& s) {
+    u64 h = 0xcbf29ce484222325ull;
+    auto mix = [&](u64 v) { for (int b = 0; b < 8; ++b) { h ^= (v >> (8 * b)) & 0xff; h *= 0x100000001b3ull; } };
+    mix((u64)E->k); mix((u64)E->world); mix((u64)E->rank); mix((u64)E->cfg.variant);
+    mix((u64)E->in()); mix((u64)E->hid()); mix((u64)E->lab());
+    mix((u64)E->G.num_edges); mix((u64)E->G.row_of_vid.size()); mix((u64)s.owner); mix((u64)s.n);
+    return h;
+}
+const u64 kC1Magic = 0x32435F4E4E474F43ull;                   // "COGNN_C2": header = magic, seed, M, N, K, transA, fingerprint
 
 // ---------------------------------------------------------------------------------------------
 // setup
@@ -1198,14 +1245,17 @@ int cognn_engine_offline_save(cognn_engine* E, const char* dir) {
         if (!E || !dir) throw EngineError("cognn_engine_offline_save: bad arguments");
         for (auto& s : E->sides)
             for (auto& kv : s.c1) {
-                const int64_t elems = s.c1_elems[kv.first];
+                GemmSpec g;
+                if (!gemm_of_iteration(E, s, kv.first.first, g) || g.op != kv.first.second || g.M * g.N != kv.second.elems)
+                    throw EngineError("cognn_engine_offline_save: inconsistent product share table");
+                const int64_t elems = kv.second.elems;
                 std::vector<u64> host((size_t)elems);
-                BE(cognn_memcpy_d2h(E->ctx, host.data(), kv.second, (size_t)elems * 8));
+                BE(cognn_memcpy_d2h(E->ctx, host.data(), kv.second.ptr, (size_t)elems * 8));
                 const std::string path = c1_path(E, dir, s, kv.first.first, kv.first.second);
                 FILE* f = fopen(path.c_str(), "wb");
                 if (!f) throw EngineError("cognn_engine_offline_save: cannot write " + path);
-                const u64 hdr[3] = {0x31435F4E4E474F43ull /* "COGNN_C1" */, E->cfg.seed, (u64)elems};
-                const bool ok = fwrite(hdr, 8, 3, f) == 3 && fwrite(host.data(), 8, (size_t)elems, f) == (size_t)elems;
+                const u64 hdr[7] = {kC1Magic, E->cfg.seed, (u64)g.M, (u64)g.N, (u64)g.K, (u64)g.transA, run_fingerprint(E, s)};
+                const bool ok = fwrite(hdr, 8, 7, f) == 7 && fwrite(host.data(), 8, (size_t)elems, f) == (size_t)elems;
                 fclose(f);
                 if (!ok) throw EngineError("cognn_engine_offline_save: short write to " + path);
             }
@@ -1215,27 +1265,28 @@ int cognn_engine_offline_load(cognn_engine* E, const char* dir, int64_t it0, int
     return guard([&] {
         if (!E || !dir || !E->started) throw EngineError("cognn_engine_offline_load: bad arguments or engine not started");
         int64_t n = 0;
-        const int ops[2] = {COGNN_OP_PS_GEMM, COGNN_OP_AP_GEMM};
         for (auto& s : E->sides) {
             if (s.p != 1) continue;
-            for (int64_t it = it0; it < it1; ++it)
-                for (int op : ops) {
-                    if (s.c1.count({it, op})) continue;
-                    FILE* f = fopen(c1_path(E, dir, s, it, op).c_str(), "rb");
-                    if (!f) continue;
-                    u64 hdr[3];
-                    if (fread(hdr, 8, 3, f) == 3 && hdr[0] == 0x31435F4E4E474F43ull && hdr[1] == E->cfg.seed && hdr[2] < (1ull << 40)) {
-                        std::vector<u64> host((size_t)hdr[2]);
-                        if (fread(host.data(), 8, host.size(), f) == host.size()) {
-                            u64* c = dalloc<u64>(E, host.size());
-                            BE(cognn_memcpy_h2d(E->ctx, c, host.data(), host.size() * 8));
-                            s.c1[{it, op}] = c;
-                            s.c1_elems[{it, op}] = (int64_t)host.size();
-                            ++n;
-                        }
+            for (int64_t it = it0; it < it1; ++it) {
+                GemmSpec g;
+                if (!gemm_of_iteration(E, s, it, g) || s.c1.count({it, g.op})) continue;
+                FILE* f = fopen(c1_path(E, dir, s, it, g.op).c_str(), "rb");
+                if (!f) continue;
+                u64 hdr[7];
+                // only a file written for exactly this product of exactly this run is accepted; anything else is dealt on demand
+                const bool match = fread(hdr, 8, 7, f) == 7 && hdr[0] == kC1Magic && hdr[1] == E->cfg.seed && hdr[2] == (u64)g.M &&
+                                   hdr[3] == (u64)g.N && hdr[4] == (u64)g.K && hdr[5] == (u64)g.transA && hdr[6] == run_fingerprint(E, s);
+                if (match) {
+                    std::vector<u64> host((size_t)(g.M * g.N));
+                    if (fread(host.data(), 8, host.size(), f) == host.size() && fgetc(f) == EOF) {
+                        u64* c = c1_alloc(E, g.M * g.N);
+                        BE(cognn_memcpy_h2d(E->ctx, c, host.data(), host.size() * 8));
+                        s.c1[{it, g.op}] = Side::C1{c, g.M * g.N};
+                        ++n;
                     }
-                    fclose(f);
                 }
+                fclose(f);
+            }
         }
         if (loaded) *loaded = n;
     });
@@ -1244,15 +1295,45 @@ int cognn_engine_run(cognn_engine* E, int64_t it0, int64_t it1) {
     return guard([&] {
         if (!E || !E->started) throw EngineError("cognn_engine_run: engine not started");
         for (int64_t it = it0; it < it1; ++it) {
-            auto t0 = std::chrono::high_resolution_clock::now();
+            const int64_t rounds0 = E->rounds;
+            double before[5] = {0, 0, 0, 0, 0};
+            int64_t nl;
+            if (E->cfg.verbose)
+                for (int j = 0; j < 5; ++j) BE(cognn_timer_read(E->ctx, T_PH_PRESCATTER + j, &nl, &before[j]));
             run_iteration(E, it);
             exchange_wait(E);                               // nothing stays in flight across iterations / API calls
-            if (E->cfg.verbose) {
-                BE(cognn_ctx_sync(E->ctx));
-                const double sec = std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - t0).count();
-                printf("tid-> %d, iteration-> %lld\n::iteration took %lf seconds\n", E->hosted.empty() ? -1 : E->hosted[0], (long long)it, sec);
+            if (E->cfg.verbose) {                           // (reads synchronise the stream)
+                for (int j = 0; j < 5; ++j) {
+                    double after = 0;
+                    BE(cognn_timer_read(E->ctx, T_PH_PRESCATTER + j, &nl, &after));
+                    E->phase_s[j] = (after - before[j]) * 1e-3;
+                }
+                E->phase_s[5] = (double)(E->rounds - rounds0);
+                if (!E->timing) BE(cognn_timer_reset(E->ctx));   // keep the event lists short
             }
         }
+    });
+}
+int cognn_engine_sync(cognn_engine* E) {
+    return guard([&] { if (!E) throw EngineError("null engine"); exchange_wait(E); BE(cognn_ctx_sync(E->ctx)); });
+}
+int cognn_engine_get_phase_seconds(cognn_engine* E, double* out6) {
+    return guard([&] {
+        if (!E || !out6) throw EngineError("cognn_engine_get_phase_seconds: bad arguments");
+        for (int j = 0; j < 6; ++j) out6[j] = E->phase_s[j];
+    });
+}
+int cognn_engine_set_option(cognn_engine* E, int32_t option, int64_t value) {
+    return guard([&] {
+        if (!E || option != COGNN_OPT_RETAIN_OFFLINE) throw EngineError("cognn_engine_set_option: unknown option");
+        E->retain_offline = value != 0;
+    });
+}
+int cognn_engine_get_memory(cognn_engine* E, int64_t* allocations, int64_t* bytes) {
+    return guard([&] {
+        if (!E) throw EngineError("null engine");
+        if (allocations) *allocations = (int64_t)E->allocs.size();
+        if (bytes) *bytes = E->alloc_bytes;
     });
 }
 int cognn_engine_get_shares(cognn_engine* E, int32_t owner, int32_t sd, uint64_t* host_out, int64_t* rows, int64_t* cols) {

@@ -4,14 +4,21 @@
 //   gcn-optimize -t <parties> -g <tiles> -i <party index> -m <iterations> -p <parts> -s <setting>
 //                [-n 1] [-c 1] [-r 1] [-u] <edge list> <vertex list> <partition> <output> <config> [src]
 //
-// The reference starts one process per party and connects them over TCP; this binary hosts all parties of the
-// run on one GPU (in-device share exchange) and prints the log lines of party `-i` (its "::<tag> took X seconds"
-// and accuracy lines, tools/plot/*.py).  One-party-per-GPU runs go through the torch.distributed launcher
-// (tools/run_cluster.py).  `-r 0` (power-of-two dummy edges, ss_...h:358-398) is not supported: no script of the
-// reference uses it and its dummy contributions are never masked.
+// The reference starts one process per party and connects them over TCP (include/engine.h:157-201).  This binary runs
+//   * by default all parties of the run on one GPU (in-device share exchange), printing the log lines of party `-i`
+//     (its "::<tag> took X seconds" and accuracy lines, tools/plot/*.py);
+//   * with `-c 1` (the reference's cluster switch) or WORLD_SIZE > 1 in the environment as ONE RANK of a multi-GPU run:
+//     the k parties are mapped to `world` processes in contiguous blocks, one process per GPU, shares travel over RCCL
+//     p2p (include/cognn_exchange.h).  `-c 1` alone means one party per GPU: world = k, rank = `-i`, exactly the
+//     reference's k command lines; RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR / MASTER_PORT override (torchrun style).
+// `-r 0` (power-of-two dummy edges, ss_...h:358-398) is not supported: no script of the reference uses it and its dummy
+// contributions are never masked.
 #include <getopt.h>
+#include <sys/stat.h>
 #include <unistd.h>
 
+#include <algorithm>
+#include <cerrno>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -23,6 +30,9 @@
 #include <vector>
 
 #include "../../include/cognn_engine.h"
+#ifndef COGNN_NO_RCCL        /* the CPU test build (oracle/gcn-optimize-cpuref) has no device and no communicator */
+#include "../../include/cognn_exchange.h"
+#endif
 #include "graph.h"
 
 namespace {
@@ -61,7 +71,7 @@ void printHelp(const char* prog) {
               << "\t-p [numParts]         Number of partitions per thread (unused).\n"
               << "\t-s <setting>          Setting string (keys the dealer / offline phase).\n"
               << "\t-n <0|1>              1: skip the offline phase up front (products are dealt on demand).\n"
-              << "\t-c <0|1>              Cluster mode (accepted, ignored: there are no sockets).\n"
+              << "\t-c <0|1>              1: this process is one rank of a multi-GPU run (one party per GPU unless WORLD_SIZE says otherwise).\n"
               << "\t-r <0|1>              1: no dummy edges (required).\n"
               << "\t-u                    Treat the edge list as undirected.\n"
               << "\t-h                    Print this help message.\n";
@@ -70,6 +80,18 @@ void printHelp(const char* prog) {
 void print_duration(std::chrono::high_resolution_clock::time_point t0, const char* tag) {
     const double sec = std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - t0).count();
     printf("::%s took %lf seconds\n", tag, sec);
+}
+
+void print_seconds(double sec, const char* tag) { printf("::%s took %lf seconds\n", tag, sec); }
+
+// mkdir -p without a shell (the setting string comes from the command line)
+bool make_dirs(const std::string& path) {
+    for (size_t i = 1; i <= path.size(); ++i) {
+        if (i != path.size() && path[i] != '/') continue;
+        const std::string sub = path.substr(0, i);
+        if (mkdir(sub.c_str(), 0777) != 0 && errno != EEXIST) return false;
+    }
+    return true;
 }
 
 uint64_t fnv1a(const std::string& s) {
@@ -121,7 +143,7 @@ int main(int argc, char* argv[]) {
         return -1;
     }
     const std::string edgelistFile = argv[0], vertexlistFile = argv[1], partitionFile = argv[2], outputFile = argv[3], configFile = argv[4];
-    (void)outputFile; (void)numParts; (void)isCluster;
+    (void)outputFile; (void)numParts;
     if (!isNoDummyEdge) {
         std::cerr << "Only the no-dummy-edge mode (-r 1) is supported." << std::endl;
         return -1;
@@ -132,6 +154,15 @@ int main(int argc, char* argv[]) {
     GnnParam gp;
     gp.readConfig(configFile);
     const int k = (int)threadCount;
+    // rank layout of a multi-GPU run
+    auto env_int = [](const char* name, int dflt) { const char* v = getenv(name); return v && *v ? atoi(v) : dflt; };
+    int world = env_int("WORLD_SIZE", isCluster ? k : 1);
+    if (world < 1 || k % world != 0) { std::cerr << "The number of parties must be a multiple of the number of ranks." << std::endl; return -1; }
+    const int perRank = k / world;
+    const int rank = world > 1 ? env_int("RANK", (int)tileIndex / perRank) : 0;
+    if (rank < 0 || rank >= world) { std::cerr << "Rank out of range." << std::endl; return -1; }
+    const int device = world > 1 ? env_int("LOCAL_RANK", rank) : 0;
+    if (world > 1 && ((int)tileIndex < rank * perRank || (int)tileIndex >= (rank + 1) * perRank)) tileIndex = (size_t)(rank * perRank);
     try {
         auto t_pre = std::chrono::high_resolution_clock::now();
         std::vector<int32_t> part;
@@ -144,16 +175,30 @@ int main(int argc, char* argv[]) {
         }
         for (auto& t : part) { t /= (int32_t)(graphTileCount / threadCount); }      // tileMergeFactor (graph_io_util.h:76)
         cognn_engine_config cfg{};
-        cfg.num_parties = k; cfg.rank = 0; cfg.world = 1;
+        cfg.num_parties = k; cfg.rank = rank; cfg.world = world;
         cfg.variant = inference ? COGNN_VARIANT_OPTIMIZE_GCN_INFERENCE : COGNN_VARIANT_OPTIMIZE_GCN;
         cfg.num_layers = gp.num_layers; cfg.num_labels = gp.num_labels; cfg.input_dim = gp.input_dim; cfg.hidden_dim = gp.hidden_dim;
         cfg.learning_rate = gp.learning_rate; cfg.train_ratio = gp.train_ratio; cfg.val_ratio = gp.val_ratio; cfg.test_ratio = gp.test_ratio;
-        cfg.seed = fnv1a(setting); cfg.device = 0; cfg.stream = nullptr; cfg.undirected = undirected; cfg.verbose = 0;
+        cfg.seed = fnv1a(setting); cfg.device = device; cfg.stream = nullptr; cfg.undirected = undirected; cfg.verbose = 1;
         cognn_engine* e = nullptr;
         if (cognn_engine_create(&cfg, (int64_t)part.size(), (int64_t)src.size(), src.data(), dst.data(), part.data(), &e)) {
             std::cerr << cognn_engine_last_error() << std::endl;
             return -1;
         }
+#ifdef COGNN_NO_RCCL
+        if (world > 1) { std::cerr << "This build has no RCCL transport." << std::endl; return -1; }
+#else
+        cognn_rccl_exchange* xch = nullptr;
+        if (world > 1) {                                         // communicator bootstrap: the counterpart of engine.h:166-201
+            unsigned char id[COGNN_RCCL_ID_BYTES];
+            const char* addr = getenv("MASTER_ADDR");
+            if (cognn_rccl_rendezvous_tcp(addr && *addr ? addr : "127.0.0.1", env_int("MASTER_PORT", 0), rank, world, 120.0, id) ||
+                cognn_rccl_exchange_create(id, rank, world, device, nullptr, &xch) || cognn_engine_set_exchange_rccl(e, xch)) {
+                std::cerr << cognn_exchange_last_error() << std::endl;
+                return -1;
+            }
+        }
+#endif
         // vertex data: "<vid> f_0 ... f_{in-1} <label>" (harness.cpp:21-48, kernel_harness.h:37-44)
         std::vector<std::vector<double>> feats(k);
         std::vector<std::vector<int32_t>> labels(k);
@@ -165,6 +210,7 @@ int main(int argc, char* argv[]) {
             std::vector<int64_t> vids((size_t)rows[p]);
             cognn_engine_party_vids(e, p, vids.data());
             for (int64_t r = 0; r < rows[p]; ++r) rowIndex[(size_t)vids[r]] = r;
+            if (p / perRank != rank) continue;                  // only the parties hosted here need their vertex data
             feats[p].assign((size_t)rows[p] * gp.input_dim, 0.0);
             labels[p].assign((size_t)rows[p], 0);
         }
@@ -179,12 +225,13 @@ int main(int argc, char* argv[]) {
                 if (!(iss >> vid)) { std::cerr << "Invalid format in vertex list file." << std::endl; return -1; }
                 if (vid >= part.size()) continue;
                 const int p = part[vid];
+                if (p / perRank != rank) continue;
                 const int64_t r = rowIndex[vid];
                 for (int j = 0; j < gp.input_dim; ++j) iss >> feats[p][(size_t)r * gp.input_dim + j];
                 iss >> labels[p][(size_t)r];
             }
         }
-        for (int p = 0; p < k; ++p)
+        for (int p = rank * perRank; p < (rank + 1) * perRank; ++p)
             if (cognn_engine_set_party_data(e, p, feats[p].data(), labels[p].data())) { std::cerr << cognn_engine_last_error() << std::endl; return -1; }
         std::cout << "Graph loaded from " << edgelistFile << " and " << partitionFile << " with " << graphTileCount << " graph tiles, into "
                   << threadCount << " tiles. Treated as " << (undirected ? "undirected" : "directed") << " graph.Current tile is the No."
@@ -192,31 +239,63 @@ int main(int argc, char* argv[]) {
         std::cout << tileIndex << " Initialize graph algo kernel" << std::endl;
         if (cognn_engine_start(e)) { std::cerr << cognn_engine_last_error() << std::endl; return -1; }
         print_duration(t_pre, "preprocess");
-        // offline phase and its cache: ./preprocess/<setting>/ is written by a run without -n and reused by `-n 1`
-        // (README.md:215-216, 306-307 of the reference); what is missing is dealt on demand
+        // Offline phase and its cache: ./preprocess/<setting>/ is written by a run without -n and reused by `-n 1`
+        // (README.md:215-216, 306-307 of the reference); what is missing is dealt on demand.  Products are dealt one epoch
+        // ahead and released once consumed, so device memory does not grow with -m.
         std::string cacheDir = "preprocess/" + setting;
         for (auto& ch : cacheDir) if (ch == ' ') ch = '_';
-        if (!noPreprocess) {
-            auto t_om = std::chrono::high_resolution_clock::now();
-            if (cognn_engine_offline(e, 0, (int64_t)maxIters)) { std::cerr << cognn_engine_last_error() << std::endl; return -1; }
-            print_duration(t_om, "preprocess_OM");
-            if (!getenv("COGNN_NO_PREPROCESS_CACHE")) {
-                const std::string cmd = "mkdir -p '" + cacheDir + "'";
-                if (system(cmd.c_str()) == 0 && cognn_engine_offline_save(e, cacheDir.c_str()))
-                    std::cerr << "warning: offline cache not written: " << cognn_engine_last_error() << std::endl;
-            }
-        } else {
-            int64_t loaded = 0;
-            if (cognn_engine_offline_load(e, cacheDir.c_str(), 0, (int64_t)maxIters, &loaded) == 0)
-                std::cout << tileIndex << " Reused " << loaded << " offline products from " << cacheDir << std::endl;
+        const bool useCache = !getenv("COGNN_NO_PREPROCESS_CACHE");
+        bool cacheDirOk = false;
+        if (!noPreprocess && useCache) {
+            cacheDirOk = make_dirs(cacheDir);
+            if (!cacheDirOk) std::cerr << "warning: cannot create " << cacheDir << ": offline cache not written" << std::endl;
         }
-        std::cout << tileIndex << " Begin algo kernel iteration" << std::endl;
         const int epoch = 3 * gp.num_layers;
+        int64_t reused = 0;
+        auto deal_epoch = [&](uint64_t it0) -> bool {
+            const int64_t it1 = (int64_t)std::min<uint64_t>(it0 + (uint64_t)epoch, maxIters);
+            auto t_om = std::chrono::high_resolution_clock::now();
+            if (!noPreprocess) {
+                if (cognn_engine_offline(e, (int64_t)it0, it1)) return false;
+                if (cacheDirOk && cognn_engine_offline_save(e, cacheDir.c_str()))
+                    std::cerr << "warning: offline cache not written: " << cognn_engine_last_error() << std::endl;
+            } else {
+                int64_t loaded = 0;
+                if (cognn_engine_offline_load(e, cacheDir.c_str(), (int64_t)it0, it1, &loaded)) return false;
+                reused += loaded;
+            }
+            if (cognn_engine_sync(e)) return false;
+            if (it0 == 0) {
+                if (!noPreprocess) print_duration(t_om, "preprocess_OM");
+                else std::cout << tileIndex << " Reused " << reused << " offline products from " << cacheDir << std::endl;
+            }
+            return true;
+        };
+        std::cout << tileIndex << " Begin algo kernel iteration" << std::endl;
         for (uint64_t it = 0; it < maxIters; ++it) {
+            if (it % (uint64_t)epoch == 0 && !deal_epoch(it)) { std::cerr << cognn_engine_last_error() << std::endl; return -1; }
             printf("tid-> %lld, iteration-> %lld\n", (long long)tileIndex, (long long)it);
             auto t_it = std::chrono::high_resolution_clock::now();
-            if (cognn_engine_run(e, (int64_t)it, (int64_t)it + 1)) { std::cerr << cognn_engine_last_error() << std::endl; return -1; }
-            if ((int)(it % epoch) == gp.num_layers - 1) {                  // prediction layer: gcn.h:619-632
+            if (cognn_engine_run(e, (int64_t)it, (int64_t)it + 1) || cognn_engine_sync(e)) { std::cerr << cognn_engine_last_error() << std::endl; return -1; }
+            const int ei = (int)(it % epoch);
+            const bool applyOnly = ei != 0 && ei % gp.num_layers == 0;             // ss_...h:709
+            double ph[6];
+            if (cognn_engine_get_phase_seconds(e, ph)) { std::cerr << cognn_engine_last_error() << std::endl; return -1; }
+            if (!applyOnly) {
+                // The tags of the reference's print_duration sites (ss_...h:745,765,802,808,822,856,881,897; parsed by
+                // tools/plot/plot_duration_breakdown_and_comm.py:23-46,99), from HIP-event timers.  OEP, ScatterComp, the prefix
+                // aggregation and the masked additions are ONE fused CSR launch pair here: its time is reported as
+                // "premerging" (the aggregation) and the steps that no longer exist separately as 0.
+                print_seconds(ph[0], "PreScatterComp Client");
+                print_seconds(ph[0], "PreScatterComp Server");
+                print_seconds(0.0, "Scatter_preparation");
+                print_seconds(0.0, "Scatter_computation");
+                print_seconds(ph[1], "premerging");
+                print_seconds(0.0, "premerged_extraction");
+                print_seconds(0.0, "Gather_preparation");
+                print_seconds(ph[2], "Gather_computation");
+            }
+            if (ei == gp.num_layers - 1) {                                         // prediction layer: gcn.h:619-632
                 double m[8];
                 if (cognn_engine_get_metrics(e, (int32_t)tileIndex, m)) { std::cerr << cognn_engine_last_error() << std::endl; return -1; }
                 printf("--------\n");
@@ -227,16 +306,23 @@ int main(int argc, char* argv[]) {
                 printf("test set accuracy = %lf\n", m[3]);
                 printf("border test set accuracy = %lf\n", m[4]);
                 printf("the number of vertices is %lu, the number of border vertices is %lu\n", (unsigned long)m[6], (unsigned long)m[7]);
-            } else {
-                double m[8];
-                (void)m;
-                int64_t r, c;
-                cognn_engine_get_shares(e, (int32_t)tileIndex, 0, nullptr, &r, &c);   // forces completion for the timing line
             }
+            if (!applyOnly) print_seconds(ph[3] + ph[4], "Apply_computation");     // incl. weight averaging (inside ApplyComp, gcn.h:747-802)
             print_duration(t_it, "iteration");
         }
         std::cout << tileIndex << " Finish algo kernel" << std::endl;
+#ifndef COGNN_NO_RCCL
+        if (xch) {                                               // sendFinish / recvFinish (ss_...h:270-272)
+            int64_t rounds = 0, sent = 0, recvd = 0;
+            cognn_rccl_exchange_stats(xch, &rounds, &sent, &recvd);
+            printf("%zu exchange rounds %lld, sent %.2fMB, received %.2fMB\n", tileIndex, (long long)rounds, sent / 1048576.0, recvd / 1048576.0);
+            if (cognn_rccl_exchange_barrier(xch)) std::cerr << cognn_exchange_last_error() << std::endl;
+        }
         cognn_engine_destroy(e);
+        cognn_rccl_exchange_destroy(xch);
+#else
+        cognn_engine_destroy(e);
+#endif
     } catch (const std::exception& ex) {
         std::cerr << ex.what() << std::endl;
         return -1;

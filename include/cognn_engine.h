@@ -34,7 +34,8 @@ typedef struct {
     int32_t device;
     void* stream;            /* hipStream_t (NULL = default stream) */
     int32_t undirected;      /* -u */
-    int32_t verbose;         /* print the reference's "::tag took X seconds" lines */
+    int32_t verbose;         /* record per-phase HIP-event timers of every GAS iteration (cognn_engine_get_phase_seconds):
+                                the source of the reference's "::<tag> took X seconds" lines */
 } cognn_engine_config;
 
 /* one logical message of an exchange round; buffers are device pointers on this rank */
@@ -71,14 +72,31 @@ int cognn_engine_set_weights(cognn_engine* e, const double* w0, const double* w1
 int cognn_engine_start(cognn_engine* e);
 /* dealer ("offline") phase for iterations [begin,end): Beaver-triple product shares of every GEMM */
 int cognn_engine_offline(cognn_engine* e, int64_t iter_begin, int64_t iter_end);
+/* A dealt product share is released as soon as the product that consumes it has run, so device memory stays bounded however
+ * many iterations a run has (the reference default is -m 1000): deal one epoch ahead.  Replaying the same iterations
+ * (bench.py's repeated inference pass) keeps them instead: cognn_engine_set_option(e, COGNN_OPT_RETAIN_OFFLINE, 1). */
+enum { COGNN_OPT_RETAIN_OFFLINE = 1 };
+int cognn_engine_set_option(cognn_engine* e, int32_t option, int64_t value);
 /* Offline-phase cache on disk, the counterpart of the reference's preprocess/<setting>/ directory reused with `-n 1`
- * (include/harness.h:140-146, README.md:215-216): save writes every dealt product share held on this rank to
- * <dir>/c1_r<rank>_o<owner>_i<iter>_op<op>.bin (header: magic, seed, M*N); load reads whatever matching files exist and
- * returns the number loaded in *loaded (missing ones are dealt on demand). */
+ * (include/harness.h:140-146, README.md:215-216): save writes every dealt product share currently held on this rank to
+ * <dir>/c1_r<rank>_o<owner>_i<iter>_op<op>.bin.  The header records magic, seed, M, N, K, transA and a fingerprint of
+ * the run (parties, ranks, dimensions, graph size, rows of the owner); load reads the files whose header matches the
+ * product of that (owner, iteration) exactly and returns their number in *loaded - anything else (stale cache of another
+ * dataset / partition / shape) is ignored and dealt on demand. */
 int cognn_engine_offline_save(cognn_engine* e, const char* dir);
 int cognn_engine_offline_load(cognn_engine* e, const char* dir, int64_t iter_begin, int64_t iter_end, int64_t* loaded);
-/* GAS iterations [begin,end) (ss_...h:239-248) */
+/* GAS iterations [begin,end) (ss_...h:239-248); asynchronous on the engine's stream */
 int cognn_engine_run(cognn_engine* e, int64_t iter_begin, int64_t iter_end);
+/* waits until everything enqueued so far has finished on the device (what the reference's print_duration sites measure) */
+int cognn_engine_sync(cognn_engine* e);
+/* Per-phase device time of the LAST iteration run with cfg.verbose != 0, in seconds (HIP events on the engine's stream):
+ * out[0] PreScatterComp (gcn.h:198-255), out[1] the fused message passing = Scatter_preparation + Scatter_computation +
+ * premerging + premerged_extraction + Gather_preparation + the masked additions of GatherComp (ss_...h:748-856),
+ * out[2] the post-gather scale of GatherComp (gcn.h:470-483), out[3] ApplyComp (gcn.h:515-811),
+ * out[4] weight averaging (gcn.h:747-802), out[5] number of exchange rounds of that iteration. */
+int cognn_engine_get_phase_seconds(cognn_engine* e, double* out6);
+/* live device allocations of the engine (count, bytes): stays constant over iterations */
+int cognn_engine_get_memory(cognn_engine* e, int64_t* allocations, int64_t* bytes);
 /* current vertex tensor share of `owner` held by side 0 (owner) / 1 (co-party); host_out may be NULL to query shape */
 int cognn_engine_get_shares(cognn_engine* e, int32_t owner, int32_t side, uint64_t* host_out, int64_t* rows, int64_t* cols);
 int cognn_engine_get_weight(cognn_engine* e, int32_t owner, int32_t side, int32_t layer, uint64_t* host_out);

@@ -803,6 +803,7 @@ class PlainEngine:
         self.X = [x.copy() for x in self.X0]
         self.inter = [[dict() for _ in range(g.num_layers)] for _ in range(o.k)]
         self.vid_row = {}
+        self.metrics = []                                     # what the client would print at every prediction layer (gcn.h:611-632)
         for P in range(o.k):
             for r, v in enumerate(o.states[P].localVertexPos):
                 self.vid_row[v] = (P, r)
@@ -867,6 +868,7 @@ class PlainEngine:
                     y = np.zeros_like(p); y[np.arange(n), o.states[P].labels] = 1.0
                     d = p - y; d[train:] = 0
                     I["p"] = p; self.X[P] = d
+                    self.metrics.append(o._metrics(P, it, p, train, int(n * g.val_ratio)))
             else:
                 first = ((e - f) % 2 == 0)
                 if first:
@@ -920,3 +922,37 @@ def synth_features(num_vertices, input_dim, num_labels, seed, density=0.01):
     feats = (rng.random((num_vertices, input_dim)) < density).astype(np.float64)
     labels = rng.integers(0, num_labels, size=num_vertices)
     return feats, labels
+
+
+def synth_planted(num_vertices, num_undirected, input_dim, num_labels, seed, p_intra=0.85, p_on=0.06, p_off=0.004):
+    """A LEARNABLE synthetic stand-in for a citation dataset (the Planetoid files are not available offline): every vertex
+    gets a class; an edge joins two vertices of the same class with probability p_intra; the bag-of-words features are
+    Bernoulli(p_on) inside the class's block of input_dim/num_labels words and Bernoulli(p_off) elsewhere.  Returns
+    (src, dst, features, labels) with the edge list symmetric like synth_graph's."""
+    rng = np.random.default_rng(seed)
+    labels = rng.integers(0, num_labels, size=num_vertices)
+    by_class = [np.flatnonzero(labels == c) for c in range(num_labels)]
+    keys = np.empty(0, dtype=np.int64)
+    while len(keys) < num_undirected:
+        m = num_undirected - len(keys) + 64
+        a = rng.integers(0, num_vertices, size=m, dtype=np.int64)
+        b = rng.integers(0, num_vertices, size=m, dtype=np.int64)
+        intra = rng.random(m) < p_intra
+        for c in range(num_labels):                           # redraw the second endpoint inside the first one's class
+            sel = intra & (labels[a] == c)
+            if sel.any() and len(by_class[c]):
+                b[sel] = by_class[c][rng.integers(0, len(by_class[c]), size=int(sel.sum()))]
+        ok = a != b
+        lo = np.minimum(a, b)[ok]; hi = np.maximum(a, b)[ok]
+        fresh = np.setdiff1d(lo * np.int64(num_vertices) + hi, keys)
+        if len(fresh) > num_undirected - len(keys):
+            fresh = rng.permutation(fresh)[:num_undirected - len(keys)]
+        keys = np.union1d(keys, fresh)
+    lo = keys // num_vertices; hi = keys % num_vertices
+    src = np.concatenate([lo, hi]).astype(np.int64); dst = np.concatenate([hi, lo]).astype(np.int64)
+    block = max(1, input_dim // num_labels)
+    prob = np.full((num_vertices, input_dim), p_off)
+    for c in range(num_labels):
+        prob[np.ix_(by_class[c], np.arange(c * block, min(input_dim, (c + 1) * block)))] = p_on
+    feats = (rng.random((num_vertices, input_dim)) < prob).astype(np.float64)
+    return src, dst, feats, labels

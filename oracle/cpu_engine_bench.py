@@ -18,7 +18,8 @@ def main():
     variant, iters, steps = sys.argv[7], int(sys.argv[8]), int(sys.argv[9])
     import cognn_oracle as co
     from cognn_amd import capi
-    capi.load(os.path.join(ROOT, "oracle", "libcognn_engine_cpu.so"))
+    capi.LIB_PATH = os.path.join(ROOT, "oracle", "libcognn_engine_cpu.so")   # test infrastructure: the plain-C++ reference backend
+    capi.load()
     from cognn_amd.engine import Engine, GnnParam
     V, Eu = 1 << lv, 1 << (le - 1)
     src, dst = co.synth_graph(V, Eu, 0xC06A11)

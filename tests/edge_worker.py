@@ -35,7 +35,8 @@ def main():
     import cognn_oracle as co
     from cognn_amd import capi
     if backend == "cpu":
-        capi.load(os.path.join(ROOT, "oracle", "libcognn_engine_cpu.so"))
+        capi.LIB_PATH = os.path.join(ROOT, "oracle", "libcognn_engine_cpu.so")          # test infrastructure: the plain-C++ reference backend
+        capi.load()
     from cognn_amd.engine import Engine, GnnParam
     k, V, src, dst, part, variant, iters = cases()[name]
     in_dim, hid, lab = 6, 4, 3

@@ -1,0 +1,88 @@
+"""Worker of tests/test_hostlogic_*.py: engine host logic that does not depend on the arithmetic backend - bounded device
+memory over many epochs, the offline cache's header validation, replay retention - on the CPU reference backend ("cpu") or
+the HIP library ("hip").  Prints one JSON line."""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+
+def make(k, V, Eu, in_dim, hid, lab, seed=5, verbose=False):
+    import cognn_oracle as co
+    from cognn_amd.engine import Engine, GnnParam
+    src, dst = co.synth_graph(V, Eu, 2)
+    part = np.array([v % k for v in range(V)], dtype=np.int32)
+    feats, labels = co.synth_features(V, in_dim, lab, 3, density=0.3)
+    gp = GnnParam(num_labels=lab, input_dim=in_dim, hidden_dim=hid, num_samples=V, learning_rate=0.5)
+    kw = {"stream": 0} if BACKEND == "cpu" else {}
+    eng = Engine(k, src, dst, part, gp, seed=seed, verbose=verbose, **kw)
+    eng.set_global_data(feats, labels)
+    eng.start()
+    return eng
+
+
+def main():
+    global BACKEND
+    BACKEND, tmp = sys.argv[1], sys.argv[2]
+    from cognn_amd import capi
+    if BACKEND == "cpu":
+        capi.LIB_PATH = os.path.join(ROOT, "oracle", "libcognn_engine_cpu.so")   # test infrastructure: the plain-C++ reference backend
+    out = {}
+    # 1. memory stays bounded: deal one epoch ahead, run it, repeat
+    eng = make(3, 60, 150, 12, 6, 4, verbose=True)
+    mem = []
+    for ep in range(6):
+        eng.offline(6 * ep, 6 * ep + 6)
+        eng.run(6 * ep, 6 * ep + 6)
+        eng.sync()
+        mem.append(eng.memory())
+    out["mem"] = mem
+    out["phases"] = eng.phase_seconds()
+    ref_shares = eng.shares(0, 0).tolist()
+    # 2. offline cache: written by this run's next epoch, accepted by an identical engine, rejected by a different shape / seed
+    eng.offline(36, 42)
+    cache = os.path.join(tmp, "cache")
+    os.makedirs(cache, exist_ok=True)
+    eng.offline_save(cache)
+    out["files"] = len(os.listdir(cache))
+    eng.close()
+    same = make(3, 60, 150, 12, 6, 4)
+    out["loaded_same"] = same.offline_load(cache, 36, 42)
+    same.close()
+    for name, args in (("other_hidden", (3, 60, 150, 12, 8, 4)), ("other_graph", (3, 66, 150, 12, 6, 4)), ("other_parties", (2, 60, 150, 12, 6, 4))):
+        e2 = make(*args)
+        out["loaded_" + name] = e2.offline_load(cache, 36, 42)
+        e2.run(0, 6)                                   # and it still runs (dealing on demand)
+        e2.close()
+    e3 = make(3, 60, 150, 12, 6, 4, seed=6)
+    out["loaded_other_seed"] = e3.offline_load(cache, 36, 42)
+    e3.close()
+    # a truncated file is ignored as well
+    victim = sorted(os.listdir(cache))[0]
+    data = open(os.path.join(cache, victim), "rb").read()
+    open(os.path.join(cache, victim), "wb").write(data[:-8])
+    e4 = make(3, 60, 150, 12, 6, 4)
+    out["loaded_truncated"] = e4.offline_load(cache, 36, 42)
+    e4.close()
+    # 3. replay with retention keeps the shares and reproduces the results; without it the second pass deals on demand (same results)
+    res = {}
+    for keep in (True, False):
+        e5 = make(3, 60, 150, 12, 6, 4)
+        e5.retain_offline(keep)
+        e5.offline(0, 2)
+        e5.run(0, 2); a = e5.shares(1, 1).copy(); m0 = e5.memory()
+        e5.run(0, 2); b = e5.shares(1, 1).copy(); m1 = e5.memory()
+        res[str(keep)] = {"same": bool(np.array_equal(a, b)), "grew": m1[0] - m0[0]}
+        e5.close()
+    out["replay"] = res
+    out["ref_rows"] = len(ref_shares)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

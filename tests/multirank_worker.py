@@ -21,7 +21,8 @@ def main():
     from cognn_amd import capi
     hip = cfg.get("backend") == "hip"                      # tests/test_multirank_gpu.py: ranks share cuda:0, gloo moves host copies
     if not hip:
-        capi.load(os.path.join(ROOT, "oracle", "libcognn_engine_cpu.so"))
+        capi.LIB_PATH = os.path.join(ROOT, "oracle", "libcognn_engine_cpu.so")          # test infrastructure: the plain-C++ reference backend
+        capi.load()
     from cognn_amd import dist as cdist
     from cognn_amd.engine import Engine, GnnParam
     k = cfg["k"]; V = cfg["V"]

@@ -1,37 +1,116 @@
-"""tools/run_cluster.py + cognn_amd/worker.py on CPU: 2 ranks over gloo with the reference CPU backend, reference-format
-files written by the launcher's --synthetic mode; per-party logs must carry the reference's log lines and the oracle's metrics."""
+"""tools/run_cluster.py on CPU: ranks are tests/cpu_worker.py (cognn_amd/worker.py on the reference CPU backend) over gloo,
+reference-format files written by the launcher's synthetic mode; per-party logs must carry the reference's log lines -
+parsed here with the expressions of the reference's plot scripts - and the oracle's metrics."""
 import os
 import re
 import subprocess
 import sys
 
 import numpy as np
+import pytest
 
 import cognn_oracle as co
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LAUNCH = [sys.executable, os.path.join(ROOT, "tools", "run_cluster.py")]
+CPU_WORKER = os.path.join(ROOT, "tests", "cpu_worker.py")
+# tools/plot/plot_duration_breakdown_and_comm.py:99 (+ the two tags its list leaves out)
+TAGS = ["preprocess", "PreScatterComp Client", "Scatter_preparation", "Scatter_computation", "premerging", "premerged_extraction",
+        "Gather_computation", "Apply_computation", "PreScatterComp Server", "Gather_preparation", "iteration", "preprocess_OM"]
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _build():
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
+
+
+def extract_cognn_durations(text, tag):
+    """The parser of plot_duration_breakdown_and_comm.py:23-46, on a string."""
+    out = []
+    for line in text.splitlines():
+        if "::" + tag + " took" in line:
+            out.append(float(line.split(" took ")[1].split(" ")[0].strip()))
+    return out
+
+
+def _oracle_for(data, dataset, k, setting, iters):
+    from cognn_amd import worker
+    src, dst = worker.read_edge_list(str(data / (dataset + ".edge.preprocessed")))
+    part = worker.read_partition(str(data / (dataset + ".part.preprocessed")))
+    p = co.GnnParam.read_config(str(data / (dataset + "_config.txt")))
+    rows = worker.read_vertex_rows(str(data / (dataset + ".vertex.preprocessed")), set(range(len(part))), p.input_dim)
+    feats = np.stack([rows[v][0] for v in range(len(part))]); labels = [rows[v][1] for v in range(len(part))]
+    o = co.OracleEngine(k, src, dst, part, feats, labels, p, seed=worker.fnv1a(setting))
+    o.run(iters)
+    return o
 
 
 def test_two_rank_launcher_logs_match_oracle(tmp_path):
-    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
     data, logs = tmp_path / "data", tmp_path / "log"
-    cmd = [sys.executable, os.path.join(ROOT, "tools", "run_cluster.py"), "--dataset", "cora_small", "--parties", "2", "--gpus", "2",
-           "--iterations", "6", "--data-dir", str(data), "--log-dir", str(logs), "--synthetic", "--backend", "gloo",
-           "--lib", os.path.join(ROOT, "oracle", "libcognn_engine_cpu.so")]
+    cmd = LAUNCH + ["--dataset", "cora_small", "--parties", "2", "--gpus", "2", "--iterations", "6", "--data-dir", str(data),
+                    "--log-dir", str(logs), "--synthetic", "--backend", "gloo", "--worker", CPU_WORKER]
     env = dict(os.environ, OMP_NUM_THREADS="1")
-    res = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env, cwd=tmp_path)
     assert res.returncode == 0, res.stderr + res.stdout
-    from cognn_amd import worker
-    src, dst = worker.read_edge_list(str(data / "cora_small.edge.preprocessed"))
-    part = worker.read_partition(str(data / "cora_small.part.preprocessed"))
-    p = co.GnnParam.read_config(str(data / "cora_small_config.txt"))
-    rows = worker.read_vertex_rows(str(data / "cora_small.vertex.preprocessed"), set(range(len(part))), p.input_dim)
-    feats = np.stack([rows[v][0] for v in range(len(part))]); labels = [rows[v][1] for v in range(len(part))]
-    o = co.OracleEngine(2, src, dst, part, feats, labels, p, seed=worker.fnv1a("gcn-optimize/cora_small/2s"))
-    o.run(6)
+    o = _oracle_for(data, "cora_small", 2, "gcn-optimize/cora_small/2s", 6)
     for party in range(2):
-        text = (logs / ("gcn_test_%d.log" % party)).read_text()
-        assert len(re.findall(r"::iteration took [0-9.]+ seconds", text)) == 6
+        text = (logs / ("gcn_test_cora_small_%d.log" % party)).read_text()       # tmp_run_cluster.py:146
+        assert len(extract_cognn_durations(text, "iteration")) == 6
+        # full iterations 0,1,3,5 print every tag once; the apply-only ones (2,4) none (ss_...h:709-732 has no print_duration)
+        for tag in TAGS[1:10]:
+            assert len(extract_cognn_durations(text, tag)) == 4, tag
+        assert len(extract_cognn_durations(text, "preprocess")) == 1 and len(extract_cognn_durations(text, "preprocess_OM")) == 1
         want = [m for m in o.metrics if m["party"] == party][0]
         assert abs(float(re.findall(r"cross-entropy-loss = ([0-9.]+)", text)[0]) - want["loss"]) < 1e-6
         assert abs(float(re.findall(r"full set accuracy = ([0-9.]+)", text)[0]) - want["full"]) < 1e-6
+        assert "border test set accuracy" in text                                # plot_accuracy.py:17-24
+    # the offline cache of that run serves a second one started with -n 1 (same results)
+    res2 = subprocess.run(cmd + ["--no-preprocess"], capture_output=True, text=True, timeout=300, env=env, cwd=tmp_path)
+    assert res2.returncode == 0, res2.stderr + res2.stdout
+    text2 = (logs / "gcn_test_cora_small_0.log").read_text()
+    assert re.search(r"Reused [1-9][0-9]* offline products", text2)
+    want0 = [m for m in o.metrics if m["party"] == 0][0]
+    assert abs(float(re.findall(r"cross-entropy-loss = ([0-9.]+)", text2)[0]) - want0["loss"]) < 1e-6
+
+
+def test_reference_experiment_option_builds_the_reference_layout(tmp_path):
+    """--smallest-cognn-efficiency (tmp_run_cluster.py:438-448): gcn-optimize, Cora 2s, 2 parties, 12 iterations, with preprocessing."""
+    env = dict(os.environ, OMP_NUM_THREADS="2")
+    res = subprocess.run(LAUNCH + ["--smallest-cognn-efficiency", "--gpus", "2", "--backend", "gloo", "--worker", CPU_WORKER,
+                                   "--root", str(tmp_path)], capture_output=True, text=True, timeout=600, env=env, cwd=tmp_path)
+    assert res.returncode == 0, res.stderr + res.stdout
+    logd = tmp_path / "cognn-smallest" / "log" / "gcn-optimize" / "cora" / "2s"
+    datad = tmp_path / "cognn-smallest" / "data" / "Cora" / "transformed" / "2s"
+    cfg = co.GnnParam.read_config(str(datad / "cora_config.txt"))
+    assert cfg.input_dim == 1433 and cfg.num_samples == 2 * 542                  # two fifths of Cora's 2708 vertices
+    for party in range(2):
+        text = (logd / ("gcn_test_cora_%d.log" % party)).read_text()
+        assert len(extract_cognn_durations(text, "iteration")) == 12
+        acc = [float(x) for x in re.findall(r"full set accuracy = ([0-9.]+)", text)]
+        assert len(acc) == 2                                                     # two epochs, like README.md:225-235
+    assert (tmp_path / "preprocess" / "gcn-optimize" / "cora" / "2s").is_dir()    # the offline cache keyed by the setting
+
+
+def test_unsupported_experiments_are_refused(tmp_path):
+    res = subprocess.run(LAUNCH + ["--cognn-unopt-efficiency"], capture_output=True, text=True, timeout=60)
+    assert res.returncode == 2 and "gcn-original" in res.stderr
+
+
+def test_rank_killed_by_signal_fails_the_launch(tmp_path):
+    """A rank that dies by a signal (GPU abort, segfault) must fail the run and take its peers down instead of leaving them
+    blocked in recv (the launcher used to report max(0, -11) == 0)."""
+    bad = tmp_path / "dying_worker.py"
+    bad.write_text("import os, signal, sys, time\n"
+                   "if os.environ['RANK'] == '1':\n"
+                   "    os.kill(os.getpid(), signal.SIGSEGV)\n"
+                   "time.sleep(600)\n")
+    data, logs = tmp_path / "data", tmp_path / "log"
+    cmd = LAUNCH + ["--dataset", "cora_small", "--parties", "2", "--gpus", "2", "--iterations", "2", "--data-dir", str(data),
+                    "--log-dir", str(logs), "--synthetic", "--backend", "gloo", "--worker", str(bad)]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=120, cwd=tmp_path)
+    assert res.returncode == 128 + 11, (res.returncode, res.stderr)
+    # and a hung run is cut by --timeout
+    hang = tmp_path / "hanging_worker.py"
+    hang.write_text("import time\ntime.sleep(600)\n")
+    res = subprocess.run(cmd[:-1] + [str(hang), "--timeout", "2"], capture_output=True, text=True, timeout=120, cwd=tmp_path)
+    assert res.returncode == 124
