@@ -23,6 +23,17 @@ class Keys(ctypes.Structure):
     _fields_ = [("k", ctypes.c_uint64 * NUM_SLOTS)]
 
 
+class PairChain(ctypes.Structure):
+    """cognn_pair_chain (include/cognn_hip.h)."""
+    _fields_ = [("x", ctypes.c_void_p * 2), ("c1", ctypes.c_void_p), ("scale", ctypes.c_void_p * 2), ("out", ctypes.c_void_p * 2),
+                ("open", ctypes.c_void_p * 2), ("mask", ctypes.c_void_p), ("open_key", ctypes.c_uint64 * 2),
+                ("gemm_keys", Keys), ("trunc_in_keys", Keys), ("scale_keys", Keys), ("scale_trunc_keys", Keys), ("relu_keys", Keys),
+                ("rows", ctypes.c_int64), ("F", ctypes.c_int64), ("flags", ctypes.c_int32)]
+
+
+PC_TRUNC_IN, PC_SCALE, PC_RELU, PC_INPUT_OPENED, PC_NO_C = 1, 2, 4, 8, 16
+
+
 class CognnError(RuntimeError):
     pass
 
@@ -78,6 +89,7 @@ _SIGNATURES = {
     "cognn_mask_select_u64": (_I, [_P, _P, _P, _P, _L]),
     "cognn_softmax_u64": (_I, [_P, _P, _P, _P, _P, _P, _P, _KP, _I, _L, _L, _L]),
     "cognn_metrics_q16": (_I, [_P, _P, _P, _P, _L, _L, _L, _L, _P, _P]),
+    "cognn_pair_chain_u64": (_I, [_P, ctypes.POINTER(PairChain), ctypes.c_int32]),
     "cognn_transpose_u64": (_I, [_P, _P, _P, _L, _L]),
     "cognn_timer_begin": (_I, [_P, _I]),
     "cognn_timer_end": (_I, [_P, _I]),

@@ -134,6 +134,10 @@ class Engine:
         """Keep dealt product shares after use (replaying the same iterations, e.g. bench.py); default: release them."""
         _check(self.lib.cognn_engine_set_option(self.h, 1, int(on)))
 
+    def pair_fusion(self, on=True):
+        """Co-located share-holders run their two-party steps as pair chains (default) or through the per-side kernels."""
+        _check(self.lib.cognn_engine_set_option(self.h, 2, int(on)))
+
     def phase_seconds(self):
         """Device time per phase of the last iteration (engine created with verbose=True), see cognn_engine_get_phase_seconds."""
         out = np.zeros(6, dtype=np.float64)

@@ -88,6 +88,7 @@ struct cognn_engine {
     int64_t alloc_bytes = 0;
     std::map<int64_t, std::vector<u64*>> c1_pool;   // released product-share buffers by element count, reused by later deals
     bool retain_offline = false;                    // COGNN_OPT_RETAIN_OFFLINE
+    bool pair_fusion = true;                        // COGNN_OPT_PAIR_FUSION: co-located share-holders run their two-party steps as pair chains
     double phase_s[6] = {0, 0, 0, 0, 0, 0};         // cognn_engine_get_phase_seconds
     int64_t rounds = 0;                             // exchange rounds started (all iterations)
     cognn_exchange_fn xfn = nullptr;
@@ -279,20 +280,48 @@ enum { X_OPEN_HERE = 0, X_H1E_FRESH = 1, X_H1E_REUSE = 2 };
 // that may still be in flight has completed - the sides whose peer is remote.  With an asynchronous exchange the interior
 // sides' kernels overlap the boundary sides' messages.  batched: the calls are independent element-wise launches of one
 // kind (see Batch).
+// Co-located share-holders (both sides of an owner on this rank) run their two-party steps as ONE pair chain per owner
+// (cognn_pair_chain_u64: both sides' local arithmetic in one kernel, opened values handed over in registers) instead of
+// open -> HBM -> close passes; the per-side stages below then skip those sides.
+bool paired(const cognn_engine* E, const Side& s) { return E->pair_fusion && s.peer != nullptr; }
+
 template <class Fn>
-void for_sides(cognn_engine* E, bool batched, Fn fn) {
+void for_sides(cognn_engine* E, bool batched, Fn fn, bool skip_paired = false) {
     for (int pass = 0; pass < 2; ++pass) {
         if (pass == 1) exchange_wait(E);
-        if (batched) {
-            Batch batch(E);
-            for (size_t i = 0; i < E->sides.size(); ++i)
-                if ((E->sides[i].peer != nullptr) == (pass == 0)) fn(E->sides[i], i);
-        } else {
-            for (size_t i = 0; i < E->sides.size(); ++i)
-                if ((E->sides[i].peer != nullptr) == (pass == 0)) fn(E->sides[i], i);
-        }
+        auto body = [&] {
+            for (size_t i = 0; i < E->sides.size(); ++i) {
+                Side& s = E->sides[i];
+                if ((s.peer != nullptr) != (pass == 0) || (skip_paired && paired(E, s))) continue;
+                fn(s, i);
+            }
+        };
+        if (batched) { Batch batch(E); body(); }
+        else body();
     }
 }
+// the pair chains of one phase: filled per owner (from its p = 0 side), launched together
+struct PairChains {
+    std::vector<cognn_pair_chain> v;
+    cognn_pair_chain& add(Side& s0, const u64* x0, const u64* x1, int64_t rows, int64_t F) {
+        cognn_pair_chain c;
+        memset(&c, 0, sizeof(c));
+        c.x[0] = x0; c.x[1] = x1; c.rows = rows; c.F = F;
+        v.push_back(c);
+        (void)s0;
+        return v.back();
+    }
+    void launch(cognn_engine* E) {
+        if (!v.empty()) BE(cognn_pair_chain_u64(E->ctx, v.data(), (int32_t)v.size()));
+        v.clear();
+    }
+};
+// what follows a Beaver product on the same tensor (PreScatterComp: product, then row scale, gcn.h:233-254)
+struct FollowScale {
+    int op = 0, top = 0;
+    std::function<u64*(Side&)> dst;
+    explicit operator bool() const { return (bool)dst; }
+};
 
 // truncation of every side's `x` (elems) scaled by `mul`; result written/applied to dst(side)
 template <class DstFn>
@@ -332,20 +361,23 @@ struct OpenNext {
     explicit operator bool() const { return (bool)key; }
 };
 template <class DstFn>
-void trunc_close_all(cognn_engine* E, int64_t it, int top, DstFn dst, const std::vector<int64_t>& elems, const OpenNext& open_next) {
+void trunc_close_all(cognn_engine* E, int64_t it, int top, DstFn dst, const std::vector<int64_t>& elems, const OpenNext& open_next,
+                     bool skip_paired = false) {
     for_sides(E, true, [&](Side& s, size_t i) {
         cognn_keys tk = keys(E, s.owner, it, top);
         const u64* c0 = s.p == 0 ? s.ob[2] : nullptr;
         const u64* c1 = s.p == 0 ? s.ib[2] : nullptr;
         if (open_next) BE(cognn_trunc_close_open_u64(E->ctx, dst(s), s.ob[open_next.ob], c0, c1, &tk, s.p, open_next.key(s), elems[i]));
         else BE(cognn_trunc_close_u64(E->ctx, dst(s), c0, c1, &tk, s.p, 0, elems[i]));
-    });
+    }, skip_paired);
 }
 
 // Beaver GEMM for every side: X(side), Wm(side) -> truncated product written to dst(side)
 template <class XFn, class WFn, class SpecFn, class DstFn>
 void gemm_stage(cognn_engine* E, int64_t it, XFn X, WFn Wm, SpecFn spec, DstFn dst, bool x_opened = false,
-                const OpenNext& open_next = OpenNext(), bool w_opened = false) {
+                const OpenNext& open_next = OpenNext(), bool w_opened = false, const FollowScale& follow = FollowScale()) {
+    // follow (co-located pairs only): the row scale that consumes the product joins the pair chain; the caller's rowscale_stage
+    // then handles the other sides
     // w_opened: ob[1] already holds F_p = W_p - B_p (written by the truncation close that produced W)
     const size_t ns = E->sides.size();
     std::vector<int64_t> e0(ns), e1(ns), eo(ns);
@@ -400,40 +432,103 @@ void gemm_stage(cognn_engine* E, int64_t it, XFn X, WFn Wm, SpecFn spec, DstFn d
         BE(cognn_beaver_gemm_close2_u64(E->ctx, s.zbuf, e_own, e_peer, s.ob[1], s.ib[1], c1, &k, s.p, g.M, g.N, g.K, g.transA, s.scratch,
                                         all_raw ? 1 : 0));
         if (E->timing) { BE(cognn_timer_end(E->ctx, T_GEMM)); E->algo[T_GEMM] += 2.0 * 36 * 2 * (double)g.M * g.K * g.N; }
-        if (all_raw) {
+        if (all_raw && !paired(E, s)) {
             cognn_keys tk = keys(E, s.owner, it, g.top);
             BE(cognn_trunc_open_add_u64(E->ctx, s.ob[2], s.zbuf, c1, &k, &tk, s.p, eo[i]));
         }
-        if (s.p == 1) c1_release(E, s, {it, g.op});       // consumed: the buffer serves a later deal
+        if (s.p == 1 && !paired(E, s)) c1_release(E, s, {it, g.op});   // consumed: the buffer serves a later deal
         z[i] = s.zbuf;
     });
+    // co-located pairs: truncation of the product (+ the row scale that follows) as one chain per owner
+    {
+        PairChains pc;
+        for (auto& s : E->sides) {
+            if (!paired(E, s) || s.p != 0) continue;
+            Side& t = *s.peer;
+            GemmSpec g = spec(s);
+            cognn_pair_chain& c = pc.add(s, s.zbuf, t.zbuf, g.M, g.N);
+            c.flags = COGNN_PC_TRUNC_IN | (all_raw ? 0 : COGNN_PC_NO_C);
+            c.gemm_keys = gkeys(s, g);
+            c.trunc_in_keys = keys(E, s.owner, it, g.top);
+            if (all_raw) c.c1 = t.c1.at({it, g.op}).ptr;
+            if (follow) {
+                c.flags |= COGNN_PC_SCALE;
+                c.scale[0] = s.svec; c.scale[1] = t.svec;
+                c.scale_keys = keys(E, s.owner, it, follow.op);
+                c.scale_trunc_keys = keys(E, s.owner, it, follow.top);
+                c.out[0] = follow.dst(s); c.out[1] = follow.dst(t);
+            } else {
+                c.out[0] = dst(s); c.out[1] = dst(t);
+                if (open_next) {
+                    c.open[0] = s.ob[open_next.ob]; c.open[1] = t.ob[open_next.ob];
+                    c.open_key[0] = open_next.key(s); c.open_key[1] = open_next.key(t);
+                }
+            }
+        }
+        pc.launch(E);
+        for (auto& s : E->sides)
+            if (paired(E, s) && s.p == 1) c1_release(E, s, {it, spec(s).op});
+    }
     // all GEMMs of one stage share the truncation op id
     if (!all_raw) {
         for_sides(E, true, [&](Side& s, size_t i) {
             cognn_keys tk = keys(E, s.owner, it, g0.top);
             BE(cognn_trunc_open_u64(E->ctx, s.ob[2], z[i], 1, &tk, s.p, eo[i]));
-        });
+        }, true);
     }
     exchange_ob(E, 2, eo);
-    trunc_close_all(E, it, g0.top, dst, eo, open_next);
+    trunc_close_all(E, it, g0.top, dst, eo, open_next, true);
 }
 
 // row scale by the (owner-known) normaliser followed by truncation; x(side) [n x F] -> dst(side)
 enum { E_FROM_X = 0, E_IN_X = 1, E_IN_OB0 = 2 };
 template <class XFn, class DstFn>
 void rowscale_stage(cognn_engine* E, int64_t it, int op, int top, int F, XFn X, DstFn dst, int e_mode = E_FROM_X,
-                    const OpenNext& open_next = OpenNext()) {
+                    const OpenNext& open_next = OpenNext(), bool pairs_done = false, bool relu_follows = false) {
     // e_mode: E_FROM_X  open E_p = X_p - a_p here;
     //         E_IN_X    X(side) already holds E_p (written by the gather epilogue);
     //         E_IN_OB0  ob[0] already holds E_p (written by the truncation close that produced X)
+    // (modes of the sides whose peer is remote; a co-located pair always hands its chain the plain X)
+    // pairs_done: the co-located pairs ran this scale inside the chain of the product before it (gemm_stage, FollowScale);
+    // relu_follows: the ReLU of ApplyComp consumes the result - co-located pairs run it in the same chain (relu_stage skips them)
     const bool e_opened = e_mode == E_IN_X;
     const size_t ns = E->sides.size();
     std::vector<int64_t> eF(ns), e1(ns);
+    if (!pairs_done) {
+        PairChains pc;
+        for (auto& s : E->sides) {
+            if (!paired(E, s) || s.p != 0) continue;
+            Side& t = *s.peer;
+            cognn_pair_chain& c = pc.add(s, X(s), X(t), s.n, F);
+            c.flags = COGNN_PC_SCALE;
+            c.scale[0] = s.svec; c.scale[1] = t.svec;
+            c.scale_keys = keys(E, s.owner, it, op);
+            c.scale_trunc_keys = keys(E, s.owner, it, top);
+            if (relu_follows) {
+                // H is the next iteration's PreScatter GEMM input (layer 1): straight into its h_t slot, with the Beaver opening
+                // E_p = H_p - A_p of that product (gcn.h:230-239 of iteration it+1), as relu_stage does for the other sides
+                c.flags |= COGNN_PC_RELU;
+                c.relu_keys = keys(E, s.owner, it, COGNN_OP_AP_RELU);
+                c.mask = s.relu_mask;
+                cognn_keys nk = keys(E, s.owner, it + 1, COGNN_OP_PS_GEMM);
+                c.out[0] = s.h1; c.out[1] = t.h1;
+                c.open[0] = s.h1E; c.open[1] = t.h1E;
+                c.open_key[0] = nk.k[COGNN_SL_A0]; c.open_key[1] = nk.k[COGNN_SL_A1];
+            } else {
+                c.out[0] = dst(s); c.out[1] = dst(t);
+                if (open_next) {
+                    c.open[0] = s.ob[open_next.ob]; c.open[1] = t.ob[open_next.ob];
+                    c.open_key[0] = open_next.key(s); c.open_key[1] = open_next.key(t);
+                }
+            }
+        }
+        pc.launch(E);
+    }
     for_sides(E, true, [&](Side& s, size_t i) {
         cognn_keys k = keys(E, s.owner, it, op);
         BE(cognn_rowscale_open_u64(E->ctx, e_mode == E_FROM_X ? s.ob[0] : nullptr, s.ob[1], X(s), s.svec, &k, s.p, s.n, F));
         eF[i] = (int64_t)s.n * F; e1[i] = s.n;
-    });
+    }, true);
     if (e_opened) {
         XList xl;
         for (size_t i = 0; i < ns; ++i) {
@@ -453,26 +548,44 @@ void rowscale_stage(cognn_engine* E, int64_t it, int op, int top, int F, XFn X, 
         const u64* e_own = e_opened ? X(s) : s.ob[0];
         const u64* e_peer = e_opened ? (s.peer ? X(*s.peer) : s.ib[0]) : s.ib[0];
         BE(cognn_rowscale_close_u64(E->ctx, s.ob[2], e_own, e_peer, s.ob[1], s.ib[1], &k, &tk, s.p, s.n, F));
-    });
+    }, true);
     exchange_ob(E, 2, eF);
-    trunc_close_all(E, it, top, dst, eF, open_next);
+    trunc_close_all(E, it, top, dst, eF, open_next, true);
 }
 
-void relu_stage(cognn_engine* E, int64_t it, bool e_opened) {
+void relu_stage(cognn_engine* E, int64_t it, bool e_opened, bool pairs_done) {
     // e_opened: ob[0] already holds E = z - a (written by the truncation close that produced z)
+    // pairs_done: the co-located pairs ran the ReLU inside the chain of the scale before it (rowscale_stage, relu_follows)
     const int F = E->hid();
     std::vector<int64_t> eF(E->sides.size());
+    if (!pairs_done) {
+        PairChains pc;
+        for (auto& s : E->sides) {
+            if (!paired(E, s) || s.p != 0) continue;
+            Side& t = *s.peer;
+            cognn_pair_chain& c = pc.add(s, s.cur, t.cur, s.n, F);
+            c.flags = COGNN_PC_RELU;
+            c.relu_keys = keys(E, s.owner, it, COGNN_OP_AP_RELU);
+            c.mask = s.relu_mask;
+            cognn_keys nk = keys(E, s.owner, it + 1, COGNN_OP_PS_GEMM);
+            c.out[0] = s.h1; c.out[1] = t.h1;
+            c.open[0] = s.h1E; c.open[1] = t.h1E;
+            c.open_key[0] = nk.k[COGNN_SL_A0]; c.open_key[1] = nk.k[COGNN_SL_A1];
+        }
+        pc.launch(E);
+    }
+    for (auto& s : E->sides) if (paired(E, s)) s.cur = s.h1;
     for_sides(E, true, [&](Side& s, size_t i) {
         cognn_keys k = keys(E, s.owner, it, COGNN_OP_AP_RELU);
         // only E = z - a is opened online: g = t - b is input-independent and published by the dealer offline
         if (!e_opened) BE(cognn_relu_open_u64(E->ctx, s.ob[0], nullptr, s.cur, &k, s.p, (int64_t)s.n * F));
         eF[i] = (int64_t)s.n * F;
-    });
+    }, true);
     exchange_ob(E, 0, eF);
     for_sides(E, true, [&](Side& s, size_t i) {
         cognn_keys k = keys(E, s.owner, it, COGNN_OP_AP_RELU);
         BE(cognn_relu_mul_u64(E->ctx, s.ob[2], s.ob[0], s.ib[0], nullptr, nullptr, &k, s.p, eF[i]));
-    });
+    }, true);
     exchange_ob(E, 2, eF);
     // H is the next iteration's PreScatter GEMM input (layer 1): write it straight into its h_t slot and emit the
     // Beaver opening E_p = H_p - A_p of that product in the same pass (gcn.h:230-239 of iteration it+1)
@@ -481,7 +594,7 @@ void relu_stage(cognn_engine* E, int64_t it, bool e_opened) {
         BE(cognn_relu_close_open_u64(E->ctx, s.h1, s.h1E, s.relu_mask, s.cur, s.ob[2], s.ib[2],
                                      nk.k[s.p == 0 ? COGNN_SL_A0 : COGNN_SL_A1], eF[i]));
         s.cur = s.h1;
-    });
+    }, true);
     E->gemm_x_opened_for = it + 1;
 }
 
@@ -563,12 +676,14 @@ void message_passing(cognn_engine* E, int F, int64_t it, bool open_scale) {
         std::vector<int64_t> sb, se;
         std::vector<u64> sk;
         for (auto& s : E->sides) {
+            if (paired(E, s)) continue;                       // a co-located pair hands the plain result to its chain
             const int64_t off = s.p == 0 ? E->A_off[s.owner] : E->B_off[s.owner];
             cognn_keys k = keys(E, s.owner, it, COGNN_OP_GA_SCALE);
             sb.push_back(off); se.push_back(off + s.n); sk.push_back(k.k[s.p == 0 ? COGNN_SL_A0 : COGNN_SL_A1]);
         }
-        BE(cognn_gather_csr_open_u64(E->ctx, E->aggOut, E->table, E->table, E->agg_rowptr, E->agg_col, E->aggRows, F,
-                                     (int32_t)sb.size(), sb.data(), se.data(), sk.data()));
+        if (sb.empty()) BE(cognn_gather_csr_u64(E->ctx, E->aggOut, E->table, E->table, E->agg_rowptr, E->agg_col, E->aggRows, F));
+        else BE(cognn_gather_csr_open_u64(E->ctx, E->aggOut, E->table, E->table, E->agg_rowptr, E->agg_col, E->aggRows, F,
+                                          (int32_t)sb.size(), sb.data(), se.data(), sk.data()));
     } else {
         BE(cognn_gather_csr_u64(E->ctx, E->aggOut, E->table, E->table, E->agg_rowptr, E->agg_col, E->aggRows, F));
     }
@@ -718,7 +833,7 @@ void weight_update_chain(cognn_engine* E, int64_t it, int layer) {
 
 void run_iteration(cognn_engine* E, int64_t it) {
     const IterInfo I = iter_info(E, it);
-    bool relu_opened = false, wgrad_w_opened = false;
+    bool relu_opened = false, wgrad_w_opened = false, relu_pairs_done = false;
     if (I.e == 0) {                                        // ss_...h:695, 938: back to the input features
         for (auto& s : E->sides) { s.cur = s.feat; s.curF = E->in(); }
     }
@@ -739,13 +854,15 @@ void run_iteration(cognn_engine* E, int64_t it) {
             const bool scale_follows = I.e != 0;
             // the truncation close of the product also opens the row scale that consumes it
             OpenNext open_scale([&](Side& s) { return keys(E, s.owner, it, COGNN_OP_PS_SCALE).k[s.p == 0 ? COGNN_SL_A0 : COGNN_SL_A1]; });
+            FollowScale follow;
+            if (scale_follows) { follow.op = COGNN_OP_PS_SCALE; follow.top = COGNN_OP_PS_SCALE_TRUNC; follow.dst = [&](Side& s) { return table_seg(E, s, F); }; }
             gemm_stage(E, it, [&](Side& s) { return s.cur; }, [&](Side& s) { return s.W[I.layer]; },
                        [&](Side& s) { return prescatter_spec(E, s, I.layer); },
                        [&](Side& s) { return scale_follows ? s.buf[1] : table_seg(E, s, F); }, x_opened,
-                       scale_follows ? open_scale : OpenNext());
+                       scale_follows ? open_scale : OpenNext(), false, follow);
             if (scale_follows)
                 rowscale_stage(E, it, COGNN_OP_PS_SCALE, COGNN_OP_PS_SCALE_TRUNC, F, [&](Side& s) { return s.buf[1]; },
-                               [&](Side& s) { return table_seg(E, s, F); }, E_IN_OB0);
+                               [&](Side& s) { return table_seg(E, s, F); }, E_IN_OB0, OpenNext(), true);
         } else {
             rowscale_stage(E, it, COGNN_OP_PS_SCALE, COGNN_OP_PS_SCALE_TRUNC, F, [&](Side& s) { return s.cur; },
                            [&](Side& s) { return table_seg(E, s, F); });
@@ -769,14 +886,15 @@ void run_iteration(cognn_engine* E, int64_t it) {
             OpenNext open_wgrad([&](Side& s) { return gemm_keys(E, s, it, wgrad_spec(E, s, I.layer, it)).k[s.p == 0 ? COGNN_SL_B0 : COGNN_SL_B1]; }, 1);
             rowscale_stage(E, it, COGNN_OP_GA_SCALE, COGNN_OP_GA_SCALE_TRUNC, F, [&](Side& s) { return s.cur; },
                            [&](Side& s) { return s.buf[1]; }, fuse_open ? E_IN_X : E_FROM_X,
-                           relu_opened ? open_relu : wgrad_w_opened ? open_wgrad : OpenNext());
-            for (auto& s : E->sides) s.cur = s.buf[1];
+                           relu_opened ? open_relu : wgrad_w_opened ? open_wgrad : OpenNext(), false, relu_opened);
+            relu_pairs_done = relu_opened;
+            for (auto& s : E->sides) if (!(relu_pairs_done && paired(E, s))) s.cur = s.buf[1];
         }
     }
     // ---- ApplyComp (gcn.h:515-811) ----
     Phase ph_ap(E, T_PH_APPLY);
     if (I.fwd) {
-        if (I.e != I.f - 1) relu_stage(E, it, relu_opened);
+        if (I.e != I.f - 1) relu_stage(E, it, relu_opened, relu_pairs_done);
         else softmax_stage(E, it);
         for (auto& s : E->sides) s.curF = (I.e != I.f - 1) ? E->hid() : E->lab();
         return;
@@ -792,7 +910,8 @@ void run_iteration(cognn_engine* E, int64_t it) {
             Batch batch(E);
             for (auto& s : E->sides) {
                 u64* dstb = (s.cur == s.buf[1]) ? s.buf[0] : s.buf[1];
-                BE(cognn_mask_select_u64(E->ctx, dstb, s.cur, s.relu_mask, (int64_t)s.n * E->hid()));
+                const uint8_t* mask = (paired(E, s) && s.p == 1) ? s.peer->relu_mask : s.relu_mask;   // a pair chain writes one (public) mask
+                BE(cognn_mask_select_u64(E->ctx, dstb, s.cur, mask, (int64_t)s.n * E->hid()));
                 s.cur = dstb;
             }
         }
@@ -1325,8 +1444,10 @@ int cognn_engine_get_phase_seconds(cognn_engine* E, double* out6) {
 }
 int cognn_engine_set_option(cognn_engine* E, int32_t option, int64_t value) {
     return guard([&] {
-        if (!E || option != COGNN_OPT_RETAIN_OFFLINE) throw EngineError("cognn_engine_set_option: unknown option");
-        E->retain_offline = value != 0;
+        if (!E) throw EngineError("null engine");
+        if (option == COGNN_OPT_RETAIN_OFFLINE) E->retain_offline = value != 0;
+        else if (option == COGNN_OPT_PAIR_FUSION) E->pair_fusion = value != 0;
+        else throw EngineError("cognn_engine_set_option: unknown option");
     });
 }
 int cognn_engine_get_memory(cognn_engine* E, int64_t* allocations, int64_t* bytes) {

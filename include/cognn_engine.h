@@ -75,7 +75,11 @@ int cognn_engine_offline(cognn_engine* e, int64_t iter_begin, int64_t iter_end);
 /* A dealt product share is released as soon as the product that consumes it has run, so device memory stays bounded however
  * many iterations a run has (the reference default is -m 1000): deal one epoch ahead.  Replaying the same iterations
  * (bench.py's repeated inference pass) keeps them instead: cognn_engine_set_option(e, COGNN_OPT_RETAIN_OFFLINE, 1). */
-enum { COGNN_OPT_RETAIN_OFFLINE = 1 };
+/* COGNN_OPT_PAIR_FUSION (default 1): when both share-holders of a vertex set are hosted by this process, their two-party
+ * steps between two linear ops run as one pair chain (cognn_pair_chain_u64: exchange in registers) instead of per-side
+ * open -> HBM -> close passes.  0 forces the per-side kernels everywhere (the ones a one-party-per-GPU run uses); the shares
+ * are bit-identical either way.  Change it only between iterations whose first GAS iteration is a multiple of the epoch. */
+enum { COGNN_OPT_RETAIN_OFFLINE = 1, COGNN_OPT_PAIR_FUSION = 2 };
 int cognn_engine_set_option(cognn_engine* e, int32_t option, int64_t value);
 /* Offline-phase cache on disk, the counterpart of the reference's preprocess/<setting>/ directory reused with `-n 1`
  * (include/harness.h:140-146, README.md:215-216): save writes every dealt product share currently held on this rank to

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define COGNN_ABI_VERSION 1
+#define COGNN_ABI_VERSION 2
 #define COGNN_NUM_SLOTS 11
 
 typedef struct cognn_ctx cognn_ctx;
@@ -167,6 +167,37 @@ int cognn_softmax_u64(cognn_ctx*, uint64_t* p_out, uint64_t* d_out, uint64_t* pf
  * out[0..5] (int64 counts: correct full/train/border-train/test/border-test, n) + loss (double). */
 int cognn_metrics_q16(cognn_ctx*, const uint64_t* pfx, const int32_t* labels, const uint8_t* border,
                       int64_t rows, int64_t L, int64_t train_rows, int64_t val_rows, int64_t* counts6, double* loss);
+
+/* ---- both share-holders on one device: a chain of protocol steps with the exchange in registers ---------------------------
+ * When the owner AND the co-party of a vertex set are hosted by the same process (BASELINE configs "co-located on one
+ * MI355X, in-device share exchange") every opening of a two-party step would be written to HBM by one side only to be read
+ * back by the other.  A pair chain runs the steps between two linear ops (GEMM / Gather) for BOTH sides in one kernel: each
+ * thread evaluates side 0's and side 1's local arithmetic exactly as the per-side entry points above do (same dealer
+ * streams, same formulas) and hands the opened values over in registers.  Results are bit-identical to the per-side
+ * sequence; only HBM passes disappear.  Steps, in this order, selected by `flags`:
+ *   COGNN_PC_TRUNC_IN   x_p is a raw Beaver product share: truncation of x_p + C_p (C_0 from gemm_keys, C_1 = c1[]; with
+ *                       COGNN_PC_NO_C the product already contains C_p)       = trunc_open[_add] + exchange + trunc_close
+ *   COGNN_PC_SCALE      row scale by the shared vector (scale[0], scale[1]) then truncation = rowscale_open + exchange +
+ *                       rowscale_close + exchange + trunc_close; with COGNN_PC_INPUT_OPENED x_p already is V_p - a_p (written
+ *                       by cognn_gather_csr_open_u64)
+ *   COGNN_PC_RELU       masked-sign ReLU = relu_open(G = NULL) + exchange + relu_mul + exchange + relu_close; mask optional
+ * Outputs: out[p] (may be NULL) and, when open[p] != NULL, the opening of the op that consumes the result:
+ * open[p][i] = out_p[i] - prng(open_key[p], i).  rows * F < 2^32. */
+enum { COGNN_PC_TRUNC_IN = 1, COGNN_PC_SCALE = 2, COGNN_PC_RELU = 4, COGNN_PC_INPUT_OPENED = 8, COGNN_PC_NO_C = 16 };
+typedef struct {
+    const uint64_t* x[2];        /* the two sides' input shares [rows x F] */
+    const uint64_t* c1;          /* side 1's dealt product share (COGNN_PC_TRUNC_IN without COGNN_PC_NO_C) */
+    const uint64_t* scale[2];    /* the two sides' shares of the row scale [rows] (COGNN_PC_SCALE) */
+    uint64_t* out[2];
+    uint64_t* open[2];
+    uint8_t* mask;               /* public ReLU sign, 1 byte per element (COGNN_PC_RELU, optional) */
+    uint64_t open_key[2];
+    cognn_keys gemm_keys, trunc_in_keys, scale_keys, scale_trunc_keys, relu_keys;
+    int64_t rows, F;
+    int32_t flags;
+} cognn_pair_chain;
+/* independent chains (the co-located pairs of one protocol phase) are issued as shared launches */
+int cognn_pair_chain_u64(cognn_ctx*, const cognn_pair_chain* chains, int32_t count);
 
 /* out[c,r] = in[r,c] for a small [rows x cols] matrix (transpose(), include/task/task.h:243; gcn.h:648) */
 int cognn_transpose_u64(cognn_ctx*, uint64_t* out, const uint64_t* in, int64_t rows, int64_t cols);

@@ -364,6 +364,64 @@ int cognn_metrics_q16(cognn_ctx*, const uint64_t* pfx, const int32_t* labels, co
     *loss = ls;
     return 0;
 }
+// The pair chain of the HIP library fuses both sides' steps into one kernel; this reference runs the SAME steps through the
+// per-side entry points above, one after the other, with the exchanged values in ordinary buffers - an independent statement
+// of what the fused kernel has to produce.
+int cognn_pair_chain_u64(cognn_ctx* ctx, const cognn_pair_chain* chains, int32_t count) {
+    for (int32_t ci = 0; ci < count; ++ci) {
+        const cognn_pair_chain& s = chains[ci];
+        const int64_t n = s.rows * s.F;
+        if (n <= 0) continue;
+        REQ(s.x[0] && s.x[1], "pair_chain: null input");
+        std::vector<u64> cur[2], o0[2], o1[2];
+        for (int p = 0; p < 2; ++p) { cur[p].assign(s.x[p], s.x[p] + n); o0[p].resize((size_t)n); o1[p].resize((size_t)n); }
+        bool opened = (s.flags & COGNN_PC_INPUT_OPENED) != 0;
+        if (s.flags & COGNN_PC_TRUNC_IN) {
+            for (int p = 0; p < 2; ++p) {
+                int rc = (s.flags & COGNN_PC_NO_C) ? cognn_trunc_open_u64(ctx, o0[p].data(), cur[p].data(), 1, &s.trunc_in_keys, p, n)
+                                                 : cognn_trunc_open_add_u64(ctx, o0[p].data(), cur[p].data(), s.c1, &s.gemm_keys, &s.trunc_in_keys, p, n);
+                if (rc) return rc;
+            }
+            for (int p = 0; p < 2; ++p)
+                if (int rc = cognn_trunc_close_u64(ctx, cur[p].data(), p == 0 ? o0[0].data() : nullptr, p == 0 ? o0[1].data() : nullptr,
+                                                   &s.trunc_in_keys, p, 0, n)) return rc;
+        }
+        if (s.flags & COGNN_PC_SCALE) {
+            REQ(s.scale[0] && s.scale[1], "pair_chain: null scale");
+            std::vector<u64> g[2];
+            for (int p = 0; p < 2; ++p) {
+                g[p].resize((size_t)s.rows);
+                if (int rc = cognn_rowscale_open_u64(ctx, opened ? nullptr : o0[p].data(), g[p].data(), cur[p].data(), s.scale[p], &s.scale_keys, p,
+                                                     s.rows, s.F)) return rc;
+                if (opened) o0[p] = cur[p];
+            }
+            for (int p = 0; p < 2; ++p)
+                if (int rc = cognn_rowscale_close_u64(ctx, o1[p].data(), o0[p].data(), o0[1 - p].data(), g[p].data(), g[1 - p].data(), &s.scale_keys,
+                                                      &s.scale_trunc_keys, p, s.rows, s.F)) return rc;
+            for (int p = 0; p < 2; ++p)
+                if (int rc = cognn_trunc_close_u64(ctx, cur[p].data(), p == 0 ? o1[0].data() : nullptr, p == 0 ? o1[1].data() : nullptr,
+                                                   &s.scale_trunc_keys, p, 0, n)) return rc;
+        }
+        if (s.flags & COGNN_PC_RELU) {
+            std::vector<u64> h[2];
+            for (int p = 0; p < 2; ++p)
+                if (int rc = cognn_relu_open_u64(ctx, o0[p].data(), nullptr, cur[p].data(), &s.relu_keys, p, n)) return rc;
+            for (int p = 0; p < 2; ++p)
+                if (int rc = cognn_relu_mul_u64(ctx, o1[p].data(), o0[p].data(), o0[1 - p].data(), nullptr, nullptr, &s.relu_keys, p, n)) return rc;
+            for (int p = 0; p < 2; ++p) {
+                h[p].resize((size_t)n);
+                if (int rc = cognn_relu_close_u64(ctx, h[p].data(), p == 0 ? s.mask : nullptr, cur[p].data(), o1[p].data(), o1[1 - p].data(), n)) return rc;
+            }
+            for (int p = 0; p < 2; ++p) cur[p].swap(h[p]);
+        }
+        for (int p = 0; p < 2; ++p) {
+            if (s.open[p])
+                for (int64_t i = 0; i < n; ++i) s.open[p][i] = cur[p][(size_t)i] - cognn_prng(s.open_key[p], (u64)i);
+            if (s.out[p]) memcpy(s.out[p], cur[p].data(), (size_t)n * 8);
+        }
+    }
+    return 0;
+}
 int cognn_transpose_u64(cognn_ctx*, uint64_t* out, const uint64_t* in, int64_t rows, int64_t cols) {
     for (int64_t r = 0; r < rows; ++r)
         for (int64_t c = 0; c < cols; ++c) out[c * rows + r] = in[r * cols + c];

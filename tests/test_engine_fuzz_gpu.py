@@ -40,6 +40,7 @@ def test_engine_random_configuration(seed):
     eng = Engine(k, src, dst, part, gp, seed=seed, variant=variant)
     eng.set_global_data(feats, labels)
     eng.start()
+    eng.pair_fusion(seed % 4 != 3)                                        # every fourth configuration through the per-side kernels
     try:
         for it in range(iters):
             oracle.iteration(it)

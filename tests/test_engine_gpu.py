@@ -35,9 +35,13 @@ def _compare(oracle, eng, k, it):
             assert np.array_equal(eng.weight(P, 1, l), oracle.states[c].remoteWeight[l]), (it, P, l)
 
 
+@pytest.mark.parametrize("pair_fusion", [True, False])
 @pytest.mark.parametrize("k", [2, 3, 4])
-def test_training_two_epochs_bit_exact(k):
+def test_training_two_epochs_bit_exact(k, pair_fusion):
+    """pair_fusion: co-located share-holders run their steps as pair chains (exchange in registers, the default) or through the
+    per-side open / close kernels a one-party-per-GPU run uses; the shares are the oracle's either way."""
     oracle, eng = _setup(k, 60, 150, 24, 8, 5)
+    eng.pair_fusion(pair_fusion)
     for P in range(k):
         assert list(eng.party_vids(P)) == oracle.states[P].localVertexPos
         t, i, b = eng.party_degrees(P)
@@ -72,10 +76,12 @@ def test_inference_variant_and_offline_phase():
     eng.close()
 
 
-def test_odd_dims_cora_like_shapes():
+@pytest.mark.parametrize("pair_fusion", [True, False])
+def test_odd_dims_cora_like_shapes(pair_fusion):
     """labels=7 (odd row width -> scalar gather path), hidden 16, several isolated vertices."""
     k = 2
     oracle, eng = _setup(k, 90, 100, 33, 16, 7, seed=3, gseed=5)
+    eng.pair_fusion(pair_fusion)
     for it in range(6):
         oracle.iteration(it)
         eng.run(it, it + 1)
@@ -122,6 +128,8 @@ def test_dataset_shaped_training_bit_exact(name, iters):
     eng = Engine(k, src, dst, part, GnnParam(**kw), seed=0xC06A11)
     eng.set_global_data(feats, labels)
     eng.start()
+    if name == "citeseer-2p":
+        eng.pair_fusion(False)                       # one of the dataset shapes through the per-side kernels
     for it in range(iters):
         oracle.iteration(it)
         eng.run(it, it + 1)

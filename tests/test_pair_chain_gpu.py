@@ -1,0 +1,122 @@
+"""cognn_pair_chain_u64: both share-holders' protocol steps in one kernel with the exchange in registers.  Every flag
+combination the engine uses (and the opened-input form) against the oracle's two-party functions, bit for bit, including odd
+widths (a thread's two elements fall into different rows) and odd lengths (single-element tail)."""
+import ctypes
+
+import numpy as np
+import pytest
+
+import cognn_oracle as co
+from gpu_util import dev, dev_empty, host, ptr, rand_u64, U64
+
+pytestmark = pytest.mark.gpu
+
+TRUNC_IN, SCALE, RELU, OPENED, NO_C = 1, 2, 4, 8, 16
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from cognn_amd import capi
+    c = capi.Context(0)
+    yield c
+    c.close()
+
+
+def _keys(seed, owner, it, op):
+    from cognn_amd import capi
+    return capi.make_keys(seed, owner, it, op), (lambda slot: co.stream_key(seed, owner, it, op, slot))
+
+
+def _expect(flags, x0, x1, c1, s0, s1, kf):
+    """The oracle's per-step functions chained the way the flags say."""
+    with np.errstate(over="ignore"):
+        v0, v1 = x0.copy(), x1.copy()
+        pos = None
+        if flags & TRUNC_IN:
+            if not flags & NO_C:
+                v0 = v0 + co.prng_shape(kf["gemm"](co.SL_C0), v0.shape); v1 = v1 + c1
+            v0, v1 = co.trunc_pair(v0, v1, kf["tin"])
+        if flags & SCALE:
+            if flags & OPENED:      # the inputs already are V_p - a_p: recover V_p for the oracle's function
+                v0 = v0 + co.prng_shape(kf["scale"](co.SL_A0), v0.shape); v1 = v1 + co.prng_shape(kf["scale"](co.SL_A1), v1.shape)
+            z0, z1 = co.beaver_rowscale_pair(v0, v1, s0, s1, kf["scale"])
+            v0, v1 = co.trunc_pair(z0, z1, kf["strunc"])
+        if flags & RELU:
+            v0, v1, pos = co.relu_pair(v0, v1, kf["relu"])
+    return v0, v1, pos
+
+
+@pytest.mark.parametrize("flags", [TRUNC_IN, TRUNC_IN | NO_C, TRUNC_IN | SCALE, SCALE, SCALE | OPENED, SCALE | RELU, RELU,
+                                   TRUNC_IN | SCALE | RELU, SCALE | OPENED | RELU])
+@pytest.mark.parametrize("rows,F", [(257, 16), (301, 7), (64, 64), (1, 1), (33, 3)])
+def test_pair_chain_matches_the_two_party_oracle(ctx, flags, rows, F):
+    from cognn_amd import capi
+    rng = np.random.default_rng(rows * 131 + F * 7 + flags)
+    shape = (rows, F)
+    # fixed-point-sized values so that truncation never meets its 2^61 bound; shares are uniform
+    val = rng.integers(-(1 << 40), 1 << 40, size=shape).astype(np.int64).astype(U64)
+    x1 = rand_u64(rng, shape)
+    with np.errstate(over="ignore"):
+        x0 = val - x1
+    c1 = rand_u64(rng, shape) >> U64(30)
+    s0 = co.normalizer(rng.integers(0, 9, size=rows)); s1 = np.zeros(rows, dtype=U64)
+    ks = {n: _keys(5, 3, 9, op) for n, op in (("gemm", co.OP_PS_GEMM), ("tin", co.OP_PS_GEMM_TRUNC), ("scale", co.OP_GA_SCALE),
+                                                ("strunc", co.OP_GA_SCALE_TRUNC), ("relu", co.OP_AP_RELU))}
+    kf = {n: v[1] for n, v in ks.items()}
+    ok0, ok1 = co.stream_key(1, 2, 3, 4, 0), co.stream_key(1, 2, 3, 4, 1)
+    out0, out1, op0, op1 = (dev_empty(shape) for _ in range(4))
+    mask = dev_empty(shape, "u8")
+    c = capi.PairChain()
+    c.x[0] = dev(x0).data_ptr(); c.x[1] = dev(x1).data_ptr(); c.c1 = dev(c1).data_ptr()
+    c.scale[0] = dev(s0).data_ptr(); c.scale[1] = dev(s1).data_ptr()
+    c.out[0] = out0.data_ptr(); c.out[1] = out1.data_ptr(); c.open[0] = op0.data_ptr(); c.open[1] = op1.data_ptr()
+    c.mask = mask.data_ptr(); c.open_key[0] = ok0; c.open_key[1] = ok1
+    c.gemm_keys = ks["gemm"][0]; c.trunc_in_keys = ks["tin"][0]; c.scale_keys = ks["scale"][0]
+    c.scale_trunc_keys = ks["strunc"][0]; c.relu_keys = ks["relu"][0]
+    c.rows = rows; c.F = F; c.flags = flags
+    ctx.call("cognn_pair_chain_u64", ctypes.byref(c), 1)
+    e0, e1, pos = _expect(flags, x0, x1, c1, s0, s1, kf)
+    assert np.array_equal(host(out0), e0) and np.array_equal(host(out1), e1)
+    with np.errstate(over="ignore"):
+        assert np.array_equal(host(op0), e0 - co.prng_shape(ok0, shape))
+        assert np.array_equal(host(op1), e1 - co.prng_shape(ok1, shape))
+        if flags & (TRUNC_IN | SCALE) and not flags & RELU:      # the chain computes what it should: trunc / scaled value within 1 LSB per step
+            want = val.astype(np.int64)
+            if flags & TRUNC_IN:
+                if not flags & NO_C:
+                    want = want + (co.prng_shape(kf["gemm"](co.SL_C0), shape) + c1).astype(np.int64)
+                want = want >> 16
+            got = (host(out0) + host(out1)).astype(np.int64)
+            if not flags & SCALE:
+                assert np.abs(got - want).max() <= 1
+    if flags & RELU:
+        assert np.array_equal(host(mask, np.uint8).astype(bool), pos)
+
+
+def test_pair_chain_batches_and_rejects_bad_chains(ctx):
+    from cognn_amd import capi
+    rng = np.random.default_rng(5)
+    n_chains = 11                                     # more than one launch batch (8)
+    arr = (capi.PairChain * n_chains)()
+    exp = []
+    k, kf = _keys(8, 1, 2, co.OP_AP_GEMM_TRUNC)
+    for i in range(n_chains):
+        rows, F = 50 + 13 * i, 4 + i
+        x0 = rand_u64(rng, (rows, F)) >> U64(4); x1 = rand_u64(rng, (rows, F)) >> U64(4)
+        o0, o1 = dev_empty((rows, F)), dev_empty((rows, F))
+        arr[i].x[0] = dev(x0).data_ptr(); arr[i].x[1] = dev(x1).data_ptr(); arr[i].out[0] = o0.data_ptr(); arr[i].out[1] = o1.data_ptr()
+        arr[i].trunc_in_keys = k; arr[i].rows = rows; arr[i].F = F; arr[i].flags = TRUNC_IN | NO_C
+        exp.append((o0, o1, co.trunc_pair(x0, x1, kf)))
+    ctx.call("cognn_pair_chain_u64", arr, n_chains)
+    for o0, o1, (e0, e1) in exp:
+        assert np.array_equal(host(o0), e0) and np.array_equal(host(o1), e1)
+    bad = capi.PairChain()
+    bad.rows = 4; bad.F = 4; bad.flags = 0
+    with pytest.raises(capi.CognnError, match="no step"):
+        ctx.call("cognn_pair_chain_u64", ctypes.byref(bad), 1)
+    bad.flags = TRUNC_IN | OPENED | SCALE
+    with pytest.raises(capi.CognnError, match="opened input"):
+        ctx.call("cognn_pair_chain_u64", ctypes.byref(bad), 1)
+    bad.flags = SCALE
+    with pytest.raises(capi.CognnError, match="null"):
+        ctx.call("cognn_pair_chain_u64", ctypes.byref(bad), 1)
