@@ -497,6 +497,132 @@ void beaver_gemm_ws_kernel(u64* Z, const u64* __restrict__ E0, const u64* __rest
 }
 
 // ------------------------------------------------------------------------------------------
+// Register-direct fused Beaver close for N <= 16 (the reference datasets' hidden width and every label count):
+//   Z = [E0+E1 | A_p] . [B_p + p*F ; F]  on v_mfma_i32_16x16x64_i8, no LDS, no barriers.
+// At N <= 16 a 32-wide MFMA tile wastes half its columns and, more importantly, the product is bound by the producers' VALU
+// work (counter-PRNG mask + signed-limb split, ~40 instructions per operand element) and by the opened-share stream, not by the
+// matrix pipe.  So every wave is its own producer: lane (r = lane & 15, b = lane >> 4) loads 8 k-values of row r of its 16-row
+// tile (four 16-byte pieces, interleaved over the 4 lanes of a row so that every load instruction reads whole 64-byte
+// segments), generates the 8 mask values of the same (row, k), byte-transposes both into the 8 limb planes - which IS the A
+// fragment of the 16x16x64 MFMA (k-slots 0..7 of a lane: E, slots 8..15: A_p) - and issues the 36 limb-pair MFMAs against B
+// fragments that a prep kernel laid out in the same slot order (8 KiB per K step, L1/L2-resident).  With 32 accumulator
+// registers a SIMD holds several waves, whose VALU, MFMA and memory phases overlap each other.
+// One K step = 32 k of both segments.  SPLITK as in beaver_gemm_ws_kernel (few row tiles, long K: Cora's 1433).
+// ------------------------------------------------------------------------------------------
+constexpr int kD16Stage = 8 * 64 * 16;                       // B fragments of one K step: [plane][lane][16 B]
+__device__ __forceinline__ int d16_k(int st, int b, int e) { return st * 32 + 8 * (e >> 1) + 2 * b + (e & 1); }   // k of entry e of lane block b
+
+__global__ __launch_bounds__(256) void prep_b_planes_d16_kernel(unsigned char* planes, const u64* __restrict__ F, const u64* __restrict__ F1,
+                                                                 u64 keyB, int p, int K, int N, int nst) {
+    // one thread per (k step, lane, 4-slot quad); quads 0,1: E segment (B_p + pF), quads 2,3: mask segment (F)
+    const int total = nst * 64 * 4;
+    for (int t = blockIdx.x * 256 + threadIdx.x; t < total; t += gridDim.x * 256) {
+        const int q = t & 3, l = (t >> 2) & 63, st = t >> 8;
+        const int n = l & 15, b = l >> 4, seg = q >> 1;
+        u64 v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = d16_k(st, b, (q & 1) * 4 + j);
+            u64 x = 0;
+            if (k < K && n < N) {
+                const u64 f = F[(size_t)k * N + n] + (F1 ? F1[(size_t)k * N + n] : 0ull);
+                x = seg == 0 ? cognn_prng(keyB, (u64)k * (u64)N + (u64)n) + (p == 1 ? f : 0ull) : f;
+            }
+            v[j] = x;
+        }
+        uint32_t pl[8];
+        split4(v, pl);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) *reinterpret_cast<uint32_t*>(planes + (size_t)st * kD16Stage + (i * 64 + l) * 16 + q * 4) = pl[i];
+    }
+}
+
+template <bool FULL, bool KEVEN, bool SPLITK>   // FULL: M % 16 == 0 and K % 32 == 0 (no edge masks); KEVEN: 16-byte loads are aligned
+__global__ __launch_bounds__(256) void beaver_gemm_d16_kernel(u64* Z, const u64* __restrict__ E0, const u64* __restrict__ E1,
+                                                              const unsigned char* __restrict__ planes, u64 keyA, int M, int N, int K, int nst,
+                                                              int ksteps, int tiles) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int tile = blockIdx.x * 4 + wave;
+    if (tile >= tiles) return;                               // (no barrier in this kernel)
+    const int r = lane & 15, b = lane >> 4;
+    const int m = tile * 16 + r, mc = FULL ? m : min(m, M - 1);
+    const int st0 = SPLITK ? (int)blockIdx.y * ksteps : 0;
+    const int st1 = SPLITK ? min(nst, st0 + ksteps) : nst;
+    if (st0 >= st1) return;
+    const u64* e0row = E0 + (size_t)mc * K;
+    const u64* e1row = (E1 ? E1 : E0) + (size_t)mc * K;
+    const u64 e1mask = E1 ? ~0ull : 0ull;
+    const v4i* bp = reinterpret_cast<const v4i*>(planes) + lane;
+    v4i acc[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) acc[s] = v4i{0, 0, 0, 0};
+
+    u64 cur0[8], cur1[8];                                    // E0 / E1 values of the lane's 8 entries
+    auto load_step = [&](int st, u64 a0[8], u64 a1[8]) {
+        if (KEVEN) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                int k = st * 32 + 8 * j + 2 * b;
+                if (!FULL) k = min(k, K - 2);
+                const u64x2 x = *reinterpret_cast<const u64x2*>(e0row + k);
+                const u64x2 y = *reinterpret_cast<const u64x2*>(e1row + k);
+                a0[2 * j] = x.x; a0[2 * j + 1] = x.y; a1[2 * j] = y.x; a1[2 * j + 1] = y.y;
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int k = min(d16_k(st, b, e), K - 1);
+                a0[e] = e0row[k]; a1[e] = e1row[k];
+            }
+        }
+    };
+    load_step(st0, cur0, cur1);
+    for (int st = st0; st < st1; ++st) {
+        v4i bf[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) bf[i] = bp[(size_t)(st * 8 + i) * 64];
+        u64 v[8], w[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = cur0[e] + (cur1[e] & e1mask);
+        if (st + 1 < st1) load_step(st + 1, cur0, cur1);     // next step's opened shares are in flight during this step's arithmetic
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            u64 x = keyA + ((u64)m * (u64)K + (u64)(st * 32 + 8 * j + 2 * b) + 1ull) * COGNN_GAMMA;
+            w[2 * j] = cognn_mix64(x);
+            w[2 * j + 1] = cognn_mix64(x + COGNN_GAMMA);
+        }
+        if (!FULL) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const u64 keep = (m < M && d16_k(st, b, e) < K) ? ~0ull : 0ull;
+                v[e] &= keep; w[e] &= keep;
+            }
+        }
+        uint32_t pe0[8], pe1[8], pm0[8], pm1[8];
+        split4(v, pe0); split4(v + 4, pe1); split4(w, pm0); split4(w + 4, pm1);
+        v4i af[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) af[i] = v4i{(int)pe0[i], (int)pe1[i], (int)pm0[i], (int)pm1[i]};
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j + i < 8; ++j) acc[i + j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[i], bf[j], acc[i + j], 0, 0, 0);
+    }
+    // C/D map of the 16x16 MFMA family: col = lane & 15, row = 4 * (lane >> 4) + reg
+    const int col = lane & 15;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int row = tile * 16 + 4 * b + q;
+        const uint32_t hi = (uint32_t)acc[4][q] + ((uint32_t)acc[5][q] << 8) + ((uint32_t)acc[6][q] << 16) + ((uint32_t)acc[7][q] << 24);
+        const long long lo = (long long)acc[0][q] + (long long)acc[1][q] * 256 + (long long)acc[2][q] * 65536 + (long long)acc[3][q] * 16777216;
+        if ((FULL || row < M) && col < N) {
+            if (SPLITK) atomicAdd((unsigned long long*)&Z[(size_t)row * N + col], (u64)lo + ((u64)hi << 32));
+            else Z[(size_t)row * N + col] = (u64)lo + ((u64)hi << 32);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // Plain TN product Z += (A1 + A2)^T-stored . B (dealer's offline C1 of a weight-gradient triple): logical A [M x K] is stored
 // [K x M], K = #vertices is huge, the output [M x N] tiny.  Split-K over workgroups, 128 x 64 output block per workgroup
 // (8 waves), both operands streamed from HBM and limb-split per 32-deep K step, uint64 atomics for the partial outputs
@@ -961,6 +1087,38 @@ int beaver_close_impl(cognn_ctx* ctx, uint64_t* Z, const uint64_t* E, const uint
     int rc;
     if (cognn_beaver_gemm_fusable(M, N, K, transA)) {
         unsigned char* planes = (unsigned char*)scratch;           // B limb planes, 16 KiB per K step, in the (MxK + KxN)-word scratch
+        static const bool no_d16 = getenv("COGNN_GEMM_NO_D16") != nullptr;   // A/B switch for tools/microbench.py: the wave-specialised kernel instead
+        if (N <= 16 && !no_d16) {                                      // register-direct kernel on v_mfma_i32_16x16x64_i8
+            const int nst32 = (int)((K + 31) / 32), tiles = (int)((M + 15) / 16);
+            hipLaunchKernelGGL(prep_b_planes_d16_kernel, dim3((unsigned)std::min(nst32, 1024)), dim3(256), 0, ctx->stream, planes, (const u64*)F,
+                               (const u64*)F1, keys->k[p == 0 ? COGNN_SL_B0 : COGNN_SL_B1], p, (int)K, (int)N, nst32);
+            CG_LAUNCH_CHECK();
+            int ksplits = 1, ksteps = nst32;
+            if (tiles <= 2048 && nst32 >= 4) {                         // few row tiles, long K: split K over workgroups
+                ksplits = std::min(nst32 / 2, (4096 + tiles - 1) / tiles);
+                ksteps = (nst32 + ksplits - 1) / ksplits;
+                ksplits = (nst32 + ksteps - 1) / ksteps;
+            }
+            if (ksplits > 1) CG_HIP(hipMemsetAsync(Z, 0, (size_t)M * N * 8, ctx->stream));
+            const bool full = (M % 16 == 0) && (K % 32 == 0), keven = (K % 2 == 0);
+            const dim3 grid((unsigned)((tiles + 3) / 4), (unsigned)ksplits);
+            const u64 keyA = keys->k[p == 0 ? COGNN_SL_A0 : COGNN_SL_A1];
+#define CG_D16_LAUNCH(...)                                                                                                   \
+    hipLaunchKernelGGL((beaver_gemm_d16_kernel<__VA_ARGS__>), grid, dim3(256), 0, ctx->stream, (u64*)Z, (const u64*)E, (const u64*)E1, planes, keyA, \
+                       (int)M, (int)N, (int)K, nst32, ksteps, tiles)
+            if (ksplits > 1) { if (keven) CG_D16_LAUNCH(false, true, true); else CG_D16_LAUNCH(false, false, true); }
+            else if (full) CG_D16_LAUNCH(true, true, false);
+            else if (keven) CG_D16_LAUNCH(false, true, false);
+            else CG_D16_LAUNCH(false, false, false);
+#undef CG_D16_LAUNCH
+            CG_LAUNCH_CHECK();
+            if (raw) return 0;
+            const int64_t n = M * N;
+            hipLaunchKernelGGL(add_cp_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 8192)), dim3(256), 0, ctx->stream, (u64*)Z,
+                               (const u64*)c1, keys->k[COGNN_SL_C0], p, n);
+            CG_LAUNCH_CHECK();
+            return 0;
+        }
         const int nst = (int)((K + 15) / 16);
         hipLaunchKernelGGL(prep_b_planes_ws_kernel, dim3((unsigned)std::min(nst * kFusedBN * 8 / 256 + 1, 1024)), dim3(256), 0, ctx->stream,
                            planes, (const u64*)F, (const u64*)F1, keys->k[p == 0 ? COGNN_SL_B0 : COGNN_SL_B1], p, (int)K, (int)N, nst);

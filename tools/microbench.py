@@ -95,6 +95,9 @@ if __name__ == "__main__":
     if a.what in ("gemm", "all"):
         bench_gemm(ctx, a.iters)
         bench_gemm(ctx, a.iters, K=64, N=16)
+        bench_gemm(ctx, a.iters, K=128, N=16)
+        bench_gemm(ctx, a.iters, K=16, N=16)
+        bench_gemm(ctx, a.iters, K=64, N=32)
     if a.what in ("gemm_tn", "all"):
         bench_gemm_tn(ctx, a.iters)
         bench_gemm_tn(ctx, a.iters, M=64, N=16)
