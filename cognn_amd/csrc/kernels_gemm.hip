@@ -513,12 +513,14 @@ constexpr int kD16Stage = 8 * 64 * 16;                       // B fragments of o
 __device__ __forceinline__ int d16_k(int st, int b, int e) { return st * 32 + 8 * (e >> 1) + 2 * b + (e & 1); }   // k of entry e of lane block b
 
 __global__ __launch_bounds__(256) void prep_b_planes_d16_kernel(unsigned char* planes, const u64* __restrict__ F, const u64* __restrict__ F1,
-                                                                 u64 keyB, int p, int K, int N, int nst) {
-    // one thread per (k step, lane, 4-slot quad); quads 0,1: E segment (B_p + pF), quads 2,3: mask segment (F)
-    const int total = nst * 64 * 4;
+                                                                 u64 keyB, int p, int K, int N, int nst, int NT) {
+    // one thread per (k step, column tile, lane, 4-slot quad); quads 0,1: E segment (B_p + pF), quads 2,3: mask segment (F)
+    // image: [k step][column tile][plane][lane][16 B]
+    const int total = nst * NT * 64 * 4;
     for (int t = blockIdx.x * 256 + threadIdx.x; t < total; t += gridDim.x * 256) {
-        const int q = t & 3, l = (t >> 2) & 63, st = t >> 8;
-        const int n = l & 15, b = l >> 4, seg = q >> 1;
+        const int q = t & 3, l = (t >> 2) & 63, sn = t >> 8;
+        const int nt = sn % NT, st = sn / NT;
+        const int n = nt * 16 + (l & 15), b = l >> 4, seg = q >> 1;
         u64 v[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -533,7 +535,7 @@ __global__ __launch_bounds__(256) void prep_b_planes_d16_kernel(unsigned char* p
         uint32_t pl[8];
         split4(v, pl);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) *reinterpret_cast<uint32_t*>(planes + (size_t)st * kD16Stage + (i * 64 + l) * 16 + q * 4) = pl[i];
+        for (int i = 0; i < 8; ++i) *reinterpret_cast<uint32_t*>(planes + (size_t)sn * kD16Stage + (i * 64 + l) * 16 + q * 4) = pl[i];
     }
 }
 
@@ -618,6 +620,138 @@ __global__ __launch_bounds__(256) void beaver_gemm_d16_kernel(u64* Z, const u64*
         if ((FULL || row < M) && col < N) {
             if (SPLITK) atomicAdd((unsigned long long*)&Z[(size_t)row * N + col], (u64)lo + ((u64)hi << 32));
             else Z[(size_t)row * N + col] = (u64)lo + ((u64)hi << 32);
+        }
+    }
+}
+
+// The same register-direct scheme for 16 < N <= 64: a wave owns a 16-row tile and NT = ceil(N / 16) column tiles; the A fragments of
+// a K step (the expensive part: loads, PRNG, limb split) are built ONCE and multiplied against the NT column tiles' B fragments,
+// which live in LDS for the whole launch (all K steps: nst * NT * 8 KiB <= 128 KiB; one fill, one barrier).  Workgroups are
+// persistent over row tiles.  8 waves per workgroup, one workgroup per CU: two waves per SIMD, so one wave's VALU phase runs
+// beside the other's MFMA phase (tools/valu_probe.hip: VALU of ANOTHER wave overlaps MFMAs almost completely).
+template <int NT, bool FULL, bool KEVEN, int DBG = 0>    // DBG (timing experiments only, results wrong): 1 no E loads, 2 no PRNG, 4 no MFMA,
+                                                        // 8 no limb split, 16 no B fragment reads
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void beaver_gemm_d16n_kernel(u64* Z, const u64* __restrict__ E0, const u64* __restrict__ E1, const unsigned char* __restrict__ planes, u64 keyA,
+                             int M, int N, int K, int nst, int tiles) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    {   // B fragments of every K step -> LDS
+        const int n16 = nst * NT * (kD16Stage / 16);
+        const u64x2* src = reinterpret_cast<const u64x2*>(planes);
+        u64x2* dst = reinterpret_cast<u64x2*>(smem);
+        for (int i = threadIdx.x; i < n16; i += 512) dst[i] = src[i];
+    }
+    __syncthreads();
+    const int r = lane & 15, b = lane >> 4;
+    const bool two = E1 != nullptr;                         // (uniform) the opened value arrives as two shares, summed here
+    const v4i* bp = reinterpret_cast<const v4i*>(smem) + lane;
+    const int wid = blockIdx.x * 8 + wave, nw = gridDim.x * 8;
+    const int my_tiles = (tiles - wid + nw - 1) / nw;
+    const int total = my_tiles * nst;                      // flattened (row tile, K step) space of this wave
+    if (total <= 0) return;                                // (after the only barrier)
+    // the opened shares of step it+1 are in flight while step it is split and multiplied
+    u64 nx0[8], nx1[8];
+    auto load_step = [&](int it) {
+        const int tile = wid + (it / nst) * nw, st = it % nst;
+        const int mc = FULL ? tile * 16 + r : min(tile * 16 + r, M - 1);
+        const u64* e0row = E0 + (size_t)mc * K;
+        if (DBG & 1) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { nx0[e] = (u64)mc * 77 + st + e; nx1[e] = (u64)st; }
+        } else if (KEVEN) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                int k = st * 32 + 8 * j + 2 * b;
+                if (!FULL) k = min(k, K - 2);
+                const u64x2 x = *reinterpret_cast<const u64x2*>(e0row + k);
+                nx0[2 * j] = x.x; nx0[2 * j + 1] = x.y;
+            }
+            if (two) {
+                const u64* e1row = E1 + (size_t)mc * K;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    int k = st * 32 + 8 * j + 2 * b;
+                    if (!FULL) k = min(k, K - 2);
+                    const u64x2 y = *reinterpret_cast<const u64x2*>(e1row + k);
+                    nx1[2 * j] = y.x; nx1[2 * j + 1] = y.y;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int k = min(d16_k(st, b, e), K - 1);
+                nx0[e] = e0row[k];
+                nx1[e] = two ? E1[(size_t)mc * K + k] : 0ull;
+            }
+        }
+    };
+    load_step(0);
+    v4i acc[NT][8];
+    for (int it = 0; it < total; ++it) {
+        const int tile = wid + (it / nst) * nw, st = it % nst;
+        const int m = tile * 16 + r;
+        if (st == 0) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int s2 = 0; s2 < 8; ++s2) acc[t][s2] = v4i{0, 0, 0, 0};
+        }
+        u64 v[8], w[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = two ? nx0[e] + nx1[e] : nx0[e];
+        if (it + 1 < total) load_step(it + 1);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            u64 x = keyA + ((u64)m * (u64)K + (u64)(st * 32 + 8 * j + 2 * b) + 1ull) * COGNN_GAMMA;
+            w[2 * j] = (DBG & 2) ? x : cognn_mix64(x);
+            w[2 * j + 1] = (DBG & 2) ? x + 1 : cognn_mix64(x + COGNN_GAMMA);
+        }
+        if (!FULL) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const u64 keep = (m < M && d16_k(st, b, e) < K) ? ~0ull : 0ull;
+                v[e] &= keep; w[e] &= keep;
+            }
+        }
+        uint32_t pe0[8], pe1[8], pm0[8], pm1[8];
+        if (DBG & 8) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { pe0[i] = (uint32_t)v[i]; pe1[i] = (uint32_t)(v[i] >> 32); pm0[i] = (uint32_t)w[i]; pm1[i] = (uint32_t)(w[i] >> 32); }
+        } else {
+            split4(v, pe0); split4(v + 4, pe1); split4(w, pm0); split4(w + 4, pm1);
+        }
+        v4i af[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) af[i] = v4i{(int)pe0[i], (int)pe1[i], (int)pm0[i], (int)pm1[i]};
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            v4i bf[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) bf[i] = (DBG & 16) ? af[(i + t) & 7] : bp[(size_t)((st * NT + t) * 8 + i) * 64];
+            if (DBG & 4) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { acc[t][i][0] += af[i][0] ^ bf[i][1]; acc[t][i][1] += af[i][2] ^ bf[i][3]; acc[t][i][2] += af[i][1]; acc[t][i][3] += af[i][3] ^ bf[i][0] ^ bf[i][2]; }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+#pragma unroll
+                    for (int j = 0; j + i < 8; ++j) acc[t][i + j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[i], bf[j], acc[t][i + j], 0, 0, 0);
+            }
+        }
+        if (st == nst - 1) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int col = t * 16 + (lane & 15);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int row = tile * 16 + 4 * b + q;
+                    const uint32_t hi = (uint32_t)acc[t][4][q] + ((uint32_t)acc[t][5][q] << 8) + ((uint32_t)acc[t][6][q] << 16) + ((uint32_t)acc[t][7][q] << 24);
+                    const long long lo = (long long)acc[t][0][q] + (long long)acc[t][1][q] * 256 + (long long)acc[t][2][q] * 65536 +
+                                         (long long)acc[t][3][q] * 16777216;
+                    if ((FULL || row < M) && col < N) Z[(size_t)row * N + col] = (u64)lo + ((u64)hi << 32);
+                }
+            }
         }
     }
 }
@@ -1087,11 +1221,14 @@ int beaver_close_impl(cognn_ctx* ctx, uint64_t* Z, const uint64_t* E, const uint
     int rc;
     if (cognn_beaver_gemm_fusable(M, N, K, transA)) {
         unsigned char* planes = (unsigned char*)scratch;           // B limb planes, 16 KiB per K step, in the (MxK + KxN)-word scratch
-        static const bool no_d16 = getenv("COGNN_GEMM_NO_D16") != nullptr;   // A/B switch for tools/microbench.py: the wave-specialised kernel instead
-        if (N <= 16 && !no_d16) {                                      // register-direct kernel on v_mfma_i32_16x16x64_i8
-            const int nst32 = (int)((K + 31) / 32), tiles = (int)((M + 15) / 16);
+        static const bool no_d16 = getenv("COGNN_GEMM_NO_D16") != nullptr;   // A/B switches for tools/microbench.py: the wave-specialised kernel instead
+        static const bool no_d16n = getenv("COGNN_GEMM_NO_D16N") != nullptr;
+        const int nst32 = (int)((K + 31) / 32), tiles = (int)((M + 15) / 16), NT = (int)((N + 15) / 16);
+        const u64 keyA_ = keys->k[p == 0 ? COGNN_SL_A0 : COGNN_SL_A1];
+        const bool full16 = (M % 16 == 0) && (K % 32 == 0), keven = (K % 2 == 0);
+        if (N <= 16 && K >= 32 && !no_d16) {                           // register-direct kernel on v_mfma_i32_16x16x64_i8
             hipLaunchKernelGGL(prep_b_planes_d16_kernel, dim3((unsigned)std::min(nst32, 1024)), dim3(256), 0, ctx->stream, planes, (const u64*)F,
-                               (const u64*)F1, keys->k[p == 0 ? COGNN_SL_B0 : COGNN_SL_B1], p, (int)K, (int)N, nst32);
+                               (const u64*)F1, keys->k[p == 0 ? COGNN_SL_B0 : COGNN_SL_B1], p, (int)K, (int)N, nst32, 1);
             CG_LAUNCH_CHECK();
             int ksplits = 1, ksteps = nst32;
             if (tiles <= 2048 && nst32 >= 4) {                         // few row tiles, long K: split K over workgroups
@@ -1100,17 +1237,57 @@ int beaver_close_impl(cognn_ctx* ctx, uint64_t* Z, const uint64_t* E, const uint
                 ksplits = (nst32 + ksteps - 1) / ksteps;
             }
             if (ksplits > 1) CG_HIP(hipMemsetAsync(Z, 0, (size_t)M * N * 8, ctx->stream));
-            const bool full = (M % 16 == 0) && (K % 32 == 0), keven = (K % 2 == 0);
             const dim3 grid((unsigned)((tiles + 3) / 4), (unsigned)ksplits);
-            const u64 keyA = keys->k[p == 0 ? COGNN_SL_A0 : COGNN_SL_A1];
 #define CG_D16_LAUNCH(...)                                                                                                   \
-    hipLaunchKernelGGL((beaver_gemm_d16_kernel<__VA_ARGS__>), grid, dim3(256), 0, ctx->stream, (u64*)Z, (const u64*)E, (const u64*)E1, planes, keyA, \
+    hipLaunchKernelGGL((beaver_gemm_d16_kernel<__VA_ARGS__>), grid, dim3(256), 0, ctx->stream, (u64*)Z, (const u64*)E, (const u64*)E1, planes, keyA_, \
                        (int)M, (int)N, (int)K, nst32, ksteps, tiles)
             if (ksplits > 1) { if (keven) CG_D16_LAUNCH(false, true, true); else CG_D16_LAUNCH(false, false, true); }
-            else if (full) CG_D16_LAUNCH(true, true, false);
+            else if (full16) CG_D16_LAUNCH(true, true, false);
             else if (keven) CG_D16_LAUNCH(false, true, false);
             else CG_D16_LAUNCH(false, false, false);
 #undef CG_D16_LAUNCH
+            CG_LAUNCH_CHECK();
+            if (raw) return 0;
+            const int64_t n = M * N;
+            hipLaunchKernelGGL(add_cp_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 8192)), dim3(256), 0, ctx->stream, (u64*)Z,
+                               (const u64*)c1, keys->k[COGNN_SL_C0], p, n);
+            CG_LAUNCH_CHECK();
+            return 0;
+        }
+        // 16 < N <= 64, all B fragments fit LDS, enough row tiles to fill the chip: the same scheme with NT column tiles per wave
+        if (N > 16 && !no_d16n && (size_t)nst32 * NT * kD16Stage <= 128 * 1024 && tiles >= 1024) {
+            const size_t lds = (size_t)nst32 * NT * kD16Stage;
+            hipLaunchKernelGGL(prep_b_planes_d16_kernel, dim3((unsigned)std::min(nst32 * NT, 1024)), dim3(256), 0, ctx->stream, planes, (const u64*)F,
+                               (const u64*)F1, keys->k[p == 0 ? COGNN_SL_B0 : COGNN_SL_B1], p, (int)K, (int)N, nst32, NT);
+            CG_LAUNCH_CHECK();
+            const dim3 grid((unsigned)std::min((tiles + 7) / 8, 256));
+#define CG_D16N_LAUNCH(...)                                                                                                  \
+    do {                                                                                                                      \
+        CG_HIP(hipFuncSetAttribute((const void*)beaver_gemm_d16n_kernel<__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL((beaver_gemm_d16n_kernel<__VA_ARGS__>), grid, dim3(512), lds, ctx->stream, (u64*)Z, (const u64*)E, (const u64*)E1, planes,  \
+                           keyA_, (int)M, (int)N, (int)K, nst32, tiles);                                                      \
+    } while (0)
+#define CG_D16N_NT(nt_)                                                                                                       \
+    do {                                                                                                                      \
+        if (full16) CG_D16N_LAUNCH(nt_, true, true);                                                                          \
+        else if (keven) CG_D16N_LAUNCH(nt_, false, true);                                                                     \
+        else CG_D16N_LAUNCH(nt_, false, false);                                                                               \
+    } while (0)
+#ifdef COGNN_GEMM_ABLATION   // timing experiments only (`make ABLATION=1`): these variants compute wrong results
+            static const int dbgn = getenv("COGNN_GEMM_DBG") ? atoi(getenv("COGNN_GEMM_DBG")) : 0;
+            if (NT == 4 && full16 && dbgn == 1) CG_D16N_LAUNCH(4, true, true, 1);
+            else if (NT == 4 && full16 && dbgn == 2) CG_D16N_LAUNCH(4, true, true, 2);
+            else if (NT == 4 && full16 && dbgn == 4) CG_D16N_LAUNCH(4, true, true, 4);
+            else if (NT == 4 && full16 && dbgn == 8) CG_D16N_LAUNCH(4, true, true, 8);
+            else if (NT == 4 && full16 && dbgn == 10) CG_D16N_LAUNCH(4, true, true, 10);
+            else if (NT == 4 && full16 && dbgn == 11) CG_D16N_LAUNCH(4, true, true, 11);
+            else if (NT == 4 && full16 && dbgn == 16) CG_D16N_LAUNCH(4, true, true, 16);
+            else if (NT == 4 && full16 && dbgn == 27) CG_D16N_LAUNCH(4, true, true, 27);
+            else
+#endif
+            if (NT == 2) CG_D16N_NT(2); else if (NT == 3) CG_D16N_NT(3); else CG_D16N_NT(4);
+#undef CG_D16N_NT
+#undef CG_D16N_LAUNCH
             CG_LAUNCH_CHECK();
             if (raw) return 0;
             const int64_t n = M * N;

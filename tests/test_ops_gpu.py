@@ -332,7 +332,10 @@ def test_softmax_pair_and_metrics(ctx, L):
 
 @pytest.mark.parametrize("M,N,K,transA", [(300, 64, 128, 0), (270, 7, 16, 0), (16, 7, 300, 1), (1433, 16, 270, 1),
                                              (300, 16, 77, 0), (1354, 16, 1433, 0), (260, 7, 7, 0), (64, 16, 2000, 1),
-                                             (128, 64, 1000, 2), (24, 5, 300, 2)])
+                                             (128, 64, 1000, 2), (24, 5, 300, 2),
+                                             # the register-direct kernels (N <= 16: any M; 16 < N <= 64: >= 1024 row tiles):
+                                             (2048, 16, 64, 0), (2051, 13, 130, 0), (515, 16, 33, 0), (16384, 64, 128, 0),
+                                             (16390, 33, 66, 0), (16400, 48, 35, 0), (16384, 32, 64, 0)])
 def test_beaver_gemm_pair(ctx, M, N, K, transA):
     """Full Beaver product: mask-open, exchange, dealer C1, close; vs oracle twoPartyGCNMatMul stand-in."""
     rng = np.random.default_rng(M * 3 + N)

@@ -47,6 +47,10 @@ def bench_gemm(ctx, iters, M=1 << 17, K=128, N=64):
         ms = timeit(lambda: ctx.call("cognn_beaver_gemm_close_raw_u64", P(Z), P(E0), P(E1), P(F), ctypes.byref(k), p, M, N, K, P(scratch)), iters)
         ops = 2.0 * 36 * 2 * M * K * N
         print("beaver_gemm_close_raw p=%d M=%d K=%d N=%d: %.3f ms  %.1f i8-TOP/s (%.1f%% of 5000)" % (p, M, K, N, ms, ops / ms / 1e9, ops / ms / 1e9 / 50.0))
+        # the layer-0 product of the engine: the opened feature tensor is kept pre-summed (one stream)
+        ms = timeit(lambda: ctx.call("cognn_beaver_gemm_close_raw_u64", P(Z), P(E0), None, P(F), ctypes.byref(k), p, M, N, K, P(scratch)), iters)
+        print("beaver_gemm_close_raw one E stream p=%d M=%d K=%d N=%d: %.3f ms  %.1f i8-TOP/s (%.1f%% of 5000)  %.0f GB/s"
+              % (p, M, K, N, ms, ops / ms / 1e9, ops / ms / 1e9 / 50.0, (M * K + M * N) * 8 / ms / 1e6))
     A = E0; B = F; C = Z
     ms = timeit(lambda: ctx.call("cognn_ring_gemm_u64", P(C), P(A), P(B), M, N, K, 0, 0), iters)
     print("ring_gemm (single product) M=%d K=%d N=%d: %.3f ms  %.1f i8-TOP/s" % (M, K, N, ms, 36 * 2.0 * M * K * N / ms / 1e9))
