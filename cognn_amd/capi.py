@@ -34,6 +34,13 @@ class PairChain(ctypes.Structure):
 PC_TRUNC_IN, PC_SCALE, PC_RELU, PC_INPUT_OPENED, PC_NO_C = 1, 2, 4, 8, 16
 
 
+class SoftmaxJob(ctypes.Structure):
+    """cognn_softmax_job (include/cognn_hip.h)."""
+    _fields_ = [("d_out", ctypes.c_void_p), ("z0", ctypes.c_void_p), ("z1", ctypes.c_void_p), ("labels", ctypes.c_void_p),
+                ("border", ctypes.c_void_p), ("keys", Keys), ("p", ctypes.c_int32), ("rows", ctypes.c_int64),
+                ("train_rows", ctypes.c_int64), ("val_rows", ctypes.c_int64), ("counts6", ctypes.c_void_p), ("loss", ctypes.c_void_p)]
+
+
 class CognnError(RuntimeError):
     pass
 
@@ -90,6 +97,7 @@ _SIGNATURES = {
     "cognn_softmax_u64": (_I, [_P, _P, _P, _P, _P, _P, _P, _KP, _I, _L, _L, _L]),
     "cognn_metrics_q16": (_I, [_P, _P, _P, _P, _L, _L, _L, _L, _P, _P]),
     "cognn_pair_chain_u64": (_I, [_P, ctypes.POINTER(PairChain), ctypes.c_int32]),
+    "cognn_softmax_jobs_u64": (_I, [_P, ctypes.POINTER(SoftmaxJob), ctypes.c_int32, _L]),
     "cognn_transpose_u64": (_I, [_P, _P, _P, _L, _L]),
     "cognn_timer_begin": (_I, [_P, _I]),
     "cognn_timer_end": (_I, [_P, _I]),

@@ -419,6 +419,88 @@ __global__ __launch_bounds__(kThreads) void metrics_kernel(const u64* pfx, const
     if (threadIdx.x == 0) atomicAdd(loss, s_loss);
 }
 
+// ---- prediction layer of all hosted sides in one launch; owner jobs fuse the metrics (gcn.h:578-632) --------------------------
+struct SoftmaxJobDev {
+    u64* d_out; const u64* z0; const u64* z1; const int32_t* labels; const uint8_t* border;
+    u64 keyRho; int p; int64_t rows, train_rows, val_rows;
+    unsigned long long* counts; double* loss;
+};
+constexpr int kSoftmaxJobsMax = 16;
+struct SoftmaxBatch {
+    SoftmaxJobDev j[kSoftmaxJobsMax];
+    unsigned blk_end[kSoftmaxJobsMax];
+    int count;
+};
+__global__ void softmax_jobs_zero_kernel(SoftmaxBatch b) {
+    const int t = threadIdx.x;
+    if (t < b.count * 8 && b.j[t >> 3].p == 0) {
+        if ((t & 7) < 6) b.j[t >> 3].counts[t & 7] = 0ull;
+        else if ((t & 7) == 6) *b.j[t >> 3].loss = 0.0;
+    }
+}
+template <int G>
+__global__ __launch_bounds__(kThreads) void softmax_jobs_kernel(SoftmaxBatch b, int L) {
+    __shared__ unsigned long long s_cnt[5];
+    __shared__ double s_loss;
+    const unsigned blk = blockIdx.x;
+    int seg = 0;
+    while (seg < b.count - 1 && blk >= b.blk_end[seg]) ++seg;
+    const SoftmaxJobDev& d = b.j[seg];
+    const unsigned blk0 = seg ? b.blk_end[seg - 1] : 0u;
+    const int64_t r = ((int64_t)(blk - blk0) * kThreads + threadIdx.x) / G;
+    const int j = threadIdx.x % G;
+    const bool valid = r < d.rows && j < L;
+    const bool keep = r < d.train_rows;
+    const int64_t idx = r * L + j;
+    const u64 rho = valid ? cognn_prng(d.keyRho, (u64)idx) : 0ull;
+    if (d.p == 1) {                                          // (uniform per workgroup)
+        if (valid) d.d_out[idx] = keep ? rho : 0ull;
+        return;
+    }
+    if (threadIdx.x < 5) s_cnt[threadIdx.x] = 0;
+    if (threadIdx.x == 0) s_loss = 0.0;
+    __syncthreads();
+    const long long NEG = -(1ll << 62);
+    long long z = valid ? (long long)(d.z0[idx] + d.z1[idx]) : NEG;
+    long long m = z;
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) { long long t = __shfl_xor(m, o, G); m = t > m ? t : m; }
+    long long e = valid ? cognn_exp_neg_q30(m - z) : 0;
+    long long S = e;
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) S += __shfl_xor(S, o, G);
+    const u64 pf = valid ? (u64)(((e << 16) + (S >> 1)) / S) : 0ull;          // the revealed Q16 probability (softmax_kernel)
+    const int lab = r < d.rows ? d.labels[r] : 0;
+    if (valid) d.d_out[idx] = keep ? ((pf - rho) - (j == lab ? COGNN_FX_ONE : 0ull)) : 0ull;
+    // metrics on the revealed probabilities (metrics_kernel): argmax with the first maximum winning ties, -log p[label]
+    u64 bv = valid ? pf : 0ull;
+    int bj = valid ? j : (1 << 20);
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) {
+        u64 ov = __shfl_xor(bv, o, G);
+        int oj = __shfl_xor(bj, o, G);
+        if (ov > bv || (ov == bv && oj < bj)) { bv = ov; bj = oj; }
+    }
+    if (r < d.rows && j == lab) {                            // one lane per row (labels are < L)
+        const bool ok = bj == lab;
+        const bool bd = d.border ? d.border[r] != 0 : false;
+        const bool tr = r < d.train_rows, te = r >= d.train_rows + d.val_rows;
+        if (ok) {
+            atomicAdd(&s_cnt[0], 1ull);
+            if (tr) atomicAdd(&s_cnt[1], 1ull);
+            if (tr && bd) atomicAdd(&s_cnt[2], 1ull);
+            if (te) atomicAdd(&s_cnt[3], 1ull);
+            if (te && bd) atomicAdd(&s_cnt[4], 1ull);
+        }
+        double pl = (double)pf / (double)COGNN_FX_ONE;
+        if (pl == 0.0) pl = 0.001;                           /* gcn.h:613-615 */
+        atomicAdd(&s_loss, -log(pl));
+    }
+    __syncthreads();
+    if (threadIdx.x < 5 && s_cnt[threadIdx.x]) atomicAdd(&d.counts[threadIdx.x], s_cnt[threadIdx.x]);
+    if (threadIdx.x == 0 && s_loss != 0.0) atomicAdd(d.loss, s_loss);
+}
+
 __global__ __launch_bounds__(kThreads) void transpose_kernel(u64* out, const u64* in, int64_t rows, int64_t cols) {
     const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
     if (i >= rows * cols) return;
@@ -646,6 +728,39 @@ int cognn_metrics_q16(cognn_ctx* ctx, const uint64_t* pfx, const int32_t* labels
     switch (G) { CG_MT_CASE(1) CG_MT_CASE(2) CG_MT_CASE(4) CG_MT_CASE(8) CG_MT_CASE(16) CG_MT_CASE(32) CG_MT_CASE(64) }
 #undef CG_MT_CASE
     CG_LAUNCH_CHECK();
+    return 0;
+}
+
+int cognn_softmax_jobs_u64(cognn_ctx* ctx, const cognn_softmax_job* jobs, int32_t count, int64_t L) {
+    { const int rc_flush_ = cg_flush(ctx); if (rc_flush_) return rc_flush_; }
+    CG_REQUIRE(ctx && (count == 0 || jobs) && count >= 0, "cognn_softmax_jobs_u64: bad arguments");
+    CG_REQUIRE(L > 0 && L <= 64, "cognn_softmax_jobs_u64: unsupported label count %lld (max 64)", (long long)L);
+    int G = 1;
+    while (G < L) G <<= 1;
+    for (int32_t c0 = 0; c0 < count; c0 += kSoftmaxJobsMax) {
+        SoftmaxBatch b;
+        b.count = 0;
+        for (int32_t c = c0; c < count && c < c0 + kSoftmaxJobsMax; ++c) {
+            const cognn_softmax_job& s = jobs[c];
+            CG_REQUIRE(s.d_out && (s.p == 0 || s.p == 1) && s.rows >= 0, "cognn_softmax_jobs_u64: job %d is malformed", c);
+            CG_REQUIRE(s.p == 1 || (s.z0 && s.z1 && s.labels && s.counts6 && s.loss), "cognn_softmax_jobs_u64: owner job %d needs z0, z1, labels, counts6, loss", c);
+            SoftmaxJobDev& d = b.j[b.count];
+            d.d_out = (u64*)s.d_out; d.z0 = (const u64*)s.z0; d.z1 = (const u64*)s.z1; d.labels = s.labels; d.border = s.border;
+            d.keyRho = s.keys.k[COGNN_SL_RHO]; d.p = s.p; d.rows = s.rows; d.train_rows = s.train_rows; d.val_rows = s.val_rows;
+            d.counts = (unsigned long long*)s.counts6; d.loss = s.loss;
+            const unsigned blocks = (unsigned)cg_div_up(s.rows * G, kThreads);
+            b.blk_end[b.count] = (b.count ? b.blk_end[b.count - 1] : 0u) + blocks;
+            ++b.count;
+        }
+        hipLaunchKernelGGL(softmax_jobs_zero_kernel, dim3(1), dim3(128), 0, ctx->stream, b);
+        CG_LAUNCH_CHECK();
+        const unsigned blocks = b.blk_end[b.count - 1];
+        if (blocks == 0) continue;
+#define CG_SJ_CASE(g) case g: hipLaunchKernelGGL(softmax_jobs_kernel<g>, dim3(blocks), dim3(kThreads), 0, ctx->stream, b, (int)L); break;
+        switch (G) { CG_SJ_CASE(1) CG_SJ_CASE(2) CG_SJ_CASE(4) CG_SJ_CASE(8) CG_SJ_CASE(16) CG_SJ_CASE(32) CG_SJ_CASE(64) }
+#undef CG_SJ_CASE
+        CG_LAUNCH_CHECK();
+    }
     return 0;
 }
 

@@ -607,20 +607,23 @@ void softmax_stage(cognn_engine* E, int64_t it) {
         else xl.recv(s.peer_rank, s.ib[0], (int64_t)s.n * L * 8);
     }
     run_exchange_sync(E, xl);
+    std::vector<cognn_softmax_job> jobs;                   // every hosted side in one launch, the owners' metrics fused in
     for (auto& s : E->sides) {
-        cognn_keys k = keys(E, s.owner, it, COGNN_OP_AP_SOFTMAX);
-        const int64_t train = (int64_t)((double)s.n * E->cfg.train_ratio);      // gcn.h:560
-        const int64_t val = (int64_t)((double)s.n * E->cfg.val_ratio);
-        u64* dstb = (s.cur == s.buf[1]) ? s.buf[0] : s.buf[1];
+        cognn_softmax_job j;
+        memset(&j, 0, sizeof(j));
+        j.keys = keys(E, s.owner, it, COGNN_OP_AP_SOFTMAX);
+        j.p = s.p; j.rows = s.n;
+        j.train_rows = (int64_t)((double)s.n * E->cfg.train_ratio);      // gcn.h:560
+        j.val_rows = (int64_t)((double)s.n * E->cfg.val_ratio);
+        j.d_out = (s.cur == s.buf[1]) ? s.buf[0] : s.buf[1];
         if (s.p == 0) {
-            const u64* z1 = s.peer ? s.peer->cur : s.ib[0];
-            BE(cognn_softmax_u64(E->ctx, nullptr, dstb, s.pfx, s.cur, z1, s.labels, &k, 0, s.n, L, train));
-            BE(cognn_metrics_q16(E->ctx, s.pfx, s.labels, s.border, s.n, L, train, val, s.counts, s.loss));
+            j.z0 = s.cur; j.z1 = s.peer ? s.peer->cur : s.ib[0];
+            j.labels = s.labels; j.border = s.border; j.counts6 = s.counts; j.loss = s.loss;
             s.has_metrics = true;
-        } else {
-            BE(cognn_softmax_u64(E->ctx, nullptr, dstb, nullptr, nullptr, nullptr, nullptr, &k, 1, s.n, L, train));
         }
+        jobs.push_back(j);
     }
+    BE(cognn_softmax_jobs_u64(E->ctx, jobs.data(), (int32_t)jobs.size(), L));
     for (auto& s : E->sides) s.cur = (s.cur == s.buf[1]) ? s.buf[0] : s.buf[1];   // after every owner has read its peer's z
 }
 

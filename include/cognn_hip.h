@@ -168,6 +168,20 @@ int cognn_softmax_u64(cognn_ctx*, uint64_t* p_out, uint64_t* d_out, uint64_t* pf
 int cognn_metrics_q16(cognn_ctx*, const uint64_t* pfx, const int32_t* labels, const uint8_t* border,
                       int64_t rows, int64_t L, int64_t train_rows, int64_t val_rows, int64_t* counts6, double* loss);
 
+/* The prediction layer of every side hosted by a process in ONE launch: owner jobs (p = 0) run cognn_softmax_u64 and
+ * cognn_metrics_q16 fused (the revealed probabilities stay in registers: no pfx tensor is written or re-read), co-party jobs
+ * (p = 1) write their mask share.  d_out as in cognn_softmax_u64; counts6 / loss as in cognn_metrics_q16 (owner jobs only). */
+typedef struct {
+    uint64_t* d_out;
+    const uint64_t* z0; const uint64_t* z1;
+    const int32_t* labels; const uint8_t* border;
+    cognn_keys keys;
+    int32_t p;
+    int64_t rows, train_rows, val_rows;
+    int64_t* counts6; double* loss;
+} cognn_softmax_job;
+int cognn_softmax_jobs_u64(cognn_ctx*, const cognn_softmax_job* jobs, int32_t count, int64_t L);
+
 /* ---- both share-holders on one device: a chain of protocol steps with the exchange in registers ---------------------------
  * When the owner AND the co-party of a vertex set are hosted by the same process (BASELINE configs "co-located on one
  * MI355X, in-device share exchange") every opening of a two-party step would be written to HBM by one side only to be read

@@ -364,6 +364,20 @@ int cognn_metrics_q16(cognn_ctx*, const uint64_t* pfx, const int32_t* labels, co
     *loss = ls;
     return 0;
 }
+// the batched prediction layer = the per-side softmax followed by the metrics on its revealed probabilities
+int cognn_softmax_jobs_u64(cognn_ctx* ctx, const cognn_softmax_job* jobs, int32_t count, int64_t L) {
+    for (int32_t c = 0; c < count; ++c) {
+        const cognn_softmax_job& s = jobs[c];
+        if (s.p == 1) {
+            if (int rc = cognn_softmax_u64(ctx, nullptr, s.d_out, nullptr, nullptr, nullptr, nullptr, &s.keys, 1, s.rows, L, s.train_rows)) return rc;
+            continue;
+        }
+        std::vector<u64> pfx((size_t)std::max<int64_t>(s.rows * L, 1));
+        if (int rc = cognn_softmax_u64(ctx, nullptr, s.d_out, pfx.data(), s.z0, s.z1, s.labels, &s.keys, 0, s.rows, L, s.train_rows)) return rc;
+        if (int rc = cognn_metrics_q16(ctx, pfx.data(), s.labels, s.border, s.rows, L, s.train_rows, s.val_rows, s.counts6, s.loss)) return rc;
+    }
+    return 0;
+}
 // The pair chain of the HIP library fuses both sides' steps into one kernel; this reference runs the SAME steps through the
 // per-side entry points above, one after the other, with the exchanged values in ordinary buffers - an independent statement
 // of what the fused kernel has to produce.

@@ -111,33 +111,98 @@ def test_gpu_binary_matches_oracle(tmp_path):
     assert abs(float(re.findall(r"full set accuracy = ([0-9.]+)", res.stdout)[0]) - want["full"]) < 1e-6
 
 
-def test_offline_cache_roundtrip(tmp_path):
+def _offline_cache_roundtrip(exe, tmp_path):
     """`-n 1` reuses the preprocess/<setting>/ products written by an earlier run; the results do not change."""
     k, V, Eu, in_dim, lab, hid = 2, 40, 90, 8, 3, 4
     _write_inputs(tmp_path, k, V, Eu, in_dim, lab, hid)
     files = [str(tmp_path / n) for n in ("edges.txt", "vertices.txt", "part.txt", "out.txt", "config.txt")]
-    base = [BIN, "-t", "2", "-g", "2", "-i", "0", "-m", "6", "-s", "cache/test-1", "-r", "1"]
+    base = [exe, "-t", "2", "-g", "2", "-i", "0", "-m", "12", "-s", "cache/test-1", "-r", "1"]
     r1 = subprocess.run(base + files, capture_output=True, text=True, cwd=tmp_path, timeout=120)
     assert r1.returncode == 0, r1.stderr
     cached = os.listdir(tmp_path / "preprocess" / "cache" / "test-1")
-    assert len(cached) == 2 * 5            # 2 co-party sides x (2 forward + 3 backward) Beaver products per epoch
+    assert len(cached) == 2 * 2 * 5        # 2 epochs x 2 co-party sides x (2 forward + 3 backward) Beaver products per epoch
     r2 = subprocess.run(base + ["-n", "1"] + files, capture_output=True, text=True, cwd=tmp_path, timeout=120)
     assert r2.returncode == 0, r2.stderr
-    assert "Reused 10 offline products" in r2.stdout
+    assert "Reused 10 offline products" in r2.stdout           # the first epoch's; the second epoch's are loaded when it starts
     pick = lambda out: re.findall(r"(cross-entropy-loss|accuracy) = ([0-9.]+)", out)
-    assert pick(r1.stdout) == pick(r2.stdout) and len(pick(r1.stdout)) == 6
+    assert pick(r1.stdout) == pick(r2.stdout) and len(pick(r1.stdout)) == 12
+    # a cache written for another shape is ignored, not trusted (stale preprocess/<setting>/ of another dataset)
+    _write_inputs(tmp_path, k, V + 10, Eu, in_dim, lab, hid)
+    r3 = subprocess.run(base + ["-n", "1"] + files, capture_output=True, text=True, cwd=tmp_path, timeout=120)
+    assert r3.returncode == 0, r3.stderr
+    assert "Reused 0 offline products" in r3.stdout
+    # the setting string never reaches a shell
+    evil = "x'; touch INJECTED; echo '"
+    r4 = subprocess.run(base[:9] + ["-s", evil, "-r", "1"] + files, capture_output=True, text=True, cwd=tmp_path, timeout=120)
+    assert r4.returncode == 0 and not (tmp_path / "INJECTED").exists()
 
 
-def test_binary_graph_container_gives_identical_run(tmp_path):
+def _binary_container(exe, tmp_path):
     k, V, Eu, in_dim, lab, hid = 2, 40, 90, 8, 3, 4
     _write_inputs(tmp_path, k, V, Eu, in_dim, lab, hid)
     subprocess.check_call([os.sys.executable, os.path.join(ROOT, "tools", "convert_graph.py"), str(tmp_path / "edges.txt"),
                            str(tmp_path / "part.txt"), str(tmp_path / "graph.cgb")])
     tail = [str(tmp_path / n) for n in ("vertices.txt", "part.txt", "out.txt", "config.txt")]
-    base = [BIN, "-t", "2", "-g", "2", "-i", "1", "-m", "2", "-s", "bin", "-r", "1", "-n", "1"]
+    base = [exe, "-t", "2", "-g", "2", "-i", "1", "-m", "2", "-s", "bin", "-r", "1", "-n", "1"]
     a = subprocess.run(base + [str(tmp_path / "edges.txt")] + tail, capture_output=True, text=True, cwd=tmp_path, timeout=120)
     b = subprocess.run(base + [str(tmp_path / "graph.cgb")] + tail[:1] + ["ignored"] + tail[2:], capture_output=True, text=True,
                        cwd=tmp_path, timeout=120)
     assert a.returncode == 0 and b.returncode == 0, a.stderr + b.stderr
     pick = lambda out: re.findall(r"(cross-entropy-loss|accuracy) = ([0-9.]+)", out)
     assert pick(a.stdout) == pick(b.stdout) and len(pick(a.stdout)) == 6
+
+
+def _log_contract(exe, tmp_path):
+    """The tags of the reference's print_duration sites, parsed like tools/plot/plot_duration_breakdown_and_comm.py:23-46 does;
+    the `iteration` line covers the device work of its iteration (the harness synchronises before it prints)."""
+    k, V, Eu, in_dim, lab, hid = 2, 60, 150, 8, 3, 4
+    _write_inputs(tmp_path, k, V, Eu, in_dim, lab, hid)
+    files = [str(tmp_path / n) for n in ("edges.txt", "vertices.txt", "part.txt", "out.txt", "config.txt")]
+    r = subprocess.run([exe, "-t", "2", "-g", "2", "-i", "0", "-m", "6", "-s", "tags", "-r", "1"] + files, capture_output=True, text=True,
+                       cwd=tmp_path, timeout=120)
+    assert r.returncode == 0, r.stderr
+    blocks = r.stdout.split("tid-> 0, iteration-> ")[1:]
+    assert len(blocks) == 6
+    tags = ["PreScatterComp Client", "PreScatterComp Server", "Scatter_preparation", "Scatter_computation", "premerging", "premerged_extraction",
+            "Gather_preparation", "Gather_computation", "Apply_computation"]
+    for it, blk in enumerate(blocks):
+        dur = {t: [float(l.split(" took ")[1].split(" ")[0]) for l in blk.splitlines() if "::" + t + " took" in l] for t in tags + ["iteration"]}
+        assert len(dur["iteration"]) == 1
+        apply_only = it in (2, 4)                                  # ss_...h:709: no print_duration on that path
+        for t in tags:
+            assert len(dur[t]) == (0 if apply_only else 1), (it, t)
+        if not apply_only:
+            phases = dur["PreScatterComp Client"][0] + dur["premerging"][0] + dur["Gather_computation"][0] + dur["Apply_computation"][0]
+            assert dur["premerging"][0] > 0 and dur["Apply_computation"][0] > 0
+            assert dur["iteration"][0] >= 0.9 * phases, (it, dur)   # the wall time of an iteration covers its device phases
+    assert "::preprocess took" in r.stdout and "::preprocess_OM took" in r.stdout
+
+
+def test_offline_cache_roundtrip(tmp_path):
+    _offline_cache_roundtrip(BIN, tmp_path)
+
+
+def test_binary_graph_container_gives_identical_run(tmp_path):
+    _binary_container(BIN, tmp_path)
+
+
+def test_log_contract_tags(tmp_path):
+    _log_contract(BIN, tmp_path)
+
+
+HIP_BIN = os.path.join(ROOT, "bin", "gcn-optimize")
+
+
+@pytest.mark.gpu
+def test_gpu_offline_cache_roundtrip(tmp_path):
+    _offline_cache_roundtrip(HIP_BIN, tmp_path)
+
+
+@pytest.mark.gpu
+def test_gpu_binary_graph_container(tmp_path):
+    _binary_container(HIP_BIN, tmp_path)
+
+
+@pytest.mark.gpu
+def test_gpu_log_contract_tags(tmp_path):
+    _log_contract(HIP_BIN, tmp_path)

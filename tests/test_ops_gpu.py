@@ -330,6 +330,49 @@ def test_softmax_pair_and_metrics(ctx, L):
     assert abs(float(host(loss, np.float64)[0]) - want_loss) < 1e-9 * max(1.0, abs(want_loss))   # fp tolerance: atomics order
 
 
+@pytest.mark.parametrize("L", [3, 7, 16])
+def test_softmax_jobs_batch_with_fused_metrics(ctx, L):
+    """cognn_softmax_jobs_u64: every hosted side's prediction layer in one launch, the owners' metrics fused in (no pfx
+    tensor); against the oracle's softmax_pair and the metric definitions of gcn.h:611-632."""
+    from cognn_amd import capi
+    rng = np.random.default_rng(40 + L)
+    sides = []
+    for owner, rows in enumerate((400, 1, 513)):
+        train, val = rows // 5, rows // 5
+        z = co.fx_encode(rng.normal(size=(rows, L)) * 3)
+        z0 = rand_u64(rng, (rows, L))
+        with np.errstate(over="ignore"):
+            z1 = z - z0
+        labels = rng.integers(0, L, size=rows).astype(np.int32)
+        border = (rng.random(rows) < 0.3).astype(np.uint8)
+        sides.append(dict(owner=owner, rows=rows, train=train, val=val, z0=z0, z1=z1, labels=labels, border=border))
+    jobs = (capi.SoftmaxJob * (2 * len(sides)))()
+    outs = []
+    for i, sd in enumerate(sides):
+        k, kf = keys_of(5, sd["owner"], 1, co.OP_AP_SOFTMAX)
+        sd["kf"] = kf
+        for p in (0, 1):
+            j = jobs[2 * i + p]
+            d = dev_empty((sd["rows"], L)); outs.append(d)
+            j.d_out = d.data_ptr(); j.keys = k; j.p = p; j.rows = sd["rows"]; j.train_rows = sd["train"]; j.val_rows = sd["val"]
+            if p == 0:
+                cnt, loss = dev_empty(6), dev_empty(1, "f64")
+                sd["cnt"], sd["loss"] = cnt, loss
+                j.z0 = dev(sd["z0"]).data_ptr(); j.z1 = dev(sd["z1"]).data_ptr(); j.labels = dev(sd["labels"]).data_ptr()
+                j.border = dev(sd["border"]).data_ptr(); j.counts6 = cnt.data_ptr(); j.loss = loss.data_ptr()
+    ctx.call("cognn_softmax_jobs_u64", jobs, len(jobs), L)
+    for i, sd in enumerate(sides):
+        p0, p1, d0, d1, plainP = co.softmax_pair(sd["z0"], sd["z1"], sd["labels"], sd["train"], sd["kf"])
+        assert np.array_equal(host(outs[2 * i]), d0) and np.array_equal(host(outs[2 * i + 1]), d1)
+        pp = np.where(plainP == 0, 0.001, plainP)
+        ok = pp.argmax(1) == sd["labels"]
+        idx = np.arange(sd["rows"]); tr = idx < sd["train"]; te = idx >= sd["train"] + sd["val"]; b = sd["border"].astype(bool)
+        cnt = host(sd["cnt"], np.int64)
+        assert list(cnt[:5]) == [ok.sum(), (ok & tr).sum(), (ok & tr & b).sum(), (ok & te).sum(), (ok & te & b).sum()]
+        want_loss = -np.log(pp[idx, sd["labels"]]).sum()
+        assert abs(float(host(sd["loss"], np.float64)[0]) - want_loss) < 1e-9 * max(1.0, abs(want_loss))   # fp tolerance: atomics order
+
+
 @pytest.mark.parametrize("M,N,K,transA", [(300, 64, 128, 0), (270, 7, 16, 0), (16, 7, 300, 1), (1433, 16, 270, 1),
                                              (300, 16, 77, 0), (1354, 16, 1433, 0), (260, 7, 7, 0), (64, 16, 2000, 1),
                                              (128, 64, 1000, 2), (24, 5, 300, 2),
