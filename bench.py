@@ -248,6 +248,8 @@ def main():
         out["exchange"] = {"rounds_per_step": (x1["rounds"] - x0["rounds"]) / args.steps,
                            "MB_sent_per_step": (x1["bytes_sent"] - x0["bytes_sent"]) / args.steps / 1e6,
                            "MB_received_per_step": (x1["bytes_received"] - x0["bytes_received"]) / args.steps / 1e6,
+                           "comm_stream_ms_per_step": (x1["comm_ms"] - x0["comm_ms"]) / args.steps,
+                           "GBps_while_communicating": ((x1["bytes_sent"] - x0["bytes_sent"]) / 1e9) / max((x1["comm_ms"] - x0["comm_ms"]) / 1e3, 1e-12),
                            "transport": "native RCCL p2p groups on a communication stream (csrc/exchange_rccl.hip)"}
     if args.check and world == 1:
         a = eng.shares(0, 0); b = eng.shares(0, 1)

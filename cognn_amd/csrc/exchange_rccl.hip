@@ -13,6 +13,8 @@
 
 #include <chrono>
 #include <thread>
+#include <utility>
+#include <vector>
 
 #include "common.h"
 #include "../../include/cognn_exchange.h"
@@ -46,7 +48,11 @@ struct cognn_rccl_exchange {
     hipStream_t compute = nullptr;      // the engine's stream (not owned)
     hipStream_t comm_stream = nullptr;  // owned
     hipEvent_t ready = nullptr;         // compute -> comm: the round's send buffers are written
-    hipEvent_t done = nullptr;          // comm -> compute: the round's messages have arrived
+    hipEvent_t done = nullptr;          // comm -> compute: the messages of the newest round (and, in stream order, all before) have arrived
+    // every round is bracketed by a pair of timing events on the communication stream: its duration there is the time the
+    // p2p group took (cognn_rccl_exchange_time)
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> timing, spare;
+    double comm_ms = 0;
     int64_t rounds = 0, sent = 0, received = 0;
     uint64_t* scratch = nullptr;        // barrier payload
 };
@@ -165,6 +171,8 @@ int cognn_rccl_exchange_destroy(cognn_rccl_exchange* x) {
     if (x->comm) (void)ncclCommDestroy(x->comm);
     if (x->ready) (void)hipEventDestroy(x->ready);
     if (x->done) (void)hipEventDestroy(x->done);
+    for (auto* v : {&x->timing, &x->spare})
+        for (auto& pr : *v) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     if (x->comm_stream) (void)hipStreamDestroy(x->comm_stream);
     if (x->scratch) (void)hipFree(x->scratch);
     delete x;
@@ -180,6 +188,19 @@ int cognn_rccl_exchange_begin(void* user, const cognn_xfer* xfers, int32_t n) {
     // the messages may only leave once the kernels that write them have run ...
     X_HIP(hipEventRecord(x->ready, x->compute));
     X_HIP(hipStreamWaitEvent(x->comm_stream, x->ready, 0));
+    if (x->timing.size() >= 256) {                           // nobody reads the clock: fold the rounds that have completed
+        size_t keep = 0;
+        for (auto& pr : x->timing) {
+            float ms = 0;
+            if (hipEventQuery(pr.second) == hipSuccess && hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) { x->comm_ms += ms; x->spare.push_back(pr); }
+            else x->timing[keep++] = pr;
+        }
+        x->timing.resize(keep);
+    }
+    std::pair<hipEvent_t, hipEvent_t> tm;
+    if (!x->spare.empty()) { tm = x->spare.back(); x->spare.pop_back(); }
+    else { X_HIP(hipEventCreate(&tm.first)); X_HIP(hipEventCreate(&tm.second)); }
+    X_HIP(hipEventRecord(tm.first, x->comm_stream));
     X_NCCL(ncclGroupStart());
     for (int32_t i = 0; i < n; ++i) {
         const cognn_xfer& t = xfers[i];
@@ -189,6 +210,8 @@ int cognn_rccl_exchange_begin(void* user, const cognn_xfer* xfers, int32_t n) {
         (t.is_send ? x->sent : x->received) += t.bytes;
     }
     X_NCCL(ncclGroupEnd());
+    X_HIP(hipEventRecord(tm.second, x->comm_stream));
+    x->timing.push_back(tm);
     // ... and whoever consumes a received buffer (or overwrites a sent one) waits for this event on the compute stream
     X_HIP(hipEventRecord(x->done, x->comm_stream));
     ++x->rounds;
@@ -214,6 +237,20 @@ int cognn_rccl_exchange_stats(cognn_rccl_exchange* x, int64_t* rounds, int64_t* 
     if (rounds) *rounds = x->rounds;
     if (bytes_sent) *bytes_sent = x->sent;
     if (bytes_received) *bytes_received = x->received;
+    return 0;
+}
+
+int cognn_rccl_exchange_time(cognn_rccl_exchange* x, double* comm_ms) {
+    X_REQUIRE(x && comm_ms, "cognn_rccl_exchange_time: bad arguments");
+    X_HIP(hipStreamSynchronize(x->comm_stream));
+    for (auto& pr : x->timing) {
+        float ms = 0;
+        X_HIP(hipEventElapsedTime(&ms, pr.first, pr.second));
+        x->comm_ms += ms;
+        x->spare.push_back(pr);
+    }
+    x->timing.clear();
+    *comm_ms = x->comm_ms;
     return 0;
 }
 

@@ -29,7 +29,10 @@ class RcclExchange:
         r = ctypes.c_int64(); s = ctypes.c_int64(); v = ctypes.c_int64()
         if self.lib.cognn_rccl_exchange_stats(self.h, ctypes.byref(r), ctypes.byref(s), ctypes.byref(v)) != 0:
             raise RuntimeError(self.lib.cognn_exchange_last_error().decode())
-        return {"rounds": r.value, "bytes_sent": s.value, "bytes_received": v.value}
+        ms = ctypes.c_double()
+        if self.lib.cognn_rccl_exchange_time(self.h, ctypes.byref(ms)) != 0:
+            raise RuntimeError(self.lib.cognn_exchange_last_error().decode())
+        return {"rounds": r.value, "bytes_sent": s.value, "bytes_received": v.value, "comm_ms": ms.value}
 
     def barrier(self):
         if self.lib.cognn_rccl_exchange_barrier(self.h) != 0:

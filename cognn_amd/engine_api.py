@@ -62,6 +62,7 @@ _EXCHANGE_SIGNATURES = {
     "cognn_rccl_exchange_wait": (ctypes.c_int, [_P]),
     "cognn_engine_set_exchange_rccl": (ctypes.c_int, [_P, _P]),
     "cognn_rccl_exchange_stats": (ctypes.c_int, [_P, ctypes.POINTER(_L), ctypes.POINTER(_L), ctypes.POINTER(_L)]),
+    "cognn_rccl_exchange_time": (ctypes.c_int, [_P, ctypes.POINTER(_D)]),
     "cognn_rccl_exchange_barrier": (ctypes.c_int, [_P]),
 }
 RCCL_ID_BYTES = 128

@@ -104,7 +104,8 @@ struct cognn_engine {
     u64* table = nullptr;
     u64* aggOut = nullptr;
     uint32_t *agg_rowptr = nullptr, *agg_col = nullptr, *part_rowptr = nullptr, *part_col = nullptr;
-    int64_t aggEdges = 0, partEdges = 0;
+    uint32_t *rem_rowptr = nullptr, *rem_col = nullptr;   // world > 1: the aggregate's entries that read RECEIVED rows (replicas, inbox)
+    int64_t aggEdges = 0, partEdges = 0, remEdges = 0;
     // One partial-sum segment per (source rank, destination owner g): row i = sum over ALL parties Q hosted by the source rank
     // of Q's own-share rows over the edges Q -> rows_vid[i] (pre-summed on the sender: one row per destination vertex however
     // many of the sender's parties reach it).
@@ -219,8 +220,10 @@ void exchange_wait(cognn_engine* E) {
 }
 // starts a round.  With a wait function registered the call only enqueues the messages; whoever consumes received data - or
 // overwrites a buffer that is being sent - calls exchange_wait first (for_sides does, before it touches a side whose peer is remote).
-void run_exchange(cognn_engine* E, XList& xl) {
-    exchange_wait(E);
+void run_exchange(cognn_engine* E, XList& xl, bool keep_inflight = false) {
+    // keep_inflight: the round already in flight keeps going (its buffers are disjoint from this round's and from the kernels
+    // launched in between); exchange_wait then completes both
+    if (!keep_inflight) exchange_wait(E);
     if (xl.v.empty()) return;
     if (!E->xfn) throw EngineError("engine: world > 1 needs an exchange function (cognn_engine_set_exchange)");
     if (E->xfn(E->xuser, xl.v.data(), (int32_t)xl.v.size()) != 0) throw EngineError("engine: exchange function failed");
@@ -670,30 +673,37 @@ void message_passing(cognn_engine* E, int F, int64_t it, bool open_scale) {
             if (sg.src_rank == E->rank && sg.dst_rank != E->rank) xl.send(sg.dst_rank, E->table + sg.out_off * F, sg.rows * F * 8);
             if (sg.dst_rank == E->rank && sg.src_rank != E->rank) xl.recv(sg.src_rank, E->table + sg.inbox_off * F, sg.rows * F * 8);
         }
-        run_exchange_sync(E, xl);
-    }
-    // aggregate: out = self + local in-edges + replica in-edges (owner rows) / + received partials (co rows)
-    if (E->timing) BE(cognn_timer_begin(E->ctx, T_AGG));
+        run_exchange(E, xl, true);                          // the replication round may still be in flight: both travel while the
+    }                                                       // local part of the aggregate runs
+    // aggregate: out = self + local in-edges + replica in-edges (owner rows) / + received partials (co rows).  With several
+    // ranks it is split: the entries that read rows held on this rank run now, beside the two exchange rounds; the entries
+    // that read received rows (co-share replicas, partial-sum inbox) are added in place once the messages have arrived.
+    std::vector<int64_t> sb, se;
+    std::vector<u64> sk;
     if (open_scale) {
-        // the row scale that follows needs E_p = V_p - a_p: emit it from the gather epilogue instead of V_p
-        std::vector<int64_t> sb, se;
-        std::vector<u64> sk;
+        // the row scale that follows needs E_p = V_p - a_p: emit it from the (last) gather epilogue instead of V_p
         for (auto& s : E->sides) {
             if (paired(E, s)) continue;                       // a co-located pair hands the plain result to its chain
             const int64_t off = s.p == 0 ? E->A_off[s.owner] : E->B_off[s.owner];
             cognn_keys k = keys(E, s.owner, it, COGNN_OP_GA_SCALE);
             sb.push_back(off); se.push_back(off + s.n); sk.push_back(k.k[s.p == 0 ? COGNN_SL_A0 : COGNN_SL_A1]);
         }
-        if (sb.empty()) BE(cognn_gather_csr_u64(E->ctx, E->aggOut, E->table, E->table, E->agg_rowptr, E->agg_col, E->aggRows, F));
-        else BE(cognn_gather_csr_open_u64(E->ctx, E->aggOut, E->table, E->table, E->agg_rowptr, E->agg_col, E->aggRows, F,
-                                          (int32_t)sb.size(), sb.data(), se.data(), sk.data()));
-    } else {
-        BE(cognn_gather_csr_u64(E->ctx, E->aggOut, E->table, E->table, E->agg_rowptr, E->agg_col, E->aggRows, F));
     }
-    if (E->timing) {
-        BE(cognn_timer_end(E->ctx, T_AGG));
-        E->algo[T_AGG] += 8.0 * F * ((double)E->aggEdges + 2.0 * E->aggRows) + 4.0 * E->aggEdges + 4.0 * (E->aggRows + 1);
-    }
+    auto aggregate = [&](const u64* base, const uint32_t* rowptr, const uint32_t* col, int64_t edges, bool last) {
+        if (E->timing) BE(cognn_timer_begin(E->ctx, T_AGG));
+        if (last && !sb.empty())
+            BE(cognn_gather_csr_open_u64(E->ctx, E->aggOut, base, E->table, rowptr, col, E->aggRows, F, (int32_t)sb.size(), sb.data(), se.data(), sk.data()));
+        else
+            BE(cognn_gather_csr_u64(E->ctx, E->aggOut, base, E->table, rowptr, col, E->aggRows, F));
+        if (E->timing) {
+            BE(cognn_timer_end(E->ctx, T_AGG));
+            E->algo[T_AGG] += 8.0 * F * ((double)edges + 2.0 * E->aggRows) + 4.0 * edges + 4.0 * (E->aggRows + 1);
+        }
+    };
+    const bool split = E->world > 1 && E->remEdges > 0;
+    aggregate(E->table, E->agg_rowptr, E->agg_col, E->aggEdges, !split);
+    exchange_wait(E);
+    if (split) aggregate(E->aggOut, E->rem_rowptr, E->rem_col, E->remEdges, true);
     for (auto& s : E->sides) {
         const int64_t off = s.p == 0 ? E->A_off[s.owner] : E->B_off[s.owner];
         s.cur = E->aggOut + off * F;
@@ -1111,10 +1121,15 @@ void build_csrs(cognn_engine* E) {
         const int64_t rbase = E->B_off[sg.dst_owner];
         for (size_t r = 0; r < sg.rows_vid.size(); ++r) lists[rbase + G.row_of_vid[sg.rows_vid[r]]].push_back((uint32_t)(sg.inbox_off + r));
     }
-    std::vector<uint32_t> arp{0}, acol;
-    for (auto& l : lists) { acol.insert(acol.end(), l.begin(), l.end()); arp.push_back((uint32_t)acol.size()); }
-    E->aggEdges = (int64_t)acol.size();
+    // entries that read rows held on this rank (table rows < aggRows) / rows received from other ranks (replicas, inbox)
+    std::vector<uint32_t> arp{0}, acol, rrp{0}, rcol;
+    for (auto& l : lists) {
+        for (uint32_t c : l) ((int64_t)c < E->aggRows ? acol : rcol).push_back(c);
+        arp.push_back((uint32_t)acol.size()); rrp.push_back((uint32_t)rcol.size());
+    }
+    E->aggEdges = (int64_t)acol.size(); E->remEdges = (int64_t)rcol.size();
     E->agg_rowptr = upload(E, arp); E->agg_col = upload(E, acol);
+    E->rem_rowptr = upload(E, rrp); E->rem_col = upload(E, rcol);
     E->part_rowptr = upload(E, prp); E->part_col = upload(E, pcol);
 }
 
@@ -1518,7 +1533,7 @@ int cognn_engine_get_timing(cognn_engine* E, int32_t kind, int64_t* launches, do
 int cognn_engine_get_workload(cognn_engine* E, int64_t* out6) {
     return guard([&] {
         if (!E || !out6) throw EngineError("cognn_engine_get_workload: bad arguments");
-        out6[0] = E->aggEdges; out6[1] = E->aggRows; out6[2] = E->partEdges; out6[3] = E->partRows;
+        out6[0] = E->aggEdges + E->remEdges; out6[1] = E->aggRows; out6[2] = E->partEdges; out6[3] = E->partRows;
         out6[4] = E->G.num_edges; out6[5] = E->tableRows;
     });
 }

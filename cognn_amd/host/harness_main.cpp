@@ -314,8 +314,11 @@ int main(int argc, char* argv[]) {
 #ifndef COGNN_NO_RCCL
         if (xch) {                                               // sendFinish / recvFinish (ss_...h:270-272)
             int64_t rounds = 0, sent = 0, recvd = 0;
+            double comm_ms = 0;
             cognn_rccl_exchange_stats(xch, &rounds, &sent, &recvd);
-            printf("%zu exchange rounds %lld, sent %.2fMB, received %.2fMB\n", tileIndex, (long long)rounds, sent / 1048576.0, recvd / 1048576.0);
+            cognn_rccl_exchange_time(xch, &comm_ms);
+            printf("%zu exchange rounds %lld, sent %.2fMB, received %.2fMB, %.3f ms on the communication stream\n", tileIndex, (long long)rounds,
+                   sent / 1048576.0, recvd / 1048576.0, comm_ms);
             if (cognn_rccl_exchange_barrier(xch)) std::cerr << cognn_exchange_last_error() << std::endl;
         }
         cognn_engine_destroy(e);

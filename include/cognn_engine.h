@@ -51,7 +51,9 @@ typedef int (*cognn_exchange_fn)(void* user, const cognn_xfer* xfers, int32_t n)
 /* Asynchronous form: with a wait function registered, cognn_exchange_fn only ENQUEUES the round (ordered after the work
  * already enqueued on the engine's stream) and returns; cognn_exchange_wait_fn makes later work of the engine's stream wait
  * for every enqueued round.  The engine then runs the kernels of the sides whose peer is on the same rank between the two
- * calls, so their compute overlaps the messages of the sides whose peer is remote.  At most one round is in flight. */
+ * calls, so their compute overlaps the messages of the sides whose peer is remote.  Up to two rounds may be enqueued before a
+ * wait (message passing: the co-share replication and the partial-sum exchange travel while the local part of the aggregate
+ * runs); the wait covers every enqueued round. */
 typedef int (*cognn_exchange_wait_fn)(void* user);
 
 const char* cognn_engine_last_error(void);

@@ -42,6 +42,9 @@ int cognn_rccl_exchange_wait(void* user);
 int cognn_engine_set_exchange_rccl(cognn_engine* e, cognn_rccl_exchange* x);
 /* rounds started, bytes sent and received by this rank so far (achieved xGMI GB/s = bytes / measured time) */
 int cognn_rccl_exchange_stats(cognn_rccl_exchange* x, int64_t* rounds, int64_t* bytes_sent, int64_t* bytes_received);
+/* total time the p2p groups of all rounds so far took on the communication stream (HIP events around every group; waits
+ * for the stream to drain).  bytes / this time = the achieved xGMI rate of this rank. */
+int cognn_rccl_exchange_time(cognn_rccl_exchange* x, double* comm_ms);
 /* an all-ranks barrier on the communication stream followed by a host wait (end-of-run hand-shake, sendFinish/recvFinish
  * of ss_...h:270-272) */
 int cognn_rccl_exchange_barrier(cognn_rccl_exchange* x);

@@ -48,6 +48,7 @@ def test_world1_loopback_rounds_are_stream_ordered():
             assert np.array_equal(gu.host(d), want_b + want_b)
     st = x.stats()
     assert st["rounds"] == 3 and st["bytes_sent"] == st["bytes_received"] == 3 * (n * 8 + 800)
+    assert st["comm_ms"] > 0
     x.barrier()
     bad = (Xfer * 1)(Xfer(3, 1, a.data_ptr(), 8))
     assert lib.cognn_rccl_exchange_begin(x.h, bad, 1) != 0 and b"malformed" in lib.cognn_exchange_last_error()
