@@ -210,12 +210,14 @@ def main():
     n_gemm, ms_gemm, ops_gemm = eng.timing(2)
     eng.enable_timing(False)
 
-    # HBM traffic of the dominant kernel from the committed PMC passes (profiles/; collected with this same command)
+    # HBM traffic of the dominant kernel from the committed PMC passes (profiles/; collected with this same command by
+    # tools/collect_profiles.sh, summarised by tools/summarize_profiles.py)
     traffic, traffic_src = None, None
-    pmc = os.path.join(ROOT, "profiles", "r01_h_pmc_traffic.json")
-    if args.workload == "config5" and world == 1 and os.path.exists(pmc):
-        traffic = json.load(open(pmc)).get("aggregate_launch_avg_bytes")
-        traffic_src = "profiles/r01_h_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH x2 gfx950 correction)"
+    pmc = os.path.join(ROOT, "profiles", "r02_pmc.json")
+    if world == 1 and os.path.exists(pmc):
+        traffic = json.load(open(pmc)).get(args.workload, {}).get("aggregate_launch_avg_bytes")
+        if traffic is not None:
+            traffic_src = "profiles/r02_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH x2 gfx950 correction)"
     ms_per_step = dt / args.steps * 1e3
     ef_per_step = float(len(src)) * message_widths(variant, iters, hid, lab)
     value = ef_per_step / (dt / args.steps)

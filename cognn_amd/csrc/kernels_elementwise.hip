@@ -438,6 +438,9 @@ __global__ void softmax_jobs_zero_kernel(SoftmaxBatch b) {
         else if ((t & 7) == 6) *b.j[t >> 3].loss = 0.0;
     }
 }
+// A group of G lanes (G = power of two >= L) owns G consecutive rows: row i of the group is evaluated across the G lanes
+// (lane j = column j, reductions by shuffles, coalesced 8*L-byte row accesses), and lane i keeps row i's bookkeeping, so that
+// the double-precision log of the loss runs once per lane instead of once per row on 1 lane in G.
 template <int G>
 __global__ __launch_bounds__(kThreads) void softmax_jobs_kernel(SoftmaxBatch b, int L) {
     __shared__ unsigned long long s_cnt[5];
@@ -447,55 +450,66 @@ __global__ __launch_bounds__(kThreads) void softmax_jobs_kernel(SoftmaxBatch b, 
     while (seg < b.count - 1 && blk >= b.blk_end[seg]) ++seg;
     const SoftmaxJobDev& d = b.j[seg];
     const unsigned blk0 = seg ? b.blk_end[seg - 1] : 0u;
-    const int64_t r = ((int64_t)(blk - blk0) * kThreads + threadIdx.x) / G;
     const int j = threadIdx.x % G;
-    const bool valid = r < d.rows && j < L;
-    const bool keep = r < d.train_rows;
-    const int64_t idx = r * L + j;
-    const u64 rho = valid ? cognn_prng(d.keyRho, (u64)idx) : 0ull;
-    if (d.p == 1) {                                          // (uniform per workgroup)
-        if (valid) d.d_out[idx] = keep ? rho : 0ull;
+    const int64_t rb = (((int64_t)(blk - blk0) * kThreads + threadIdx.x) / G) * G;     // first row of this lane group
+    if (d.p == 1) {                                          // (uniform per workgroup) the co-party's share is its mask
+        for (int i = 0; i < G; ++i) {
+            const int64_t r = rb + i, idx = r * L + j;
+            if (r < d.rows && j < L) d.d_out[idx] = r < d.train_rows ? cognn_prng(d.keyRho, (u64)idx) : 0ull;
+        }
         return;
     }
     if (threadIdx.x < 5) s_cnt[threadIdx.x] = 0;
     if (threadIdx.x == 0) s_loss = 0.0;
     __syncthreads();
     const long long NEG = -(1ll << 62);
-    long long z = valid ? (long long)(d.z0[idx] + d.z1[idx]) : NEG;
-    long long m = z;
+    double my_pl = 1.0;                                      // log(1) = 0 for lanes without a row
+    bool ok = false, tr = false, te = false, bd = false;
+    for (int i = 0; i < G; ++i) {                            // (uniform inside every shuffle group)
+        const int64_t r = rb + i;
+        const bool valid = r < d.rows && j < L;
+        const int64_t idx = r * L + j;
+        long long z = valid ? (long long)(d.z0[idx] + d.z1[idx]) : NEG;
+        long long m = z;
 #pragma unroll
-    for (int o = G / 2; o > 0; o >>= 1) { long long t = __shfl_xor(m, o, G); m = t > m ? t : m; }
-    long long e = valid ? cognn_exp_neg_q30(m - z) : 0;
-    long long S = e;
+        for (int o = G / 2; o > 0; o >>= 1) { long long t = __shfl_xor(m, o, G); m = t > m ? t : m; }
+        long long e = valid ? cognn_exp_neg_q30(m - z) : 0;
+        long long S = e;
 #pragma unroll
-    for (int o = G / 2; o > 0; o >>= 1) S += __shfl_xor(S, o, G);
-    const u64 pf = valid ? (u64)(((e << 16) + (S >> 1)) / S) : 0ull;          // the revealed Q16 probability (softmax_kernel)
-    const int lab = r < d.rows ? d.labels[r] : 0;
-    if (valid) d.d_out[idx] = keep ? ((pf - rho) - (j == lab ? COGNN_FX_ONE : 0ull)) : 0ull;
-    // metrics on the revealed probabilities (metrics_kernel): argmax with the first maximum winning ties, -log p[label]
-    u64 bv = valid ? pf : 0ull;
-    int bj = valid ? j : (1 << 20);
-#pragma unroll
-    for (int o = G / 2; o > 0; o >>= 1) {
-        u64 ov = __shfl_xor(bv, o, G);
-        int oj = __shfl_xor(bj, o, G);
-        if (ov > bv || (ov == bv && oj < bj)) { bv = ov; bj = oj; }
-    }
-    if (r < d.rows && j == lab) {                            // one lane per row (labels are < L)
-        const bool ok = bj == lab;
-        const bool bd = d.border ? d.border[r] != 0 : false;
-        const bool tr = r < d.train_rows, te = r >= d.train_rows + d.val_rows;
-        if (ok) {
-            atomicAdd(&s_cnt[0], 1ull);
-            if (tr) atomicAdd(&s_cnt[1], 1ull);
-            if (tr && bd) atomicAdd(&s_cnt[2], 1ull);
-            if (te) atomicAdd(&s_cnt[3], 1ull);
-            if (te && bd) atomicAdd(&s_cnt[4], 1ull);
+        for (int o = G / 2; o > 0; o >>= 1) S += __shfl_xor(S, o, G);
+        const u64 pf = valid ? (u64)(((e << 16) + (S >> 1)) / S) : 0ull;      // the revealed Q16 probability (softmax_kernel)
+        const int lab = r < d.rows ? d.labels[r] : 0;
+        if (valid) {
+            const u64 rho = cognn_prng(d.keyRho, (u64)idx);
+            d.d_out[idx] = r < d.train_rows ? ((pf - rho) - (j == lab ? COGNN_FX_ONE : 0ull)) : 0ull;
         }
-        double pl = (double)pf / (double)COGNN_FX_ONE;
-        if (pl == 0.0) pl = 0.001;                           /* gcn.h:613-615 */
-        atomicAdd(&s_loss, -log(pl));
+        // metrics on the revealed probabilities (metrics_kernel): argmax with the first maximum winning ties, p[label]
+        u64 bv = valid ? pf : 0ull;
+        int bj = valid ? j : (1 << 20);
+#pragma unroll
+        for (int o = G / 2; o > 0; o >>= 1) {
+            u64 ov = __shfl_xor(bv, o, G);
+            int oj = __shfl_xor(bj, o, G);
+            if (ov > bv || (ov == bv && oj < bj)) { bv = ov; bj = oj; }
+        }
+        const u64 p_lab = __shfl(pf, lab, G);
+        if (j == i && r < d.rows) {                          // lane i takes over row i
+            ok = bj == lab;
+            bd = d.border ? d.border[r] != 0 : false;
+            tr = r < d.train_rows; te = r >= d.train_rows + d.val_rows;
+            my_pl = (double)p_lab / (double)COGNN_FX_ONE;
+            if (my_pl == 0.0) my_pl = 0.001;                 /* gcn.h:613-615 */
+        }
     }
+    const double ls = -log(my_pl);
+    if (ok) {
+        atomicAdd(&s_cnt[0], 1ull);
+        if (tr) atomicAdd(&s_cnt[1], 1ull);
+        if (tr && bd) atomicAdd(&s_cnt[2], 1ull);
+        if (te) atomicAdd(&s_cnt[3], 1ull);
+        if (te && bd) atomicAdd(&s_cnt[4], 1ull);
+    }
+    if (ls != 0.0) atomicAdd(&s_loss, ls);
     __syncthreads();
     if (threadIdx.x < 5 && s_cnt[threadIdx.x]) atomicAdd(&d.counts[threadIdx.x], s_cnt[threadIdx.x]);
     if (threadIdx.x == 0 && s_loss != 0.0) atomicAdd(d.loss, s_loss);
@@ -748,7 +762,7 @@ int cognn_softmax_jobs_u64(cognn_ctx* ctx, const cognn_softmax_job* jobs, int32_
             d.d_out = (u64*)s.d_out; d.z0 = (const u64*)s.z0; d.z1 = (const u64*)s.z1; d.labels = s.labels; d.border = s.border;
             d.keyRho = s.keys.k[COGNN_SL_RHO]; d.p = s.p; d.rows = s.rows; d.train_rows = s.train_rows; d.val_rows = s.val_rows;
             d.counts = (unsigned long long*)s.counts6; d.loss = s.loss;
-            const unsigned blocks = (unsigned)cg_div_up(s.rows * G, kThreads);
+            const unsigned blocks = (unsigned)cg_div_up(s.rows, kThreads);      // a lane group of G lanes owns G rows
             b.blk_end[b.count] = (b.count ? b.blk_end[b.count - 1] : 0u) + blocks;
             ++b.count;
         }
