@@ -11,7 +11,7 @@ HIPFLAGS := --offload-arch=$(ARCH) -O3 -fPIC -std=c++17 -Wall -Wno-unused-functi
 ifdef ABLATION
 HIPFLAGS += -DCOGNN_GEMM_ABLATION
 endif
-KERNEL_SRCS := $(CSRC)/capi.hip $(CSRC)/kernels_elementwise.hip $(CSRC)/kernels_gather.hip $(CSRC)/kernels_gemm.hip $(CSRC)/exchange_rccl.hip
+KERNEL_SRCS := $(CSRC)/capi.hip $(CSRC)/kernels_elementwise.hip $(CSRC)/kernels_gather.hip $(CSRC)/kernels_gemm.hip $(CSRC)/exchange_rccl.hip $(CSRC)/graph_build.hip
 HOST_SRCS := $(filter-out $(HOST)/harness_main.cpp,$(wildcard $(HOST)/*.cpp))
 HARNESS := bin/gcn-optimize
 OBJS := $(KERNEL_SRCS:.hip=.o) $(HOST_SRCS:.cpp=.o)

@@ -98,6 +98,7 @@ _SIGNATURES = {
     "cognn_metrics_q16": (_I, [_P, _P, _P, _P, _L, _L, _L, _L, _P, _P]),
     "cognn_pair_chain_u64": (_I, [_P, ctypes.POINTER(PairChain), ctypes.c_int32]),
     "cognn_softmax_jobs_u64": (_I, [_P, ctypes.POINTER(SoftmaxJob), ctypes.c_int32, _L]),
+    "cognn_graph_build_colocated": (_I, [_P, _L, _L, ctypes.c_int32] + [_P] * 6 + [_L] + [_P] * 8),
     "cognn_transpose_u64": (_I, [_P, _P, _P, _L, _L]),
     "cognn_timer_begin": (_I, [_P, _I]),
     "cognn_timer_end": (_I, [_P, _I]),

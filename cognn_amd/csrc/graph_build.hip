@@ -1,0 +1,110 @@
+// Index construction on the device for a run whose parties all live in ONE process (include/cognn_hip.h,
+// cognn_graph_build_colocated): degree accounting (include/graph.h:607-633, include/graph_io_util.h:167-177), the
+// dummy-source rule of onPreprocessClient (ss_...h:411-418) and the aggregate CSR of the fused message passing
+// straight from the edge list: count -> scan -> fill, no sort.  The order of the entries inside a CSR row is whatever the
+// atomics produce: the gather adds uint64 shares, so any order gives the same bits.
+#include "common.h"
+#include <hipcub/hipcub.hpp>
+#include "../../include/cognn_hip.h"
+
+namespace {
+
+// table row of vertex v in the owner-side (A) / co-party-side (B) segment of its party
+struct Layout {
+    const int32_t* tid; const uint32_t* row_of_vid; const int64_t* a_off; const int64_t* b_off;
+    __device__ uint32_t a(uint32_t v) const { return (uint32_t)(a_off[tid[v]] + row_of_vid[v]); }
+    __device__ uint32_t b(uint32_t v) const { return (uint32_t)(b_off[tid[v]] + row_of_vid[v]); }
+};
+
+template <bool FILL>
+__global__ __launch_bounds__(256) void edge_pass_kernel(const int64_t* __restrict__ src, const int64_t* __restrict__ dst, int64_t E, int undirected,
+                                                         int64_t V, Layout L, uint32_t* in_deg, uint32_t* out_deg, uint8_t* border, uint32_t* local_in,
+                                                         uint32_t* count, const uint32_t* __restrict__ rowptr, uint32_t* cursor, uint32_t* col,
+                                                         int* bad) {
+    const int64_t total = undirected ? 2 * E : E;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t e = undirected ? i >> 1 : i;
+        int64_t s = src[e], d = dst[e];
+        if (undirected && (i & 1)) { const int64_t t = s; s = d; d = t; }       // graph_io_util.h:161-163
+        if (s < 0 || s >= V || d < 0 || d >= V) { *bad = 1; continue; }
+        const uint32_t u = (uint32_t)s, v = (uint32_t)d;
+        const bool same = L.tid[u] == L.tid[v];
+        // the owner side of v aggregates its own party's shares for local sources and the CO-share replica of the source's
+        // party otherwise; the co-party side the other way round (ss_...h:1063-1067, 1089-1100)
+        const uint32_t rowA = L.a(v), rowB = L.b(v);
+        const uint32_t colA = same ? L.a(u) : L.b(u);
+        const uint32_t colB = same ? L.b(u) : L.a(u);
+        if (!FILL) {
+            atomicAdd(&out_deg[u], 1u);
+            atomicAdd(&in_deg[v], 1u);
+            if (same) atomicAdd(&local_in[v], 1u); else border[u] = 1;
+            atomicAdd(&count[rowA], 1u);
+            atomicAdd(&count[rowB], 1u);
+        } else {
+            col[rowptr[rowA] + atomicAdd(&cursor[rowA], 1u)] = colA;
+            col[rowptr[rowB] + atomicAdd(&cursor[rowB], 1u)] = colB;
+        }
+    }
+}
+
+// vertices without a local in-edge get the dummy self source: it contributes nothing but inflates both degrees (ss_...h:411-418)
+__global__ __launch_bounds__(256) void dummy_rule_kernel(int64_t V, const uint32_t* __restrict__ local_in, const uint32_t* __restrict__ true_in,
+                                                          uint32_t* in_deg, uint32_t* out_deg, uint8_t* self_dummy) {
+    const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (v >= V) return;
+    const bool dummy = local_in[v] == 0;
+    self_dummy[v] = dummy ? 1 : 0;
+    in_deg[v] = true_in[v] + (dummy ? 1u : 0u);
+    if (dummy) out_deg[v] += 1u;
+}
+
+}  // namespace
+
+extern "C" int cognn_graph_build_colocated(cognn_ctx* ctx, int64_t V, int64_t E, int32_t undirected, const int64_t* src, const int64_t* dst,
+                                           const int32_t* tid, const uint32_t* row_of_vid, const int64_t* a_off, const int64_t* b_off,
+                                           int64_t table_rows, uint32_t* rowptr, uint32_t* col, uint32_t* true_in_deg, uint32_t* in_deg,
+                                           uint32_t* out_deg, uint8_t* is_border, uint8_t* self_dummy, uint32_t* scratch) {
+    { const int rc_flush_ = cg_flush(ctx); if (rc_flush_) return rc_flush_; }
+    CG_REQUIRE(ctx && tid && row_of_vid && a_off && b_off && rowptr && true_in_deg && in_deg && out_deg && is_border && self_dummy && scratch,
+               "cognn_graph_build_colocated: null argument");
+    CG_REQUIRE(V >= 0 && E >= 0 && (E == 0 || (src && dst && col)), "cognn_graph_build_colocated: bad edge list");
+    const int64_t total = undirected ? 2 * E : E;
+    CG_REQUIRE(2 * total < (1ll << 32) && table_rows < (1ll << 32), "cognn_graph_build_colocated: graph too large for 32-bit CSR indices");
+    uint32_t* local_in = scratch;                              // [V]
+    uint32_t* count = scratch + V;                             // [table_rows + 1]
+    uint32_t* cursor = count + table_rows + 1;                 // [table_rows]
+    int* bad = (int*)(cursor + table_rows);                    // [1]
+    CG_HIP(hipMemsetAsync(scratch, 0, (size_t)(V + 2 * table_rows + 2) * 4, ctx->stream));
+    CG_HIP(hipMemsetAsync(true_in_deg, 0, (size_t)V * 4, ctx->stream));
+    CG_HIP(hipMemsetAsync(out_deg, 0, (size_t)V * 4, ctx->stream));
+    CG_HIP(hipMemsetAsync(is_border, 0, (size_t)V, ctx->stream));
+    Layout L{tid, row_of_vid, a_off, b_off};
+    const unsigned blocks = (unsigned)std::min<int64_t>((total + 255) / 256, 256 * 64);
+    if (total > 0) {
+        hipLaunchKernelGGL(edge_pass_kernel<false>, dim3(blocks), dim3(256), 0, ctx->stream, src, dst, E, (int)undirected, V, L, true_in_deg, out_deg,
+                           is_border, local_in, count, (const uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, bad);
+        CG_LAUNCH_CHECK();
+    }
+    // row pointers = exclusive scan of the per-row counts (count has table_rows + 1 entries, the last one 0)
+    size_t tmp_bytes = 0;
+    CG_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, count, rowptr, (int)(table_rows + 1), ctx->stream));
+    void* tmp = nullptr;
+    CG_HIP(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16));
+    hipError_t se = hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, count, rowptr, (int)(table_rows + 1), ctx->stream);
+    if (se != hipSuccess) { (void)hipFree(tmp); return cognn_set_error("cognn_graph_build_colocated: scan failed: %s", hipGetErrorString(se)); }
+    if (total > 0) {
+        hipLaunchKernelGGL(edge_pass_kernel<true>, dim3(blocks), dim3(256), 0, ctx->stream, src, dst, E, (int)undirected, V, L, (uint32_t*)nullptr,
+                           (uint32_t*)nullptr, (uint8_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)rowptr, cursor, col, bad);
+    }
+    if (V > 0)
+        hipLaunchKernelGGL(dummy_rule_kernel, dim3((unsigned)((V + 255) / 256)), dim3(256), 0, ctx->stream, V, local_in, true_in_deg, in_deg, out_deg,
+                           self_dummy);
+    int host_bad = 0;
+    hipError_t ce = hipMemcpyAsync(&host_bad, bad, sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
+    if (ce == hipSuccess) ce = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(tmp);
+    if (ce != hipSuccess) return cognn_set_error("cognn_graph_build_colocated: %s", hipGetErrorString(ce));
+    CG_LAUNCH_CHECK();
+    CG_REQUIRE(!host_bad, "edge list: vertex id out of range");
+    return 0;
+}

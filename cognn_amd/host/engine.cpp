@@ -1133,6 +1133,64 @@ void build_csrs(cognn_engine* E) {
     E->part_rowptr = upload(E, prp); E->part_col = upload(E, pcol);
 }
 
+// Single-process runs (every party hosted here): degrees and the aggregate CSR are built on the device straight from the edge
+// list (cognn_graph_build_colocated) instead of bucketing / sorting edges and assembling per-row lists on the host.
+void build_graph_on_device(cognn_engine* E, int64_t V, int64_t Ecount, const int64_t* src, const int64_t* dst, bool undirected) {
+    auto& G = E->G;
+    const int64_t total = undirected ? 2 * Ecount : Ecount;
+    G.num_edges = total;
+    struct Tmp {                                             // device temporaries of the build, released when it is done
+        cognn_engine* E; std::vector<void*> p;
+        void* get(size_t bytes) { void* q = nullptr; if (E->be->cognn_malloc(E->ctx, &q, bytes ? bytes : 16) != 0) throw EngineError(std::string(E->be->cognn_last_error())); p.push_back(q); return q; }
+        ~Tmp() { for (void* q : p) E->be->cognn_free(E->ctx, q); }
+    } tmp{E, {}};
+    int64_t* dsrc = (int64_t*)tmp.get((size_t)Ecount * 8);
+    int64_t* ddst = (int64_t*)tmp.get((size_t)Ecount * 8);
+    int32_t* dtid = (int32_t*)tmp.get((size_t)V * 4);
+    uint32_t* drow = (uint32_t*)tmp.get((size_t)V * 4);
+    int64_t* daoff = (int64_t*)tmp.get((size_t)E->k * 8);
+    int64_t* dboff = (int64_t*)tmp.get((size_t)E->k * 8);
+    uint32_t* dtin = (uint32_t*)tmp.get((size_t)V * 4);
+    uint32_t* din = (uint32_t*)tmp.get((size_t)V * 4);
+    uint32_t* dout = (uint32_t*)tmp.get((size_t)V * 4);
+    uint8_t* dborder = (uint8_t*)tmp.get((size_t)V);
+    uint8_t* ddummy = (uint8_t*)tmp.get((size_t)V);
+    uint32_t* scratch = (uint32_t*)tmp.get((size_t)(V + 2 * E->tableRows + 2) * 4);
+    if (Ecount > 0) {
+        BE(cognn_memcpy_h2d(E->ctx, dsrc, src, (size_t)Ecount * 8));
+        BE(cognn_memcpy_h2d(E->ctx, ddst, dst, (size_t)Ecount * 8));
+    }
+    if (V > 0) {
+        BE(cognn_memcpy_h2d(E->ctx, dtid, G.tid.data(), (size_t)V * 4));
+        BE(cognn_memcpy_h2d(E->ctx, drow, G.row_of_vid.data(), (size_t)V * 4));
+    }
+    BE(cognn_memcpy_h2d(E->ctx, daoff, E->A_off.data(), (size_t)E->k * 8));
+    BE(cognn_memcpy_h2d(E->ctx, dboff, E->B_off.data(), (size_t)E->k * 8));
+    E->aggEdges = 2 * total; E->remEdges = 0; E->partEdges = 0;
+    E->agg_rowptr = dalloc<uint32_t>(E, (size_t)E->tableRows + 1);
+    E->agg_col = dalloc<uint32_t>(E, (size_t)E->aggEdges);
+    BE(cognn_graph_build_colocated(E->ctx, V, Ecount, undirected ? 1 : 0, dsrc, ddst, dtid, drow, daoff, dboff, E->tableRows, E->agg_rowptr, E->agg_col,
+                                   dtin, din, dout, dborder, ddummy, scratch));
+    const std::vector<uint32_t> zero{0};
+    E->part_rowptr = upload(E, zero); E->part_col = upload(E, std::vector<uint32_t>());
+    E->rem_rowptr = upload(E, std::vector<uint32_t>((size_t)E->aggRows + 1, 0)); E->rem_col = upload(E, std::vector<uint32_t>());
+    // the per-vertex results the host still needs (feature pre-scale, normalisers, metrics, cognn_engine_party_degrees)
+    std::vector<uint32_t> tin((size_t)V), in((size_t)V), out((size_t)V);
+    std::vector<uint8_t> border((size_t)V), dummy((size_t)V);
+    if (V > 0) {
+        BE(cognn_memcpy_d2h(E->ctx, tin.data(), dtin, (size_t)V * 4));
+        BE(cognn_memcpy_d2h(E->ctx, in.data(), din, (size_t)V * 4));
+        BE(cognn_memcpy_d2h(E->ctx, out.data(), dout, (size_t)V * 4));
+        BE(cognn_memcpy_d2h(E->ctx, border.data(), dborder, (size_t)V));
+        BE(cognn_memcpy_d2h(E->ctx, dummy.data(), ddummy, (size_t)V));
+    }
+    for (int64_t v = 0; v < V; ++v) {
+        auto& pg = G.party[G.tid[v]];
+        const uint32_t r = G.row_of_vid[v];
+        pg.trueInDeg[r] = tin[v]; pg.inDeg[r] = in[v]; pg.outDeg[r] = out[v]; pg.isBorder[r] = border[v]; pg.selfDummy[r] = dummy[v];
+    }
+}
+
 void alloc_sides(cognn_engine* E) {
     const int in = E->in(), hid = E->hid(), lab = E->lab();
     const int fm = std::max(hid, lab);
@@ -1284,9 +1342,17 @@ int cognn_engine_create(const cognn_engine_config* cfg, int64_t V, int64_t Ecoun
             throw EngineError(msg);
         }
         try {
-            E->G = cognn::build_partitioned_graph(E->k, V, Ecount, src, dst, part, cfg->undirected != 0);
-            build_layout(E);
-            build_csrs(E);
+            // COGNN_HOST_GRAPH_BUILD forces the host builder (tests compare the two)
+            const bool device_build = E->world == 1 && !getenv("COGNN_HOST_GRAPH_BUILD");
+            if (device_build) {
+                E->G = cognn::build_vertex_layout(E->k, V, part);
+                build_layout(E);
+                build_graph_on_device(E, V, Ecount, src, dst, cfg->undirected != 0);
+            } else {
+                E->G = cognn::build_partitioned_graph(E->k, V, Ecount, src, dst, part, cfg->undirected != 0);
+                build_layout(E);
+                build_csrs(E);
+            }
             alloc_sides(E);
             E->hostFeat.resize(E->hosted.size());
             E->hostLabels.resize(E->hosted.size());

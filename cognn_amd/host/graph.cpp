@@ -15,8 +15,7 @@ struct E2 {
 };
 }  // namespace
 
-PartitionedGraph build_partitioned_graph(int k, int64_t V, int64_t E, const int64_t* src, const int64_t* dst,
-                                         const int32_t* part, bool undirected) {
+PartitionedGraph build_vertex_layout(int k, int64_t V, const int32_t* part) {
     if (k < 1) throw std::runtime_error("build_partitioned_graph: need at least one party");
     if (V < 0 || V >= (int64_t)1 << 31) throw std::runtime_error("build_partitioned_graph: vertex count out of range");
     PartitionedGraph G;
@@ -35,8 +34,14 @@ PartitionedGraph build_partitioned_graph(int k, int64_t V, int64_t E, const int6
     }
     for (auto& pg : G.party) {
         const size_t n = pg.localVertexPos.size();
-        pg.trueInDeg.assign(n, 0); pg.outDeg.assign(n, 0); pg.isBorder.assign(n, 0); pg.selfDummy.assign(n, 0);
+        pg.trueInDeg.assign(n, 0); pg.inDeg.assign(n, 0); pg.outDeg.assign(n, 0); pg.isBorder.assign(n, 0); pg.selfDummy.assign(n, 0);
     }
+    return G;
+}
+
+PartitionedGraph build_partitioned_graph(int k, int64_t V, int64_t E, const int64_t* src, const int64_t* dst,
+                                         const int32_t* part, bool undirected) {
+    PartitionedGraph G = build_vertex_layout(k, V, part);
     // degree accounting + bucket own-tile edges by source party (graph.h:607-633, graph_io_util.h:167-177)
     std::vector<std::vector<E2>> own(k);
     const int64_t total = undirected ? 2 * E : E;

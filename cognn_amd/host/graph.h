@@ -43,6 +43,10 @@ struct PartitionedGraph {
 PartitionedGraph build_partitioned_graph(int k, int64_t num_vertices, int64_t num_edges, const int64_t* src,
                                          const int64_t* dst, const int32_t* part, bool undirected);
 
+// Vertex ordering only (tid check, localVertexPos / row_of_vid, empty degree arrays): what a single-process run needs on the
+// host before the device builds degrees and the CSR from the edge list (cognn_graph_build_colocated).
+PartitionedGraph build_vertex_layout(int k, int64_t num_vertices, const int32_t* part);
+
 // Text loaders with the reference's formats (graph_io_util.h:17-22,67-73,121-147; harness.cpp:21-48).
 void load_partition_file(const std::string& path, std::vector<int32_t>& part);
 void load_edge_list_file(const std::string& path, std::vector<int64_t>& src, std::vector<int64_t>& dst);

@@ -213,6 +213,20 @@ typedef struct {
 /* independent chains (the co-located pairs of one protocol phase) are issued as shared launches */
 int cognn_pair_chain_u64(cognn_ctx*, const cognn_pair_chain* chains, int32_t count);
 
+/* ---- onPreprocessClient index construction (ss_...h:295-534) + degree accounting (graph.h:607-633, graph_io_util.h:167-177)
+ *      on the device, for a run whose parties are all hosted by ONE process ------------------------------------------------
+ * All pointers are DEVICE pointers.  In: the directed edge list in file order (both directions are generated when
+ * `undirected`), vid -> party (`tid`), vid -> row inside its party (`row_of_vid`, ascending vid = localVertexPos order), and the
+ * share-table offsets of every party's owner-side (a_off) and co-party-side (b_off) row segment.
+ * Out: the aggregate CSR over the table (rowptr[table_rows + 1], col[2 * #directed edges]; entry order inside a row is
+ * unspecified - uint64 addition commutes), and per vertex the in-degree as onAlgoKernelStart sees it (true_in_deg), the
+ * degrees after the dummy-source rule of ss_...h:411-418 (in_deg, out_deg), isLocalVertexBorder and the dummy flag.
+ * scratch: V + 2 * table_rows + 2 uint32.  Synchronises the stream (it reports malformed edges). */
+int cognn_graph_build_colocated(cognn_ctx*, int64_t V, int64_t E, int32_t undirected, const int64_t* src, const int64_t* dst,
+                                const int32_t* tid, const uint32_t* row_of_vid, const int64_t* a_off, const int64_t* b_off,
+                                int64_t table_rows, uint32_t* rowptr, uint32_t* col, uint32_t* true_in_deg, uint32_t* in_deg,
+                                uint32_t* out_deg, uint8_t* is_border, uint8_t* self_dummy, uint32_t* scratch);
+
 /* out[c,r] = in[r,c] for a small [rows x cols] matrix (transpose(), include/task/task.h:243; gcn.h:648) */
 int cognn_transpose_u64(cognn_ctx*, uint64_t* out, const uint64_t* in, int64_t rows, int64_t cols);
 

@@ -436,6 +436,46 @@ int cognn_pair_chain_u64(cognn_ctx* ctx, const cognn_pair_chain* chains, int32_t
     }
     return 0;
 }
+// the device index construction, as plain loops (count, scan, fill in edge order)
+int cognn_graph_build_colocated(cognn_ctx*, int64_t V, int64_t E, int32_t undirected, const int64_t* src, const int64_t* dst, const int32_t* tid,
+                                const uint32_t* row_of_vid, const int64_t* a_off, const int64_t* b_off, int64_t table_rows, uint32_t* rowptr,
+                                uint32_t* col, uint32_t* true_in_deg, uint32_t* in_deg, uint32_t* out_deg, uint8_t* is_border, uint8_t* self_dummy,
+                                uint32_t* scratch) {
+    uint32_t* local_in = scratch;
+    std::vector<uint32_t> cursor((size_t)table_rows, 0);
+    memset(scratch, 0, (size_t)V * 4);
+    memset(true_in_deg, 0, (size_t)V * 4); memset(out_deg, 0, (size_t)V * 4); memset(is_border, 0, (size_t)V);
+    memset(rowptr, 0, (size_t)(table_rows + 1) * 4);
+    const int64_t total = undirected ? 2 * E : E;
+    auto edge = [&](int64_t i, int64_t& s, int64_t& d) {
+        const int64_t e = undirected ? i >> 1 : i;
+        s = src[e]; d = dst[e];
+        if (undirected && (i & 1)) std::swap(s, d);
+    };
+    auto A = [&](int64_t v) { return (uint32_t)(a_off[tid[v]] + row_of_vid[v]); };
+    auto B = [&](int64_t v) { return (uint32_t)(b_off[tid[v]] + row_of_vid[v]); };
+    for (int64_t i = 0; i < total; ++i) {
+        int64_t s, d;
+        edge(i, s, d);
+        REQ(s >= 0 && s < V && d >= 0 && d < V, "edge list: vertex id out of range");
+        out_deg[s]++; true_in_deg[d]++;
+        if (tid[s] == tid[d]) local_in[d]++; else is_border[s] = 1;
+        rowptr[A(d) + 1]++; rowptr[B(d) + 1]++;
+    }
+    for (int64_t r = 0; r < table_rows; ++r) rowptr[r + 1] += rowptr[r];
+    for (int64_t i = 0; i < total; ++i) {
+        int64_t s, d;
+        edge(i, s, d);
+        const bool same = tid[s] == tid[d];
+        col[rowptr[A(d)] + cursor[A(d)]++] = same ? A(s) : B(s);
+        col[rowptr[B(d)] + cursor[B(d)]++] = same ? B(s) : A(s);
+    }
+    for (int64_t v = 0; v < V; ++v) {
+        const bool dummy = local_in[v] == 0;
+        self_dummy[v] = dummy; in_deg[v] = true_in_deg[v] + dummy; out_deg[v] += dummy;
+    }
+    return 0;
+}
 int cognn_transpose_u64(cognn_ctx*, uint64_t* out, const uint64_t* in, int64_t rows, int64_t cols) {
     for (int64_t r = 0; r < rows; ++r)
         for (int64_t c = 0; c < cols; ++c) out[c * rows + r] = in[r * cols + c];
