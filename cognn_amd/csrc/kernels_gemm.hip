@@ -552,8 +552,8 @@ __global__ __launch_bounds__(256) void beaver_gemm_d16_kernel(u64* Z, const u64*
     const int st1 = SPLITK ? min(nst, st0 + ksteps) : nst;
     if (st0 >= st1) return;
     const u64* e0row = E0 + (size_t)mc * K;
-    const u64* e1row = (E1 ? E1 : E0) + (size_t)mc * K;
-    const u64 e1mask = E1 ? ~0ull : 0ull;
+    const bool two = E1 != nullptr;                         // (uniform) the opened value arrives as two shares, summed here
+    const u64* e1row = two ? E1 + (size_t)mc * K : e0row;
     const v4i* bp = reinterpret_cast<const v4i*>(planes) + lane;
     v4i acc[8];
 #pragma unroll
@@ -567,14 +567,23 @@ __global__ __launch_bounds__(256) void beaver_gemm_d16_kernel(u64* Z, const u64*
                 int k = st * 32 + 8 * j + 2 * b;
                 if (!FULL) k = min(k, K - 2);
                 const u64x2 x = *reinterpret_cast<const u64x2*>(e0row + k);
-                const u64x2 y = *reinterpret_cast<const u64x2*>(e1row + k);
-                a0[2 * j] = x.x; a0[2 * j + 1] = x.y; a1[2 * j] = y.x; a1[2 * j + 1] = y.y;
+                a0[2 * j] = x.x; a0[2 * j + 1] = x.y;
+            }
+            if (two) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    int k = st * 32 + 8 * j + 2 * b;
+                    if (!FULL) k = min(k, K - 2);
+                    const u64x2 y = *reinterpret_cast<const u64x2*>(e1row + k);
+                    a1[2 * j] = y.x; a1[2 * j + 1] = y.y;
+                }
             }
         } else {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const int k = min(d16_k(st, b, e), K - 1);
-                a0[e] = e0row[k]; a1[e] = e1row[k];
+                a0[e] = e0row[k];
+                a1[e] = two ? e1row[k] : 0ull;
             }
         }
     };
@@ -585,7 +594,7 @@ __global__ __launch_bounds__(256) void beaver_gemm_d16_kernel(u64* Z, const u64*
         for (int i = 0; i < 8; ++i) bf[i] = bp[(size_t)(st * 8 + i) * 64];
         u64 v[8], w[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = cur0[e] + (cur1[e] & e1mask);
+        for (int e = 0; e < 8; ++e) v[e] = two ? cur0[e] + cur1[e] : cur0[e];
         if (st + 1 < st1) load_step(st + 1, cur0, cur1);     // next step's opened shares are in flight during this step's arithmetic
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
