@@ -15,8 +15,8 @@ pytestmark = pytest.mark.gpu
 
 # fixed point f = 16: every truncation is off by at most 1 LSB (2^-16) and the learning rate of the PubMed config is 8.0, so
 # the secret-shared trajectory drifts from the float64 one; these are the bounds the drift has to stay under at every epoch
-TOL_LOSS = 0.02
-TOL_ACC = 0.02
+TOL_LOSS = 0.005     # measured on MI355X: 0.0014
+TOL_ACC = 0.01       # measured: 0.0041
 
 
 def test_pubmed_shaped_four_party_90_epochs_track_plaintext():
