@@ -91,13 +91,14 @@ def cpu_baseline(args, wl):
         except (OSError, ValueError):
             pass
         cores = min(cores, 16)                              # a one-GPU box's CPU share is 16 cores; more threads only oversubscribe
-        dt_all, edges_all, lva, lea = _cpu_engine_run(wl, 2, cores, 2)
-        dt_1, edges_1, lv1, le1 = _cpu_engine_run(wl, 4, 1, 1)
+        dt_all, edges_all, lva, lea = _cpu_engine_run(wl, 2, cores, 5)      # median of 5 passes
+        dt_1, edges_1, lv1, le1 = _cpu_engine_run(wl, 4, 1, 3)              # median of 3 passes
         return {"value": edges_all * widths / dt_all, "unit": "edges*feat/s", "cores": cores, "kind": "port",
                 "value_1core": edges_1 * widths / dt_1,
                 "sample": "engine host code on the plain-C++ reference backend (oracle/cpu_backend.cpp, OpenMP): %d-party %s pass, "
                           "in=%d hid=%d labels=%d; %d threads on a 2^%d-vertex/2^%d-edge graph: %.2f s per pass; 1 thread on "
-                          "2^%d/2^%d: %.2f s per pass" % (k, variant, in_dim, hid, lab, cores, lva, lea, dt_all, lv1, le1, dt_1)}
+                          "2^%d/2^%d: %.2f s per pass (medians of 5 and 3 timed passes after a warm-up pass; dealer phase outside the timed region)"
+                          % (k, variant, in_dim, hid, lab, cores, lva, lea, dt_all, lv1, le1, dt_1)}
     except Exception as ex:  # noqa: BLE001 - the baseline must not take the bench down
         sys.stderr.write("cpu_baseline: C++ reference backend unavailable (%r), using the numpy oracle\n" % (ex,))
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -180,6 +181,8 @@ def main():
     eng.start()
     t_off = time.perf_counter()
     eng.retain_offline(True)                  # every step replays the same iterations: keep their dealt product shares
+    if "inference" in variant:
+        eng.forward_only(True)                # -m 2: the hidden activation and the ReLU sign mask have no reader
     eng.offline(0, iters)
     torch.cuda.synchronize()
     offline_ms = (time.perf_counter() - t_off) * 1e3

@@ -748,7 +748,14 @@ void beaver_gemm_d16n_kernel(u64* Z, const u64* __restrict__ E0, const u64* __re
                     for (int j = 0; j + i < 8; ++j) acc[t][i + j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[i], bf[j], acc[t][i + j], 0, 0, 0);
             }
         }
-        if (st == nst - 1) {
+        if (st == nst - 1 && (DBG & 32)) {                   // timing experiment: one store per tile instead of the epilogue
+            int x = 0;
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int s2 = 0; s2 < 8; ++s2) x ^= acc[t][s2][0] ^ acc[t][s2][1] ^ acc[t][s2][2] ^ acc[t][s2][3];
+            if (x == 0x12345678) Z[tile] = (u64)x;
+        } else if (st == nst - 1) {
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 const int col = t * 16 + (lane & 15);
@@ -1292,6 +1299,8 @@ int beaver_close_impl(cognn_ctx* ctx, uint64_t* Z, const uint64_t* E, const uint
             else if (NT == 4 && full16 && dbgn == 11) CG_D16N_LAUNCH(4, true, true, 11);
             else if (NT == 4 && full16 && dbgn == 16) CG_D16N_LAUNCH(4, true, true, 16);
             else if (NT == 4 && full16 && dbgn == 27) CG_D16N_LAUNCH(4, true, true, 27);
+            else if (NT == 4 && full16 && dbgn == 32) CG_D16N_LAUNCH(4, true, true, 32);
+            else if (NT == 4 && full16 && dbgn == 59) CG_D16N_LAUNCH(4, true, true, 59);
             else
 #endif
             if (NT == 2) CG_D16N_NT(2); else if (NT == 3) CG_D16N_NT(3); else CG_D16N_NT(4);

@@ -138,6 +138,10 @@ class Engine:
         """Co-located share-holders run their two-party steps as pair chains (default) or through the per-side kernels."""
         _check(self.lib.cognn_engine_set_option(self.h, 2, int(on)))
 
+    def forward_only(self, on=True):
+        """Promise that no backward iteration follows (inference): stores that only the backward pass reads are skipped."""
+        _check(self.lib.cognn_engine_set_option(self.h, 3, int(on)))
+
     def phase_seconds(self):
         """Device time per phase of the last iteration (engine created with verbose=True), see cognn_engine_get_phase_seconds."""
         out = np.zeros(6, dtype=np.float64)

@@ -89,6 +89,7 @@ struct cognn_engine {
     std::map<int64_t, std::vector<u64*>> c1_pool;   // released product-share buffers by element count, reused by later deals
     bool retain_offline = false;                    // COGNN_OPT_RETAIN_OFFLINE
     bool pair_fusion = true;                        // COGNN_OPT_PAIR_FUSION: co-located share-holders run their two-party steps as pair chains
+    bool forward_only = false;                      // COGNN_OPT_FORWARD_ONLY: no backward iteration will follow (inference, -m 2)
     double phase_s[6] = {0, 0, 0, 0, 0, 0};         // cognn_engine_get_phase_seconds
     int64_t rounds = 0;                             // exchange rounds started (all iterations)
     cognn_exchange_fn xfn = nullptr;
@@ -517,6 +518,10 @@ void rowscale_stage(cognn_engine* E, int64_t it, int op, int top, int F, XFn X, 
                 c.out[0] = s.h1; c.out[1] = t.h1;
                 c.open[0] = s.h1E; c.open[1] = t.h1E;
                 c.open_key[0] = nk.k[COGNN_SL_A0]; c.open_key[1] = nk.k[COGNN_SL_A1];
+                if (E->forward_only) {                       // inference: the next product only reads the opening; h_t and the sign mask
+                    c.out[0] = c.out[1] = nullptr;           // serve the backward pass, which will not run
+                    c.mask = nullptr;
+                }
             } else {
                 c.out[0] = dst(s); c.out[1] = dst(t);
                 if (open_next) {
@@ -574,6 +579,7 @@ void relu_stage(cognn_engine* E, int64_t it, bool e_opened, bool pairs_done) {
             c.out[0] = s.h1; c.out[1] = t.h1;
             c.open[0] = s.h1E; c.open[1] = t.h1E;
             c.open_key[0] = nk.k[COGNN_SL_A0]; c.open_key[1] = nk.k[COGNN_SL_A1];
+            if (E->forward_only) { c.out[0] = c.out[1] = nullptr; c.mask = nullptr; }
         }
         pc.launch(E);
     }
@@ -846,6 +852,7 @@ void weight_update_chain(cognn_engine* E, int64_t it, int layer) {
 
 void run_iteration(cognn_engine* E, int64_t it) {
     const IterInfo I = iter_info(E, it);
+    if (E->forward_only && !I.fwd) throw EngineError("engine: COGNN_OPT_FORWARD_ONLY is set but a backward iteration was requested");
     bool relu_opened = false, wgrad_w_opened = false, relu_pairs_done = false;
     if (I.e == 0) {                                        // ss_...h:695, 938: back to the input features
         for (auto& s : E->sides) { s.cur = s.feat; s.curF = E->in(); }
@@ -1531,6 +1538,7 @@ int cognn_engine_set_option(cognn_engine* E, int32_t option, int64_t value) {
         if (!E) throw EngineError("null engine");
         if (option == COGNN_OPT_RETAIN_OFFLINE) E->retain_offline = value != 0;
         else if (option == COGNN_OPT_PAIR_FUSION) E->pair_fusion = value != 0;
+        else if (option == COGNN_OPT_FORWARD_ONLY) E->forward_only = value != 0;
         else throw EngineError("cognn_engine_set_option: unknown option");
     });
 }

@@ -185,6 +185,7 @@ int main(int argc, char* argv[]) {
             std::cerr << cognn_engine_last_error() << std::endl;
             return -1;
         }
+        if (inference && maxIters <= (uint64_t)gp.num_layers) cognn_engine_set_option(e, COGNN_OPT_FORWARD_ONLY, 1);   // -m 2: one inference pass
 #ifdef COGNN_NO_RCCL
         if (world > 1) { std::cerr << "This build has no RCCL transport." << std::endl; return -1; }
 #else

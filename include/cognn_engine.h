@@ -80,8 +80,12 @@ int cognn_engine_offline(cognn_engine* e, int64_t iter_begin, int64_t iter_end);
 /* COGNN_OPT_PAIR_FUSION (default 1): when both share-holders of a vertex set are hosted by this process, their two-party
  * steps between two linear ops run as one pair chain (cognn_pair_chain_u64: exchange in registers) instead of per-side
  * open -> HBM -> close passes.  0 forces the per-side kernels everywhere (the ones a one-party-per-GPU run uses); the shares
- * are bit-identical either way.  Change it only between iterations whose first GAS iteration is a multiple of the epoch. */
-enum { COGNN_OPT_RETAIN_OFFLINE = 1, COGNN_OPT_PAIR_FUSION = 2 };
+ * are bit-identical either way.  Change it only between iterations whose first GAS iteration is a multiple of the epoch.
+ * COGNN_OPT_FORWARD_ONLY (default 0): a promise that only forward iterations will run (gcn-inference-optimize with -m 2,
+ * tools/tmp_run_cluster.py:396-415).  Co-located pairs then skip the stores that only the backward pass reads - the hidden
+ * activation h_t and the public ReLU sign mask - so cognn_engine_get_shares after a hidden-layer iteration is unspecified for
+ * them; the prediction layer's shares and metrics are unaffected.  A backward iteration is refused while it is set. */
+enum { COGNN_OPT_RETAIN_OFFLINE = 1, COGNN_OPT_PAIR_FUSION = 2, COGNN_OPT_FORWARD_ONLY = 3 };
 int cognn_engine_set_option(cognn_engine* e, int32_t option, int64_t value);
 /* Offline-phase cache on disk, the counterpart of the reference's preprocess/<setting>/ directory reused with `-n 1`
  * (include/harness.h:140-146, README.md:215-216): save writes every dealt product share currently held on this rank to

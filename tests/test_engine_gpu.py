@@ -62,6 +62,26 @@ def test_training_two_epochs_bit_exact(k, pair_fusion):
     eng.close()
 
 
+def test_forward_only_inference_pass_matches():
+    """COGNN_OPT_FORWARD_ONLY (what bench.py and `gcn-inference-optimize -m 2` set): the prediction layer's shares and metrics are those of
+    the full path; a backward iteration is refused."""
+    from cognn_amd import capi
+    k = 4
+    oracle, eng = _setup(k, 80, 240, 16, 16, 4, variant="optimize-gcn-inference", seed=11)
+    eng.forward_only(True)
+    for it in range(2):
+        oracle.iteration(it)
+    eng.run(0, 2)
+    _compare(oracle, eng, k, 1)
+    for P in range(k):
+        m = eng.metrics(P)
+        om = [x for x in oracle.metrics if x["party"] == P][0]
+        assert abs(m["loss"] - om["loss"]) < 1e-9 and abs(m["full"] - om["full"]) < 1e-12
+    with pytest.raises(capi.CognnError, match="FORWARD_ONLY"):
+        eng.run(2, 3)
+    eng.close()
+
+
 def test_inference_variant_and_offline_phase():
     k = 4
     oracle, eng = _setup(k, 80, 240, 16, 16, 4, variant="optimize-gcn-inference", seed=11)

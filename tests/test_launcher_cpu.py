@@ -114,3 +114,25 @@ def test_rank_killed_by_signal_fails_the_launch(tmp_path):
     hang.write_text("import time\ntime.sleep(600)\n")
     res = subprocess.run(cmd[:-1] + [str(hang), "--timeout", "2"], capture_output=True, text=True, timeout=120, cwd=tmp_path)
     assert res.returncode == 124
+
+
+@pytest.mark.gpu
+def test_launcher_runs_the_cpp_binary_on_the_gpu(tmp_path):
+    """--gpus 1 without --worker: bin/gcn-optimize (no Python in the run) once per party log, all parties co-located on the GPU."""
+    data, logs = tmp_path / "data", tmp_path / "log"
+    cmd = LAUNCH + ["--dataset", "cora_small", "--parties", "2", "--iterations", "6", "--data-dir", str(data), "--log-dir", str(logs), "--synthetic"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=tmp_path)
+    assert res.returncode == 0, res.stderr + res.stdout
+    o = _oracle_for(data, "cora_small", 2, "gcn-optimize/cora_small/2s", 6)
+    for party in range(2):
+        text = (logs / ("gcn_test_cora_small_%d.log" % party)).read_text()
+        assert len(extract_cognn_durations(text, "iteration")) == 6 and len(extract_cognn_durations(text, "premerging")) == 4
+        want = [m for m in o.metrics if m["party"] == party][0]
+        assert abs(float(re.findall(r"cross-entropy-loss = ([0-9.]+)", text)[0]) - want["loss"]) < 1e-6
+    # the reference's cluster switch with a one-rank world: the RCCL bootstrap path of bin/gcn-optimize (-c 1) on one GPU
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    files = [str(data / ("cora_small" + e)) for e in (".edge.preprocessed", ".vertex.preprocessed", ".part.preprocessed")]
+    r = subprocess.run([os.path.join(ROOT, "bin", "gcn-optimize"), "-t", "2", "-g", "2", "-i", "1", "-m", "2", "-s", "c1", "-r", "1", "-c", "1", "-n", "1"] + files +
+                       [str(tmp_path / "out"), str(data / "cora_small_config.txt")], capture_output=True, text=True, timeout=120, cwd=tmp_path, env=env)
+    assert r.returncode == 0, r.stderr
+    assert "full set accuracy" in r.stdout
