@@ -24,7 +24,7 @@ $(HARNESS): $(HOST)/harness_main.cpp $(OUT) $(HOST)/graph.h include/cognn_engine
 	$(HOSTCXX) $(HOSTFLAGS) -o $@ $(HOST)/harness_main.cpp -Lcognn_amd -lcognn_hip -Wl,-rpath,'$$ORIGIN/../cognn_amd' -Wl,-rpath,/opt/rocm/lib
 	ln -sf gcn-optimize bin/gcn-inference-optimize
 
-$(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/common.h $(CSRC)/cognn_spec.h include/cognn_hip.h include/cognn_engine.h include/cognn_exchange.h
+$(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/common.h $(CSRC)/pair_chain.h $(CSRC)/cognn_spec.h include/cognn_hip.h include/cognn_engine.h include/cognn_exchange.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
 $(HOST)/%.o: $(HOST)/%.cpp $(wildcard $(HOST)/*.h) $(CSRC)/cognn_spec.h include/cognn_hip.h include/cognn_engine.h

@@ -95,7 +95,7 @@ def cpu_baseline(args, wl):
         dt_1, edges_1, lv1, le1 = _cpu_engine_run(wl, 4, 1, 3)              # median of 3 passes
         return {"value": edges_all * widths / dt_all, "unit": "edges*feat/s", "cores": cores, "kind": "port",
                 "value_1core": edges_1 * widths / dt_1,
-                "sample": "engine host code on the plain-C++ reference backend (oracle/cpu_backend.cpp, OpenMP): %d-party %s pass, "
+                "sample": "engine host code on the plain-C++ reference backend (oracle/cpu_backend.cpp, OpenMP, per-side loops): %d-party %s pass, "
                           "in=%d hid=%d labels=%d; %d threads on a 2^%d-vertex/2^%d-edge graph: %.2f s per pass; 1 thread on "
                           "2^%d/2^%d: %.2f s per pass (medians of 5 and 3 timed passes after a warm-up pass; dealer phase outside the timed region)"
                           % (k, variant, in_dim, hid, lab, cores, lva, lea, dt_all, lv1, le1, dt_1)}
@@ -189,9 +189,12 @@ def main():
     setup_s = time.perf_counter() - t_setup
 
     def barrier():
+        # drain this rank's own work first: the engine's p2p groups run on their own communicator, and a torch collective
+        # enqueued while they are still in flight would put two communicators' kernels on the device in rank-dependent order
+        torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+            torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         eng.run(0, iters)

@@ -34,6 +34,11 @@ class PairChain(ctypes.Structure):
 PC_TRUNC_IN, PC_SCALE, PC_RELU, PC_INPUT_OPENED, PC_NO_C = 1, 2, 4, 8, 16
 
 
+class GatherPair(ctypes.Structure):
+    """cognn_gather_pair (include/cognn_hip.h)."""
+    _fields_ = [("a_row0", ctypes.c_int64), ("b_row0", ctypes.c_int64), ("chain", PairChain)]
+
+
 class SoftmaxJob(ctypes.Structure):
     """cognn_softmax_job (include/cognn_hip.h)."""
     _fields_ = [("d_out", ctypes.c_void_p), ("z0", ctypes.c_void_p), ("z1", ctypes.c_void_p), ("labels", ctypes.c_void_p),
@@ -98,6 +103,7 @@ _SIGNATURES = {
     "cognn_metrics_q16": (_I, [_P, _P, _P, _P, _L, _L, _L, _L, _P, _P]),
     "cognn_pair_chain_u64": (_I, [_P, ctypes.POINTER(PairChain), ctypes.c_int32]),
     "cognn_softmax_jobs_u64": (_I, [_P, ctypes.POINTER(SoftmaxJob), ctypes.c_int32, _L]),
+    "cognn_gather_pair_chain_u64": (_I, [_P, _P, _P, _P, _L, ctypes.POINTER(GatherPair), ctypes.c_int32]),
     "cognn_graph_build_colocated": (_I, [_P, _L, _L, ctypes.c_int32] + [_P] * 6 + [_L] + [_P] * 8),
     "cognn_transpose_u64": (_I, [_P, _P, _P, _L, _L]),
     "cognn_timer_begin": (_I, [_P, _I]),

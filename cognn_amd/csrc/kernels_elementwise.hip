@@ -6,6 +6,7 @@
 #include "common.h"
 #include <algorithm>
 #include "../../include/cognn_hip.h"
+#include "pair_chain.h"
 
 namespace {
 
@@ -522,33 +523,13 @@ __global__ __launch_bounds__(kThreads) void transpose_kernel(u64* out, const u64
     out[c * rows + r] = in[i];
 }
 
-// ---- pair chain: both share-holders' local arithmetic in one thread, opened values handed over in registers --------------
-// (include/cognn_hip.h, cognn_pair_chain_u64).  Every formula below restates the per-side functor it replaces - TruncOpen[Add] /
-// TruncClose, RowscaleOpenE/G / RowscaleClose, ReluOpen / ReluMul / ReluClose - for p = 0 and p = 1 side by side.
-struct PairChainDev {
-    const u64* x0; const u64* x1; const u64* c1; const u64* sc0; const u64* sc1;
-    u64* out0; u64* out1; u64* open0; u64* open1; uint8_t* mask;
-    u64 open_key0, open_key1;
-    u64 keyC0, tiR, tiR0, tiRP0;                     // truncation of the raw product
-    u64 sA0, sA1, sB0, sB1, sC0, stR, stR0, stRP0;   // row scale and its truncation
-    u64 rA0, rA1, rB0, rB1, rC0, rT;                 // ReLU
-    int64_t n; uint32_t F; uint32_t flags;
-};
+// ---- pair chain launcher (device code: pair_chain.h) ---------------------------------------------------------------------
 constexpr int kPairBatchMax = 8;
 struct PairBatch {
     PairChainDev d[kPairBatchMax];
     unsigned blk_end[kPairBatchMax];
     int count;
 };
-// dealer-assisted truncation of the pair (c0, c1 = the two sides' values before their masks are added)
-__device__ __forceinline__ void pair_trunc(u64 kR, u64 kR0, u64 kRP0, u64 idx, u64& v0, u64& v1) {
-    const u64 r0 = cognn_prng(kR0, idx), rfull = cognn_prng(kR, idx) & COGNN_TRUNC_MASK;
-    const u64 c0 = v0 + r0 + COGNN_TRUNC_OFFSET;            // side 0's opening (TruncOpen, p = 0)
-    const u64 c1 = v1 + (rfull - r0);                       // side 1's opening
-    const u64 rp0 = cognn_prng(kRP0, idx);
-    v0 = ((c0 + c1) >> COGNN_FX_BITS) - (COGNN_TRUNC_OFFSET >> COGNN_FX_BITS) - rp0;     // TruncClose, p = 0
-    v1 = 0ull - ((rfull >> COGNN_FX_BITS) - rp0);                                        // TruncClose, p = 1
-}
 __global__ __launch_bounds__(kThreads) void pair_chain_kernel(PairBatch b) {
     const unsigned blk = blockIdx.x;
     int seg = 0;
@@ -576,33 +557,13 @@ __global__ __launch_bounds__(kThreads) void pair_chain_kernel(PairBatch b) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const u64 idx = (u64)(i + j);
-            const u64 row = (u64)((uint32_t)idx / d.F);
-            const u64 a0 = cognn_prng(d.sA0, idx), a1 = cognn_prng(d.sA1, idx), c0m = cognn_prng(d.sC0, idx);
-            const u64 b0 = cognn_prng(d.sB0, row), b1 = cognn_prng(d.sB1, row);
-            const u64 e = (flags & COGNN_PC_INPUT_OPENED) ? v0[j] + v1[j] : (v0[j] - a0) + (v1[j] - a1);   // RowscaleOpenE, both sides
-            const u64 g = (d.sc0[row] - b0) + (d.sc1[row] - b1);                                          // RowscaleOpenG, both sides
-            const u64 z0 = e * b0 + a0 * g + c0m;                                                         // beaver_mul_b, p = 0
-            const u64 c1m = (a0 + a1) * (b0 + b1) - c0m;
-            const u64 z1 = e * g + e * b1 + a1 * g + c1m;                                                 // beaver_mul_b, p = 1
-            v0[j] = z0; v1[j] = z1;
-            pair_trunc(d.stR, d.stR0, d.stRP0, idx, v0[j], v1[j]);
+            pair_scale(d, idx, (u64)((uint32_t)idx / d.F), (flags & COGNN_PC_INPUT_OPENED) != 0, v0[j], v1[j]);
         }
     }
-    bool pos[2] = {true, true};
     if (flags & COGNN_PC_RELU) {
+        bool pos[2];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const u64 idx = (u64)(i + j);
-            const u64 a0 = cognn_prng(d.rA0, idx), a1 = cognn_prng(d.rA1, idx);
-            const u64 e = (v0[j] - a0) + (v1[j] - a1);                                                    // ReluOpen, both sides
-            const u64 b0 = cognn_prng(d.rB0, idx), b1 = cognn_prng(d.rB1, idx);
-            const u64 g = ((cognn_prng(d.rT, idx) & 0xFFFFFull) | 1ull) - b0 - b1;                        // dealer-published g (ReluMul)
-            const u64 c0m = cognn_prng(d.rC0, idx);
-            const u64 w0 = e * b0 + a0 * g + c0m;
-            const u64 w1 = e * g + e * b1 + a1 * g + ((a0 + a1) * (b0 + b1) - c0m);
-            pos[j] = (long long)(w0 + w1) > 0;                                                            // ReluClose
-            v0[j] = pos[j] ? v0[j] : 0ull; v1[j] = pos[j] ? v1[j] : 0ull;
-        }
+        for (int j = 0; j < 2; ++j) pos[j] = pair_relu(d, (u64)(i + j), v0[j], v1[j]);
         if (d.mask) { d.mask[i] = pos[0] ? 1 : 0; if (w == 2) d.mask[i + 1] = pos[1] ? 1 : 0; }
     }
     if (d.out0) st2(d.out0, i, w, v0);
@@ -806,14 +767,7 @@ int cognn_pair_chain_u64(cognn_ctx* ctx, const cognn_pair_chain* chains, int32_t
         PairChainDev d;
         d.x0 = (const u64*)s.x[0]; d.x1 = (const u64*)s.x[1]; d.c1 = (const u64*)s.c1; d.sc0 = (const u64*)s.scale[0]; d.sc1 = (const u64*)s.scale[1];
         d.out0 = (u64*)s.out[0]; d.out1 = (u64*)s.out[1]; d.open0 = (u64*)s.open[0]; d.open1 = (u64*)s.open[1]; d.mask = s.mask;
-        d.open_key0 = s.open_key[0]; d.open_key1 = s.open_key[1];
-        d.keyC0 = s.gemm_keys.k[COGNN_SL_C0];
-        d.tiR = s.trunc_in_keys.k[COGNN_SL_R]; d.tiR0 = s.trunc_in_keys.k[COGNN_SL_R0]; d.tiRP0 = s.trunc_in_keys.k[COGNN_SL_RP0];
-        d.sA0 = s.scale_keys.k[COGNN_SL_A0]; d.sA1 = s.scale_keys.k[COGNN_SL_A1]; d.sB0 = s.scale_keys.k[COGNN_SL_B0];
-        d.sB1 = s.scale_keys.k[COGNN_SL_B1]; d.sC0 = s.scale_keys.k[COGNN_SL_C0];
-        d.stR = s.scale_trunc_keys.k[COGNN_SL_R]; d.stR0 = s.scale_trunc_keys.k[COGNN_SL_R0]; d.stRP0 = s.scale_trunc_keys.k[COGNN_SL_RP0];
-        d.rA0 = s.relu_keys.k[COGNN_SL_A0]; d.rA1 = s.relu_keys.k[COGNN_SL_A1]; d.rB0 = s.relu_keys.k[COGNN_SL_B0];
-        d.rB1 = s.relu_keys.k[COGNN_SL_B1]; d.rC0 = s.relu_keys.k[COGNN_SL_C0]; d.rT = s.relu_keys.k[COGNN_SL_T];
+        pair_chain_fill_keys(d, s);
         d.n = n; d.F = (uint32_t)std::max<int64_t>(s.F, 1); d.flags = (uint32_t)fl;
         const int64_t pairs = (n + 1) / 2;
         const unsigned blocks = (unsigned)((pairs + kThreads - 1) / kThreads);

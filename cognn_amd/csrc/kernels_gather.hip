@@ -18,6 +18,7 @@
 #include "common.h"
 #include <algorithm>
 #include "../../include/cognn_hip.h"
+#include "pair_chain.h"
 
 namespace {
 
@@ -133,6 +134,95 @@ __global__ __launch_bounds__(kThreads) void scatter_add_rows_kernel(u64* __restr
     }
 }
 
+// ---- gather with the pair chain as its epilogue (cognn_gather_pair_chain_u64) ---------------------------------------------------
+// A tile is 32 vertices of one owner; the lane group that owns vertex r aggregates the owner-side row and the co-party-side
+// row one after the other (same 16-byte chunk of both), then runs the chain on the two sums in registers.
+constexpr int kPairTile = 32;
+constexpr int kPairColCap = 1536;                            // staged col entries per side and tile
+constexpr int kGatherPairsMax = 8;
+struct GatherPairSeg {
+    PairChainDev d;                                          // x0/x1/c1 unused; n = rows * F
+    int a_row0, b_row0, rows, tile_end;                      // tile_end: exclusive prefix of tile counts
+};
+struct GatherPairBatch {
+    GatherPairSeg s[kGatherPairsMax];
+    int count;
+};
+template <int LPR>
+__global__ __launch_bounds__(kThreads) void gather_pair_chain_kernel(const u64* __restrict__ table, const uint32_t* __restrict__ rowptr,
+                                                                      const uint32_t* __restrict__ col, int F, int ntiles, GatherPairBatch b) {
+    __shared__ uint32_t s_rp[2][kPairTile + 1];
+    __shared__ uint32_t s_col[2][kPairColCap];
+    constexpr int kGroups = kThreads / LPR;
+    const int tid = threadIdx.x;
+    const int grp = tid / LPR, ln = tid % LPR;
+    const int nchunk = F / 2;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        int seg = 0;
+        while (seg < b.count - 1 && tile >= b.s[seg].tile_end) ++seg;
+        const GatherPairSeg& S = b.s[seg];
+        const PairChainDev& d = S.d;
+        const int t0 = seg ? b.s[seg - 1].tile_end : 0;
+        const int v0row = (tile - t0) * kPairTile;           // first vertex (row inside the owner's tensors) of this tile
+        const int nr = min(kPairTile, S.rows - v0row);
+        const int rbase[2] = {S.a_row0 + v0row, S.b_row0 + v0row};
+        __syncthreads();                                     // previous tile's LDS reads are done
+        for (int i = tid; i < 2 * (nr + 1); i += kThreads) { const int sd = i / (nr + 1), j = i % (nr + 1); s_rp[sd][j] = rowptr[rbase[sd] + j]; }
+        __syncthreads();
+        bool staged[2];
+#pragma unroll
+        for (int sd = 0; sd < 2; ++sd) {
+            const uint32_t e0 = s_rp[sd][0], e1 = s_rp[sd][nr];
+            staged[sd] = (e1 - e0) <= (uint32_t)kPairColCap;
+            if (staged[sd]) for (uint32_t i = tid; i < e1 - e0; i += kThreads) s_col[sd][i] = col[e0 + i];
+        }
+        __syncthreads();
+        for (int lr = grp; lr < nr; lr += kGroups) {
+            const int vr = v0row + lr;                       // vertex row
+            for (int c = ln; c < nchunk; c += LPR) {
+                const int off = c * 2;
+                u64x2 sum[2];
+#pragma unroll
+                for (int sd = 0; sd < 2; ++sd) {
+                    const uint32_t e0 = s_rp[sd][0], bq = s_rp[sd][lr], eq = s_rp[sd][lr + 1];
+                    Chunk<2> acc;
+                    acc.load(table + (size_t)(rbase[sd] + lr) * F + off);                 // the self row
+                    uint32_t q = bq;
+                    if (staged[sd]) {
+                        for (; q + 4 <= eq; q += 4) {
+                            Chunk<2> t0c, t1c, t2c, t3c;
+                            const uint32_t c0 = s_col[sd][q - e0], c1 = s_col[sd][q + 1 - e0], c2 = s_col[sd][q + 2 - e0], c3 = s_col[sd][q + 3 - e0];
+                            t0c.load(table + (size_t)c0 * F + off);
+                            t1c.load(table + (size_t)c1 * F + off);
+                            t2c.load(table + (size_t)c2 * F + off);
+                            t3c.load(table + (size_t)c3 * F + off);
+                            t0c.add(t1c); t2c.add(t3c); acc.add(t0c); acc.add(t2c);
+                        }
+                        for (; q < eq; ++q) { Chunk<2> t; t.load(table + (size_t)s_col[sd][q - e0] * F + off); acc.add(t); }
+                    } else {
+                        for (; q < eq; ++q) { Chunk<2> t; t.load(table + (size_t)col[q] * F + off); acc.add(t); }
+                    }
+                    sum[sd] = acc.v;
+                }
+                // the chain on the two sides' sums (pair_chain.h): row scale + truncation [+ ReLU], outputs / openings
+                const u64 idx = (u64)vr * (u64)F + (u64)off;
+                u64 a[2] = {sum[0].x, sum[0].y}, bb[2] = {sum[1].x, sum[1].y};
+                bool pos[2] = {true, true};
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    pair_scale(d, idx + j, (u64)vr, false, a[j], bb[j]);
+                    if (d.flags & COGNN_PC_RELU) pos[j] = pair_relu(d, idx + j, a[j], bb[j]);
+                }
+                if ((d.flags & COGNN_PC_RELU) && d.mask) { d.mask[idx] = pos[0] ? 1 : 0; d.mask[idx + 1] = pos[1] ? 1 : 0; }
+                if (d.out0) { u64x2 t; t.x = a[0]; t.y = a[1]; *reinterpret_cast<u64x2*>(d.out0 + idx) = t; }
+                if (d.out1) { u64x2 t; t.x = bb[0]; t.y = bb[1]; *reinterpret_cast<u64x2*>(d.out1 + idx) = t; }
+                if (d.open0) { u64x2 t; t.x = a[0] - cognn_prng(d.open_key0, idx); t.y = a[1] - cognn_prng(d.open_key0, idx + 1); *reinterpret_cast<u64x2*>(d.open0 + idx) = t; }
+                if (d.open1) { u64x2 t; t.x = bb[0] - cognn_prng(d.open_key1, idx); t.y = bb[1] - cognn_prng(d.open_key1, idx + 1); *reinterpret_cast<u64x2*>(d.open1 + idx) = t; }
+            }
+        }
+    }
+}
+
 int pick_lpr(int nchunk) {
     int l = 1;
     while (l < nchunk && l < 64) l <<= 1;
@@ -215,6 +305,47 @@ static int gather_impl(cognn_ctx* ctx, uint64_t* out, const uint64_t* base, cons
     const bool vec = (F % 2 == 0) && cg_aligned16(out) && cg_aligned16(table) && (base == nullptr || cg_aligned16(base));
     if (vec) return launch_gather<2>(ctx, (u64*)out, (const u64*)base, (const u64*)table, rowptr, col, (int)n_rows, (int)F, segs);
     return launch_gather<1>(ctx, (u64*)out, (const u64*)base, (const u64*)table, rowptr, col, (int)n_rows, (int)F, segs);
+}
+
+int cognn_gather_pair_chain_u64(cognn_ctx* ctx, const uint64_t* table, const uint32_t* rowptr, const uint32_t* col, int64_t F,
+                                const cognn_gather_pair* pairs, int32_t count) {
+    { const int rc_flush_ = cg_flush(ctx); if (rc_flush_) return rc_flush_; }
+    CG_REQUIRE(ctx && table && rowptr && (count == 0 || pairs) && count >= 0 && count <= kGatherPairsMax, "cognn_gather_pair_chain_u64: bad arguments");
+    CG_REQUIRE(F > 0 && F % 2 == 0 && F < (1 << 20) && cg_aligned16(table), "cognn_gather_pair_chain_u64: F must be even and the table 16-byte aligned");
+    GatherPairBatch b;
+    b.count = 0;
+    int ntiles = 0;
+    for (int32_t c = 0; c < count; ++c) {
+        const cognn_gather_pair& p = pairs[c];
+        const cognn_pair_chain& s = p.chain;
+        if (s.rows <= 0) continue;
+        const int fl = s.flags;
+        CG_REQUIRE((fl & COGNN_PC_SCALE) && !(fl & (COGNN_PC_TRUNC_IN | COGNN_PC_INPUT_OPENED)), "cognn_gather_pair_chain_u64: pair %d: the chain must start with the row scale", c);
+        CG_REQUIRE(s.scale[0] && s.scale[1] && s.rows * F < (1ll << 32) && p.a_row0 >= 0 && p.b_row0 >= 0, "cognn_gather_pair_chain_u64: pair %d is malformed", c);
+        CG_REQUIRE(cg_aligned16(s.out[0]) && cg_aligned16(s.out[1]) && cg_aligned16(s.open[0]) && cg_aligned16(s.open[1]), "cognn_gather_pair_chain_u64: pair %d: misaligned output", c);
+        GatherPairSeg& g = b.s[b.count];
+        PairChainDev& d = g.d;
+        d.x0 = d.x1 = d.c1 = nullptr;
+        d.sc0 = (const u64*)s.scale[0]; d.sc1 = (const u64*)s.scale[1];
+        d.out0 = (u64*)s.out[0]; d.out1 = (u64*)s.out[1]; d.open0 = (u64*)s.open[0]; d.open1 = (u64*)s.open[1]; d.mask = s.mask;
+        pair_chain_fill_keys(d, s);
+        d.n = s.rows * F; d.F = (uint32_t)F; d.flags = (uint32_t)fl;
+        g.a_row0 = (int)p.a_row0; g.b_row0 = (int)p.b_row0; g.rows = (int)s.rows;
+        ntiles += (int)((s.rows + kPairTile - 1) / kPairTile);
+        g.tile_end = ntiles;
+        ++b.count;
+    }
+    if (ntiles == 0) return 0;
+    const int lpr = pick_lpr((int)(F / 2));
+    dim3 grid((unsigned)std::min(ntiles, 256 * 16)), block(kThreads);
+#define CG_GP_CASE(L) case L: hipLaunchKernelGGL((gather_pair_chain_kernel<L>), grid, block, 0, ctx->stream, (const u64*)table, rowptr, col, (int)F, ntiles, b); break;
+    switch (lpr) {
+        CG_GP_CASE(1) CG_GP_CASE(2) CG_GP_CASE(4) CG_GP_CASE(8) CG_GP_CASE(16) CG_GP_CASE(32) CG_GP_CASE(64)
+        default: return cognn_set_error("gather_pair_chain: bad lanes-per-row %d", lpr);
+    }
+#undef CG_GP_CASE
+    CG_LAUNCH_CHECK();
+    return 0;
 }
 
 int cognn_scatter_add_rows_u64(cognn_ctx* ctx, uint64_t* v, const uint64_t* partial, const uint32_t* row_index,

@@ -717,6 +717,63 @@ void message_passing(cognn_engine* E, int F, int64_t it, bool open_scale) {
     }
 }
 
+// Single process, every pair co-located: the aggregate launch carries GatherComp's scale (+ the ReLU of ApplyComp) as its
+// epilogue (cognn_gather_pair_chain_u64): the lanes that aggregate vertex r's owner-side row also aggregate its co-party-side
+// row and run the pair chain on the two sums in registers, so the aggregate itself is never written or re-read.
+bool can_fuse_gather_chain(const cognn_engine* E, int F) {
+    if (E->world != 1 || !E->pair_fusion || (F & 1) || E->k > 8) return false;
+    for (auto& s : E->sides) if (!s.peer) return false;
+    return true;
+}
+void message_passing_fused(cognn_engine* E, int F, int64_t it, bool relu_follows, const OpenNext& open_next) {
+    std::vector<cognn_gather_pair> gp;
+    double out_bytes = 0;
+    for (auto& s : E->sides) {
+        if (s.p != 0) continue;
+        Side& t = *s.peer;
+        cognn_gather_pair g;
+        memset(&g, 0, sizeof(g));
+        g.a_row0 = E->A_off[s.owner]; g.b_row0 = E->B_off[s.owner];
+        cognn_pair_chain& c = g.chain;
+        c.rows = s.n; c.F = F;
+        c.flags = COGNN_PC_SCALE;
+        c.scale[0] = s.svec; c.scale[1] = t.svec;
+        c.scale_keys = keys(E, s.owner, it, COGNN_OP_GA_SCALE);
+        c.scale_trunc_keys = keys(E, s.owner, it, COGNN_OP_GA_SCALE_TRUNC);
+        if (relu_follows) {
+            c.flags |= COGNN_PC_RELU;
+            c.relu_keys = keys(E, s.owner, it, COGNN_OP_AP_RELU);
+            c.mask = s.relu_mask;
+            cognn_keys nk = keys(E, s.owner, it + 1, COGNN_OP_PS_GEMM);
+            c.out[0] = s.h1; c.out[1] = t.h1;
+            c.open[0] = s.h1E; c.open[1] = t.h1E;
+            c.open_key[0] = nk.k[COGNN_SL_A0]; c.open_key[1] = nk.k[COGNN_SL_A1];
+            if (E->forward_only) { c.out[0] = c.out[1] = nullptr; c.mask = nullptr; }
+        } else {
+            c.out[0] = s.buf[1]; c.out[1] = t.buf[1];
+            if (open_next) {
+                c.open[0] = s.ob[open_next.ob]; c.open[1] = t.ob[open_next.ob];
+                c.open_key[0] = open_next.key(s); c.open_key[1] = open_next.key(t);
+            }
+        }
+        const double elems = (double)s.n * F;
+        out_bytes += 8.0 * elems * ((c.out[0] ? 2 : 0) + (c.open[0] ? 2 : 0)) + (c.mask ? elems : 0.0);
+        gp.push_back(g);
+    }
+    if (E->timing) BE(cognn_timer_begin(E->ctx, T_AGG));
+    BE(cognn_gather_pair_chain_u64(E->ctx, E->table, E->agg_rowptr, E->agg_col, F, gp.data(), (int32_t)gp.size()));
+    if (E->timing) {
+        BE(cognn_timer_end(E->ctx, T_AGG));
+        // source row per entry, base row per output row, u32 col / rowptr + what the epilogue writes
+        E->algo[T_AGG] += 8.0 * F * ((double)E->aggEdges + (double)E->aggRows) + 4.0 * E->aggEdges + 4.0 * (E->aggRows + 1) + out_bytes;
+    }
+    for (auto& s : E->sides) {
+        s.cur = relu_follows ? s.h1 : s.buf[1];
+        s.curF = F;
+    }
+    if (relu_follows) E->gemm_x_opened_for = it + 1;
+}
+
 // ---------------------------------------------------------------------------------------------
 // weight averaging (gcn.h:747-802)
 // ---------------------------------------------------------------------------------------------
@@ -853,7 +910,7 @@ void weight_update_chain(cognn_engine* E, int64_t it, int layer) {
 void run_iteration(cognn_engine* E, int64_t it) {
     const IterInfo I = iter_info(E, it);
     if (E->forward_only && !I.fwd) throw EngineError("engine: COGNN_OPT_FORWARD_ONLY is set but a backward iteration was requested");
-    bool relu_opened = false, wgrad_w_opened = false, relu_pairs_done = false;
+    bool relu_opened = false, wgrad_w_opened = false, relu_pairs_done = false, gather_chain_fused = false;
     if (I.e == 0) {                                        // ss_...h:695, 938: back to the input features
         for (auto& s : E->sides) { s.cur = s.feat; s.curF = E->in(); }
     }
@@ -891,13 +948,22 @@ void run_iteration(cognn_engine* E, int64_t it) {
         // ---- Scatter / PreMerge / Gather ----
         const bool gscale = (it + 1) % I.ep != 0;          // gcn.h:470
         const bool fuse_open = gscale && E->sides.size() <= 32;
-        {
+        relu_opened = false;
+        if (gscale && can_fuse_gather_chain(E, F)) {
+            // the scale (and ReLU) of the co-located pairs rides in the aggregate launch's epilogue
+            relu_opened = I.fwd && I.e != I.f - 1;
+            wgrad_w_opened = !I.fwd;
+            OpenNext open_wgrad([&](Side& s) { return gemm_keys(E, s, it, wgrad_spec(E, s, I.layer, it)).k[s.p == 0 ? COGNN_SL_B0 : COGNN_SL_B1]; }, 1);
+            Phase ph_mp(E, T_PH_MP);
+            message_passing_fused(E, F, it, relu_opened, wgrad_w_opened ? open_wgrad : OpenNext());
+            relu_pairs_done = relu_opened;
+            gather_chain_fused = true;
+        } else {
             Phase ph_mp(E, T_PH_MP);
             message_passing(E, F, it, fuse_open);
         }
-        relu_opened = false;
         Phase ph_ga(E, T_PH_GATHER);
-        if (gscale) {
+        if (gscale && !gather_chain_fused) {
             // a hidden forward layer feeds the ReLU next: the close of this scale already opens it
             relu_opened = I.fwd && I.e != I.f - 1;
             // ... and in a backward iteration the weight-gradient product d = h_t^T . in is next: its right operand is this result

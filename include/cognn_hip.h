@@ -213,6 +213,19 @@ typedef struct {
 /* independent chains (the co-located pairs of one protocol phase) are issued as shared launches */
 int cognn_pair_chain_u64(cognn_ctx*, const cognn_pair_chain* chains, int32_t count);
 
+/* Gather whose epilogue IS the pair chain (co-located pairs, single process): for every owner, row r of its owner-side segment
+ * (first row a_row0) and row r of its co-party-side segment (b_row0) are aggregated by the same lanes -
+ *   V_p[r,:] = table[row_p(r),:] + sum_{e in CSR row row_p(r)} table[col[e],:]        (the self row is the base)
+ * - and the chain (COGNN_PC_SCALE, optionally | COGNN_PC_RELU; chain.x / rows-of-x are unused, chain.rows = rows of the segment)
+ * runs on (V_0, V_1) in registers: the aggregate is never written, only the chain's outputs / openings are.  Bit-identical to
+ * cognn_gather_csr_u64 followed by cognn_pair_chain_u64.  rowptr / col index rows of `table`; F even; count <= 8. */
+typedef struct {
+    int64_t a_row0, b_row0;
+    cognn_pair_chain chain;
+} cognn_gather_pair;
+int cognn_gather_pair_chain_u64(cognn_ctx*, const uint64_t* table, const uint32_t* rowptr, const uint32_t* col, int64_t F,
+                                const cognn_gather_pair* pairs, int32_t count);
+
 /* ---- onPreprocessClient index construction (ss_...h:295-534) + degree accounting (graph.h:607-633, graph_io_util.h:167-177)
  *      on the device, for a run whose parties are all hosted by ONE process ------------------------------------------------
  * All pointers are DEVICE pointers.  In: the directed edge list in file order (both directions are generated when

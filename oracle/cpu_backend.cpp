@@ -436,6 +436,26 @@ int cognn_pair_chain_u64(cognn_ctx* ctx, const cognn_pair_chain* chains, int32_t
     }
     return 0;
 }
+// the fused gather = the plain gather of both sides' row segments into temporaries, then the pair chain on them
+int cognn_gather_pair_chain_u64(cognn_ctx* ctx, const uint64_t* table, const uint32_t* rowptr, const uint32_t* col, int64_t F,
+                                const cognn_gather_pair* pairs, int32_t count) {
+    for (int32_t c = 0; c < count; ++c) {
+        const cognn_gather_pair& p = pairs[c];
+        const int64_t rows = p.chain.rows;
+        if (rows <= 0) continue;
+        std::vector<u64> v[2];
+        const int64_t r0[2] = {p.a_row0, p.b_row0};
+        for (int sd = 0; sd < 2; ++sd) {
+            v[sd].resize((size_t)(rows * F));
+            // rowptr is indexed by table row: shift it so that row 0 of the temporary is the segment's first row
+            if (int rc = cognn_gather_csr_u64(ctx, v[sd].data(), table + r0[sd] * F, table, rowptr + r0[sd], col, rows, F)) return rc;
+        }
+        cognn_pair_chain ch = p.chain;
+        ch.x[0] = v[0].data(); ch.x[1] = v[1].data(); ch.F = F;
+        if (int rc = cognn_pair_chain_u64(ctx, &ch, 1)) return rc;
+    }
+    return 0;
+}
 // the device index construction, as plain loops (count, scan, fill in edge order)
 int cognn_graph_build_colocated(cognn_ctx*, int64_t V, int64_t E, int32_t undirected, const int64_t* src, const int64_t* dst, const int32_t* tid,
                                 const uint32_t* row_of_vid, const int64_t* a_off, const int64_t* b_off, int64_t table_rows, uint32_t* rowptr,

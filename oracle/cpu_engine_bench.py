@@ -31,6 +31,9 @@ def main():
         rng = np.random.default_rng(0xC06A12 + P)
         eng.set_party_data(P, (rng.random((len(vids), in_dim)) < 0.01).astype(np.float64), rng.integers(0, lab, size=len(vids)))
     eng.start()
+    # the plain-C++ backend's pair chain is a reference composition of the per-side entry points (extra copies, no OpenMP): the CPU
+    # baseline runs the per-side loops themselves
+    eng.pair_fusion(os.environ.get("COGNN_CPU_BENCH_PAIR_FUSION", "0") == "1")
     eng.retain_offline(True)                              # the passes replay the same iterations, like bench.py's GPU steps: the
     eng.offline(0, iters)                                 # dealer phase stays outside the timed region
     eng.run(0, iters)                                     # warm-up pass

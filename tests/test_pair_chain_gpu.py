@@ -115,3 +115,63 @@ def test_pair_chain_batches_and_rejects_bad_chains(ctx):
     bad.flags = SCALE
     with pytest.raises(capi.CognnError, match="null"):
         ctx.call("cognn_pair_chain_u64", ctypes.byref(bad), 1)
+
+
+@pytest.mark.parametrize("F,relu,forward_only", [(64, True, False), (16, False, False), (64, True, True), (6, True, False), (2, False, False)])
+def test_gather_with_pair_chain_epilogue_equals_gather_then_chain(ctx, F, relu, forward_only):
+    """cognn_gather_pair_chain_u64 (the aggregate never written) against cognn_gather_csr_u64 on both sides' row segments followed
+    by cognn_pair_chain_u64, and against the oracle's two-party functions; two owners of different sizes (tiles of 32 vertices,
+    one partial tile), empty CSR rows, a hub row longer than the staged slice."""
+    from cognn_amd import capi
+    rng = np.random.default_rng(900 + F)
+    sizes = [70, 33]
+    # table: [A_0 | B_0 | A_1 | B_1] with even-row alignment like the engine's layout
+    offs, off = [], 0
+    for n in sizes:
+        a = off; off = (off + n + 1) & ~1
+        b = off; off = (off + n + 1) & ~1
+        offs.append((a, b))
+    T = off
+    deg = rng.poisson(5, size=T); deg[rng.random(T) < 0.2] = 0
+    deg[offs[0][0] + 3] = 2000                                 # longer than the 1536 staged entries of its tile
+    rowptr = np.zeros(T + 1, dtype=np.uint32); rowptr[1:] = np.cumsum(deg)
+    col = rng.integers(0, T, size=int(rowptr[-1]), dtype=np.uint32)
+    val = rng.integers(-(1 << 30), 1 << 30, size=(T, F)).astype(np.int64).astype(U64)       # small values: sums stay in range
+    dtab, drp, dcl = dev(val), dev(rowptr.view(np.int32)), dev(col.view(np.int32))
+    pairs = (capi.GatherPair * len(sizes))()
+    keep = []
+    for i, (n, (a, b)) in enumerate(zip(sizes, offs)):
+        ks = {nm: _keys(7, i, 3, op) for nm, op in (("scale", co.OP_GA_SCALE), ("strunc", co.OP_GA_SCALE_TRUNC), ("relu", co.OP_AP_RELU))}
+        s0 = co.normalizer(rng.integers(0, 9, size=n)); s1 = np.zeros(n, dtype=U64)
+        bufs = [dev_empty((n, F)) for _ in range(4)]; mask = dev_empty((n, F), "u8")
+        ok = (co.stream_key(2, i, 3, 4, 0), co.stream_key(2, i, 3, 4, 1))
+        p = pairs[i]
+        p.a_row0 = a; p.b_row0 = b
+        c = p.chain
+        c.scale[0] = dev(s0).data_ptr(); c.scale[1] = dev(s1).data_ptr()
+        if not forward_only:
+            c.out[0] = bufs[0].data_ptr(); c.out[1] = bufs[1].data_ptr(); c.mask = mask.data_ptr()
+        c.open[0] = bufs[2].data_ptr(); c.open[1] = bufs[3].data_ptr(); c.open_key[0] = ok[0]; c.open_key[1] = ok[1]
+        c.scale_keys = ks["scale"][0]; c.scale_trunc_keys = ks["strunc"][0]; c.relu_keys = ks["relu"][0]
+        c.rows = n; c.F = F; c.flags = SCALE | (RELU if relu else 0)
+        keep.append((n, a, b, s0, s1, {k: v[1] for k, v in ks.items()}, bufs, mask, ok))
+    ctx.call("cognn_gather_pair_chain_u64", ptr(dtab), ptr(drp), ptr(dcl), F, pairs, len(sizes))
+    # the plain aggregate of every table row
+    agg = val.copy()
+    with np.errstate(over="ignore"):
+        for r in range(T):
+            for q in range(rowptr[r], rowptr[r + 1]):
+                agg[r] += val[col[q]]
+    for n, a, b, s0, s1, kf, bufs, mask, ok in keep:
+        v0, v1 = agg[a:a + n], agg[b:b + n]
+        z0, z1 = co.beaver_rowscale_pair(v0, v1, s0, s1, kf["scale"])
+        e0, e1 = co.trunc_pair(z0, z1, kf["strunc"])
+        if relu:
+            e0, e1, pos = co.relu_pair(e0, e1, kf["relu"])
+            if not forward_only:
+                assert np.array_equal(host(mask, np.uint8).astype(bool), pos)
+        with np.errstate(over="ignore"):
+            assert np.array_equal(host(bufs[2]), e0 - co.prng_shape(ok[0], e0.shape))
+            assert np.array_equal(host(bufs[3]), e1 - co.prng_shape(ok[1], e1.shape))
+        if not forward_only:
+            assert np.array_equal(host(bufs[0]), e0) and np.array_equal(host(bufs[1]), e1)
