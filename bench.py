@@ -240,7 +240,8 @@ def main():
         "epoch_time_s": dt / args.steps,
         "edges_feat_per_s_per_party": value / k,
         "offline_ms": offline_ms, "setup_s": setup_s,
-        "roofline": {"bound": "hbm", "kernel": "gather_csr_kernel (aggregate launch)",
+        "roofline": {"bound": "hbm", "kernel": "aggregate launch of the message passing (gather_pair_chain_kernel when every pair is co-located, "
+                                                "gather_csr_kernel otherwise)",
                      "achieved": (bytes_agg / 1e9) / (ms_agg / 1e3) if ms_agg > 0 else None, "peak": 8000.0, "unit": "GB/s",
                      "frac": ((bytes_agg / 1e9) / (ms_agg / 1e3) / 8000.0) if ms_agg > 0 else None, "traffic": traffic,
                      "traffic_unit": "bytes per launch", "traffic_source": traffic_src,

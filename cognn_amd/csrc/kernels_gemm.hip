@@ -696,6 +696,8 @@ void beaver_gemm_d16n_kernel(u64* Z, const u64* __restrict__ E0, const u64* __re
         }
     };
     load_step(0);
+    // (measured and dropped: starting waves 4..7 up to 80 x 64 cycles late and / or at priority 1 changes nothing - the two
+    // waves of a SIMD are not in lockstep; what bounds the kernel is VALU issue)
     v4i acc[NT][8];
     for (int it = 0; it < total; ++it) {
         const int tile = wid + (it / nst) * nw, st = it % nst;

@@ -71,7 +71,8 @@ def main():
                          gui_cycles_per_launch=mfma[k]["GRBM_GUI_ACTIVE"] / 8.0 / nm[k])
             out[k] = e
         # what bench.py reports as roofline.traffic: bytes per aggregate gather launch, averaged over the launches of a step
-        g = [(v["hbm_bytes_per_launch"], v["launches_profiled"]) for k, v in out.items() if k.startswith("gather_csr_kernel") and "hbm_bytes_per_launch" in v]
+        g = [(v["hbm_bytes_per_launch"], v["launches_profiled"]) for k, v in out.items()
+             if k.startswith(("gather_csr_kernel", "gather_pair_chain_kernel")) and "hbm_bytes_per_launch" in v]
         if g:
             out["aggregate_launch_avg_bytes"] = sum(b * n for b, n in g) / sum(n for _, n in g)
         pmc[wl] = out
