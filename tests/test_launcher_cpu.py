@@ -33,6 +33,17 @@ def extract_cognn_durations(text, tag):
     return out
 
 
+def extract_cognn_accuracies(text):
+    """The parser of tools/plot/plot_accuracy.py:8-27, on a string."""
+    test_acc, border_acc = [], []
+    for line in text.splitlines():
+        if "border test set accuracy" in line:
+            border_acc.append(float(line.split("=")[1].strip()))
+        elif "test set accuracy" in line:
+            test_acc.append(float(line.split("=")[1].strip()))
+    return test_acc, border_acc
+
+
 def _oracle_for(data, dataset, k, setting, iters):
     from cognn_amd import worker
     src, dst = worker.read_edge_list(str(data / (dataset + ".edge.preprocessed")))
@@ -63,7 +74,9 @@ def test_two_rank_launcher_logs_match_oracle(tmp_path):
         want = [m for m in o.metrics if m["party"] == party][0]
         assert abs(float(re.findall(r"cross-entropy-loss = ([0-9.]+)", text)[0]) - want["loss"]) < 1e-6
         assert abs(float(re.findall(r"full set accuracy = ([0-9.]+)", text)[0]) - want["full"]) < 1e-6
-        assert "border test set accuracy" in text                                # plot_accuracy.py:17-24
+        test_acc, border_acc = extract_cognn_accuracies(text)                    # plot_accuracy.py:17-24
+        assert len(test_acc) == 1 and len(border_acc) == 1
+        assert abs(test_acc[0] - want["test"]) < 1e-6 and abs(border_acc[0] - want["border_test"]) < 1e-6
     # the offline cache of that run serves a second one started with -n 1 (same results)
     res2 = subprocess.run(cmd + ["--no-preprocess"], capture_output=True, text=True, timeout=300, env=env, cwd=tmp_path)
     assert res2.returncode == 0, res2.stderr + res2.stdout
