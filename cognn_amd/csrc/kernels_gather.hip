@@ -210,7 +210,7 @@ __global__ __launch_bounds__(kThreads) void gather_pair_chain_kernel(const u64* 
                 bool pos[2] = {true, true};
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    pair_scale(d, idx + j, (u64)vr, false, a[j], bb[j]);
+                    if (d.flags & COGNN_PC_SCALE) pair_scale(d, idx + j, (u64)vr, false, a[j], bb[j]);
                     if (d.flags & COGNN_PC_RELU) pos[j] = pair_relu(d, idx + j, a[j], bb[j]);
                 }
                 if ((d.flags & COGNN_PC_RELU) && d.mask) { d.mask[idx] = pos[0] ? 1 : 0; d.mask[idx + 1] = pos[1] ? 1 : 0; }
@@ -320,8 +320,10 @@ int cognn_gather_pair_chain_u64(cognn_ctx* ctx, const uint64_t* table, const uin
         const cognn_pair_chain& s = p.chain;
         if (s.rows <= 0) continue;
         const int fl = s.flags;
-        CG_REQUIRE((fl & COGNN_PC_SCALE) && !(fl & (COGNN_PC_TRUNC_IN | COGNN_PC_INPUT_OPENED)), "cognn_gather_pair_chain_u64: pair %d: the chain must start with the row scale", c);
-        CG_REQUIRE(s.scale[0] && s.scale[1] && s.rows * F < (1ll << 32) && p.a_row0 >= 0 && p.b_row0 >= 0, "cognn_gather_pair_chain_u64: pair %d is malformed", c);
+        CG_REQUIRE(!(fl & (COGNN_PC_TRUNC_IN | COGNN_PC_INPUT_OPENED)), "cognn_gather_pair_chain_u64: pair %d: the aggregate is neither a raw product nor an opening", c);
+        CG_REQUIRE((fl & COGNN_PC_SCALE) || !(fl & COGNN_PC_RELU), "cognn_gather_pair_chain_u64: pair %d: a ReLU follows the row scale only", c);
+        CG_REQUIRE((!(fl & COGNN_PC_SCALE) || (s.scale[0] && s.scale[1])) && s.rows * F < (1ll << 32) && p.a_row0 >= 0 && p.b_row0 >= 0, "cognn_gather_pair_chain_u64: pair %d is malformed", c);
+        CG_REQUIRE(s.out[0] || s.out[1] || s.open[0] || s.open[1], "cognn_gather_pair_chain_u64: pair %d writes nothing", c);
         CG_REQUIRE(cg_aligned16(s.out[0]) && cg_aligned16(s.out[1]) && cg_aligned16(s.open[0]) && cg_aligned16(s.open[1]), "cognn_gather_pair_chain_u64: pair %d: misaligned output", c);
         GatherPairSeg& g = b.s[b.count];
         PairChainDev& d = g.d;

@@ -725,7 +725,9 @@ bool can_fuse_gather_chain(const cognn_engine* E, int F) {
     for (auto& s : E->sides) if (!s.peer) return false;
     return true;
 }
-void message_passing_fused(cognn_engine* E, int F, int64_t it, bool relu_follows, const OpenNext& open_next) {
+void message_passing_fused(cognn_engine* E, int F, int64_t it, bool scale, bool relu_follows, const OpenNext& open_next, bool out_read) {
+    // scale: GatherComp's post-gather scale follows (every Gather but the last of an epoch, gcn.h:470); out_read: somebody reads
+    // the result itself, not only its opening (the weight-gradient product reads the opening alone)
     std::vector<cognn_gather_pair> gp;
     double out_bytes = 0;
     for (auto& s : E->sides) {
@@ -736,10 +738,12 @@ void message_passing_fused(cognn_engine* E, int F, int64_t it, bool relu_follows
         g.a_row0 = E->A_off[s.owner]; g.b_row0 = E->B_off[s.owner];
         cognn_pair_chain& c = g.chain;
         c.rows = s.n; c.F = F;
-        c.flags = COGNN_PC_SCALE;
-        c.scale[0] = s.svec; c.scale[1] = t.svec;
-        c.scale_keys = keys(E, s.owner, it, COGNN_OP_GA_SCALE);
-        c.scale_trunc_keys = keys(E, s.owner, it, COGNN_OP_GA_SCALE_TRUNC);
+        if (scale) {
+            c.flags = COGNN_PC_SCALE;
+            c.scale[0] = s.svec; c.scale[1] = t.svec;
+            c.scale_keys = keys(E, s.owner, it, COGNN_OP_GA_SCALE);
+            c.scale_trunc_keys = keys(E, s.owner, it, COGNN_OP_GA_SCALE_TRUNC);
+        }
         if (relu_follows) {
             c.flags |= COGNN_PC_RELU;
             c.relu_keys = keys(E, s.owner, it, COGNN_OP_AP_RELU);
@@ -750,7 +754,7 @@ void message_passing_fused(cognn_engine* E, int F, int64_t it, bool relu_follows
             c.open_key[0] = nk.k[COGNN_SL_A0]; c.open_key[1] = nk.k[COGNN_SL_A1];
             if (E->forward_only) { c.out[0] = c.out[1] = nullptr; c.mask = nullptr; }
         } else {
-            c.out[0] = s.buf[1]; c.out[1] = t.buf[1];
+            if (out_read || !open_next) { c.out[0] = s.buf[1]; c.out[1] = t.buf[1]; }
             if (open_next) {
                 c.open[0] = s.ob[open_next.ob]; c.open[1] = t.ob[open_next.ob];
                 c.open_key[0] = open_next.key(s); c.open_key[1] = open_next.key(t);
@@ -949,13 +953,14 @@ void run_iteration(cognn_engine* E, int64_t it) {
         const bool gscale = (it + 1) % I.ep != 0;          // gcn.h:470
         const bool fuse_open = gscale && E->sides.size() <= 32;
         relu_opened = false;
-        if (gscale && can_fuse_gather_chain(E, F)) {
-            // the scale (and ReLU) of the co-located pairs rides in the aggregate launch's epilogue
-            relu_opened = I.fwd && I.e != I.f - 1;
+        if (can_fuse_gather_chain(E, F)) {                 // (no scale <=> last iteration of an epoch, a backward one)
+            // the scale (and ReLU) of the co-located pairs rides in the aggregate launch's epilogue; in a backward iteration
+            // the aggregate's only reader is the weight-gradient product, which takes it as an opening
+            relu_opened = gscale && I.fwd && I.e != I.f - 1;
             wgrad_w_opened = !I.fwd;
             OpenNext open_wgrad([&](Side& s) { return gemm_keys(E, s, it, wgrad_spec(E, s, I.layer, it)).k[s.p == 0 ? COGNN_SL_B0 : COGNN_SL_B1]; }, 1);
             Phase ph_mp(E, T_PH_MP);
-            message_passing_fused(E, F, it, relu_opened, wgrad_w_opened ? open_wgrad : OpenNext());
+            message_passing_fused(E, F, it, gscale, relu_opened, wgrad_w_opened ? open_wgrad : OpenNext(), !wgrad_w_opened);
             relu_pairs_done = relu_opened;
             gather_chain_fused = true;
         } else {

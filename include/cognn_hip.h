@@ -218,7 +218,8 @@ int cognn_pair_chain_u64(cognn_ctx*, const cognn_pair_chain* chains, int32_t cou
  *   V_p[r,:] = table[row_p(r),:] + sum_{e in CSR row row_p(r)} table[col[e],:]        (the self row is the base)
  * - and the chain (COGNN_PC_SCALE, optionally | COGNN_PC_RELU; chain.x / rows-of-x are unused, chain.rows = rows of the segment)
  * runs on (V_0, V_1) in registers: the aggregate is never written, only the chain's outputs / openings are.  Bit-identical to
- * cognn_gather_csr_u64 followed by cognn_pair_chain_u64.  rowptr / col index rows of `table`; F even; count <= 8. */
+ * cognn_gather_csr_u64 followed by cognn_pair_chain_u64.  flags = 0 (the last backward Gather has no scale, gcn.h:470): the
+ * outputs / openings are those of the aggregate itself.  rowptr / col index rows of `table`; F even; count <= 8. */
 typedef struct {
     int64_t a_row0, b_row0;
     cognn_pair_chain chain;

@@ -117,11 +117,13 @@ def test_pair_chain_batches_and_rejects_bad_chains(ctx):
         ctx.call("cognn_pair_chain_u64", ctypes.byref(bad), 1)
 
 
-@pytest.mark.parametrize("F,relu,forward_only", [(64, True, False), (16, False, False), (64, True, True), (6, True, False), (2, False, False)])
+@pytest.mark.parametrize("F,relu,forward_only", [(64, True, False), (16, False, False), (64, True, True), (6, True, False), (2, False, False),
+                                                 (64, None, True), (16, None, False)])
 def test_gather_with_pair_chain_epilogue_equals_gather_then_chain(ctx, F, relu, forward_only):
     """cognn_gather_pair_chain_u64 (the aggregate never written) against cognn_gather_csr_u64 on both sides' row segments followed
     by cognn_pair_chain_u64, and against the oracle's two-party functions; two owners of different sizes (tiles of 32 vertices,
-    one partial tile), empty CSR rows, a hub row longer than the staged slice."""
+    one partial tile), empty CSR rows, a hub row longer than the staged slice.  relu=None: no step at all (the last backward
+    Gather of an epoch): outputs / openings of the aggregate itself."""
     from cognn_amd import capi
     rng = np.random.default_rng(900 + F)
     sizes = [70, 33]
@@ -153,7 +155,7 @@ def test_gather_with_pair_chain_epilogue_equals_gather_then_chain(ctx, F, relu, 
             c.out[0] = bufs[0].data_ptr(); c.out[1] = bufs[1].data_ptr(); c.mask = mask.data_ptr()
         c.open[0] = bufs[2].data_ptr(); c.open[1] = bufs[3].data_ptr(); c.open_key[0] = ok[0]; c.open_key[1] = ok[1]
         c.scale_keys = ks["scale"][0]; c.scale_trunc_keys = ks["strunc"][0]; c.relu_keys = ks["relu"][0]
-        c.rows = n; c.F = F; c.flags = SCALE | (RELU if relu else 0)
+        c.rows = n; c.F = F; c.flags = 0 if relu is None else SCALE | (RELU if relu else 0)
         keep.append((n, a, b, s0, s1, {k: v[1] for k, v in ks.items()}, bufs, mask, ok))
     ctx.call("cognn_gather_pair_chain_u64", ptr(dtab), ptr(drp), ptr(dcl), F, pairs, len(sizes))
     # the plain aggregate of every table row
@@ -164,8 +166,11 @@ def test_gather_with_pair_chain_epilogue_equals_gather_then_chain(ctx, F, relu, 
                 agg[r] += val[col[q]]
     for n, a, b, s0, s1, kf, bufs, mask, ok in keep:
         v0, v1 = agg[a:a + n], agg[b:b + n]
-        z0, z1 = co.beaver_rowscale_pair(v0, v1, s0, s1, kf["scale"])
-        e0, e1 = co.trunc_pair(z0, z1, kf["strunc"])
+        if relu is None:
+            e0, e1 = v0, v1
+        else:
+            z0, z1 = co.beaver_rowscale_pair(v0, v1, s0, s1, kf["scale"])
+            e0, e1 = co.trunc_pair(z0, z1, kf["strunc"])
         if relu:
             e0, e1, pos = co.relu_pair(e0, e1, kf["relu"])
             if not forward_only:
