@@ -248,7 +248,8 @@ def main():
                      "launches": n_agg, "avg_ms": ms_agg / max(n_agg, 1), "algo_bytes_per_launch": bytes_agg / max(n_agg, 1)},
         "kernels": {"gather_partials": {"launches": n_part, "avg_ms": ms_part / max(n_part, 1),
                                         "GBps": (bytes_part / 1e9) / (ms_part / 1e3) if ms_part > 0 else None},
-                    "beaver_gemm_close": {"launches": n_gemm, "avg_ms": ms_gemm / max(n_gemm, 1),
+                    # one timed phase = the products of all hosted sides in one GAS iteration (they overlap on two launch lanes)
+                    "beaver_gemm_close": {"phases": n_gemm, "avg_ms_per_phase": ms_gemm / max(n_gemm, 1),
                                           "i8_TOPs": (ops_gemm / 1e12) / (ms_gemm / 1e3) if ms_gemm > 0 else None,
                                           "frac_of_5000_TOPs": ((ops_gemm / 1e12) / (ms_gemm / 1e3) / 5000.0) if ms_gemm > 0 else None}},
         "graph": wlinfo,

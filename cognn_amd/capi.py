@@ -65,6 +65,9 @@ _SIGNATURES = {
     "cognn_ctx_sync": (_I, [_P]),
     "cognn_batch_begin": (_I, [_P]),
     "cognn_batch_end": (_I, [_P]),
+    "cognn_lane_begin": (_I, [_P, ctypes.c_int32]),
+    "cognn_lane_select": (_I, [_P, ctypes.c_int32]),
+    "cognn_lane_end": (_I, [_P]),
     "cognn_malloc": (_I, [_P, ctypes.POINTER(_P), ctypes.c_size_t]),
     "cognn_free": (_I, [_P, _P]),
     "cognn_memcpy_h2d": (_I, [_P, _P, _P, ctypes.c_size_t]),

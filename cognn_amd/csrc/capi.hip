@@ -44,6 +44,10 @@ int cognn_ctx_create_private(int device, cognn_ctx** out) {
 int cognn_ctx_destroy(cognn_ctx* ctx) {
     if (!ctx) return 0;
     (void)cognn_timer_reset(ctx);
+    if (ctx->lanes_active) ctx->stream = ctx->main_stream;
+    for (auto st : ctx->lanes) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
+    for (auto ev : ctx->lane_done) (void)hipEventDestroy(ev);
+    if (ctx->lane_fork) (void)hipEventDestroy(ctx->lane_fork);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return 0;
@@ -52,6 +56,44 @@ int cognn_ctx_sync(cognn_ctx* ctx) {
     { const int rc_flush_ = cg_flush(ctx); if (rc_flush_) return rc_flush_; }
     CG_REQUIRE(ctx, "cognn_ctx_sync: null ctx");
     CG_HIP(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+int cognn_lane_begin(cognn_ctx* ctx, int32_t lanes) {
+    { const int rc_flush_ = cg_flush(ctx); if (rc_flush_) return rc_flush_; }
+    CG_REQUIRE(ctx && lanes >= 1 && lanes <= 4 && !ctx->lanes_active, "cognn_lane_begin: bad arguments or lanes already open");
+    while ((int)ctx->lanes.size() < lanes) {
+        hipStream_t st; hipEvent_t ev;
+        CG_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        ctx->lanes.push_back(st);
+        CG_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        ctx->lane_done.push_back(ev);
+    }
+    if (!ctx->lane_fork) CG_HIP(hipEventCreateWithFlags(&ctx->lane_fork, hipEventDisableTiming));
+    CG_HIP(hipEventRecord(ctx->lane_fork, ctx->stream));
+    for (int l = 0; l < lanes; ++l) CG_HIP(hipStreamWaitEvent(ctx->lanes[l], ctx->lane_fork, 0));
+    ctx->main_stream = ctx->stream;
+    ctx->lanes_active = lanes;
+    ctx->lane_used.assign((size_t)lanes, 0);
+    return 0;
+}
+int cognn_lane_select(cognn_ctx* ctx, int32_t lane) {
+    { const int rc_flush_ = cg_flush(ctx); if (rc_flush_) return rc_flush_; }
+    CG_REQUIRE(ctx && ctx->lanes_active && lane >= 0 && lane < ctx->lanes_active, "cognn_lane_select: no such lane");
+    ctx->stream = ctx->lanes[lane];
+    ctx->lane_used[lane] = 1;
+    return 0;
+}
+int cognn_lane_end(cognn_ctx* ctx) {
+    { const int rc_flush_ = cg_flush(ctx); if (rc_flush_) return rc_flush_; }
+    CG_REQUIRE(ctx && ctx->lanes_active, "cognn_lane_end: no lanes open");
+    ctx->stream = ctx->main_stream;
+    const int n = ctx->lanes_active;
+    ctx->lanes_active = 0;
+    for (int l = 0; l < n; ++l) {
+        if (!ctx->lane_used[l]) continue;
+        CG_HIP(hipEventRecord(ctx->lane_done[l], ctx->lanes[l]));
+        CG_HIP(hipStreamWaitEvent(ctx->stream, ctx->lane_done[l], 0));
+    }
     return 0;
 }
 int cognn_batch_begin(cognn_ctx* ctx) {

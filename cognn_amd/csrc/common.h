@@ -23,6 +23,13 @@ struct cognn_ctx {
     std::vector<hipEvent_t> open_begin[8];
     int batch_depth = 0;
     cognn_pending_batch pending;
+    // launch lanes (cognn_lane_begin): auxiliary streams, created on first use
+    hipStream_t main_stream = nullptr;
+    std::vector<hipStream_t> lanes;
+    std::vector<hipEvent_t> lane_done;
+    std::vector<char> lane_used;
+    hipEvent_t lane_fork = nullptr;
+    int lanes_active = 0;
 };
 // launches whatever is queued (every non-element-wise entry point calls it first, so stream order is preserved)
 static inline int cg_flush(cognn_ctx* ctx) { return (ctx && ctx->pending.flush) ? ctx->pending.flush(ctx) : 0; }

@@ -88,6 +88,7 @@ struct cognn_engine {
     int64_t alloc_bytes = 0;
     std::map<int64_t, std::vector<u64*>> c1_pool;   // released product-share buffers by element count, reused by later deals
     bool retain_offline = false;                    // COGNN_OPT_RETAIN_OFFLINE
+    int gemm_lanes = getenv("COGNN_GEMM_LANES") ? atoi(getenv("COGNN_GEMM_LANES")) : 2;   // launch lanes of the per-side products (A/B switch: 1 = one stream)
     bool pair_fusion = true;                        // COGNN_OPT_PAIR_FUSION: co-located share-holders run their two-party steps as pair chains
     bool forward_only = false;                      // COGNN_OPT_FORWARD_ONLY: no backward iteration will follow (inference, -m 2)
     double phase_s[6] = {0, 0, 0, 0, 0, 0};         // cognn_engine_get_phase_seconds
@@ -289,14 +290,25 @@ enum { X_OPEN_HERE = 0, X_H1E_FRESH = 1, X_H1E_REUSE = 2 };
 // open -> HBM -> close passes; the per-side stages below then skip those sides.
 bool paired(const cognn_engine* E, const Side& s) { return E->pair_fusion && s.peer != nullptr; }
 
+// lanes > 1 (independent multi-launch sequences per side, disjoint buffers): the sides of a pass go round-robin to that many
+// launch lanes (cognn_lane_begin), joined before the pass ends.
+struct Lanes {
+    cognn_engine* E;
+    int n, next = 0;
+    Lanes(cognn_engine* e, int lanes) : E(e), n(lanes) { if (n > 1) BE(cognn_lane_begin(E->ctx, n)); }
+    void advance() { if (n > 1) { BE(cognn_lane_select(E->ctx, next)); next = (next + 1) % n; } }
+    ~Lanes() { if (n > 1) E->be->cognn_lane_end(E->ctx); }   // a failure here resurfaces at the next call (sticky HIP error)
+};
 template <class Fn>
-void for_sides(cognn_engine* E, bool batched, Fn fn, bool skip_paired = false) {
+void for_sides(cognn_engine* E, bool batched, Fn fn, bool skip_paired = false, int lanes = 0) {
     for (int pass = 0; pass < 2; ++pass) {
         if (pass == 1) exchange_wait(E);
         auto body = [&] {
+            Lanes ln(E, lanes);
             for (size_t i = 0; i < E->sides.size(); ++i) {
                 Side& s = E->sides[i];
                 if ((s.peer != nullptr) != (pass == 0) || (skip_paired && paired(E, s))) continue;
+                ln.advance();
                 fn(s, i);
             }
         };
@@ -416,6 +428,20 @@ void gemm_stage(cognn_engine* E, int64_t it, XFn X, WFn Wm, SpecFn spec, DstFn d
     GemmSpec g0 = spec(E->sides[0]);
     bool all_raw = true;
     for (auto& s : E->sides) { GemmSpec g = spec(s); all_raw = all_raw && E->be->cognn_beaver_gemm_fusable(g.M, g.N, g.K, g.transA); }
+    // every side's product is its own launch sequence (operand planes, product, truncation opening) on its own buffers: two
+    // launch lanes, so that one side's start-up runs in the drain of another's - unless a product share still has to be dealt
+    // here (its buffer comes from a pool that the releases below feed)
+    // (small products are launch-bound: the fork / join would cost more than the overlap gains)
+    bool dealt = true, large = false;
+    for (auto& s : E->sides) {
+        GemmSpec g = spec(s);
+        dealt = dealt && (s.p != 1 || s.c1.count({it, g.op}));
+        large = large || g.M * g.K * g.N >= (1ll << 26);
+    }
+    const int lanes = (dealt && large && E->gemm_lanes > 1 && ns > 1) ? E->gemm_lanes : 0;
+    // timed as one phase on the engine's stream (the lanes overlap each other): all sides' products of this stage, with their
+    // operand preparation (and, for sides whose peer is remote, the truncation opening and the wait for the peer's opening)
+    if (E->timing) BE(cognn_timer_begin(E->ctx, T_GEMM));
     for_sides(E, false, [&](Side& s, size_t i) {
         GemmSpec g = spec(s);
         cognn_keys k = gkeys(s, g);
@@ -431,18 +457,18 @@ void gemm_stage(cognn_engine* E, int64_t it, XFn X, WFn Wm, SpecFn spec, DstFn d
             }
             c1 = f->second.ptr;
         }
-        if (E->timing) BE(cognn_timer_begin(E->ctx, T_GEMM));
         // all_raw: fused single-launch product without C_p; C_p joins in the truncation opening below
         BE(cognn_beaver_gemm_close2_u64(E->ctx, s.zbuf, e_own, e_peer, s.ob[1], s.ib[1], c1, &k, s.p, g.M, g.N, g.K, g.transA, s.scratch,
                                         all_raw ? 1 : 0));
-        if (E->timing) { BE(cognn_timer_end(E->ctx, T_GEMM)); E->algo[T_GEMM] += 2.0 * 36 * 2 * (double)g.M * g.K * g.N; }
+        if (E->timing) E->algo[T_GEMM] += 2.0 * 36 * 2 * (double)g.M * g.K * g.N;
         if (all_raw && !paired(E, s)) {
             cognn_keys tk = keys(E, s.owner, it, g.top);
             BE(cognn_trunc_open_add_u64(E->ctx, s.ob[2], s.zbuf, c1, &k, &tk, s.p, eo[i]));
         }
         if (s.p == 1 && !paired(E, s)) c1_release(E, s, {it, g.op});   // consumed: the buffer serves a later deal
         z[i] = s.zbuf;
-    });
+    }, false, lanes);
+    if (E->timing) BE(cognn_timer_end(E->ctx, T_GEMM));
     // co-located pairs: truncation of the product (+ the row scale that follows) as one chain per owner
     {
         PairChains pc;

@@ -113,7 +113,9 @@ int cognn_engine_get_weight(cognn_engine* e, int32_t owner, int32_t side, int32_
 /* metrics of the last prediction layer of a hosted party: out[0..4] = accuracies (full, train, border-train,
  * test, border-test), out[5] = cross-entropy loss, out[6] = #vertices, out[7] = #border (gcn.h:620-632) */
 int cognn_engine_get_metrics(cognn_engine* e, int32_t party, double* out8);
-/* kernel timing (HIP events on the engine's stream). kind: 0 gather-aggregate, 1 gather-partials, 2 gemm */
+/* kernel timing (HIP events on the engine's stream). kind: 0 gather-aggregate launches, 1 gather-partials launches, 2 the
+ * Beaver product phase of a GAS iteration (all hosted sides' products; they overlap each other on two launch lanes, so the unit
+ * timed is the phase, `launches` = number of phases) */
 int cognn_engine_enable_timing(cognn_engine* e, int32_t on);
 int cognn_engine_get_timing(cognn_engine* e, int32_t kind, int64_t* launches, double* total_ms, double* algo_bytes_or_ops);
 /* static workload numbers: per message-passing round at width F=1 (multiply by F):

@@ -46,6 +46,14 @@ int cognn_ctx_sync(cognn_ctx* ctx);
  * launches what is queued first, so stream order is otherwise preserved.  Nestable. */
 int cognn_batch_begin(cognn_ctx*);
 int cognn_batch_end(cognn_ctx*);
+/* Launch lanes: independent launch sequences (the per-side products of one protocol phase) issued round-robin on auxiliary
+ * streams, so that one sequence's start-up (its operand preparation, its first workgroups) runs in the drain of another's.
+ * lane_begin forks `lanes` (1..4) auxiliary streams after everything enqueued on the context's stream so far; lane_select
+ * directs the following calls to lane l; lane_end makes the context's stream wait for every lane and returns to it.  The
+ * caller guarantees that work on different lanes touches disjoint buffers. */
+int cognn_lane_begin(cognn_ctx*, int32_t lanes);
+int cognn_lane_select(cognn_ctx*, int32_t lane);
+int cognn_lane_end(cognn_ctx*);
 int cognn_malloc(cognn_ctx* ctx, void** ptr, size_t bytes);
 int cognn_free(cognn_ctx* ctx, void* ptr);
 int cognn_memcpy_h2d(cognn_ctx* ctx, void* dst, const void* src, size_t bytes);

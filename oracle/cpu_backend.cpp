@@ -107,6 +107,9 @@ int cognn_share_split_u64(cognn_ctx*, const uint64_t* fx, uint64_t key, uint64_t
 }
 int cognn_batch_begin(cognn_ctx*) { return 0; }              // the reference backend runs every call immediately
 int cognn_batch_end(cognn_ctx*) { return 0; }
+int cognn_lane_begin(cognn_ctx*, int32_t) { return 0; }      // ... and in program order
+int cognn_lane_select(cognn_ctx*, int32_t) { return 0; }
+int cognn_lane_end(cognn_ctx*) { return 0; }
 int cognn_prng_fill_u64(cognn_ctx*, uint64_t* out, uint64_t key, int64_t n) {
     CG_PAR
     for (int64_t i = 0; i < n; ++i) out[i] = cognn_prng(key, (u64)i);

@@ -437,3 +437,34 @@ def test_relu_close_open(ctx):
         hw = np.where(pos, z, U64(0))
         assert np.array_equal(host(h), hw) and np.array_equal(host(E), hw - co.prng(key, n))
     assert np.array_equal(host(mask, np.uint8).astype(bool), pos)
+
+
+def test_launch_lanes_fork_and_join(ctx):
+    """cognn_lane_begin / _select / _end: work issued on the lanes starts after what the context's stream held before the fork,
+    and the stream continues only after every lane has finished (two dependent chains on two lanes, combined afterwards)."""
+    from cognn_amd import capi
+    n = 1 << 22
+    keys = [co.stream_key(3, 1, 4, 1, s) for s in range(3)]
+    base, a, b, out = dev_empty(n), dev_empty(n), dev_empty(n), dev_empty(n)
+    ctx.call("cognn_prng_fill_u64", ptr(base), ctypes.c_uint64(keys[0]), n)          # before the fork: both lanes read it
+    ctx.call("cognn_lane_begin", 2)
+    for lane, (t, k) in enumerate(((a, keys[1]), (b, keys[2]))):
+        ctx.call("cognn_lane_select", lane)
+        ctx.call("cognn_prng_fill_u64", ptr(t), ctypes.c_uint64(k), n)
+        for _ in range(3):
+            ctx.call("cognn_add_u64", ptr(t), ptr(t), ptr(base), n)
+    ctx.call("cognn_lane_end")
+    ctx.call("cognn_add_u64", ptr(out), ptr(a), ptr(b), n)                           # after the join: reads both lanes' results
+    with np.errstate(over="ignore"):
+        want = co.prng(keys[1], n) + co.prng(keys[2], n) + U64(6) * co.prng(keys[0], n)
+    assert np.array_equal(host(out), want)
+    with pytest.raises(capi.CognnError, match="lane"):
+        ctx.call("cognn_lane_select", 0)                                             # no lanes open
+    with pytest.raises(capi.CognnError, match="lane"):
+        ctx.call("cognn_lane_end")
+    ctx.call("cognn_lane_begin", 1)
+    with pytest.raises(capi.CognnError, match="lane"):
+        ctx.call("cognn_lane_begin", 2)                                              # already open
+    with pytest.raises(capi.CognnError, match="lane"):
+        ctx.call("cognn_lane_select", 1)
+    ctx.call("cognn_lane_end")
