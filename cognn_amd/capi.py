@@ -87,6 +87,8 @@ _SIGNATURES = {
     "cognn_mask_open_u64": (_I, [_P, _P, _P, _U, _L, _L, _I]),
     "cognn_add_u64": (_I, [_P, _P, _P, _P, _L]),
     "cognn_sub_u64": (_I, [_P, _P, _P, _P, _L]),
+    "cognn_sum_u64": (_I, [_P, _P, _P, ctypes.c_int32, _L]),
+    "cognn_fanout_u64": (_I, [_P, _P, ctypes.c_int32, _P, _L]),
     "cognn_dealer_gemm_c1_u64": (_I, [_P, _P, _KP, _L, _L, _L, _I, _P, _P]),
     "cognn_beaver_gemm_close_u64": (_I, [_P, _P, _P, _P, _P, _P, _KP, _I, _L, _L, _L, _I, _P]),
     "cognn_trunc_open_u64": (_I, [_P, _P, _P, _U, _KP, _I, _L]),

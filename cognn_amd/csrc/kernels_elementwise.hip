@@ -153,6 +153,23 @@ struct AddSub {
         st2(out, i, w, r);
     }
 };
+constexpr int kFanMax = 16;
+struct SumN {                                  // out = in[0] + ... + in[count-1]
+    u64* out; const u64* in[kFanMax]; int count;
+    __device__ void operator()(int64_t i, int w) const {
+        u64 r[2] = {0, 0}, x[2];
+        for (int c = 0; c < count; ++c) { ld2(in[c], i, w, x); r[0] += x[0]; r[1] += x[1]; }
+        st2(out, i, w, r);
+    }
+};
+struct FanOut {                                // out[0..count) = in
+    u64* out[kFanMax]; const u64* in; int count;
+    __device__ void operator()(int64_t i, int w) const {
+        u64 x[2];
+        ld2(in, i, w, x);
+        for (int c = 0; c < count; ++c) st2(out[c], i, w, x);
+    }
+};
 struct TruncOpen {
     u64* c; const u64* x; u64 mul; cognn_opkeys k; int p;
     __device__ void operator()(int64_t i, int w) const {
@@ -605,6 +622,20 @@ int cognn_mask_open_u64(cognn_ctx* ctx, uint64_t* E, const uint64_t* X, uint64_t
 int cognn_add_u64(cognn_ctx* ctx, uint64_t* out, const uint64_t* a, const uint64_t* b, int64_t n) {
     CG_REQUIRE(ctx && out && a && b && al(out) && al(a) && al(b), "cognn_add_u64: bad arguments");
     return launch_ew(ctx, n, AddSub{(u64*)out, (const u64*)a, (const u64*)b, 0});
+}
+int cognn_sum_u64(cognn_ctx* ctx, uint64_t* out, const uint64_t* const* in, int32_t count, int64_t n) {
+    CG_REQUIRE(ctx && out && in && count >= 1 && count <= kFanMax && al(out), "cognn_sum_u64: bad arguments (1..%d inputs)", kFanMax);
+    SumN f;
+    f.out = (u64*)out; f.count = count;
+    for (int c = 0; c < count; ++c) { CG_REQUIRE(in[c] && al(in[c]), "cognn_sum_u64: input %d is null or misaligned", c); f.in[c] = (const u64*)in[c]; }
+    return launch_ew(ctx, n, f);
+}
+int cognn_fanout_u64(cognn_ctx* ctx, uint64_t* const* out, int32_t count, const uint64_t* in, int64_t n) {
+    CG_REQUIRE(ctx && out && in && count >= 1 && count <= kFanMax && al(in), "cognn_fanout_u64: bad arguments (1..%d outputs)", kFanMax);
+    FanOut f;
+    f.in = (const u64*)in; f.count = count;
+    for (int c = 0; c < count; ++c) { CG_REQUIRE(out[c] && al(out[c]), "cognn_fanout_u64: output %d is null or misaligned", c); f.out[c] = (u64*)out[c]; }
+    return launch_ew(ctx, n, f);
 }
 int cognn_sub_u64(cognn_ctx* ctx, uint64_t* out, const uint64_t* a, const uint64_t* b, int64_t n) {
     CG_REQUIRE(ctx && out && a && b && al(out) && al(a) && al(b), "cognn_sub_u64: bad arguments");

@@ -17,6 +17,7 @@
 #include <cstring>
 #include <functional>
 #include <map>
+#include <memory>
 #include <stdexcept>
 #include <string>
 #include <tuple>
@@ -436,7 +437,7 @@ void gemm_stage(cognn_engine* E, int64_t it, XFn X, WFn Wm, SpecFn spec, DstFn d
     for (auto& s : E->sides) {
         GemmSpec g = spec(s);
         dealt = dealt && (s.p != 1 || s.c1.count({it, g.op}));
-        large = large || g.M * g.K * g.N >= (1ll << 26);
+        large = large || g.M * g.K * g.N >= (1ll << 27);
     }
     const int lanes = (dealt && large && E->gemm_lanes > 1 && ns > 1) ? E->gemm_lanes : 0;
     // timed as one phase on the engine's stream (the lanes overlap each other): all sides' products of this stage, with their
@@ -817,11 +818,20 @@ void weight_average(cognn_engine* E, int64_t it, int layer) {
     const size_t bytes = (size_t)elems * 8;
     const int r0 = E->rank_of(0), r1 = E->rank_of(1);
     u64* part[2] = {E->wa[0], E->wa[1]};
-    BE(cognn_memset0(E->ctx, part[0], bytes));
-    BE(cognn_memset0(E->ctx, part[1], bytes));
-    for (auto& s : E->sides) {
-        const int to = (s.owner == 0) ? s.p : 1 - s.p;     // (0,0)->sum0 (0,1)->sum1 ; (o,1)->sum0 (o,0)->sum1 for o>=1
-        BE(cognn_add_u64(E->ctx, part[to], part[to], s.W[layer], elems));
+    {
+        std::vector<const uint64_t*> in[2];
+        for (auto& s : E->sides) in[(s.owner == 0) ? s.p : 1 - s.p].push_back(s.W[layer]);   // (0,0)->sum0 (0,1)->sum1 ; (o,1)->sum0 (o,0)->sum1 for o>=1
+        const bool one_each = in[0].size() <= 15 && in[1].size() <= 15;   // then the two sums are independent launches: one batch
+        std::unique_ptr<Batch> batch(one_each ? new Batch(E) : nullptr);
+        for (int h = 0; h < 2; ++h) {
+            if (in[h].empty()) { BE(cognn_memset0(E->ctx, part[h], bytes)); continue; }
+            for (size_t b = 0; b < in[h].size(); b += 15) {             // 16 inputs per launch; later launches carry the running sum
+                std::vector<const uint64_t*> v;
+                if (b) v.push_back(part[h]);
+                v.insert(v.end(), in[h].begin() + b, in[h].begin() + std::min(in[h].size(), b + 15));
+                BE(cognn_sum_u64(E->ctx, part[h], v.data(), (int32_t)v.size(), elems));
+            }
+        }
     }
     const int holder[2] = {r0, r1};
     {
@@ -867,9 +877,13 @@ void weight_average(cognn_engine* E, int64_t it, int layer) {
         }
         run_exchange_sync(E, xl);
     }
-    for (auto& s : E->sides) {                             // owner 0 keeps (s0, s1); owners >= 1 keep (s1, s0)
-        const int which = (s.owner == 0) ? s.p : 1 - s.p;
-        BE(cognn_memcpy_d2d(E->ctx, s.W[layer], avg[which], bytes));
+    {                                                      // owner 0 keeps (s0, s1); owners >= 1 keep (s1, s0)
+        std::vector<uint64_t*> out[2];
+        for (auto& s : E->sides) out[(s.owner == 0) ? s.p : 1 - s.p].push_back(s.W[layer]);
+        Batch batch(E);
+        for (int h = 0; h < 2; ++h)
+            for (size_t b = 0; b < out[h].size(); b += 16)
+                BE(cognn_fanout_u64(E->ctx, out[h].data() + b, (int32_t)std::min<size_t>(16, out[h].size() - b), avg[h], elems));
     }
 }
 

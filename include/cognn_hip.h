@@ -102,6 +102,10 @@ int cognn_ring_gemm2_u64(cognn_ctx*, uint64_t* C, const uint64_t* A1, const uint
 int cognn_mask_open_u64(cognn_ctx*, uint64_t* E, const uint64_t* X, uint64_t key, int64_t rows, int64_t cols, int transposed);
 int cognn_add_u64(cognn_ctx*, uint64_t* out, const uint64_t* a, const uint64_t* b, int64_t n);
 int cognn_sub_u64(cognn_ctx*, uint64_t* out, const uint64_t* a, const uint64_t* b, int64_t n);
+/* out = in[0] + ... + in[count-1]  /  out[0..count) = in; count <= 16 (weight averaging, gcn.h:753-778: the weight shares of all
+ * hosted sides are summed per holder and the average is handed back to every side: one launch each instead of one per side) */
+int cognn_sum_u64(cognn_ctx*, uint64_t* out, const uint64_t* const* in, int32_t count, int64_t n);
+int cognn_fanout_u64(cognn_ctx*, uint64_t* const* out, int32_t count, const uint64_t* in, int64_t n);
 /* dealer (offline): C1 = (A0+A1).(B0+B1) - C0 with all five streams evaluated from keys */
 int cognn_dealer_gemm_c1_u64(cognn_ctx*, uint64_t* C1, const cognn_keys* keys, int64_t M, int64_t N, int64_t K, int transA,
                              uint64_t* scratchA /*MxK*/, uint64_t* scratchB /*KxN*/);

@@ -166,6 +166,16 @@ int cognn_add_u64(cognn_ctx*, uint64_t* o, const uint64_t* a, const uint64_t* b,
     for (int64_t i = 0; i < n; ++i) o[i] = a[i] + b[i];
     return 0;
 }
+int cognn_sum_u64(cognn_ctx*, uint64_t* out, const uint64_t* const* in, int32_t count, int64_t n) {
+    REQ(out && in && count >= 1 && count <= 16, "sum: bad arguments");
+    for (int64_t i = 0; i < n; ++i) { u64 r = 0; for (int c = 0; c < count; ++c) r += in[c][i]; out[i] = r; }
+    return 0;
+}
+int cognn_fanout_u64(cognn_ctx*, uint64_t* const* out, int32_t count, const uint64_t* in, int64_t n) {
+    REQ(out && in && count >= 1 && count <= 16, "fanout: bad arguments");
+    for (int c = 0; c < count; ++c) if (out[c] != in) memcpy(out[c], in, (size_t)n * 8);
+    return 0;
+}
 int cognn_sub_u64(cognn_ctx*, uint64_t* o, const uint64_t* a, const uint64_t* b, int64_t n) {
     CG_PAR
     for (int64_t i = 0; i < n; ++i) o[i] = a[i] - b[i];

@@ -468,3 +468,31 @@ def test_launch_lanes_fork_and_join(ctx):
     with pytest.raises(capi.CognnError, match="lane"):
         ctx.call("cognn_lane_select", 1)
     ctx.call("cognn_lane_end")
+
+
+@pytest.mark.parametrize("count,n", [(1, 7), (3, 8192), (16, 100001)])
+def test_sum_and_fanout(ctx, count, n):
+    """cognn_sum_u64 / cognn_fanout_u64 (weight averaging: all hosted weight shares summed in one launch, the average handed
+    back in one launch); in-place accumulation (output among the inputs) and the argument checks."""
+    from cognn_amd import capi
+    rng = np.random.default_rng(count * 31 + n)
+    xs = [rand_u64(rng, n) for _ in range(count)]
+    dx = [dev(x) for x in xs]
+    ins = (ctypes.c_void_p * count)(*[t.data_ptr() for t in dx])
+    out = dev_empty(n)
+    ctx.call("cognn_sum_u64", ptr(out), ins, count, n)
+    with np.errstate(over="ignore"):
+        want = np.sum(np.stack(xs), axis=0, dtype=U64)
+        assert np.array_equal(host(out), want)
+        ins2 = (ctypes.c_void_p * 2)(out.data_ptr(), dx[0].data_ptr())               # running sum: out += x0
+        ctx.call("cognn_sum_u64", ptr(out), ins2, 2, n)
+        assert np.array_equal(host(out), want + xs[0])
+    outs = [dev_empty(n) for _ in range(count)]
+    op = (ctypes.c_void_p * count)(*[t.data_ptr() for t in outs])
+    ctx.call("cognn_fanout_u64", op, count, ptr(dx[0]), n)
+    for t in outs:
+        assert np.array_equal(host(t), xs[0])
+    with pytest.raises(capi.CognnError, match="1..16"):
+        ctx.call("cognn_sum_u64", ptr(out), ins, 17, n)
+    with pytest.raises(capi.CognnError, match="1..16"):
+        ctx.call("cognn_fanout_u64", op, 0, ptr(dx[0]), n)

@@ -90,6 +90,42 @@ def bench_gather(ctx, iters, rows=1 << 21, table_rows=1 << 21, deg=12, F=64):
     print("gather_csr rows=%d edges=%d F=%d: %.3f ms  %.0f GB/s algorithmic (%.1f%% of 8000)" % (rows, E, F, ms, by / ms / 1e6, by / ms / 1e6 / 80.0))
 
 
+def bench_overlap(ctx, iters, rows=1 << 21, deg=16, F=64, M=1 << 17, K=64, N=16, n_gemm=16):
+    """Does the HBM-bound gather hide the VALU-bound N <= 16 products of other owners?  Gather on lane 0, n_gemm Beaver closes
+    on lane 1 (cognn_lane_*), against each alone."""
+    rng = np.random.default_rng(0)
+    d = rng.poisson(deg, size=rows)
+    rowptr = np.zeros(rows + 1, dtype=np.uint32); rowptr[1:] = np.cumsum(d)
+    col = rng.integers(0, rows, size=int(rowptr[-1]), dtype=np.uint32)
+    g = torch.Generator(device="cuda"); g.manual_seed(1)
+    table = torch.randint(-2**62, 2**62, (rows, F), dtype=torch.int64, device="cuda", generator=g)
+    out = torch.empty((rows, F), dtype=torch.int64, device="cuda")
+    rp = torch.from_numpy(rowptr.view(np.int32)).cuda(); cl = torch.from_numpy(col.view(np.int32)).cuda()
+    E0 = torch.randint(-2**62, 2**62, (M, K), dtype=torch.int64, device="cuda", generator=g)
+    E1 = torch.randint(-2**62, 2**62, (M, K), dtype=torch.int64, device="cuda", generator=g)
+    Fm = torch.randint(-2**62, 2**62, (K, N), dtype=torch.int64, device="cuda", generator=g)
+    Z = [torch.empty((M, N), dtype=torch.int64, device="cuda") for _ in range(n_gemm)]
+    scratch = [torch.empty(M * K + K * N, dtype=torch.int64, device="cuda") for _ in range(n_gemm)]
+    k = capi.make_keys(1, 2, 3, capi.OP_PS_GEMM)
+
+    def gather():
+        ctx.call("cognn_gather_csr_u64", P(out), P(table), P(table), P(rp), P(cl), rows, F)
+
+    def gemms():
+        for i in range(n_gemm):
+            ctx.call("cognn_beaver_gemm_close_raw_u64", P(Z[i]), P(E0), P(E1), P(Fm), ctypes.byref(k), i & 1, M, N, K, P(scratch[i]))
+
+    def both():
+        ctx.call("cognn_lane_begin", 2)
+        ctx.call("cognn_lane_select", 0); gather()
+        ctx.call("cognn_lane_select", 1); gemms()
+        ctx.call("cognn_lane_end")
+
+    tg, tm, tb = timeit(gather, iters), timeit(gemms, iters), timeit(both, iters)
+    print("overlap: gather F=%d alone %.3f ms, %d products (M=%d K=%d N=%d) alone %.3f ms, together on two lanes %.3f ms (sum %.3f)"
+          % (F, tg, n_gemm, M, K, N, tm, tb, tg + tm))
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("what", nargs="?", default="all")
@@ -105,6 +141,9 @@ if __name__ == "__main__":
     if a.what in ("gemm_tn", "all"):
         bench_gemm_tn(ctx, a.iters)
         bench_gemm_tn(ctx, a.iters, M=64, N=16)
+    if a.what in ("overlap",):
+        bench_overlap(ctx, a.iters)
+        bench_overlap(ctx, a.iters, K=128, N=64, n_gemm=8)
     if a.what in ("gather", "all"):
         bench_gather(ctx, a.iters, F=64)
         bench_gather(ctx, a.iters, F=16)
