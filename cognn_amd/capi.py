@@ -98,6 +98,7 @@ _SIGNATURES = {
     "cognn_beaver_gemm_close2_u64": (_I, [_P, _P, _P, _P, _P, _P, _P, _KP, _I, _L, _L, _L, _I, _P, _I]),
     "cognn_trunc_close_u64": (_I, [_P, _P, _P, _P, _KP, _I, _I, _L]),
     "cognn_trunc_close_open_u64": (_I, [_P, _P, _P, _P, _P, _KP, _I, _U, _L]),
+    "cognn_trunc_close_pub_u64": (_I, [_P, _P, _P, _P, _P, _KP, _I, _U, _U, _I, _L]),
     "cognn_rowscale_open_u64": (_I, [_P, _P, _P, _P, _P, _KP, _I, _L, _L]),
     "cognn_rowscale_close_u64": (_I, [_P, _P, _P, _P, _P, _P, _KP, _KP, _I, _L, _L]),
     "cognn_relu_open_u64": (_I, [_P, _P, _P, _P, _KP, _I, _L]),

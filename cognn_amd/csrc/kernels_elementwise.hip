@@ -194,14 +194,20 @@ struct TruncOpenAdd {    // c = x + C_p + r_p (+offset): opening of a raw Beaver
     }
 };
 struct TruncClose {
-    u64* out; const u64* c0; const u64* c1; cognn_opkeys k; int p; int mode; u64* E; u64 key_open;
+    // pub = 0: E (optional) = y_p - prng(key_open): this party's share of the next opening
+    // pub = 1: both opened values are present on BOTH parties: E = y_0 + y_1 - a_0 - a_1, the next opening itself (public)
+    // pub = 2: E = y_0 + y_1 (the result revealed to the caller)
+    u64* out; const u64* c0; const u64* c1; cognn_opkeys k; int p; int mode; u64* E; u64 key_open; u64 key_open1; int pub;
     __device__ void operator()(int64_t i, int w) const {
-        u64 y[2];
-        if (p == 0) {
+        u64 y[2], yt[2] = {0, 0};
+        if (p == 0 || pub) {
             u64 a[2], b[2];
             ld2(c0, i, w, a); ld2(c1, i, w, b);
-            for (int j = 0; j < 2; ++j)
-                y[j] = ((a[j] + b[j]) >> COGNN_FX_BITS) - (COGNN_TRUNC_OFFSET >> COGNN_FX_BITS) - trunc_rp(k, 0, (u64)(i + j));
+            for (int j = 0; j < 2; ++j) {
+                const u64 hi = ((a[j] + b[j]) >> COGNN_FX_BITS) - (COGNN_TRUNC_OFFSET >> COGNN_FX_BITS);
+                if (pub) yt[j] = hi - ((cognn_prng(k.k[COGNN_SL_R], (u64)(i + j)) & COGNN_TRUNC_MASK) >> COGNN_FX_BITS);
+                y[j] = p == 0 ? hi - trunc_rp(k, 0, (u64)(i + j)) : 0ull - trunc_rp(k, 1, (u64)(i + j));
+            }
         } else {
             for (int j = 0; j < 2; ++j) y[j] = 0ull - trunc_rp(k, 1, (u64)(i + j));
         }
@@ -210,9 +216,12 @@ struct TruncClose {
             ld2(out, i, w, o);
             y[0] = o[0] - y[0]; y[1] = o[1] - y[1];
         }
-        st2(out, i, w, y);
+        if (out) st2(out, i, w, y);
         if (E) {
-            u64 e[2] = {y[0] - cognn_prng(key_open, (u64)i), y[1] - cognn_prng(key_open, (u64)i + 1)};
+            u64 e[2];
+            for (int j = 0; j < 2; ++j)
+                e[j] = pub == 0 ? y[j] - cognn_prng(key_open, (u64)(i + j))
+                     : pub == 1 ? yt[j] - cognn_prng(key_open, (u64)(i + j)) - cognn_prng(key_open1, (u64)(i + j)) : yt[j];
             st2(E, i, w, e);
         }
     }
@@ -487,7 +496,7 @@ __global__ __launch_bounds__(kThreads) void softmax_jobs_kernel(SoftmaxBatch b, 
         const int64_t r = rb + i;
         const bool valid = r < d.rows && j < L;
         const int64_t idx = r * L + j;
-        long long z = valid ? (long long)(d.z0[idx] + d.z1[idx]) : NEG;
+        long long z = valid ? (long long)(d.z0[idx] + (d.z1 ? d.z1[idx] : 0ull)) : NEG;
         long long m = z;
 #pragma unroll
         for (int o = G / 2; o > 0; o >>= 1) { long long t = __shfl_xor(m, o, G); m = t > m ? t : m; }
@@ -654,13 +663,18 @@ int cognn_trunc_close_u64(cognn_ctx* ctx, uint64_t* out, const uint64_t* c0, con
                           int p, int mode, int64_t n) {
     CG_REQUIRE(ctx && out && keys && (p == 0 || p == 1) && al(out) && al(c0) && al(c1), "cognn_trunc_close_u64: bad arguments");
     CG_REQUIRE(p == 1 || (c0 && c1), "cognn_trunc_close_u64: p=0 needs both opened values");
-    return launch_ew(ctx, n, TruncClose{(u64*)out, (const u64*)c0, (const u64*)c1, K(keys), p, mode, nullptr, 0});
+    return launch_ew(ctx, n, TruncClose{(u64*)out, (const u64*)c0, (const u64*)c1, K(keys), p, mode, nullptr, 0, 0, 0});
 }
 int cognn_trunc_close_open_u64(cognn_ctx* ctx, uint64_t* out, uint64_t* E, const uint64_t* c0, const uint64_t* c1, const cognn_keys* keys,
                                int p, uint64_t key_open, int64_t n) {
     CG_REQUIRE(ctx && out && E && keys && (p == 0 || p == 1) && al(out) && al(E) && al(c0) && al(c1), "cognn_trunc_close_open_u64: bad arguments");
     CG_REQUIRE(p == 1 || (c0 && c1), "cognn_trunc_close_open_u64: p=0 needs both opened values");
-    return launch_ew(ctx, n, TruncClose{(u64*)out, (const u64*)c0, (const u64*)c1, K(keys), p, 0, (u64*)E, key_open});
+    return launch_ew(ctx, n, TruncClose{(u64*)out, (const u64*)c0, (const u64*)c1, K(keys), p, 0, (u64*)E, key_open, 0, 0});
+}
+int cognn_trunc_close_pub_u64(cognn_ctx* ctx, uint64_t* out, uint64_t* E, const uint64_t* c0, const uint64_t* c1, const cognn_keys* keys,
+                              int p, uint64_t key_open0, uint64_t key_open1, int reveal, int64_t n) {
+    CG_REQUIRE(ctx && E && c0 && c1 && keys && (p == 0 || p == 1) && al(out) && al(E) && al(c0) && al(c1), "cognn_trunc_close_pub_u64: bad arguments (both opened values are needed)");
+    return launch_ew(ctx, n, TruncClose{(u64*)out, (const u64*)c0, (const u64*)c1, K(keys), p, 0, (u64*)E, key_open0, key_open1, reveal ? 2 : 1});
 }
 int cognn_rowscale_open_u64(cognn_ctx* ctx, uint64_t* E, uint64_t* G, const uint64_t* V, const uint64_t* s,
                             const cognn_keys* keys, int p, int64_t rows, int64_t F) {
@@ -749,7 +763,7 @@ int cognn_softmax_jobs_u64(cognn_ctx* ctx, const cognn_softmax_job* jobs, int32_
         for (int32_t c = c0; c < count && c < c0 + kSoftmaxJobsMax; ++c) {
             const cognn_softmax_job& s = jobs[c];
             CG_REQUIRE(s.d_out && (s.p == 0 || s.p == 1) && s.rows >= 0, "cognn_softmax_jobs_u64: job %d is malformed", c);
-            CG_REQUIRE(s.p == 1 || (s.z0 && s.z1 && s.labels && s.counts6 && s.loss), "cognn_softmax_jobs_u64: owner job %d needs z0, z1, labels, counts6, loss", c);
+            CG_REQUIRE(s.p == 1 || (s.z0 && s.labels && s.counts6 && s.loss), "cognn_softmax_jobs_u64: owner job %d needs z0, labels, counts6, loss", c);
             SoftmaxJobDev& d = b.j[b.count];
             d.d_out = (u64*)s.d_out; d.z0 = (const u64*)s.z0; d.z1 = (const u64*)s.z1; d.labels = s.labels; d.border = s.border;
             d.keyRho = s.keys.k[COGNN_SL_RHO]; d.p = s.p; d.rows = s.rows; d.train_rows = s.train_rows; d.val_rows = s.val_rows;

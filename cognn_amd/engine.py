@@ -142,6 +142,11 @@ class Engine:
         """Promise that no backward iteration follows (inference): stores that only the backward pass reads are skipped."""
         _check(self.lib.cognn_engine_set_option(self.h, 3, int(on)))
 
+    def public_openings(self, on=True):
+        """Share-holders outside pair chains derive the opening that follows a truncation themselves (default) instead of
+        exchanging it as two shares (cognn_engine.h: COGNN_OPT_PUBLIC_OPENINGS)."""
+        _check(self.lib.cognn_engine_set_option(self.h, 4, int(on)))
+
     def phase_seconds(self):
         """Device time per phase of the last iteration (engine created with verbose=True), see cognn_engine_get_phase_seconds."""
         out = np.zeros(6, dtype=np.float64)

@@ -90,6 +90,7 @@ struct cognn_engine {
     std::map<int64_t, std::vector<u64*>> c1_pool;   // released product-share buffers by element count, reused by later deals
     bool retain_offline = false;                    // COGNN_OPT_RETAIN_OFFLINE
     int gemm_lanes = getenv("COGNN_GEMM_LANES") ? atoi(getenv("COGNN_GEMM_LANES")) : 2;   // launch lanes of the per-side products (A/B switch: 1 = one stream)
+    bool public_openings = true;                    // COGNN_OPT_PUBLIC_OPENINGS (see pub_open)
     bool pair_fusion = true;                        // COGNN_OPT_PAIR_FUSION: co-located share-holders run their two-party steps as pair chains
     bool forward_only = false;                      // COGNN_OPT_FORWARD_ONLY: no backward iteration will follow (inference, -m 2)
     double phase_s[6] = {0, 0, 0, 0, 0, 0};         // cognn_engine_get_phase_seconds
@@ -371,12 +372,21 @@ cognn_keys gemm_keys(cognn_engine* E, Side& s, int64_t it, const GemmSpec& g) {
 // closing step of a truncation; open_next (optional) returns the mask key of the op that consumes dst(side): the close then
 // also writes that op's opening E = dst - mask into ob[0] (one pass less, see cognn_trunc_close_open_u64)
 struct OpenNext {
-    std::function<u64(Side&)> key;     // empty: plain close
-    int ob = 0;                        // outbox that receives the opening (0: left / element-wise operand, 1: right GEMM operand)
+    std::function<u64(Side&, int)> keyp;   // mask key of party p's share of the operand; empty: plain close
+    int ob = 0;                            // outbox that receives the opening (0: left / element-wise operand, 1: right GEMM operand)
     OpenNext() {}
-    OpenNext(std::function<u64(Side&)> k, int o = 0) : key(std::move(k)), ob(o) {}
-    explicit operator bool() const { return (bool)key; }
+    bool reveal = false;                   // no opening follows, but the owner needs the result itself (softmax): with public openings its
+                                           // close writes z = y_0 + y_1 into ob[0] and the co-party sends nothing
+    OpenNext(std::function<u64(Side&, int)> k, int o = 0) : keyp(std::move(k)), ob(o) {}
+    static OpenNext Reveal() { OpenNext r; r.reveal = true; return r; }
+    u64 key(Side& s) const { return keyp(s, s.p); }
+    explicit operator bool() const { return (bool)keyp; }
 };
+// Public openings (COGNN_OPT_PUBLIC_OPENINGS): a truncation whose result feeds a Beaver opening is closed by
+// BOTH parties from both opened values, and each derives the next opening E itself (cognn_trunc_close_pub_u64): ob[] then
+// holds E, not E_p, the consumer takes it as the pre-summed opening and the exchange round that carried E_p disappears.
+// Applies to the sides that are not part of a pair chain.
+bool pub_open(const cognn_engine* E, const Side& s) { return E->public_openings && !paired(E, s); }
 template <class DstFn>
 void trunc_close_all(cognn_engine* E, int64_t it, int top, DstFn dst, const std::vector<int64_t>& elems, const OpenNext& open_next,
                      bool skip_paired = false) {
@@ -384,7 +394,12 @@ void trunc_close_all(cognn_engine* E, int64_t it, int top, DstFn dst, const std:
         cognn_keys tk = keys(E, s.owner, it, top);
         const u64* c0 = s.p == 0 ? s.ob[2] : nullptr;
         const u64* c1 = s.p == 0 ? s.ib[2] : nullptr;
-        if (open_next) BE(cognn_trunc_close_open_u64(E->ctx, dst(s), s.ob[open_next.ob], c0, c1, &tk, s.p, open_next.key(s), elems[i]));
+        if (open_next.reveal && pub_open(E, s) && s.p == 0)
+            BE(cognn_trunc_close_pub_u64(E->ctx, dst(s), s.ob[0], s.ob[2], s.ib[2], &tk, 0, 0, 0, 1, elems[i]));
+        else if (open_next && pub_open(E, s))
+            BE(cognn_trunc_close_pub_u64(E->ctx, dst(s), s.ob[open_next.ob], s.p == 0 ? s.ob[2] : s.ib[2], s.p == 0 ? s.ib[2] : s.ob[2], &tk, s.p,
+                                         open_next.keyp(s, 0), open_next.keyp(s, 1), 0, elems[i]));
+        else if (open_next) BE(cognn_trunc_close_open_u64(E->ctx, dst(s), s.ob[open_next.ob], c0, c1, &tk, s.p, open_next.key(s), elems[i]));
         else BE(cognn_trunc_close_u64(E->ctx, dst(s), c0, c1, &tk, s.p, 0, elems[i]));
     }, skip_paired);
 }
@@ -409,8 +424,9 @@ void gemm_stage(cognn_engine* E, int64_t it, XFn X, WFn Wm, SpecFn spec, DstFn d
         if (!w_opened) BE(cognn_mask_open_u64(E->ctx, s.ob[1], Wm(s), k.k[s.p == 0 ? COGNN_SL_B0 : COGNN_SL_B1], g.K, g.N, 0));
         e0[i] = g.M * g.K; e1[i] = g.K * g.N; eo[i] = g.M * g.N;
     });
+    const bool w_public = w_opened && E->public_openings;   // ob[1] holds F itself on the sides outside pair chains: nothing to exchange
     if (feature || xsrc == X_H1E_REUSE) {
-        exchange_ob(E, 1, e1);                              // the opening of X was exchanged earlier (start() / two iterations ago)
+        if (!w_public) exchange_ob(E, 1, e1);               // the opening of X was exchanged earlier (start() / two iterations ago)
     } else if (xsrc == X_H1E_FRESH) {
         XList xl;                                           // the ReLU close left E_p in h1E: it travels with the W opening
         for (size_t i = 0; i < ns; ++i) {
@@ -422,6 +438,8 @@ void gemm_stage(cognn_engine* E, int64_t it, XFn X, WFn Wm, SpecFn spec, DstFn d
             xl.recv(s.peer_rank, s.ib[1], e1[i] * 8);
         }
         run_exchange(E, xl);
+    } else if (w_public) {
+        exchange_ob(E, 0, e0);
     } else {
         exchange_ob2(E, 0, e0, 1, e1);
     }
@@ -459,8 +477,8 @@ void gemm_stage(cognn_engine* E, int64_t it, XFn X, WFn Wm, SpecFn spec, DstFn d
             c1 = f->second.ptr;
         }
         // all_raw: fused single-launch product without C_p; C_p joins in the truncation opening below
-        BE(cognn_beaver_gemm_close2_u64(E->ctx, s.zbuf, e_own, e_peer, s.ob[1], s.ib[1], c1, &k, s.p, g.M, g.N, g.K, g.transA, s.scratch,
-                                        all_raw ? 1 : 0));
+        BE(cognn_beaver_gemm_close2_u64(E->ctx, s.zbuf, e_own, e_peer, s.ob[1], (w_public && !paired(E, s)) ? nullptr : s.ib[1], c1, &k, s.p, g.M, g.N,
+                                        g.K, g.transA, s.scratch, all_raw ? 1 : 0));
         if (E->timing) E->algo[T_GEMM] += 2.0 * 36 * 2 * (double)g.M * g.K * g.N;
         if (all_raw && !paired(E, s)) {
             cognn_keys tk = keys(E, s.owner, it, g.top);
@@ -523,6 +541,7 @@ void rowscale_stage(cognn_engine* E, int64_t it, int op, int top, int F, XFn X, 
     // pairs_done: the co-located pairs ran this scale inside the chain of the product before it (gemm_stage, FollowScale);
     // relu_follows: the ReLU of ApplyComp consumes the result - co-located pairs run it in the same chain (relu_stage skips them)
     const bool e_opened = e_mode == E_IN_X;
+    const bool e_public = e_mode == E_IN_OB0 && E->public_openings;   // ob[0] holds E itself (cognn_trunc_close_pub_u64)
     const size_t ns = E->sides.size();
     std::vector<int64_t> eF(ns), e1(ns);
     if (!pairs_done) {
@@ -575,13 +594,15 @@ void rowscale_stage(cognn_engine* E, int64_t it, int op, int top, int F, XFn X, 
             xl.recv(s.peer_rank, s.ib[1], e1[i] * 8);
         }
         run_exchange(E, xl);
+    } else if (e_public) {
+        exchange_ob(E, 1, e1);                              // only the n scale openings travel
     } else {
         exchange_ob2(E, 0, eF, 1, e1);
     }
     for_sides(E, true, [&](Side& s, size_t) {               // the opened sums E0+E1, G0+G1 are formed inside the kernel
         cognn_keys k = keys(E, s.owner, it, op), tk = keys(E, s.owner, it, top);
         const u64* e_own = e_opened ? X(s) : s.ob[0];
-        const u64* e_peer = e_opened ? (s.peer ? X(*s.peer) : s.ib[0]) : s.ib[0];
+        const u64* e_peer = e_public ? nullptr : e_opened ? (s.peer ? X(*s.peer) : s.ib[0]) : s.ib[0];
         BE(cognn_rowscale_close_u64(E->ctx, s.ob[2], e_own, e_peer, s.ob[1], s.ib[1], &k, &tk, s.p, s.n, F));
     }, true);
     exchange_ob(E, 2, eF);
@@ -617,10 +638,11 @@ void relu_stage(cognn_engine* E, int64_t it, bool e_opened, bool pairs_done) {
         if (!e_opened) BE(cognn_relu_open_u64(E->ctx, s.ob[0], nullptr, s.cur, &k, s.p, (int64_t)s.n * F));
         eF[i] = (int64_t)s.n * F;
     }, true);
-    exchange_ob(E, 0, eF);
+    const bool e_public = e_opened && E->public_openings;   // ob[0] holds E itself: no exchange
+    if (!e_public) exchange_ob(E, 0, eF);
     for_sides(E, true, [&](Side& s, size_t i) {
         cognn_keys k = keys(E, s.owner, it, COGNN_OP_AP_RELU);
-        BE(cognn_relu_mul_u64(E->ctx, s.ob[2], s.ob[0], s.ib[0], nullptr, nullptr, &k, s.p, eF[i]));
+        BE(cognn_relu_mul_u64(E->ctx, s.ob[2], s.ob[0], e_public ? nullptr : s.ib[0], nullptr, nullptr, &k, s.p, eF[i]));
     }, true);
     exchange_ob(E, 2, eF);
     // H is the next iteration's PreScatter GEMM input (layer 1): write it straight into its h_t slot and emit the
@@ -634,11 +656,12 @@ void relu_stage(cognn_engine* E, int64_t it, bool e_opened, bool pairs_done) {
     E->gemm_x_opened_for = it + 1;
 }
 
-void softmax_stage(cognn_engine* E, int64_t it) {
+void softmax_stage(cognn_engine* E, int64_t it, bool revealed) {
+    // revealed: the truncation close before this stage left z itself in the owner's ob[0] (sides outside pair chains)
     const int L = E->lab();
     XList xl;                                            // the co-party reveals its share of z to the owner
     for (auto& s : E->sides) {
-        if (s.peer) continue;
+        if (s.peer || (revealed && pub_open(E, s))) continue;
         if (s.p == 1) xl.send(s.peer_rank, s.cur, (int64_t)s.n * L * 8);
         else xl.recv(s.peer_rank, s.ib[0], (int64_t)s.n * L * 8);
     }
@@ -653,7 +676,8 @@ void softmax_stage(cognn_engine* E, int64_t it) {
         j.val_rows = (int64_t)((double)s.n * E->cfg.val_ratio);
         j.d_out = (s.cur == s.buf[1]) ? s.buf[0] : s.buf[1];
         if (s.p == 0) {
-            j.z0 = s.cur; j.z1 = s.peer ? s.peer->cur : s.ib[0];
+            if (revealed && pub_open(E, s)) { j.z0 = s.ob[0]; j.z1 = nullptr; }
+            else { j.z0 = s.cur; j.z1 = s.peer ? s.peer->cur : s.ib[0]; }
             j.labels = s.labels; j.border = s.border; j.counts6 = s.counts; j.loss = s.loss;
             s.has_metrics = true;
         }
@@ -954,7 +978,7 @@ void weight_update_chain(cognn_engine* E, int64_t it, int layer) {
 void run_iteration(cognn_engine* E, int64_t it) {
     const IterInfo I = iter_info(E, it);
     if (E->forward_only && !I.fwd) throw EngineError("engine: COGNN_OPT_FORWARD_ONLY is set but a backward iteration was requested");
-    bool relu_opened = false, wgrad_w_opened = false, relu_pairs_done = false, gather_chain_fused = false;
+    bool relu_opened = false, wgrad_w_opened = false, relu_pairs_done = false, gather_chain_fused = false, z_revealed = false;
     if (I.e == 0) {                                        // ss_...h:695, 938: back to the input features
         for (auto& s : E->sides) { s.cur = s.feat; s.curF = E->in(); }
     }
@@ -974,7 +998,7 @@ void run_iteration(cognn_engine* E, int64_t it) {
             }
             const bool scale_follows = I.e != 0;
             // the truncation close of the product also opens the row scale that consumes it
-            OpenNext open_scale([&](Side& s) { return keys(E, s.owner, it, COGNN_OP_PS_SCALE).k[s.p == 0 ? COGNN_SL_A0 : COGNN_SL_A1]; });
+            OpenNext open_scale([&](Side& s, int p) { return keys(E, s.owner, it, COGNN_OP_PS_SCALE).k[p == 0 ? COGNN_SL_A0 : COGNN_SL_A1]; });
             FollowScale follow;
             if (scale_follows) { follow.op = COGNN_OP_PS_SCALE; follow.top = COGNN_OP_PS_SCALE_TRUNC; follow.dst = [&](Side& s) { return table_seg(E, s, F); }; }
             gemm_stage(E, it, [&](Side& s) { return s.cur; }, [&](Side& s) { return s.W[I.layer]; },
@@ -998,7 +1022,7 @@ void run_iteration(cognn_engine* E, int64_t it) {
             // the aggregate's only reader is the weight-gradient product, which takes it as an opening
             relu_opened = gscale && I.fwd && I.e != I.f - 1;
             wgrad_w_opened = !I.fwd;
-            OpenNext open_wgrad([&](Side& s) { return gemm_keys(E, s, it, wgrad_spec(E, s, I.layer, it)).k[s.p == 0 ? COGNN_SL_B0 : COGNN_SL_B1]; }, 1);
+            OpenNext open_wgrad([&](Side& s, int p) { return gemm_keys(E, s, it, wgrad_spec(E, s, I.layer, it)).k[p == 0 ? COGNN_SL_B0 : COGNN_SL_B1]; }, 1);
             Phase ph_mp(E, T_PH_MP);
             message_passing_fused(E, F, it, gscale, relu_opened, wgrad_w_opened ? open_wgrad : OpenNext(), !wgrad_w_opened);
             relu_pairs_done = relu_opened;
@@ -1013,11 +1037,12 @@ void run_iteration(cognn_engine* E, int64_t it) {
             relu_opened = I.fwd && I.e != I.f - 1;
             // ... and in a backward iteration the weight-gradient product d = h_t^T . in is next: its right operand is this result
             wgrad_w_opened = !I.fwd;
-            OpenNext open_relu([&](Side& s) { return keys(E, s.owner, it, COGNN_OP_AP_RELU).k[s.p == 0 ? COGNN_SL_A0 : COGNN_SL_A1]; });
-            OpenNext open_wgrad([&](Side& s) { return gemm_keys(E, s, it, wgrad_spec(E, s, I.layer, it)).k[s.p == 0 ? COGNN_SL_B0 : COGNN_SL_B1]; }, 1);
+            OpenNext open_relu([&](Side& s, int p) { return keys(E, s.owner, it, COGNN_OP_AP_RELU).k[p == 0 ? COGNN_SL_A0 : COGNN_SL_A1]; });
+            OpenNext open_wgrad([&](Side& s, int p) { return gemm_keys(E, s, it, wgrad_spec(E, s, I.layer, it)).k[p == 0 ? COGNN_SL_B0 : COGNN_SL_B1]; }, 1);
             rowscale_stage(E, it, COGNN_OP_GA_SCALE, COGNN_OP_GA_SCALE_TRUNC, F, [&](Side& s) { return s.cur; },
                            [&](Side& s) { return s.buf[1]; }, fuse_open ? E_IN_X : E_FROM_X,
-                           relu_opened ? open_relu : wgrad_w_opened ? open_wgrad : OpenNext(), false, relu_opened);
+                           relu_opened ? open_relu : wgrad_w_opened ? open_wgrad : I.fwd ? OpenNext::Reveal() : OpenNext(), false, relu_opened);
+            z_revealed = I.fwd && !relu_opened;
             relu_pairs_done = relu_opened;
             for (auto& s : E->sides) if (!(relu_pairs_done && paired(E, s))) s.cur = s.buf[1];
         }
@@ -1026,7 +1051,7 @@ void run_iteration(cognn_engine* E, int64_t it) {
     Phase ph_ap(E, T_PH_APPLY);
     if (I.fwd) {
         if (I.e != I.f - 1) relu_stage(E, it, relu_opened, relu_pairs_done);
-        else softmax_stage(E, it);
+        else softmax_stage(E, it, z_revealed);
         for (auto& s : E->sides) s.curF = (I.e != I.f - 1) ? E->hid() : E->lab();
         return;
     }
@@ -1650,6 +1675,7 @@ int cognn_engine_set_option(cognn_engine* E, int32_t option, int64_t value) {
         if (option == COGNN_OPT_RETAIN_OFFLINE) E->retain_offline = value != 0;
         else if (option == COGNN_OPT_PAIR_FUSION) E->pair_fusion = value != 0;
         else if (option == COGNN_OPT_FORWARD_ONLY) E->forward_only = value != 0;
+        else if (option == COGNN_OPT_PUBLIC_OPENINGS) E->public_openings = value != 0;
         else throw EngineError("cognn_engine_set_option: unknown option");
     });
 }

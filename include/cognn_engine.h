@@ -84,8 +84,13 @@ int cognn_engine_offline(cognn_engine* e, int64_t iter_begin, int64_t iter_end);
  * COGNN_OPT_FORWARD_ONLY (default 0): a promise that only forward iterations will run (gcn-inference-optimize with -m 2,
  * tools/tmp_run_cluster.py:396-415).  Co-located pairs then skip the stores that only the backward pass reads - the hidden
  * activation h_t and the public ReLU sign mask - so cognn_engine_get_shares after a hidden-layer iteration is unspecified for
- * them; the prediction layer's shares and metrics are unaffected.  A backward iteration is refused while it is set. */
-enum { COGNN_OPT_RETAIN_OFFLINE = 1, COGNN_OPT_PAIR_FUSION = 2, COGNN_OPT_FORWARD_ONLY = 3 };
+ * them; the prediction layer's shares and metrics are unaffected.  A backward iteration is refused while it is set.
+ * COGNN_OPT_PUBLIC_OPENINGS (default 1): share-holders that are NOT run as a pair chain (the peer is on another rank, or pair
+ * fusion is off) close a truncation from both opened values and derive the opening of the op that consumes the result
+ * themselves (cognn_trunc_close_pub_u64), so the exchange round that carried that opening - and the co-party's reveal of z
+ * before the softmax - disappears: 3 of the 17 rounds and 15 % of the bytes of an inference pass.  0: every opening is
+ * exchanged as two shares.  Shares and metrics are bit-identical either way. */
+enum { COGNN_OPT_RETAIN_OFFLINE = 1, COGNN_OPT_PAIR_FUSION = 2, COGNN_OPT_FORWARD_ONLY = 3, COGNN_OPT_PUBLIC_OPENINGS = 4 };
 int cognn_engine_set_option(cognn_engine* e, int32_t option, int64_t value);
 /* Offline-phase cache on disk, the counterpart of the reference's preprocess/<setting>/ directory reused with `-n 1`
  * (include/harness.h:140-146, README.md:215-216): save writes every dealt product share currently held on this rank to

@@ -144,6 +144,13 @@ int cognn_trunc_close_u64(cognn_ctx*, uint64_t* out, const uint64_t* c0, const u
  * (E_p = X_p - A_p of the next Beaver product / row scale / ReLU, gcn.h:233,247,549) - one pass instead of two. */
 int cognn_trunc_close_open_u64(cognn_ctx*, uint64_t* out, uint64_t* E, const uint64_t* c0, const uint64_t* c1, const cognn_keys* keys,
                                int p, uint64_t key_open, int64_t n);
+/* The same close when BOTH parties hold both opened values c0, c1: besides its share out = y_p (may be NULL) each party derives
+ * the next op's opening ITSELF, E = y_0 + y_1 - a_0 - a_1 = ((c0+c1)>>16) - 2^45 - (r>>16) - a_0 - a_1, with the dealer's published
+ * t = (r>>16) + a_0 + a_1 (a_p = prng(key_open_p, i)): identical on both parties and identical to the sum of the two E_p of
+ * cognn_trunc_close_open_u64, but no second exchange round carries it.  reveal != 0: E = y_0 + y_1, the
+ * result itself (the co-party's reveal of z to the owner before the softmax, gcn.h:603-604). */
+int cognn_trunc_close_pub_u64(cognn_ctx*, uint64_t* out, uint64_t* E, const uint64_t* c0, const uint64_t* c1, const cognn_keys* keys,
+                              int p, uint64_t key_open0, uint64_t key_open1, int reveal, int64_t n);
 
 /* ---- sci::twoPartyGCNVectorScale (gcn.h:247,476): row scale by an additively shared vector - */
 /* E_p = V_p - a_p [rows x F] (skipped when E == NULL: already opened by cognn_gather_csr_open_u64), G_p = s_p - b_p [rows] */
@@ -182,7 +189,8 @@ int cognn_metrics_q16(cognn_ctx*, const uint64_t* pfx, const int32_t* labels, co
 
 /* The prediction layer of every side hosted by a process in ONE launch: owner jobs (p = 0) run cognn_softmax_u64 and
  * cognn_metrics_q16 fused (the revealed probabilities stay in registers: no pfx tensor is written or re-read), co-party jobs
- * (p = 1) write their mask share.  d_out as in cognn_softmax_u64; counts6 / loss as in cognn_metrics_q16 (owner jobs only). */
+ * (p = 1) write their mask share.  d_out as in cognn_softmax_u64; counts6 / loss as in cognn_metrics_q16 (owner jobs only).
+ * z1 == NULL in an owner job: z0 is the revealed z itself (cognn_trunc_close_pub_u64 with reveal). */
 typedef struct {
     uint64_t* d_out;
     const uint64_t* z0; const uint64_t* z1;

@@ -270,6 +270,21 @@ int cognn_trunc_close_open_u64(cognn_ctx* c, uint64_t* out, uint64_t* E, const u
     for (int64_t i = 0; i < n; ++i) E[i] = out[i] - cognn_prng(key_open, (u64)i);
     return 0;
 }
+// both parties' closes side by side, then the opening from their sum - what the two-round form would have exchanged
+int cognn_trunc_close_pub_u64(cognn_ctx* c, uint64_t* out, uint64_t* E, const uint64_t* c0, const uint64_t* c1, const cognn_keys* keys,
+                              int p, uint64_t key_open0, uint64_t key_open1, int reveal, int64_t n) {
+    REQ(E && c0 && c1, "trunc_close_pub: both opened values are needed");
+    std::vector<u64> y0((size_t)n), y1((size_t)n);
+    if (int rc = cognn_trunc_close_u64(c, y0.data(), c0, c1, keys, 0, 0, n)) return rc;
+    if (int rc = cognn_trunc_close_u64(c, y1.data(), nullptr, nullptr, keys, 1, 0, n)) return rc;
+    for (int64_t i = 0; i < n; ++i) {
+        const u64 e0 = reveal ? y0[(size_t)i] : y0[(size_t)i] - cognn_prng(key_open0, (u64)i);
+        const u64 e1 = reveal ? y1[(size_t)i] : y1[(size_t)i] - cognn_prng(key_open1, (u64)i);
+        E[i] = e0 + e1;
+        if (out) out[i] = p == 0 ? y0[(size_t)i] : y1[(size_t)i];
+    }
+    return 0;
+}
 int cognn_rowscale_open_u64(cognn_ctx*, uint64_t* E, uint64_t* G, const uint64_t* V, const uint64_t* s, const cognn_keys* keys,
                             int p, int64_t rows, int64_t F) {
     if (E) for (int64_t i = 0; i < rows * F; ++i) E[i] = V[i] - cognn_prng(keys->k[p == 0 ? COGNN_SL_A0 : COGNN_SL_A1], (u64)i);
@@ -385,8 +400,9 @@ int cognn_softmax_jobs_u64(cognn_ctx* ctx, const cognn_softmax_job* jobs, int32_
             if (int rc = cognn_softmax_u64(ctx, nullptr, s.d_out, nullptr, nullptr, nullptr, nullptr, &s.keys, 1, s.rows, L, s.train_rows)) return rc;
             continue;
         }
-        std::vector<u64> pfx((size_t)std::max<int64_t>(s.rows * L, 1));
-        if (int rc = cognn_softmax_u64(ctx, nullptr, s.d_out, pfx.data(), s.z0, s.z1, s.labels, &s.keys, 0, s.rows, L, s.train_rows)) return rc;
+        std::vector<u64> pfx((size_t)std::max<int64_t>(s.rows * L, 1)), zero;
+        if (!s.z1) zero.assign((size_t)std::max<int64_t>(s.rows * L, 1), 0);      // z0 is the revealed z itself
+        if (int rc = cognn_softmax_u64(ctx, nullptr, s.d_out, pfx.data(), s.z0, s.z1 ? s.z1 : zero.data(), s.labels, &s.keys, 0, s.rows, L, s.train_rows)) return rc;
         if (int rc = cognn_metrics_q16(ctx, pfx.data(), s.labels, s.border, s.rows, L, s.train_rows, s.val_rows, s.counts6, s.loss)) return rc;
     }
     return 0;

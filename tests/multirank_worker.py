@@ -36,6 +36,10 @@ def main():
     eng.set_exchange(mk(torch.device("cuda", 0), host_staged=True) if hip else mk(torch.device("cpu")))
     eng.set_global_data(feats, labels)
     eng.start()
+    if cfg.get("exchanged_openings"):                      # every opening travels as two shares (COGNN_OPT_PUBLIC_OPENINGS off)
+        eng.public_openings(False)
+    if "pair_fusion" in cfg:
+        eng.pair_fusion(bool(cfg["pair_fusion"]))
     out = {}
     m = k // world
     for it in range(cfg["iters"]):

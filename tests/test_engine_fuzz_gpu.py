@@ -41,6 +41,7 @@ def test_engine_random_configuration(seed):
     eng.set_global_data(feats, labels)
     eng.start()
     eng.pair_fusion(seed % 4 != 3)                                        # every fourth configuration through the per-side kernels
+    eng.public_openings(seed % 8 != 7)                                    # ... half of those with every opening exchanged as two shares
     try:
         for it in range(iters):
             oracle.iteration(it)

@@ -35,13 +35,15 @@ def _compare(oracle, eng, k, it):
             assert np.array_equal(eng.weight(P, 1, l), oracle.states[c].remoteWeight[l]), (it, P, l)
 
 
-@pytest.mark.parametrize("pair_fusion", [True, False])
+@pytest.mark.parametrize("pair_fusion", [True, False, "exchanged"])
 @pytest.mark.parametrize("k", [2, 3, 4])
 def test_training_two_epochs_bit_exact(k, pair_fusion):
     """pair_fusion: co-located share-holders run their steps as pair chains (exchange in registers, the default) or through the
-    per-side open / close kernels a one-party-per-GPU run uses; the shares are the oracle's either way."""
+    per-side open / close kernels a one-party-per-GPU run uses - with the opening after a truncation derived by both parties
+    (COGNN_OPT_PUBLIC_OPENINGS, the default) or "exchanged" as two shares; the shares are the oracle's every way."""
     oracle, eng = _setup(k, 60, 150, 24, 8, 5)
-    eng.pair_fusion(pair_fusion)
+    eng.pair_fusion(pair_fusion is True)
+    eng.public_openings(pair_fusion != "exchanged")
     for P in range(k):
         assert list(eng.party_vids(P)) == oracle.states[P].localVertexPos
         t, i, b = eng.party_degrees(P)

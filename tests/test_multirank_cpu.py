@@ -80,6 +80,16 @@ def test_four_parties_two_ranks_training_blocking_exchange(tmp_path):
     _check(dict(BASE, k=4, blocking_exchange=True), 2, tmp_path)
 
 
+def test_four_parties_two_ranks_training_exchanged_openings(tmp_path):
+    """COGNN_OPT_PUBLIC_OPENINGS off: the openings that follow a truncation travel as two shares (two more rounds per layer)."""
+    _check(dict(BASE, k=4, exchanged_openings=True), 2, tmp_path)
+
+
+def test_four_parties_two_ranks_training_no_pair_chains(tmp_path):
+    """co-located share-holders through the per-side kernels too (public openings between them, in-process hand-off)."""
+    _check(dict(BASE, k=4, pair_fusion=False), 2, tmp_path)
+
+
 def test_three_parties_three_ranks_training(tmp_path):
     _check(dict(BASE, k=3), 3, tmp_path)
 

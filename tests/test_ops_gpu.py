@@ -222,6 +222,21 @@ def test_trunc_pair(ctx):
                  ptr(cc1) if cc1 is not None else None, ctypes.byref(k), p, ctypes.c_uint64(ko), n)
         with np.errstate(over="ignore"):
             assert np.array_equal(host(o), w) and np.array_equal(host(e), w - co.prng_shape(ko, (n,)))
+    # both parties hold both opened values: each derives the next opening itself, E = y_0 + y_1 - a_0 - a_1 (no second round),
+    # or - reveal - the result y_0 + y_1; out may be NULL
+    ko1 = 0x0FEDCBA987654321
+    with np.errstate(over="ignore"):
+        e_pub = w0 + w1 - co.prng_shape(ko, (n,)) - co.prng_shape(ko1, (n,))
+        for p, w in ((0, w0), (1, w1)):
+            o = dev_empty(n); e = dev_empty(n)
+            ctx.call("cognn_trunc_close_pub_u64", ptr(o), ptr(e), ptr(c0), ptr(c1), ctypes.byref(k), p, ctypes.c_uint64(ko), ctypes.c_uint64(ko1), 0, n)
+            assert np.array_equal(host(o), w) and np.array_equal(host(e), e_pub)
+        e = dev_empty(n)
+        ctx.call("cognn_trunc_close_pub_u64", None, ptr(e), ptr(c0), ptr(c1), ctypes.byref(k), 0, ctypes.c_uint64(0), ctypes.c_uint64(0), 1, n)
+        assert np.array_equal(host(e), w0 + w1)
+    from cognn_amd import capi
+    with pytest.raises(capi.CognnError, match="both opened values"):
+        ctx.call("cognn_trunc_close_pub_u64", None, ptr(e), ptr(c0), None, ctypes.byref(k), 1, ctypes.c_uint64(ko), ctypes.c_uint64(ko1), 0, n)
     # mode 1 (apply gradient): out -= y, with a public multiplier
     W = rand_u64(rng, n); Wd0 = dev(W); Wd1 = dev(W)
     mul = 32768
@@ -358,7 +373,13 @@ def test_softmax_jobs_batch_with_fused_metrics(ctx, L):
             if p == 0:
                 cnt, loss = dev_empty(6), dev_empty(1, "f64")
                 sd["cnt"], sd["loss"] = cnt, loss
-                j.z0 = dev(sd["z0"]).data_ptr(); j.z1 = dev(sd["z1"]).data_ptr(); j.labels = dev(sd["labels"]).data_ptr()
+                if i == 1:                                  # z already revealed to the owner: z0 = z, no second share
+                    with np.errstate(over="ignore"):
+                        j.z0 = dev(sd["z0"] + sd["z1"]).data_ptr()
+                    j.z1 = None
+                else:
+                    j.z0 = dev(sd["z0"]).data_ptr(); j.z1 = dev(sd["z1"]).data_ptr()
+                j.labels = dev(sd["labels"]).data_ptr()
                 j.border = dev(sd["border"]).data_ptr(); j.counts6 = cnt.data_ptr(); j.loss = loss.data_ptr()
     ctx.call("cognn_softmax_jobs_u64", jobs, len(jobs), L)
     for i, sd in enumerate(sides):
