@@ -194,12 +194,13 @@ class Engine:
 
 
 def print_metrics(m):
-    """The reference's log lines (gcn.h:620-632), parsed by tools/plot/plot_accuracy.py:17-24."""
+    """The reference's log lines (gcn.h:620-632), parsed by tools/plot/plot_accuracy.py:17-24.  Accuracies are printed in
+    per cent like the reference's (README.md:226-236); the metrics dictionary holds fractions."""
     print("--------")
     print("cross-entropy-loss = %f" % m["loss"])
-    print("full set accuracy = %f" % m["full"])
-    print("training set accuracy = %f" % m["train"])
-    print("border training set accuracy = %f" % m["border_train"])
-    print("test set accuracy = %f" % m["test"])
-    print("border test set accuracy = %f" % m["border_test"])
+    print("full set accuracy = %f" % (100.0 * m["full"]))
+    print("training set accuracy = %f" % (100.0 * m["train"]))
+    print("border training set accuracy = %f" % (100.0 * m["border_train"]))
+    print("test set accuracy = %f" % (100.0 * m["test"]))
+    print("border test set accuracy = %f" % (100.0 * m["border_test"]))
     print("the number of vertices is %d, the number of border vertices is %d" % (int(m["n"]), int(m["n_border"])))

@@ -301,11 +301,12 @@ int main(int argc, char* argv[]) {
                 if (cognn_engine_get_metrics(e, (int32_t)tileIndex, m)) { std::cerr << cognn_engine_last_error() << std::endl; return -1; }
                 printf("--------\n");
                 printf("cross-entropy-loss = %lf\n", m[5]);
-                printf("full set accuracy = %lf\n", m[0]);
-                printf("training set accuracy = %lf\n", m[1]);
-                printf("border training set accuracy = %lf\n", m[2]);
-                printf("test set accuracy = %lf\n", m[3]);
-                printf("border test set accuracy = %lf\n", m[4]);
+                // sci::accuracy reports per cent (README.md:226-236: "full set accuracy = 19.188192" = 104 of 542 vertices)
+                printf("full set accuracy = %lf\n", 100.0 * m[0]);
+                printf("training set accuracy = %lf\n", 100.0 * m[1]);
+                printf("border training set accuracy = %lf\n", 100.0 * m[2]);
+                printf("test set accuracy = %lf\n", 100.0 * m[3]);
+                printf("border test set accuracy = %lf\n", 100.0 * m[4]);
                 printf("the number of vertices is %lu, the number of border vertices is %lu\n", (unsigned long)m[6], (unsigned long)m[7]);
             }
             if (!applyOnly) print_seconds(ph[3] + ph[4], "Apply_computation");     // incl. weight averaging (inside ApplyComp, gcn.h:747-802)

@@ -169,11 +169,11 @@ def main(argv=None):
                 m = eng.metrics(p)
                 print("--------", file=f)
                 print("cross-entropy-loss = %f" % m["loss"], file=f)
-                print("full set accuracy = %f" % m["full"], file=f)
-                print("training set accuracy = %f" % m["train"], file=f)
-                print("border training set accuracy = %f" % m["border_train"], file=f)
-                print("test set accuracy = %f" % m["test"], file=f)
-                print("border test set accuracy = %f" % m["border_test"], file=f)
+                print("full set accuracy = %f" % (100.0 * m["full"]), file=f)   # per cent, README.md:226-236
+                print("training set accuracy = %f" % (100.0 * m["train"]), file=f)
+                print("border training set accuracy = %f" % (100.0 * m["border_train"]), file=f)
+                print("test set accuracy = %f" % (100.0 * m["test"]), file=f)
+                print("border test set accuracy = %f" % (100.0 * m["border_test"]), file=f)
                 print("the number of vertices is %d, the number of border vertices is %d" % (int(m["n"]), int(m["n_border"])), file=f)
             if not apply_only:
                 print("::Apply_computation took %f seconds" % (ph["apply"] + ph["weight_average"]), file=f)

@@ -560,16 +560,17 @@ inline size_t argmax(const std::vector<double>& v) {
     for (size_t j = 1; j < v.size(); ++j) if (v[j] > v[b]) b = j;
     return b;
 }
+// per cent, like the reference's log (README.md:226-236: "full set accuracy = 19.188192" = 104 of 542 vertices)
 inline double accuracy(const DoubleTensor& y, const DoubleTensor& p) {
     size_t ok = 0;
     for (size_t r = 0; r < y.size(); ++r) ok += argmax(y[r]) == argmax(p[r]);
-    return y.empty() ? 0.0 : (double)ok / (double)y.size();
+    return y.empty() ? 0.0 : 100.0 * (double)ok / (double)y.size();
 }
 inline double accuracy(const DoubleTensor& y, const DoubleTensor& p, const std::vector<bool>& sel) {
     size_t ok = 0, n = 0;
     for (size_t r = 0; r < y.size(); ++r)
         if (sel[r]) { ++n; ok += argmax(y[r]) == argmax(p[r]); }
-    return n ? (double)ok / (double)n : 0.0;
+    return n ? 100.0 * (double)ok / (double)n : 0.0;
 }
 inline size_t count_true(const std::vector<bool>& v) {
     size_t n = 0;

@@ -66,8 +66,8 @@ def test_cli_runs_reference_formats_and_matches_oracle(tmp_path):
                      ("border_test", r"border test set accuracy = ([0-9.]+)")):
         got = [float(x) for x in re.findall(pat, out)]
         assert len(got) == 2
-        for g, w in zip(got, want):
-            assert abs(g - w[key]) < 1e-6, (key, got, [x[key] for x in want])
+        for g, w in zip(got, want):                      # accuracies are logged in per cent (README.md:226-236)
+            assert abs(g - w[key] * (1.0 if key == "loss" else 100.0)) < 1e-5, (key, got, [x[key] for x in want])
     nv = re.findall(r"the number of vertices is (\d+), the number of border vertices is (\d+)", out)
     assert [int(x) for x in nv[0]] == [want[0]["n"], want[0]["n_border"]]
 
@@ -108,7 +108,7 @@ def test_gpu_binary_matches_oracle(tmp_path):
     o.run(6)
     want = [m for m in o.metrics if m["party"] == 0][0]
     assert abs(float(re.findall(r"cross-entropy-loss = ([0-9.]+)", res.stdout)[0]) - want["loss"]) < 1e-6
-    assert abs(float(re.findall(r"full set accuracy = ([0-9.]+)", res.stdout)[0]) - want["full"]) < 1e-6
+    assert abs(float(re.findall(r"full set accuracy = ([0-9.]+)", res.stdout)[0]) - 100.0 * want["full"]) < 1e-5
 
 
 def _offline_cache_roundtrip(exe, tmp_path):

@@ -73,10 +73,10 @@ def test_two_rank_launcher_logs_match_oracle(tmp_path):
         assert len(extract_cognn_durations(text, "preprocess")) == 1 and len(extract_cognn_durations(text, "preprocess_OM")) == 1
         want = [m for m in o.metrics if m["party"] == party][0]
         assert abs(float(re.findall(r"cross-entropy-loss = ([0-9.]+)", text)[0]) - want["loss"]) < 1e-6
-        assert abs(float(re.findall(r"full set accuracy = ([0-9.]+)", text)[0]) - want["full"]) < 1e-6
+        assert abs(float(re.findall(r"full set accuracy = ([0-9.]+)", text)[0]) - 100.0 * want["full"]) < 1e-5   # per cent
         test_acc, border_acc = extract_cognn_accuracies(text)                    # plot_accuracy.py:17-24
         assert len(test_acc) == 1 and len(border_acc) == 1
-        assert abs(test_acc[0] - want["test"]) < 1e-6 and abs(border_acc[0] - want["border_test"]) < 1e-6
+        assert abs(test_acc[0] - 100.0 * want["test"]) < 1e-5 and abs(border_acc[0] - 100.0 * want["border_test"]) < 1e-5
     # the offline cache of that run serves a second one started with -n 1 (same results)
     res2 = subprocess.run(cmd + ["--no-preprocess"], capture_output=True, text=True, timeout=300, env=env, cwd=tmp_path)
     assert res2.returncode == 0, res2.stderr + res2.stdout
