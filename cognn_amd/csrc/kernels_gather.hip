@@ -149,10 +149,9 @@ struct GatherPairBatch {
     int count;
 };
 template <int LPR>
-__global__ __launch_bounds__(kThreads) void gather_pair_chain_kernel(const u64* __restrict__ table, const uint32_t* __restrict__ rowptr,
-                                                                      const uint32_t* __restrict__ col, int F, int ntiles, GatherPairBatch b) {
-    __shared__ uint32_t s_rp[2][kPairTile + 1];
-    __shared__ uint32_t s_col[2][kPairColCap];
+__device__ __forceinline__ void gather_pair_chain_body(const u64* __restrict__ table, const uint32_t* __restrict__ rowptr,
+                                                       const uint32_t* __restrict__ col, int F, int ntiles, const GatherPairBatch& b,
+                                                       uint32_t (&s_rp)[2][kPairTile + 1], uint32_t (&s_col)[2][kPairColCap]) {
     constexpr int kGroups = kThreads / LPR;
     const int tid = threadIdx.x;
     const int grp = tid / LPR, ln = tid % LPR;
@@ -223,6 +222,22 @@ __global__ __launch_bounds__(kThreads) void gather_pair_chain_kernel(const u64* 
     }
 }
 
+template <int LPR>
+__global__ __launch_bounds__(kThreads) void gather_pair_chain_kernel(const u64* __restrict__ table, const uint32_t* __restrict__ rowptr,
+                                                                      const uint32_t* __restrict__ col, int F, int ntiles, GatherPairBatch b) {
+    __shared__ uint32_t s_rp[2][kPairTile + 1];
+    __shared__ uint32_t s_col[2][kPairColCap];
+    gather_pair_chain_body<LPR>(table, rowptr, col, F, ntiles, b, s_rp, s_col);
+}
+// Grid of the gather kernels: one workgroup per tile up to this cap (the kernels keep their grid-stride loop).  Measured on
+// MI355X (config5, fused F = 64 launch): persistent grids lose to the hardware dispatcher - 1792 workgroups (one per slot)
+// 2.09 ms average, 4096: 1.93, 7168: 1.82, 28672: 1.78 - tiles differ in cost (degree), and a retiring workgroup's slot is
+// refilled at once.  (Forcing 8 waves per SIMD on the fused kernel - 64 VGPRs, 3 spilled - is slower: 1.89 against 1.78 ms.)
+int gather_grid(int ntiles) {
+    static const int cap = getenv("COGNN_GATHER_GRID_CAP") ? std::max(1, atoi(getenv("COGNN_GATHER_GRID_CAP"))) : (1 << 20);
+    return std::min(ntiles, cap);
+}
+
 int pick_lpr(int nchunk) {
     int l = 1;
     while (l < nchunk && l < 64) l <<= 1;
@@ -235,7 +250,7 @@ int launch_gather(cognn_ctx* ctx, u64* out, const u64* base, const u64* table, c
     const int nchunk = F / W;
     const int lpr = pick_lpr(nchunk);
     const int ntiles = (n_rows + kTileRows - 1) / kTileRows;
-    dim3 grid((unsigned)std::min(ntiles, 256 * 16)), block(kThreads);
+    dim3 grid((unsigned)gather_grid(ntiles)), block(kThreads);
 #define CG_GATHER_CASE(L)                                                                                              \
     case L:                                                                                                             \
         hipLaunchKernelGGL((gather_csr_kernel<L, W>), grid, block, 0, ctx->stream, out, base, table, rowptr, col, n_rows, F, segs); \
@@ -339,7 +354,7 @@ int cognn_gather_pair_chain_u64(cognn_ctx* ctx, const uint64_t* table, const uin
     }
     if (ntiles == 0) return 0;
     const int lpr = pick_lpr((int)(F / 2));
-    dim3 grid((unsigned)std::min(ntiles, 256 * 16)), block(kThreads);
+    dim3 grid((unsigned)gather_grid(ntiles)), block(kThreads);
 #define CG_GP_CASE(L) case L: hipLaunchKernelGGL((gather_pair_chain_kernel<L>), grid, block, 0, ctx->stream, (const u64*)table, rowptr, col, (int)F, ntiles, b); break;
     switch (lpr) {
         CG_GP_CASE(1) CG_GP_CASE(2) CG_GP_CASE(4) CG_GP_CASE(8) CG_GP_CASE(16) CG_GP_CASE(32) CG_GP_CASE(64)
