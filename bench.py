@@ -49,6 +49,7 @@ WORKLOADS = {
     "config5-train": (8, 20, 24, 128, 64, 16, "optimize-gcn", 6),
     "small": (8, 14, 18, 128, 64, 16, "optimize-gcn-inference", 2),
     "config5-x4": (8, 22, 26, 128, 64, 16, "optimize-gcn-inference", 2),     # 4x config5: size-scaling check (2^22 vertices / 2^26 edges)
+    "config5-x8": (8, 23, 27, 128, 64, 16, "optimize-gcn-inference", 2),     # 8x (2^23 / 2^27)
     # BASELINE.json configs[1..3]: one training epoch on dataset-shaped synthetic graphs (exact V / E below)
     "cora-2p": (2, None, None, 1433, 16, 7, "optimize-gcn", 6),
     "citeseer-2p": (2, None, None, 3703, 16, 6, "optimize-gcn", 6),
