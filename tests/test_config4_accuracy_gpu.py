@@ -1,4 +1,5 @@
-"""BASELINE.json configs[3]: 4-party optimize-gcn training on PubMed, 90 epochs, accuracy check.
+"""BASELINE.json configs[3]: 4-party optimize-gcn training on PubMed, 90 epochs, accuracy check - and the same check on the
+shapes of configs[1] / [2] (2-party Cora, 2-party CiteSeer).
 
 The reference publishes no PubMed accuracy and its datasets are not available offline, so the check is against this repo's
 float64 plaintext GCN of the same schedule (oracle PlainEngine) on a LEARNABLE PubMed-shaped synthetic graph
@@ -15,23 +16,36 @@ pytestmark = pytest.mark.gpu
 
 # fixed point f = 16: every truncation is off by at most 1 LSB (2^-16) and the learning rate of the PubMed config is 8.0, so
 # the secret-shared trajectory drifts from the float64 one; these are the bounds the drift has to stay under at every epoch
-TOL_LOSS = 0.005     # measured on MI355X: 0.0014
-TOL_ACC = 0.01       # measured: 0.0041
+TOL = {"pubmed-4p": (0.005, 0.01),       # (loss, accuracy); measured on MI355X: 0.0014, 0.0041
+       "cora-2p": (0.01, 0.02),          # measured: 0.0025, 0.0074 (1354 vertices per party: one vertex = 0.0007)
+       "citeseer-2p": (0.02, 0.025)}     # measured: 0.0074, 0.0091
 
 
-def test_pubmed_shaped_four_party_90_epochs_track_plaintext():
+# BASELINE.json configs[1] / [2] use the same check on the other two datasets' shapes and config files (2 parties, 90 epochs:
+# tools/tmp_run_cluster.py:159-168 runs the accuracy experiment on all three datasets): (k, V, E directed, input_dim, labels,
+# learning_rate, train/val/test ratios, planted-graph parameters, final accuracy the run must reach)
+SHAPES = {
+    "pubmed-4p": (4, 19717, 128146, 500, 3, 8.0, (0.05, 0.15, 0.8), dict(p_intra=0.7, p_on=0.03, p_off=0.008), 0.95),
+    "cora-2p": (2, 2708, 10556, 1433, 7, 0.5, (0.2, 0.2, 0.6), dict(p_intra=0.8, p_on=0.02, p_off=0.002), 0.8),       # measured 0.86-0.88
+    "citeseer-2p": (2, 3312, 10016, 3703, 6, 0.8, (0.2, 0.2, 0.6), dict(p_intra=0.8, p_on=0.01, p_off=0.001), 0.85),  # measured 0.92-0.94
+}
+
+
+@pytest.mark.parametrize("shape", ["pubmed-4p", "cora-2p", "citeseer-2p"])
+def test_dataset_shaped_90_epochs_track_plaintext(shape):
     from cognn_amd.engine import Engine, GnnParam
-    k, V, E = 4, 19717, 128146
-    src, dst, feats, labels = co.synth_planted(V, E // 2, 500, 3, 3, p_intra=0.7, p_on=0.03, p_off=0.008)
+    k, V, E, in_dim, lab, lr, ratios, planted, min_acc = SHAPES[shape]
+    src, dst, feats, labels = co.synth_planted(V, E // 2, in_dim, lab, 3, **planted)
     part = np.array([v % k for v in range(V)], dtype=np.int32)
-    kw = dict(num_labels=3, input_dim=500, hidden_dim=16, num_samples=V, learning_rate=8.0, train_ratio=0.05, val_ratio=0.15,
-              test_ratio=0.8)                                   # build_from_source/config/pubmed_config.txt
+    kw = dict(num_labels=lab, input_dim=in_dim, hidden_dim=16, num_samples=V, learning_rate=lr, train_ratio=ratios[0], val_ratio=ratios[1],
+              test_ratio=ratios[2])                             # build_from_source/config/<dataset>_config.txt
     oracle = co.OracleEngine(k, src, dst, part, feats, labels, co.GnnParam(**kw), seed=0xC06A11)   # only its preprocessing / init is used
     plain = co.PlainEngine(oracle)
     eng = Engine(k, src, dst, part, GnnParam(**kw), seed=0xC06A11)
     eng.set_global_data(feats, labels)
     eng.start()
     epochs = 90
+    TOL_LOSS, TOL_ACC = TOL[shape]
     worst = {"loss": 0.0, "acc": 0.0}
     traj = []
     mem = None
@@ -57,13 +71,15 @@ def test_pubmed_shaped_four_party_90_epochs_track_plaintext():
             mem = eng.memory()
     assert eng.memory() == mem, "device allocations grew over the epochs"
     first, last = np.array(traj[0]), np.array(traj[-1])
-    print("config4: max |loss - plaintext| %.5f, max |accuracy - plaintext| %.5f over 90 epochs" % (worst["loss"], worst["acc"]))
-    print("config4: epoch 1  loss %s  full-set accuracy %s" % (np.round(first[:, 0], 4), np.round(first[:, 1], 4)))
-    print("config4: epoch 90 loss %s  full %s  train %s  test %s" % tuple(np.round(last[:, j], 4) for j in range(4)))
-    assert (last[:, 0] < first[:, 0] / 5).all(), "loss did not fall"
-    assert (last[:, 1] > 0.95).all() and (last[:, 3] > 0.95).all(), "the run did not learn the planted classes"
-    acc = np.array(traj)[:, :, 1]
-    assert (np.diff(acc[:10].mean(axis=1)) > -0.01).all()       # the first ten epochs improve monotonically (then it saturates)
+    print("%s: max |loss - plaintext| %.5f, max |accuracy - plaintext| %.5f over 90 epochs" % (shape, worst["loss"], worst["acc"]))
+    print("%s: epoch 1  loss %s  full-set accuracy %s" % (shape, np.round(first[:, 0], 4), np.round(first[:, 1], 4)))
+    print("%s: epoch 90 loss %s  full %s  train %s  test %s" % ((shape,) + tuple(np.round(last[:, j], 4) for j in range(4))))
+    assert (last[:, 0] < first[:, 0]).all(), "loss did not fall"
+    assert (last[:, 1] > min_acc).all() and (last[:, 3] > min_acc - 0.02).all(), "the run did not learn the planted classes"
+    if shape == "pubmed-4p":
+        assert (last[:, 0] < first[:, 0] / 5).all(), "loss did not fall"
+        acc = np.array(traj)[:, :, 1]
+        assert (np.diff(acc[:10].mean(axis=1)) > -0.01).all()   # the first ten epochs improve monotonically (then it saturates)
     # the weights of all parties agree after the last averaging round (gcn.h:747-802)
     with np.errstate(over="ignore"):
         w = [[eng.weight(P, 0, l) + eng.weight(P, 1, l) for l in range(2)] for P in range(k)]
