@@ -31,7 +31,7 @@ class PairChain(ctypes.Structure):
                 ("rows", ctypes.c_int64), ("F", ctypes.c_int64), ("flags", ctypes.c_int32)]
 
 
-PC_TRUNC_IN, PC_SCALE, PC_RELU, PC_INPUT_OPENED, PC_NO_C = 1, 2, 4, 8, 16
+PC_TRUNC_IN, PC_SCALE, PC_RELU, PC_INPUT_OPENED, PC_NO_C, PC_OPEN_SUM = 1, 2, 4, 8, 16, 32
 
 
 class GatherPair(ctypes.Structure):

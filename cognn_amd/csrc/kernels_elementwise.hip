@@ -594,6 +594,14 @@ __global__ __launch_bounds__(kThreads) void pair_chain_kernel(PairBatch b) {
     }
     if (d.out0) st2(d.out0, i, w, v0);
     if (d.out1) st2(d.out1, i, w, v1);
+    if (d.flags & COGNN_PC_OPEN_SUM) {
+        if (d.open0) {
+            u64 e[2];
+            for (int j = 0; j < 2; ++j) e[j] = (v0[j] - cognn_prng(d.open_key0, (u64)(i + j))) + (v1[j] - cognn_prng(d.open_key1, (u64)(i + j)));
+            st2(d.open0, i, w, e);
+        }
+        return;
+    }
     if (d.open0) { u64 e[2] = {v0[0] - cognn_prng(d.open_key0, (u64)i), v0[1] - cognn_prng(d.open_key0, (u64)i + 1)}; st2(d.open0, i, w, e); }
     if (d.open1) { u64 e[2] = {v1[0] - cognn_prng(d.open_key1, (u64)i), v1[1] - cognn_prng(d.open_key1, (u64)i + 1)}; st2(d.open1, i, w, e); }
 }
@@ -809,6 +817,7 @@ int cognn_pair_chain_u64(cognn_ctx* ctx, const cognn_pair_chain* chains, int32_t
                    "cognn_pair_chain_u64: chain %d: null or misaligned tensor", c);
         CG_REQUIRE(!(fl & COGNN_PC_TRUNC_IN) || (fl & COGNN_PC_NO_C) || s.c1, "cognn_pair_chain_u64: chain %d needs side 1's product share", c);
         CG_REQUIRE(!(fl & COGNN_PC_SCALE) || (s.scale[0] && s.scale[1]), "cognn_pair_chain_u64: chain %d needs both scale shares", c);
+        CG_REQUIRE(!(fl & COGNN_PC_OPEN_SUM) || !s.open[1], "cognn_pair_chain_u64: chain %d: COGNN_PC_OPEN_SUM writes open[0] only", c);
         PairChainDev d;
         d.x0 = (const u64*)s.x[0]; d.x1 = (const u64*)s.x[1]; d.c1 = (const u64*)s.c1; d.sc0 = (const u64*)s.scale[0]; d.sc1 = (const u64*)s.scale[1];
         d.out0 = (u64*)s.out[0]; d.out1 = (u64*)s.out[1]; d.open0 = (u64*)s.open[0]; d.open1 = (u64*)s.open[1]; d.mask = s.mask;

@@ -215,8 +215,17 @@ __device__ __forceinline__ void gather_pair_chain_body(const u64* __restrict__ t
                 if ((d.flags & COGNN_PC_RELU) && d.mask) { d.mask[idx] = pos[0] ? 1 : 0; d.mask[idx + 1] = pos[1] ? 1 : 0; }
                 if (d.out0) { u64x2 t; t.x = a[0]; t.y = a[1]; *reinterpret_cast<u64x2*>(d.out0 + idx) = t; }
                 if (d.out1) { u64x2 t; t.x = bb[0]; t.y = bb[1]; *reinterpret_cast<u64x2*>(d.out1 + idx) = t; }
-                if (d.open0) { u64x2 t; t.x = a[0] - cognn_prng(d.open_key0, idx); t.y = a[1] - cognn_prng(d.open_key0, idx + 1); *reinterpret_cast<u64x2*>(d.open0 + idx) = t; }
-                if (d.open1) { u64x2 t; t.x = bb[0] - cognn_prng(d.open_key1, idx); t.y = bb[1] - cognn_prng(d.open_key1, idx + 1); *reinterpret_cast<u64x2*>(d.open1 + idx) = t; }
+                if (d.flags & COGNN_PC_OPEN_SUM) {
+                    if (d.open0) {
+                        u64x2 t;
+                        t.x = (a[0] - cognn_prng(d.open_key0, idx)) + (bb[0] - cognn_prng(d.open_key1, idx));
+                        t.y = (a[1] - cognn_prng(d.open_key0, idx + 1)) + (bb[1] - cognn_prng(d.open_key1, idx + 1));
+                        *reinterpret_cast<u64x2*>(d.open0 + idx) = t;
+                    }
+                } else {
+                    if (d.open0) { u64x2 t; t.x = a[0] - cognn_prng(d.open_key0, idx); t.y = a[1] - cognn_prng(d.open_key0, idx + 1); *reinterpret_cast<u64x2*>(d.open0 + idx) = t; }
+                    if (d.open1) { u64x2 t; t.x = bb[0] - cognn_prng(d.open_key1, idx); t.y = bb[1] - cognn_prng(d.open_key1, idx + 1); *reinterpret_cast<u64x2*>(d.open1 + idx) = t; }
+                }
             }
         }
     }
@@ -339,6 +348,7 @@ int cognn_gather_pair_chain_u64(cognn_ctx* ctx, const uint64_t* table, const uin
         CG_REQUIRE((fl & COGNN_PC_SCALE) || !(fl & COGNN_PC_RELU), "cognn_gather_pair_chain_u64: pair %d: a ReLU follows the row scale only", c);
         CG_REQUIRE((!(fl & COGNN_PC_SCALE) || (s.scale[0] && s.scale[1])) && s.rows * F < (1ll << 32) && p.a_row0 >= 0 && p.b_row0 >= 0, "cognn_gather_pair_chain_u64: pair %d is malformed", c);
         CG_REQUIRE(s.out[0] || s.out[1] || s.open[0] || s.open[1], "cognn_gather_pair_chain_u64: pair %d writes nothing", c);
+        CG_REQUIRE(!(fl & COGNN_PC_OPEN_SUM) || !s.open[1], "cognn_gather_pair_chain_u64: pair %d: COGNN_PC_OPEN_SUM writes open[0] only", c);
         CG_REQUIRE(cg_aligned16(s.out[0]) && cg_aligned16(s.out[1]) && cg_aligned16(s.open[0]) && cg_aligned16(s.open[1]), "cognn_gather_pair_chain_u64: pair %d: misaligned output", c);
         GatherPairSeg& g = b.s[b.count];
         PairChainDev& d = g.d;

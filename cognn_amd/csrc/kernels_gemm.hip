@@ -1027,6 +1027,148 @@ void beaver_gemm_tn_ws_kernel(u64* Z, const u64* __restrict__ E0, const u64* __r
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Register-direct TN Beaver close for N <= 16 (weight gradients of every reference configuration - hidden_dim = 16 - and the
+// layer-1 gradient of the wide benchmark):  Z[M x N] += [E | A_p]^T-stored . [B_p + pF ; F],  K = #vertices.
+// The wave-specialised kernel above leaves all VALU work (counter PRNG, limb split: ~40 instructions per operand value) to ONE
+// producer wave per SIMD - measured: 21 M VALU wave-instructions per launch against 46 M busy CU-cycles, the producer's issue
+// stream is the critical path - and at N <= 16 three quarters of its B-side work is padding.  Here every wave produces:
+//   * a wave owns a 16-row tile of M (4 waves = 4 tiles per workgroup) and builds its A fragment in registers, as
+//     beaver_gemm_d16_kernel does, only with the loads running along m (lanes r = 0..15 read 128 contiguous bytes of one k row);
+//   * the B fragment of a K step (16 columns x 32 k x 2 segments) is the same for all four waves: the 256 threads build it
+//     together - thread (n, k-block, entry pair) loads F once, generates B_p, limb-splits the pair of both segments with one
+//     split4 and writes 16-bit pieces into the [plane][lane][16 B] image in LDS (double-buffered, one barrier per K step);
+//   * K is split over workgroups (uint64 atomics; Z holds C_p on entry).
+// One K step = 32 k of both segments on v_mfma_i32_16x16x64_i8; entry e of lane block b is k = 32 st + 8 b + e for A and B alike.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void beaver_gemm_tn_d16_kernel(u64* Z, const u64* __restrict__ E0, const u64* __restrict__ E1,
+                                                                 const u64* __restrict__ F, const u64* __restrict__ F1, u64 keyA, u64 keyB, int p,
+                                                                 int M, int N, int K, int nst, int ksteps, int mtiles, int a_storage) {
+    __shared__ __attribute__((aligned(16))) unsigned char sB[2][kD16Stage];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int st0 = (int)blockIdx.y * ksteps, st1 = min(nst, st0 + ksteps);
+    if (st0 >= st1) return;                                  // (uniform over the workgroup)
+    const int tile = (int)blockIdx.x * 4 + wave;
+    const bool active = tile < mtiles;                       // wave-uniform: waves beyond M still help to build the B fragments
+    const int r = lane & 15, b = lane >> 4;
+    const int m = tile * 16 + r, mc = min(m, M - 1);
+    const bool mok = active && m < M;
+    const bool twoE = E1 != nullptr, twoF = F1 != nullptr;   // (uniform) operands opened as two shares are summed here
+    // B task of this thread: column bn, lane block bkb, entries 2 bpq and 2 bpq + 1 of both segments
+    const int bn = tid & 15, bkb = (tid >> 4) & 3, bpq = tid >> 6;
+    const int bnc = min(bn, N - 1);
+    const bool nok = bn < N;
+    const int boff = (bkb * 16 + bn) * 16 + 2 * bpq;         // byte offset inside a plane of the image (segment 1: + 8)
+
+    v4i acc[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) acc[s] = v4i{0, 0, 0, 0};
+    u64 a0[8], a1[8], f0[2], f1[2];
+    auto load_a = [&](int st) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const size_t k = (size_t)min(st * 32 + b * 8 + e, K - 1);
+            a0[e] = E0[k * M + mc];
+            a1[e] = twoE ? E1[k * M + mc] : 0ull;
+        }
+    };
+    auto load_b = [&](int st) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const size_t k = (size_t)min(st * 32 + bkb * 8 + 2 * bpq + j, K - 1);
+            f0[j] = F[k * N + bnc];
+            f1[j] = twoF ? F1[k * N + bnc] : 0ull;
+        }
+    };
+    auto produce_b = [&](int st, unsigned char* img) {
+        u64 v[4];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int k = st * 32 + bkb * 8 + 2 * bpq + j;
+            const u64 keep = (nok && k < K) ? ~0ull : 0ull;
+            const u64 f = (f0[j] + f1[j]) & keep;
+            v[j] = ((cognn_mix64(keyB + ((u64)k * (u64)N + (u64)bn + 1ull) * COGNN_GAMMA) & keep) + (p == 1 ? f : 0ull));
+            v[2 + j] = f;
+        }
+        uint32_t pl[8];
+        split4(v, pl);                                       // bytes of plane i: (B_p + pF)(k), (B_p + pF)(k+1), F(k), F(k+1)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            *reinterpret_cast<uint16_t*>(img + i * 1024 + boff) = (uint16_t)pl[i];
+            *reinterpret_cast<uint16_t*>(img + i * 1024 + boff + 8) = (uint16_t)(pl[i] >> 16);
+        }
+    };
+    if (active) load_a(st0);
+    load_b(st0);
+    produce_b(st0, sB[0]);
+    if (st0 + 1 < st1) load_b(st0 + 1);
+    __syncthreads();
+    for (int st = st0; st < st1; ++st) {
+        const int buf = (st - st0) & 1;
+        v4i bf[8];
+        u64 v[8], w[8];
+        if (active) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) bf[i] = *reinterpret_cast<const v4i*>(sB[buf] + i * 1024 + lane * 16);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = a0[e] + a1[e];
+            if (st + 1 < st1) load_a(st + 1);               // the next step's opened shares are in flight during this step's arithmetic
+        }
+        if (st + 1 < st1) {
+            produce_b(st + 1, sB[buf ^ 1]);
+            if (st + 2 < st1) load_b(st + 2);
+        }
+        if (active) {
+            const int k0 = st * 32 + b * 8;
+            u64 x = keyA + ((a_storage ? (u64)k0 * (u64)M + (u64)m : (u64)m * (u64)K + (u64)k0) + 1ull) * COGNN_GAMMA;
+            const u64 xs = a_storage ? (u64)M * COGNN_GAMMA : COGNN_GAMMA;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const u64 keep = (mok && k0 + e < K) ? ~0ull : 0ull;
+                v[e] &= keep;
+                w[e] = cognn_mix64(x) & keep;
+                x += xs;
+            }
+            uint32_t pe0[8], pe1[8], pm0[8], pm1[8];
+            split4(v, pe0); split4(v + 4, pe1); split4(w, pm0); split4(w + 4, pm1);
+            v4i af[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) af[i] = v4i{(int)pe0[i], (int)pe1[i], (int)pm0[i], (int)pm1[i]};
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j + i < 8; ++j) acc[i + j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[i], bf[j], acc[i + j], 0, 0, 0);
+        }
+        __syncthreads();                                     // image buf^1 is complete; image buf may be overwritten
+    }
+    if (!active) return;
+    const int col = lane & 15;                               // C/D map of the 16x16 MFMA family: col = lane & 15, row = 4 * (lane >> 4) + reg
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int row = tile * 16 + 4 * b + q;
+        const uint32_t hi = (uint32_t)acc[4][q] + ((uint32_t)acc[5][q] << 8) + ((uint32_t)acc[6][q] << 16) + ((uint32_t)acc[7][q] << 24);
+        const long long lo = (long long)acc[0][q] + (long long)acc[1][q] * 256 + (long long)acc[2][q] * 65536 + (long long)acc[3][q] * 16777216;
+        if (row < M && col < N) atomicAdd((unsigned long long*)&Z[(size_t)row * N + col], (u64)lo + ((u64)hi << 32));
+    }
+}
+
+int launch_tn_d16(cognn_ctx* ctx, u64* Z, const u64* E0, const u64* E1, const u64* F, const u64* F1, u64 keyA, u64 keyB, int p, int64_t M,
+                  int64_t N, int64_t K, int a_storage) {
+    const int nst = (int)((K + 31) / 32);
+    const int mtiles = (int)((M + 15) / 16);
+    const int gx = (mtiles + 3) / 4;
+    // two workgroups per CU = two waves per SIMD (the kernel needs 218 registers): VALU latencies overlap, and the K range of a
+    // workgroup stays long enough to amortise its prologue and its 16 x 16 atomics per wave
+    static const int wgs = getenv("COGNN_TN16_WGS") ? atoi(getenv("COGNN_TN16_WGS")) : 512;
+    int splits = std::max(1, std::min(nst, (wgs + gx - 1) / gx));
+    const int ksteps = (nst + splits - 1) / splits;
+    splits = (nst + ksteps - 1) / ksteps;
+    hipLaunchKernelGGL(beaver_gemm_tn_d16_kernel, dim3((unsigned)gx, (unsigned)splits), dim3(256), 0, ctx->stream, Z, E0, E1, F, F1, keyA, keyB, p,
+                       (int)M, (int)N, (int)K, nst, ksteps, mtiles, a_storage);
+    CG_LAUNCH_CHECK();
+    return 0;
+}
+
 int launch_tn_ws(cognn_ctx* ctx, u64* Z, const u64* E0, const u64* E1, const u64* F, const u64* F1, u64 keyA, u64 keyB, int p, int64_t M,
                  int64_t N, int64_t K, int a_storage) {
     const int nst = (int)((K + 15) / 16);
@@ -1376,6 +1518,10 @@ int beaver_close_impl(cognn_ctx* ctx, uint64_t* Z, const uint64_t* E, const uint
         // Z <- C_p, then one split-K launch adds E.(B_p + pF) + A_p.F
         if (p == 0) { if ((rc = fill(ctx, (u64*)Z, keys->k[COGNN_SL_C0], 0, M, N, 0, 0, nullptr))) return rc; }
         else CG_HIP(hipMemcpyAsync(Z, c1, (size_t)M * N * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        static const bool no_tn16 = getenv("COGNN_GEMM_NO_TN16") != nullptr;   // A/B switch (tools/microbench.py): the wave-specialised kernel instead
+        if (N <= 16 && !no_tn16)
+            return launch_tn_d16(ctx, (u64*)Z, (const u64*)E, (const u64*)E1, (const u64*)F, (const u64*)F1, keys->k[p == 0 ? COGNN_SL_A0 : COGNN_SL_A1],
+                                 keys->k[p == 0 ? COGNN_SL_B0 : COGNN_SL_B1], p, M, N, K, transA == 2);
         return launch_tn_ws(ctx, (u64*)Z, (const u64*)E, (const u64*)E1, (const u64*)F, (const u64*)F1,
                             keys->k[p == 0 ? COGNN_SL_A0 : COGNN_SL_A1], keys->k[p == 0 ? COGNN_SL_B0 : COGNN_SL_B1], p, M, N, K, transA == 2);
     }

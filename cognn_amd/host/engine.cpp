@@ -91,6 +91,7 @@ struct cognn_engine {
     bool retain_offline = false;                    // COGNN_OPT_RETAIN_OFFLINE
     int gemm_lanes = getenv("COGNN_GEMM_LANES") ? atoi(getenv("COGNN_GEMM_LANES")) : 2;   // launch lanes of the per-side products (A/B switch: 1 = one stream)
     bool public_openings = true;                    // COGNN_OPT_PUBLIC_OPENINGS (see pub_open)
+    bool h1e_pairs_summed = false;                  // the co-located pairs' h1E holds E_0 + E_1 (written by a pair chain), not E_p
     bool pair_fusion = true;                        // COGNN_OPT_PAIR_FUSION: co-located share-holders run their two-party steps as pair chains
     bool forward_only = false;                      // COGNN_OPT_FORWARD_ONLY: no backward iteration will follow (inference, -m 2)
     double phase_s[6] = {0, 0, 0, 0, 0, 0};         // cognn_engine_get_phase_seconds
@@ -291,6 +292,10 @@ enum { X_OPEN_HERE = 0, X_H1E_FRESH = 1, X_H1E_REUSE = 2 };
 // (cognn_pair_chain_u64: both sides' local arithmetic in one kernel, opened values handed over in registers) instead of
 // open -> HBM -> close passes; the per-side stages below then skip those sides.
 bool paired(const cognn_engine* E, const Side& s) { return E->pair_fusion && s.peer != nullptr; }
+// A pair chain writes the opening of the step that follows it ONCE, as the sum of both parties' shares of it, into the owner
+// side's buffer (COGNN_PC_OPEN_SUM): both sides of the pair read it from there as a pre-summed operand.
+template <class Sel>
+const u64* pair_opening(Side& s, Sel sel) { return s.p == 0 ? sel(s) : sel(*s.peer); }
 
 // lanes > 1 (independent multi-launch sequences per side, disjoint buffers): the sides of a pass go round-robin to that many
 // launch lanes (cognn_lane_begin), joined before the pass ends.
@@ -464,8 +469,10 @@ void gemm_stage(cognn_engine* E, int64_t it, XFn X, WFn Wm, SpecFn spec, DstFn d
     for_sides(E, false, [&](Side& s, size_t i) {
         GemmSpec g = spec(s);
         cognn_keys k = gkeys(s, g);
-        const u64* e_own = feature ? s.featSum : xsrc != X_OPEN_HERE ? s.h1E : s.ob[0];   // featSum is already the sum of both shares
-        const u64* e_peer = feature ? nullptr : xsrc != X_OPEN_HERE ? s.h1E_peer : s.ib[0];
+        const bool h1e_sum = xsrc != X_OPEN_HERE && paired(E, s) && E->h1e_pairs_summed;   // written by a pair chain as E_0 + E_1
+        const u64* e_own = feature ? s.featSum : h1e_sum ? pair_opening(s, [](Side& x) { return x.h1E; })   // featSum is already the sum of both shares
+                                   : xsrc != X_OPEN_HERE ? s.h1E : s.ob[0];
+        const u64* e_peer = (feature || h1e_sum) ? nullptr : xsrc != X_OPEN_HERE ? s.h1E_peer : s.ib[0];
         const u64* c1 = nullptr;
         if (s.p == 1) {
             auto f = s.c1.find({it, g.op});
@@ -477,7 +484,11 @@ void gemm_stage(cognn_engine* E, int64_t it, XFn X, WFn Wm, SpecFn spec, DstFn d
             c1 = f->second.ptr;
         }
         // all_raw: fused single-launch product without C_p; C_p joins in the truncation opening below
-        BE(cognn_beaver_gemm_close2_u64(E->ctx, s.zbuf, e_own, e_peer, s.ob[1], (w_public && !paired(E, s)) ? nullptr : s.ib[1], c1, &k, s.p, g.M, g.N,
+        // the opened right operand: two shares (ob[1], ib[1]) - or already F itself: derived by both parties (public openings) or
+        // written once by the pair chain that produced W
+        const bool f_sum = w_opened && (paired(E, s) || w_public);
+        const u64* f_own = (w_opened && paired(E, s)) ? pair_opening(s, [](Side& x) { return x.ob[1]; }) : s.ob[1];
+        BE(cognn_beaver_gemm_close2_u64(E->ctx, s.zbuf, e_own, e_peer, f_own, f_sum ? nullptr : s.ib[1], c1, &k, s.p, g.M, g.N,
                                         g.K, g.transA, s.scratch, all_raw ? 1 : 0));
         if (E->timing) E->algo[T_GEMM] += 2.0 * 36 * 2 * (double)g.M * g.K * g.N;
         if (all_raw && !paired(E, s)) {
@@ -509,7 +520,7 @@ void gemm_stage(cognn_engine* E, int64_t it, XFn X, WFn Wm, SpecFn spec, DstFn d
             } else {
                 c.out[0] = dst(s); c.out[1] = dst(t);
                 if (open_next) {
-                    c.open[0] = s.ob[open_next.ob]; c.open[1] = t.ob[open_next.ob];
+                    c.open[0] = s.ob[open_next.ob]; c.flags |= COGNN_PC_OPEN_SUM;
                     c.open_key[0] = open_next.key(s); c.open_key[1] = open_next.key(t);
                 }
             }
@@ -562,7 +573,8 @@ void rowscale_stage(cognn_engine* E, int64_t it, int op, int top, int F, XFn X, 
                 c.mask = s.relu_mask;
                 cognn_keys nk = keys(E, s.owner, it + 1, COGNN_OP_PS_GEMM);
                 c.out[0] = s.h1; c.out[1] = t.h1;
-                c.open[0] = s.h1E; c.open[1] = t.h1E;
+                c.open[0] = s.h1E; c.flags |= COGNN_PC_OPEN_SUM;      // E_0 + E_1 once, into the owner side's buffer (pair_opening)
+                E->h1e_pairs_summed = true;
                 c.open_key[0] = nk.k[COGNN_SL_A0]; c.open_key[1] = nk.k[COGNN_SL_A1];
                 if (E->forward_only) {                       // inference: the next product only reads the opening; h_t and the sign mask
                     c.out[0] = c.out[1] = nullptr;           // serve the backward pass, which will not run
@@ -571,7 +583,7 @@ void rowscale_stage(cognn_engine* E, int64_t it, int op, int top, int F, XFn X, 
             } else {
                 c.out[0] = dst(s); c.out[1] = dst(t);
                 if (open_next) {
-                    c.open[0] = s.ob[open_next.ob]; c.open[1] = t.ob[open_next.ob];
+                    c.open[0] = s.ob[open_next.ob]; c.flags |= COGNN_PC_OPEN_SUM;
                     c.open_key[0] = open_next.key(s); c.open_key[1] = open_next.key(t);
                 }
             }
@@ -625,7 +637,8 @@ void relu_stage(cognn_engine* E, int64_t it, bool e_opened, bool pairs_done) {
             c.mask = s.relu_mask;
             cognn_keys nk = keys(E, s.owner, it + 1, COGNN_OP_PS_GEMM);
             c.out[0] = s.h1; c.out[1] = t.h1;
-            c.open[0] = s.h1E; c.open[1] = t.h1E;
+            c.open[0] = s.h1E; c.flags |= COGNN_PC_OPEN_SUM;      // E_0 + E_1 once, into the owner side's buffer (pair_opening)
+                E->h1e_pairs_summed = true;
             c.open_key[0] = nk.k[COGNN_SL_A0]; c.open_key[1] = nk.k[COGNN_SL_A1];
             if (E->forward_only) { c.out[0] = c.out[1] = nullptr; c.mask = nullptr; }
         }
@@ -801,13 +814,14 @@ void message_passing_fused(cognn_engine* E, int F, int64_t it, bool scale, bool 
             c.mask = s.relu_mask;
             cognn_keys nk = keys(E, s.owner, it + 1, COGNN_OP_PS_GEMM);
             c.out[0] = s.h1; c.out[1] = t.h1;
-            c.open[0] = s.h1E; c.open[1] = t.h1E;
+            c.open[0] = s.h1E; c.flags |= COGNN_PC_OPEN_SUM;      // E_0 + E_1 once, into the owner side's buffer (pair_opening)
+                E->h1e_pairs_summed = true;
             c.open_key[0] = nk.k[COGNN_SL_A0]; c.open_key[1] = nk.k[COGNN_SL_A1];
             if (E->forward_only) { c.out[0] = c.out[1] = nullptr; c.mask = nullptr; }
         } else {
             if (out_read || !open_next) { c.out[0] = s.buf[1]; c.out[1] = t.buf[1]; }
             if (open_next) {
-                c.open[0] = s.ob[open_next.ob]; c.open[1] = t.ob[open_next.ob];
+                c.open[0] = s.ob[open_next.ob]; c.flags |= COGNN_PC_OPEN_SUM;
                 c.open_key[0] = open_next.key(s); c.open_key[1] = open_next.key(t);
             }
         }
@@ -989,6 +1003,7 @@ void run_iteration(cognn_engine* E, int64_t it) {
         if (I.fwd) {
             bool x_opened = (I.layer == 1 && E->gemm_x_opened_for == it);   // H already sits in h_t[1], its opening in h1E
             if (I.layer == 1 && !x_opened) {               // (not reached in a normal run: the ReLU close of iteration it-1 does both)
+                E->h1e_pairs_summed = false;               // every side writes its own share of the opening here
                 for (auto& s : E->sides) {
                     BE(cognn_memcpy_d2d(E->ctx, s.h1, s.cur, (size_t)s.n * E->hid() * 8));   // h_t[1]
                     cognn_keys k = keys(E, s.owner, it, COGNN_OP_PS_GEMM);

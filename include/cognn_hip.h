@@ -217,7 +217,10 @@ int cognn_softmax_jobs_u64(cognn_ctx*, const cognn_softmax_job* jobs, int32_t co
  *   COGNN_PC_RELU       masked-sign ReLU = relu_open(G = NULL) + exchange + relu_mul + exchange + relu_close; mask optional
  * Outputs: out[p] (may be NULL) and, when open[p] != NULL, the opening of the op that consumes the result:
  * open[p][i] = out_p[i] - prng(open_key[p], i).  rows * F < 2^32. */
-enum { COGNN_PC_TRUNC_IN = 1, COGNN_PC_SCALE = 2, COGNN_PC_RELU = 4, COGNN_PC_INPUT_OPENED = 8, COGNN_PC_NO_C = 16 };
+enum { COGNN_PC_TRUNC_IN = 1, COGNN_PC_SCALE = 2, COGNN_PC_RELU = 4, COGNN_PC_INPUT_OPENED = 8, COGNN_PC_NO_C = 16,
+       /* open[0] receives (out_0 - a_0) + (out_1 - a_1), the opening as both parties hold it after the exchange; open[1] must be
+        * NULL: one tensor written instead of two, and the consuming product streams one operand instead of summing two */
+       COGNN_PC_OPEN_SUM = 32 };
 typedef struct {
     const uint64_t* x[2];        /* the two sides' input shares [rows x F] */
     const uint64_t* c1;          /* side 1's dealt product share (COGNN_PC_TRUNC_IN without COGNN_PC_NO_C) */

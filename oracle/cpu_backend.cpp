@@ -457,8 +457,14 @@ int cognn_pair_chain_u64(cognn_ctx* ctx, const cognn_pair_chain* chains, int32_t
             }
             for (int p = 0; p < 2; ++p) cur[p].swap(h[p]);
         }
+        if (s.flags & COGNN_PC_OPEN_SUM) {                  // what each party holds after exchanging the two openings
+            REQ(!s.open[1], "pair_chain: COGNN_PC_OPEN_SUM writes open[0] only");
+            if (s.open[0])
+                for (int64_t i = 0; i < n; ++i)
+                    s.open[0][i] = (cur[0][(size_t)i] - cognn_prng(s.open_key[0], (u64)i)) + (cur[1][(size_t)i] - cognn_prng(s.open_key[1], (u64)i));
+        }
         for (int p = 0; p < 2; ++p) {
-            if (s.open[p])
+            if (s.open[p] && !(s.flags & COGNN_PC_OPEN_SUM))
                 for (int64_t i = 0; i < n; ++i) s.open[p][i] = cur[p][(size_t)i] - cognn_prng(s.open_key[p], (u64)i);
             if (s.out[p]) memcpy(s.out[p], cur[p].data(), (size_t)n * 8);
         }

@@ -399,7 +399,9 @@ def test_softmax_jobs_batch_with_fused_metrics(ctx, L):
                                              (128, 64, 1000, 2), (24, 5, 300, 2),
                                              # the register-direct kernels (N <= 16: any M; 16 < N <= 64: >= 1024 row tiles):
                                              (2048, 16, 64, 0), (2051, 13, 130, 0), (515, 16, 33, 0), (16384, 64, 128, 0),
-                                             (16390, 33, 66, 0), (16400, 48, 35, 0), (16384, 32, 64, 0)])
+                                             (16390, 33, 66, 0), (16400, 48, 35, 0), (16384, 32, 64, 0),
+                                             # the register-direct TN kernel (N <= 16, K >= 256): ragged M / N / K, both mask addressings
+                                             (64, 16, 4099, 1), (70, 3, 1000, 2), (128, 16, 515, 2), (500, 16, 4929, 1), (17, 1, 257, 1)])
 def test_beaver_gemm_pair(ctx, M, N, K, transA):
     """Full Beaver product: mask-open, exchange, dealer C1, close; vs oracle twoPartyGCNMatMul stand-in."""
     rng = np.random.default_rng(M * 3 + N)

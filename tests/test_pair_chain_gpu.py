@@ -11,7 +11,7 @@ from gpu_util import dev, dev_empty, host, ptr, rand_u64, U64
 
 pytestmark = pytest.mark.gpu
 
-TRUNC_IN, SCALE, RELU, OPENED, NO_C = 1, 2, 4, 8, 16
+TRUNC_IN, SCALE, RELU, OPENED, NO_C, OPEN_SUM = 1, 2, 4, 8, 16, 32
 
 
 @pytest.fixture(scope="module")
@@ -80,6 +80,11 @@ def test_pair_chain_matches_the_two_party_oracle(ctx, flags, rows, F):
     with np.errstate(over="ignore"):
         assert np.array_equal(host(op0), e0 - co.prng_shape(ok0, shape))
         assert np.array_equal(host(op1), e1 - co.prng_shape(ok1, shape))
+        # COGNN_PC_OPEN_SUM: one tensor, the opening as both parties hold it after the exchange
+        c.open[0] = op0.data_ptr(); c.open[1] = None; c.flags = flags | OPEN_SUM
+        c.out[0] = None; c.out[1] = None
+        ctx.call("cognn_pair_chain_u64", ctypes.byref(c), 1)
+        assert np.array_equal(host(op0), (e0 - co.prng_shape(ok0, shape)) + (e1 - co.prng_shape(ok1, shape)))
         if flags == TRUNC_IN | NO_C:             # sanity of the expectation itself: a truncation is floor(x / 2^16) or that + 1
             got = (host(out0) + host(out1)).astype(np.int64)
             d = got - (val.astype(np.int64) >> 16)
@@ -118,7 +123,7 @@ def test_pair_chain_batches_and_rejects_bad_chains(ctx):
 
 
 @pytest.mark.parametrize("F,relu,forward_only", [(64, True, False), (16, False, False), (64, True, True), (6, True, False), (2, False, False),
-                                                 (64, None, True), (16, None, False)])
+                                                 (64, None, True), (16, None, False), (64, True, "sum"), (16, None, "sum")])
 def test_gather_with_pair_chain_epilogue_equals_gather_then_chain(ctx, F, relu, forward_only):
     """cognn_gather_pair_chain_u64 (the aggregate never written) against cognn_gather_csr_u64 on both sides' row segments followed
     by cognn_pair_chain_u64, and against the oracle's two-party functions; two owners of different sizes (tiles of 32 vertices,
@@ -153,9 +158,9 @@ def test_gather_with_pair_chain_epilogue_equals_gather_then_chain(ctx, F, relu, 
         c.scale[0] = dev(s0).data_ptr(); c.scale[1] = dev(s1).data_ptr()
         if not forward_only:
             c.out[0] = bufs[0].data_ptr(); c.out[1] = bufs[1].data_ptr(); c.mask = mask.data_ptr()
-        c.open[0] = bufs[2].data_ptr(); c.open[1] = bufs[3].data_ptr(); c.open_key[0] = ok[0]; c.open_key[1] = ok[1]
+        c.open[0] = bufs[2].data_ptr(); c.open[1] = None if forward_only == "sum" else bufs[3].data_ptr(); c.open_key[0] = ok[0]; c.open_key[1] = ok[1]
         c.scale_keys = ks["scale"][0]; c.scale_trunc_keys = ks["strunc"][0]; c.relu_keys = ks["relu"][0]
-        c.rows = n; c.F = F; c.flags = 0 if relu is None else SCALE | (RELU if relu else 0)
+        c.rows = n; c.F = F; c.flags = (0 if relu is None else SCALE | (RELU if relu else 0)) | (OPEN_SUM if forward_only == "sum" else 0)
         keep.append((n, a, b, s0, s1, {k: v[1] for k, v in ks.items()}, bufs, mask, ok))
     ctx.call("cognn_gather_pair_chain_u64", ptr(dtab), ptr(drp), ptr(dcl), F, pairs, len(sizes))
     # the plain aggregate of every table row
@@ -176,7 +181,10 @@ def test_gather_with_pair_chain_epilogue_equals_gather_then_chain(ctx, F, relu, 
             if not forward_only:
                 assert np.array_equal(host(mask, np.uint8).astype(bool), pos)
         with np.errstate(over="ignore"):
-            assert np.array_equal(host(bufs[2]), e0 - co.prng_shape(ok[0], e0.shape))
-            assert np.array_equal(host(bufs[3]), e1 - co.prng_shape(ok[1], e1.shape))
+            if forward_only == "sum":                     # COGNN_PC_OPEN_SUM: the two openings summed into open[0]
+                assert np.array_equal(host(bufs[2]), (e0 - co.prng_shape(ok[0], e0.shape)) + (e1 - co.prng_shape(ok[1], e1.shape)))
+            else:
+                assert np.array_equal(host(bufs[2]), e0 - co.prng_shape(ok[0], e0.shape))
+                assert np.array_equal(host(bufs[3]), e1 - co.prng_shape(ok[1], e1.shape))
         if not forward_only:
             assert np.array_equal(host(bufs[0]), e0) and np.array_equal(host(bufs[1]), e1)
