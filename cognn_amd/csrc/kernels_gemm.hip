@@ -1041,81 +1041,104 @@ void beaver_gemm_tn_ws_kernel(u64* Z, const u64* __restrict__ E0, const u64* __r
 //   * K is split over workgroups (uint64 atomics; Z holds C_p on entry).
 // One K step = 32 k of both segments on v_mfma_i32_16x16x64_i8; entry e of lane block b is k = 32 st + 8 b + e for A and B alike.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void beaver_gemm_tn_d16_kernel(u64* Z, const u64* __restrict__ E0, const u64* __restrict__ E1,
-                                                                 const u64* __restrict__ F, const u64* __restrict__ F1, u64 keyA, u64 keyB, int p,
-                                                                 int M, int N, int K, int nst, int ksteps, int mtiles, int a_storage) {
-    __shared__ __attribute__((aligned(16))) unsigned char sB[2][kD16Stage];
+// NT = ceil(N / 16) column tiles per wave (one B image of NT x 8 KiB per K step), WAVES row tiles per workgroup: <1, 4> for
+// N <= 16, <NT, 8> for 16 < N <= 64 (128 x 64 output block, as many accumulator registers as beaver_gemm_d16n_kernel).
+template <int NT, int WAVES, bool TWO>   // TWO: an operand may arrive as two shares (E1 / F1 given); false saves the second stream's registers
+__global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(2, (NT == 1 && !TWO) ? 3 : 2)))
+void beaver_gemm_tn_d16_kernel(u64* Z, const u64* __restrict__ E0, const u64* __restrict__ E1, const u64* __restrict__ F,
+                               const u64* __restrict__ F1, u64 keyA, u64 keyB, int p, int M, int N, int K, int nst, int ksteps, int mtiles,
+                               int a_storage) {
+    constexpr int kThreadsTn = WAVES * 64;
+    constexpr int kImage = NT * kD16Stage;                   // B fragments of one K step: [column tile][plane][lane][16 B]
+    constexpr int kTasks = 256 * NT;                         // (column, lane block, entry pair) triples of one K step
+    constexpr int TPT = (kTasks + kThreadsTn - 1) / kThreadsTn;
+    extern __shared__ __attribute__((aligned(16))) unsigned char sB[];   // two images
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int st0 = (int)blockIdx.y * ksteps, st1 = min(nst, st0 + ksteps);
     if (st0 >= st1) return;                                  // (uniform over the workgroup)
-    const int tile = (int)blockIdx.x * 4 + wave;
+    const int tile = (int)blockIdx.x * WAVES + wave;
     const bool active = tile < mtiles;                       // wave-uniform: waves beyond M still help to build the B fragments
     const int r = lane & 15, b = lane >> 4;
     const int m = tile * 16 + r, mc = min(m, M - 1);
     const bool mok = active && m < M;
-    const bool twoE = E1 != nullptr, twoF = F1 != nullptr;   // (uniform) operands opened as two shares are summed here
-    // B task of this thread: column bn, lane block bkb, entries 2 bpq and 2 bpq + 1 of both segments
-    const int bn = tid & 15, bkb = (tid >> 4) & 3, bpq = tid >> 6;
-    const int bnc = min(bn, N - 1);
-    const bool nok = bn < N;
-    const int boff = (bkb * 16 + bn) * 16 + 2 * bpq;         // byte offset inside a plane of the image (segment 1: + 8)
-
-    v4i acc[8];
+    const bool twoE = TWO && E1 != nullptr, twoF = TWO && F1 != nullptr;   // (uniform) operands opened as two shares are summed here
+    // B tasks of this thread: task t = column bn (16 NT), lane block bkb, entries 2 bpq and 2 bpq + 1 of both segments
+    int bn[TPT], bk[TPT], boff[TPT];
+    bool bdo[TPT];
 #pragma unroll
-    for (int s = 0; s < 8; ++s) acc[s] = v4i{0, 0, 0, 0};
-    u64 a0[8], a1[8], f0[2], f1[2];
+    for (int q = 0; q < TPT; ++q) {
+        const int t = tid + q * kThreadsTn;
+        bdo[q] = t < kTasks;
+        const int tt = bdo[q] ? t : 0;
+        bn[q] = tt % (16 * NT);
+        const int bkb = (tt / (16 * NT)) & 3, bpq = tt / (64 * NT);
+        bk[q] = bkb * 8 + 2 * bpq;                           // first of the two entries' k offset inside a step
+        boff[q] = (bn[q] >> 4) * kD16Stage + (bkb * 16 + (bn[q] & 15)) * 16 + 2 * bpq;   // byte offset inside a plane (segment 1: + 8)
+    }
+
+    v4i acc[NT][8];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int s = 0; s < 8; ++s) acc[t][s] = v4i{0, 0, 0, 0};
+    u64 a0[8], a1[TWO ? 8 : 1], f0[TPT][2], f1[TWO ? TPT : 1][2];
     auto load_a = [&](int st) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const size_t k = (size_t)min(st * 32 + b * 8 + e, K - 1);
             a0[e] = E0[k * M + mc];
-            a1[e] = twoE ? E1[k * M + mc] : 0ull;
+            if (TWO) a1[e] = twoE ? E1[k * M + mc] : 0ull;
         }
     };
     auto load_b = [&](int st) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const size_t k = (size_t)min(st * 32 + bkb * 8 + 2 * bpq + j, K - 1);
-            f0[j] = F[k * N + bnc];
-            f1[j] = twoF ? F1[k * N + bnc] : 0ull;
-        }
+        for (int q = 0; q < TPT; ++q)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const size_t k = (size_t)min(st * 32 + bk[q] + j, K - 1);
+                const int nc = min(bn[q], N - 1);
+                f0[q][j] = F[k * N + nc];
+                if (TWO) f1[q][j] = twoF ? F1[k * N + nc] : 0ull;
+            }
     };
     auto produce_b = [&](int st, unsigned char* img) {
-        u64 v[4];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int k = st * 32 + bkb * 8 + 2 * bpq + j;
-            const u64 keep = (nok && k < K) ? ~0ull : 0ull;
-            const u64 f = (f0[j] + f1[j]) & keep;
-            v[j] = ((cognn_mix64(keyB + ((u64)k * (u64)N + (u64)bn + 1ull) * COGNN_GAMMA) & keep) + (p == 1 ? f : 0ull));
-            v[2 + j] = f;
-        }
-        uint32_t pl[8];
-        split4(v, pl);                                       // bytes of plane i: (B_p + pF)(k), (B_p + pF)(k+1), F(k), F(k+1)
+        for (int q = 0; q < TPT; ++q) {
+            u64 v[4];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            *reinterpret_cast<uint16_t*>(img + i * 1024 + boff) = (uint16_t)pl[i];
-            *reinterpret_cast<uint16_t*>(img + i * 1024 + boff + 8) = (uint16_t)(pl[i] >> 16);
+            for (int j = 0; j < 2; ++j) {
+                const int k = st * 32 + bk[q] + j;
+                const u64 keep = (bn[q] < N && k < K) ? ~0ull : 0ull;
+                const u64 f = (TWO ? f0[q][j] + f1[q][j] : f0[q][j]) & keep;
+                v[j] = ((cognn_mix64(keyB + ((u64)k * (u64)N + (u64)bn[q] + 1ull) * COGNN_GAMMA) & keep) + (p == 1 ? f : 0ull));
+                v[2 + j] = f;
+            }
+            uint32_t pl[8];
+            split4(v, pl);                                   // bytes of plane i: (B_p + pF)(k), (B_p + pF)(k+1), F(k), F(k+1)
+            if (bdo[q]) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    *reinterpret_cast<uint16_t*>(img + i * 1024 + boff[q]) = (uint16_t)pl[i];
+                    *reinterpret_cast<uint16_t*>(img + i * 1024 + boff[q] + 8) = (uint16_t)(pl[i] >> 16);
+                }
+            }
         }
     };
     if (active) load_a(st0);
     load_b(st0);
-    produce_b(st0, sB[0]);
+    produce_b(st0, sB);
     if (st0 + 1 < st1) load_b(st0 + 1);
     __syncthreads();
     for (int st = st0; st < st1; ++st) {
-        const int buf = (st - st0) & 1;
-        v4i bf[8];
+        const unsigned char* img = sB + ((st - st0) & 1) * kImage;
         u64 v[8], w[8];
         if (active) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) bf[i] = *reinterpret_cast<const v4i*>(sB[buf] + i * 1024 + lane * 16);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = a0[e] + a1[e];
+            for (int e = 0; e < 8; ++e) v[e] = TWO ? a0[e] + a1[e] : a0[e];
             if (st + 1 < st1) load_a(st + 1);               // the next step's opened shares are in flight during this step's arithmetic
         }
         if (st + 1 < st1) {
-            produce_b(st + 1, sB[buf ^ 1]);
+            produce_b(st + 1, sB + (((st - st0) & 1) ^ 1) * kImage);
             if (st + 2 < st1) load_b(st + 2);
         }
         if (active) {
@@ -1135,20 +1158,30 @@ __global__ __launch_bounds__(256) void beaver_gemm_tn_d16_kernel(u64* Z, const u
 #pragma unroll
             for (int i = 0; i < 8; ++i) af[i] = v4i{(int)pe0[i], (int)pe1[i], (int)pm0[i], (int)pm1[i]};
 #pragma unroll
-            for (int i = 0; i < 8; ++i)
+            for (int t = 0; t < NT; ++t) {
+                v4i bf[8];
 #pragma unroll
-                for (int j = 0; j + i < 8; ++j) acc[i + j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[i], bf[j], acc[i + j], 0, 0, 0);
+                for (int i = 0; i < 8; ++i) bf[i] = *reinterpret_cast<const v4i*>(img + t * kD16Stage + i * 1024 + lane * 16);
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+#pragma unroll
+                    for (int j = 0; j + i < 8; ++j) acc[t][i + j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[i], bf[j], acc[t][i + j], 0, 0, 0);
+            }
         }
-        __syncthreads();                                     // image buf^1 is complete; image buf may be overwritten
+        __syncthreads();                                     // the other image is complete; this one may be overwritten
     }
     if (!active) return;
-    const int col = lane & 15;                               // C/D map of the 16x16 MFMA family: col = lane & 15, row = 4 * (lane >> 4) + reg
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int row = tile * 16 + 4 * b + q;
-        const uint32_t hi = (uint32_t)acc[4][q] + ((uint32_t)acc[5][q] << 8) + ((uint32_t)acc[6][q] << 16) + ((uint32_t)acc[7][q] << 24);
-        const long long lo = (long long)acc[0][q] + (long long)acc[1][q] * 256 + (long long)acc[2][q] * 65536 + (long long)acc[3][q] * 16777216;
-        if (row < M && col < N) atomicAdd((unsigned long long*)&Z[(size_t)row * N + col], (u64)lo + ((u64)hi << 32));
+    for (int t = 0; t < NT; ++t) {
+        const int col = t * 16 + (lane & 15);                // C/D map of the 16x16 MFMA family: col = lane & 15, row = 4 * (lane >> 4) + reg
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int row = tile * 16 + 4 * b + q;
+            const uint32_t hi = (uint32_t)acc[t][4][q] + ((uint32_t)acc[t][5][q] << 8) + ((uint32_t)acc[t][6][q] << 16) + ((uint32_t)acc[t][7][q] << 24);
+            const long long lo = (long long)acc[t][0][q] + (long long)acc[t][1][q] * 256 + (long long)acc[t][2][q] * 65536 +
+                                 (long long)acc[t][3][q] * 16777216;
+            if (row < M && col < N) atomicAdd((unsigned long long*)&Z[(size_t)row * N + col], (u64)lo + ((u64)hi << 32));
+        }
     }
 }
 
@@ -1156,15 +1189,34 @@ int launch_tn_d16(cognn_ctx* ctx, u64* Z, const u64* E0, const u64* E1, const u6
                   int64_t N, int64_t K, int a_storage) {
     const int nst = (int)((K + 31) / 32);
     const int mtiles = (int)((M + 15) / 16);
-    const int gx = (mtiles + 3) / 4;
-    // two workgroups per CU = two waves per SIMD (the kernel needs 218 registers): VALU latencies overlap, and the K range of a
-    // workgroup stays long enough to amortise its prologue and its 16 x 16 atomics per wave
-    static const int wgs = getenv("COGNN_TN16_WGS") ? atoi(getenv("COGNN_TN16_WGS")) : 512;
+    const int NT = (int)((N + 15) / 16);
+    const int waves = NT == 1 ? 4 : 8;
+    const int gx = (mtiles + waves - 1) / waves;
+    // two waves per SIMD (the kernel needs > 200 registers): two 4-wave workgroups or one 8-wave workgroup per CU; VALU latencies
+    // overlap, and the K range of a workgroup stays long enough to amortise its prologue and its atomics
+    static const int wgs_env = getenv("COGNN_TN16_WGS") ? atoi(getenv("COGNN_TN16_WGS")) : 0;
+    const int wgs = wgs_env ? wgs_env : (NT == 1 ? ((E1 || F1) ? 512 : 768) : 256);   // 2 (3: single-stream operands, 164 registers) waves per SIMD
     int splits = std::max(1, std::min(nst, (wgs + gx - 1) / gx));
     const int ksteps = (nst + splits - 1) / splits;
     splits = (nst + ksteps - 1) / ksteps;
-    hipLaunchKernelGGL(beaver_gemm_tn_d16_kernel, dim3((unsigned)gx, (unsigned)splits), dim3(256), 0, ctx->stream, Z, E0, E1, F, F1, keyA, keyB, p,
-                       (int)M, (int)N, (int)K, nst, ksteps, mtiles, a_storage);
+    const size_t lds = 2 * (size_t)NT * kD16Stage;
+#define CG_TND16_LAUNCH(NT_, W_)                                                                                                        \
+    do {                                                                                                                                 \
+        if (E1 || F1) {                                                                                                                  \
+            CG_HIP(hipFuncSetAttribute((const void*)beaver_gemm_tn_d16_kernel<NT_, W_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            hipLaunchKernelGGL((beaver_gemm_tn_d16_kernel<NT_, W_, true>), dim3((unsigned)gx, (unsigned)splits), dim3(W_ * 64), lds, ctx->stream, Z, E0, E1, \
+                               F, F1, keyA, keyB, p, (int)M, (int)N, (int)K, nst, ksteps, mtiles, a_storage);                            \
+        } else {                                                                                                                         \
+            CG_HIP(hipFuncSetAttribute((const void*)beaver_gemm_tn_d16_kernel<NT_, W_, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            hipLaunchKernelGGL((beaver_gemm_tn_d16_kernel<NT_, W_, false>), dim3((unsigned)gx, (unsigned)splits), dim3(W_ * 64), lds, ctx->stream, Z, E0,   \
+                               E1, F, F1, keyA, keyB, p, (int)M, (int)N, (int)K, nst, ksteps, mtiles, a_storage);                        \
+        }                                                                                                                                \
+    } while (0)
+    if (NT == 1) CG_TND16_LAUNCH(1, 4);
+    else if (NT == 2) CG_TND16_LAUNCH(2, 8);
+    else if (NT == 3) CG_TND16_LAUNCH(3, 8);
+    else CG_TND16_LAUNCH(4, 8);
+#undef CG_TND16_LAUNCH
     CG_LAUNCH_CHECK();
     return 0;
 }
@@ -1519,7 +1571,9 @@ int beaver_close_impl(cognn_ctx* ctx, uint64_t* Z, const uint64_t* E, const uint
         if (p == 0) { if ((rc = fill(ctx, (u64*)Z, keys->k[COGNN_SL_C0], 0, M, N, 0, 0, nullptr))) return rc; }
         else CG_HIP(hipMemcpyAsync(Z, c1, (size_t)M * N * 8, hipMemcpyDeviceToDevice, ctx->stream));
         static const bool no_tn16 = getenv("COGNN_GEMM_NO_TN16") != nullptr;   // A/B switch (tools/microbench.py): the wave-specialised kernel instead
-        if (N <= 16 && !no_tn16)
+        static const bool no_tn16n = getenv("COGNN_GEMM_NO_TN16N") != nullptr;
+        // (four column tiles with a two-share operand do not fit the register file: 79 spilled registers - the wave-specialised kernel)
+        if ((N <= 16 && !no_tn16) || (N > 16 && !no_tn16n && !no_tn16 && (N <= 48 || (!E1 && !F1))))
             return launch_tn_d16(ctx, (u64*)Z, (const u64*)E, (const u64*)E1, (const u64*)F, (const u64*)F1, keys->k[p == 0 ? COGNN_SL_A0 : COGNN_SL_A1],
                                  keys->k[p == 0 ? COGNN_SL_B0 : COGNN_SL_B1], p, M, N, K, transA == 2);
         return launch_tn_ws(ctx, (u64*)Z, (const u64*)E, (const u64*)E1, (const u64*)F, (const u64*)F1,

@@ -401,7 +401,9 @@ def test_softmax_jobs_batch_with_fused_metrics(ctx, L):
                                              (2048, 16, 64, 0), (2051, 13, 130, 0), (515, 16, 33, 0), (16384, 64, 128, 0),
                                              (16390, 33, 66, 0), (16400, 48, 35, 0), (16384, 32, 64, 0),
                                              # the register-direct TN kernel (N <= 16, K >= 256): ragged M / N / K, both mask addressings
-                                             (64, 16, 4099, 1), (70, 3, 1000, 2), (128, 16, 515, 2), (500, 16, 4929, 1), (17, 1, 257, 1)])
+                                             (64, 16, 4099, 1), (70, 3, 1000, 2), (128, 16, 515, 2), (500, 16, 4929, 1), (17, 1, 257, 1),
+                                             # ... and its 2-, 3- and 4-column-tile forms (16 < N <= 64)
+                                             (128, 64, 4100, 2), (100, 33, 700, 1), (130, 48, 1029, 2), (64, 17, 300, 1)])
 def test_beaver_gemm_pair(ctx, M, N, K, transA):
     """Full Beaver product: mask-open, exchange, dealer C1, close; vs oracle twoPartyGCNMatMul stand-in."""
     rng = np.random.default_rng(M * 3 + N)
@@ -427,6 +429,14 @@ def test_beaver_gemm_pair(ctx, M, N, K, transA):
     assert np.array_equal(host(Z[0]), z0) and np.array_equal(host(Z[1]), z1)
     with np.errstate(over="ignore"):
         assert np.array_equal(host(Z[0]) + host(Z[1]), co.ring_matmul(X, W))
+    # the same close with the opening of X handed over pre-summed (one operand stream: the engine's form for co-located pairs,
+    # public openings and the cached feature opening - and the form the register-direct TN kernel takes for four column tiles)
+    Es = dev_empty(stor(X0).shape)
+    ctx.call("cognn_add_u64", ptr(Es), ptr(E[0]), ptr(E[1]), M * K)
+    for p in range(2):
+        Zs = dev_empty((M, N))
+        ctx.call("cognn_beaver_gemm_close_u64", ptr(Zs), ptr(Es), None, ptr(Fs), ptr(c1) if p == 1 else None, ctypes.byref(k), p, M, N, K, transA, ptr(sa))
+        assert np.array_equal(host(Zs), (z0, z1)[p])
 
 
 def test_gather_csr_open_epilogue(ctx):

@@ -73,6 +73,8 @@ def bench_gemm_tn(ctx, iters, M=128, N=64, K=1 << 17):
         gb = 8.0 * (2 * M * K + K * N) / 1e9
         print("beaver_gemm_close TN p=%d M=%d K=%d N=%d: %.3f ms  %.1f i8-TOP/s  operand streams %.0f GB/s"
               % (p, M, K, N, ms, ops / ms / 1e9, gb / (ms / 1e3)))
+    ms = timeit(lambda: ctx.call("cognn_beaver_gemm_close_u64", P(Z), P(E0), None, P(F), None, ctypes.byref(k), 0, M, N, K, 1, P(scratch)), iters)
+    print("beaver_gemm_close TN one E stream p=0 M=%d K=%d N=%d: %.3f ms  %.1f i8-TOP/s" % (M, K, N, ms, 2.0 * 36 * 2 * M * K * N / ms / 1e9))
 
 
 def bench_gather(ctx, iters, rows=1 << 21, table_rows=1 << 21, deg=12, F=64):
