@@ -28,7 +28,7 @@ class PairChain(ctypes.Structure):
     _fields_ = [("x", ctypes.c_void_p * 2), ("c1", ctypes.c_void_p), ("scale", ctypes.c_void_p * 2), ("out", ctypes.c_void_p * 2),
                 ("open", ctypes.c_void_p * 2), ("mask", ctypes.c_void_p), ("open_key", ctypes.c_uint64 * 2),
                 ("gemm_keys", Keys), ("trunc_in_keys", Keys), ("scale_keys", Keys), ("scale_trunc_keys", Keys), ("relu_keys", Keys),
-                ("rows", ctypes.c_int64), ("F", ctypes.c_int64), ("flags", ctypes.c_int32)]
+                ("rows", ctypes.c_int64), ("F", ctypes.c_int64), ("flags", ctypes.c_int32), ("mask_in", ctypes.c_void_p)]
 
 
 PC_TRUNC_IN, PC_SCALE, PC_RELU, PC_INPUT_OPENED, PC_NO_C, PC_OPEN_SUM = 1, 2, 4, 8, 16, 32

@@ -568,6 +568,10 @@ __global__ __launch_bounds__(kThreads) void pair_chain_kernel(PairBatch b) {
     const uint32_t flags = d.flags;
     u64 v0[2], v1[2];
     ld2(d.x0, i, w, v0); ld2(d.x1, i, w, v1);
+    if (d.mask_in) {                                         // MaskSelect on both sides' inputs
+        if (!d.mask_in[i]) { v0[0] = 0; v1[0] = 0; }
+        if (w == 2 && !d.mask_in[i + 1]) { v0[1] = 0; v1[1] = 0; }
+    }
     if (flags & COGNN_PC_TRUNC_IN) {
         u64 cc[2] = {0, 0};
         const bool addc = !(flags & COGNN_PC_NO_C);
@@ -821,6 +825,8 @@ int cognn_pair_chain_u64(cognn_ctx* ctx, const cognn_pair_chain* chains, int32_t
         PairChainDev d;
         d.x0 = (const u64*)s.x[0]; d.x1 = (const u64*)s.x[1]; d.c1 = (const u64*)s.c1; d.sc0 = (const u64*)s.scale[0]; d.sc1 = (const u64*)s.scale[1];
         d.out0 = (u64*)s.out[0]; d.out1 = (u64*)s.out[1]; d.open0 = (u64*)s.open[0]; d.open1 = (u64*)s.open[1]; d.mask = s.mask;
+        d.mask_in = s.mask_in;
+        CG_REQUIRE(!s.mask_in || !(fl & COGNN_PC_INPUT_OPENED), "cognn_pair_chain_u64: chain %d: mask_in needs plain input shares", c);
         pair_chain_fill_keys(d, s);
         d.n = n; d.F = (uint32_t)std::max<int64_t>(s.F, 1); d.flags = (uint32_t)fl;
         const int64_t pairs = (n + 1) / 2;

@@ -352,7 +352,7 @@ int cognn_gather_pair_chain_u64(cognn_ctx* ctx, const uint64_t* table, const uin
         CG_REQUIRE(cg_aligned16(s.out[0]) && cg_aligned16(s.out[1]) && cg_aligned16(s.open[0]) && cg_aligned16(s.open[1]), "cognn_gather_pair_chain_u64: pair %d: misaligned output", c);
         GatherPairSeg& g = b.s[b.count];
         PairChainDev& d = g.d;
-        d.x0 = d.x1 = d.c1 = nullptr;
+        d.x0 = d.x1 = d.c1 = nullptr; d.mask_in = nullptr;
         d.sc0 = (const u64*)s.scale[0]; d.sc1 = (const u64*)s.scale[1];
         d.out0 = (u64*)s.out[0]; d.out1 = (u64*)s.out[1]; d.open0 = (u64*)s.open[0]; d.open1 = (u64*)s.open[1]; d.mask = s.mask;
         pair_chain_fill_keys(d, s);

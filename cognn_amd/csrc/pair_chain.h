@@ -8,7 +8,7 @@
 
 struct PairChainDev {
     const u64* x0; const u64* x1; const u64* c1; const u64* sc0; const u64* sc1;
-    u64* out0; u64* out1; u64* open0; u64* open1; uint8_t* mask;
+    u64* out0; u64* out1; u64* open0; u64* open1; uint8_t* mask; const uint8_t* mask_in;
     u64 open_key0, open_key1;
     u64 keyC0, tiR, tiR0, tiRP0;                     // truncation of the raw product
     u64 sA0, sA1, sB0, sB1, sC0, stR, stR0, stRP0;   // row scale and its truncation

@@ -50,6 +50,8 @@ struct Side {
     const u64* featSum = nullptr;  // E = E_0 + E_1 of that product, summed once in start() (one copy per co-located pair)
     u64* h1E = nullptr;            // E_p = h_p - A_p of the layer-1 forward product (written by the ReLU close); kept for the epoch:
     u64* h1E_peer = nullptr;       // the layer-1 weight gradient h^T.g reuses mask and opening (alias when co-located)
+    const uint8_t* cur_mask = nullptr;   // co-located pairs, between the backward ReLU' and the row scale that consumes it: the tensor is
+                                         // cur (.) cur_mask, the selection rides in that row scale's pair chain (apply_cur_mask otherwise)
     u64* W[2] = {nullptr, nullptr};
     u64* WT = nullptr;             // transposed W1 scratch [lab x hid]
     u64* h1 = nullptr;             // h_t of layer 1 [n x hid]   (vertexInterData["h_t"], gcn.h:230-231)
@@ -296,6 +298,14 @@ bool paired(const cognn_engine* E, const Side& s) { return E->pair_fusion && s.p
 // side's buffer (COGNN_PC_OPEN_SUM): both sides of the pair read it from there as a pre-summed operand.
 template <class Sel>
 const u64* pair_opening(Side& s, Sel sel) { return s.p == 0 ? sel(s) : sel(*s.peer); }
+// materialises a deferred ReLU' selection (Side::cur_mask) for a reader other than the pair chain it was deferred for
+void apply_cur_mask(cognn_engine* E, Side& s) {
+    if (!s.cur_mask) return;
+    u64* dstb = (s.cur == s.buf[1]) ? s.buf[0] : s.buf[1];
+    BE(cognn_mask_select_u64(E->ctx, dstb, s.cur, s.cur_mask, (int64_t)s.n * s.curF));
+    s.cur = dstb;
+    s.cur_mask = nullptr;
+}
 
 // lanes > 1 (independent multi-launch sequences per side, disjoint buffers): the sides of a pass go round-robin to that many
 // launch lanes (cognn_lane_begin), joined before the pass ends.
@@ -560,8 +570,14 @@ void rowscale_stage(cognn_engine* E, int64_t it, int op, int top, int F, XFn X, 
         for (auto& s : E->sides) {
             if (!paired(E, s) || s.p != 0) continue;
             Side& t = *s.peer;
+            const uint8_t* mask_in = nullptr;               // the deferred ReLU' selection, if both sides still carry it
+            if (s.cur_mask || t.cur_mask) {
+                if (s.cur_mask && t.cur_mask && X(s) == s.cur && X(t) == t.cur) { mask_in = s.cur_mask; s.cur_mask = t.cur_mask = nullptr; }
+                else { apply_cur_mask(E, s); apply_cur_mask(E, t); }
+            }
             cognn_pair_chain& c = pc.add(s, X(s), X(t), s.n, F);
             c.flags = COGNN_PC_SCALE;
+            c.mask_in = mask_in;
             c.scale[0] = s.svec; c.scale[1] = t.svec;
             c.scale_keys = keys(E, s.owner, it, op);
             c.scale_trunc_keys = keys(E, s.owner, it, top);
@@ -994,8 +1010,12 @@ void run_iteration(cognn_engine* E, int64_t it) {
     if (E->forward_only && !I.fwd) throw EngineError("engine: COGNN_OPT_FORWARD_ONLY is set but a backward iteration was requested");
     bool relu_opened = false, wgrad_w_opened = false, relu_pairs_done = false, gather_chain_fused = false, z_revealed = false;
     if (I.e == 0) {                                        // ss_...h:695, 938: back to the input features
-        for (auto& s : E->sides) { s.cur = s.feat; s.curF = E->in(); }
+        for (auto& s : E->sides) { s.cur = s.feat; s.curF = E->in(); s.cur_mask = nullptr; }
     }
+    // a deferred ReLU' selection is consumed by the backward PreScatter row scale of the co-located pairs; anybody else gets the
+    // selected tensor
+    if (!(!I.apply_only && !I.fwd && E->pair_fusion))
+        for (auto& s : E->sides) apply_cur_mask(E, s);
     if (!I.apply_only) {
         const int F = mp_width(E, I.e);
         // ---- PreScatterComp (gcn.h:198-255) ----
@@ -1080,8 +1100,9 @@ void run_iteration(cognn_engine* E, int64_t it) {
         } else {                                           // out = in * 1[z>0]  (gcn.h:702-708; g' skipped for layer 0)
             Batch batch(E);
             for (auto& s : E->sides) {
-                u64* dstb = (s.cur == s.buf[1]) ? s.buf[0] : s.buf[1];
                 const uint8_t* mask = (paired(E, s) && s.p == 1) ? s.peer->relu_mask : s.relu_mask;   // a pair chain writes one (public) mask
+                if (paired(E, s)) { s.cur_mask = mask; continue; }    // deferred: the next iteration's row-scale chain selects while it reads
+                u64* dstb = (s.cur == s.buf[1]) ? s.buf[0] : s.buf[1];
                 BE(cognn_mask_select_u64(E->ctx, dstb, s.cur, mask, (int64_t)s.n * E->hid()));
                 s.cur = dstb;
             }
@@ -1707,7 +1728,10 @@ int cognn_engine_get_shares(cognn_engine* E, int32_t owner, int32_t sd, uint64_t
         if (!s) throw EngineError("cognn_engine_get_shares: that share is not held on this rank");
         if (rows) *rows = s->n;
         if (cols) *cols = s->curF;
-        if (host_out && s->curF > 0) BE(cognn_memcpy_d2h(E->ctx, host_out, s->cur, (size_t)s->n * s->curF * 8));
+        if (host_out && s->curF > 0) {
+            apply_cur_mask(E, *s);                          // (a deferred ReLU' selection becomes real for this reader)
+            BE(cognn_memcpy_d2h(E->ctx, host_out, s->cur, (size_t)s->n * s->curF * 8));
+        }
     });
 }
 int cognn_engine_get_weight(cognn_engine* E, int32_t owner, int32_t sd, int32_t layer, uint64_t* host_out) {

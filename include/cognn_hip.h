@@ -232,6 +232,8 @@ typedef struct {
     cognn_keys gemm_keys, trunc_in_keys, scale_keys, scale_trunc_keys, relu_keys;
     int64_t rows, F;
     int32_t flags;
+    const uint8_t* mask_in;      /* optional: x_p is taken as mask_in[i] ? x_p[i] : 0 - the backward ReLU' (cognn_mask_select_u64 with the public
+                                  * sign mask, gcn.h:702-708) folded into the chain that consumes its result; not with COGNN_PC_INPUT_OPENED */
 } cognn_pair_chain;
 /* independent chains (the co-located pairs of one protocol phase) are issued as shared launches */
 int cognn_pair_chain_u64(cognn_ctx*, const cognn_pair_chain* chains, int32_t count);

@@ -418,6 +418,12 @@ int cognn_pair_chain_u64(cognn_ctx* ctx, const cognn_pair_chain* chains, int32_t
         REQ(s.x[0] && s.x[1], "pair_chain: null input");
         std::vector<u64> cur[2], o0[2], o1[2];
         for (int p = 0; p < 2; ++p) { cur[p].assign(s.x[p], s.x[p] + n); o0[p].resize((size_t)n); o1[p].resize((size_t)n); }
+        if (s.mask_in)                                      // cognn_mask_select_u64 on both sides' inputs
+            for (int p = 0; p < 2; ++p) {
+                std::vector<u64> sel((size_t)n);
+                if (int rc = cognn_mask_select_u64(ctx, sel.data(), cur[p].data(), s.mask_in, n)) return rc;
+                cur[p].swap(sel);
+            }
         bool opened = (s.flags & COGNN_PC_INPUT_OPENED) != 0;
         if (s.flags & COGNN_PC_TRUNC_IN) {
             for (int p = 0; p < 2; ++p) {

@@ -42,8 +42,10 @@ def main():
         eng.pair_fusion(bool(cfg["pair_fusion"]))
     out = {}
     m = k // world
-    for it in range(cfg["iters"]):
-        eng.run(it, it + 1)
+    step = 6 if cfg.get("whole_epochs") else 1             # whole epochs per call: nothing is read between their GAS iterations
+    for it0 in range(0, cfg["iters"], step):
+        eng.run(it0, it0 + step)
+        it = it0 + step - 1
         for o in range(k):
             if o // m == rank:
                 out["it%d_o%d_s0" % (it, o)] = eng.shares(o, 0)

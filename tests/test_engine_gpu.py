@@ -64,6 +64,27 @@ def test_training_two_epochs_bit_exact(k, pair_fusion):
     eng.close()
 
 
+@pytest.mark.parametrize("k", [2, 3])
+def test_whole_epochs_in_one_call_bit_exact(k):
+    """cognn_engine_run over whole epochs without reading anything in between: the paths that only exist across GAS iterations
+    (the opening the ReLU leaves for the next product, the backward ReLU' selection deferred into the row-scale chain of the
+    next iteration) end in the oracle's weights and shares."""
+    oracle, eng = _setup(k, 70, 170, 20, 8, 4, seed=21)
+    for ep in range(2):
+        for it in range(6 * ep, 6 * ep + 6):
+            oracle.iteration(it)
+        eng.run(6 * ep, 6 * ep + 6)
+        _compare(oracle, eng, k, 6 * ep + 5)
+    # ... and with a reader between the ReLU' and its consumer on one side only
+    for it in range(12, 18):
+        oracle.iteration(it)
+        eng.run(it, it + 1)
+        if it == 16:
+            eng.shares(0, 1)
+    _compare(oracle, eng, k, 17)
+    eng.close()
+
+
 def test_forward_only_inference_pass_matches():
     """COGNN_OPT_FORWARD_ONLY (what bench.py and `gcn-inference-optimize -m 2` set): the prediction layer's shares and metrics are those of
     the full path; a backward iteration is refused."""

@@ -54,6 +54,8 @@ def _check(cfg, world, tmp_path):
     got = _run(cfg, world, tmp_path)
     for it in range(cfg["iters"]):
         o.iteration(it)
+        if ("it%d_o0_s0" % it) not in got:                 # whole_epochs: only the last iteration of every call was saved
+            continue
         for P in range(k):
             a, b = o.shares(P)
             assert np.array_equal(got["it%d_o%d_s0" % (it, P)], a), (it, P)
@@ -96,6 +98,13 @@ def test_three_parties_three_ranks_training(tmp_path):
 
 def test_four_parties_four_ranks_inference(tmp_path):
     _check(dict(BASE, k=4, variant="optimize-gcn-inference", iters=2), 4, tmp_path)
+
+
+def test_whole_epochs_per_call(tmp_path):
+    """run(it0, it0 + 6): the cross-iteration paths (deferred ReLU' selection of the co-located pairs, the opening the ReLU leaves
+    for the next product) on one rank and on two."""
+    _check(dict(BASE, k=3, iters=12, whole_epochs=True), 1, tmp_path)
+    _check(dict(BASE, k=4, iters=12, whole_epochs=True), 2, tmp_path)
 
 
 def test_single_rank_host_logic_three_parties(tmp_path):

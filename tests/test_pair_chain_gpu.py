@@ -93,6 +93,36 @@ def test_pair_chain_matches_the_two_party_oracle(ctx, flags, rows, F):
         assert np.array_equal(host(mask, np.uint8).astype(bool), pos)
 
 
+@pytest.mark.parametrize("rows,F", [(130, 16), (33, 3)])
+def test_pair_chain_with_input_mask(ctx, rows, F):
+    """mask_in: the backward ReLU' selection (cognn_mask_select_u64 with the public sign mask) folded into the row-scale chain."""
+    from cognn_amd import capi
+    rng = np.random.default_rng(rows + F)
+    shape = (rows, F)
+    val = rng.integers(-(1 << 40), 1 << 40, size=shape).astype(np.int64).astype(U64)
+    x1 = rand_u64(rng, shape)
+    with np.errstate(over="ignore"):
+        x0 = val - x1
+    m = rng.random(shape) < 0.5
+    s0 = co.normalizer(rng.integers(0, 9, size=rows)); s1 = np.zeros(rows, dtype=U64)
+    ks = {n: _keys(6, 2, 11, op) for n, op in (("scale", co.OP_PS_SCALE), ("strunc", co.OP_PS_SCALE_TRUNC))}
+    kf = {n: v[1] for n, v in ks.items()}
+    out0, out1 = dev_empty(shape), dev_empty(shape)
+    c = capi.PairChain()
+    c.x[0] = dev(x0).data_ptr(); c.x[1] = dev(x1).data_ptr()
+    c.scale[0] = dev(s0).data_ptr(); c.scale[1] = dev(s1).data_ptr()
+    c.out[0] = out0.data_ptr(); c.out[1] = out1.data_ptr()
+    c.mask_in = dev(m.astype(np.uint8)).data_ptr()
+    c.scale_keys = ks["scale"][0]; c.scale_trunc_keys = ks["strunc"][0]
+    c.rows = rows; c.F = F; c.flags = SCALE
+    ctx.call("cognn_pair_chain_u64", ctypes.byref(c), 1)
+    e0, e1, _ = _expect(SCALE, np.where(m, x0, U64(0)), np.where(m, x1, U64(0)), None, s0, s1, kf)
+    assert np.array_equal(host(out0), e0) and np.array_equal(host(out1), e1)
+    c.flags = SCALE | OPENED
+    with pytest.raises(capi.CognnError, match="mask_in"):
+        ctx.call("cognn_pair_chain_u64", ctypes.byref(c), 1)
+
+
 def test_pair_chain_batches_and_rejects_bad_chains(ctx):
     from cognn_amd import capi
     rng = np.random.default_rng(5)
