@@ -842,7 +842,7 @@ void message_passing_fused(cognn_engine* E, int F, int64_t it, bool scale, bool 
             }
         }
         const double elems = (double)s.n * F;
-        out_bytes += 8.0 * elems * ((c.out[0] ? 2 : 0) + (c.open[0] ? 2 : 0)) + (c.mask ? elems : 0.0);
+        out_bytes += 8.0 * elems * ((c.out[0] ? 2 : 0) + (c.open[0] ? ((c.flags & COGNN_PC_OPEN_SUM) ? 1 : 2) : 0)) + (c.mask ? elems : 0.0);
         gp.push_back(g);
     }
     if (E->timing) BE(cognn_timer_begin(E->ctx, T_AGG));
