@@ -108,8 +108,6 @@ _SIGNATURES = {
     "cognn_softmax_u64": (_I, [_P, _P, _P, _P, _P, _P, _P, _KP, _I, _L, _L, _L]),
     "cognn_metrics_q16": (_I, [_P, _P, _P, _P, _L, _L, _L, _L, _P, _P]),
     "cognn_pair_chain_u64": (_I, [_P, ctypes.POINTER(PairChain), ctypes.c_int32]),
-    "cognn_beaver_gemm_pair_fusable": (_I, [_L, _L, _L]),
-    "cognn_beaver_gemm_pair_chain_u64": (_I, [_P, _P, _P, _P, _KP, _L, _L, _L, _P, _P, ctypes.POINTER(PairChain)]),
     "cognn_softmax_jobs_u64": (_I, [_P, ctypes.POINTER(SoftmaxJob), ctypes.c_int32, _L]),
     "cognn_gather_pair_chain_u64": (_I, [_P, _P, _P, _P, _L, ctypes.POINTER(GatherPair), ctypes.c_int32]),
     "cognn_graph_build_colocated": (_I, [_P, _L, _L, ctypes.c_int32] + [_P] * 6 + [_L] + [_P] * 8),

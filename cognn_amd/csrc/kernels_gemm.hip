@@ -16,7 +16,6 @@
 #include <algorithm>
 #include <cstdlib>
 #include "../../include/cognn_hip.h"
-#include "pair_chain.h"
 
 namespace {
 
@@ -630,112 +629,6 @@ __global__ __launch_bounds__(256) void beaver_gemm_d16_kernel(u64* Z, const u64*
         if ((FULL || row < M) && col < N) {
             if (SPLITK) atomicAdd((unsigned long long*)&Z[(size_t)row * N + col], (u64)lo + ((u64)hi << 32));
             else Z[(size_t)row * N + col] = (u64)lo + ((u64)hi << 32);
-        }
-    }
-}
-
-// Both share-holders of a co-located pair in ONE launch (cognn_beaver_gemm_pair_chain_u64): the wave builds the E half of its A
-// fragment once (the summed opening is the same for both parties) and the two mask halves A_0, A_1, multiplies against the two
-// parties' B fragments and runs the pair chain - truncation of the product (+ C_p), optionally the row scale that follows -
-// on its two accumulator tiles in registers: neither product is written, nor read back by a chain launch.
-template <bool FULL, bool KEVEN>
-__global__ __launch_bounds__(256) void beaver_gemm_d16_pair_kernel(const u64* __restrict__ E0, const unsigned char* __restrict__ planes0,
-                                                                   const unsigned char* __restrict__ planes1, u64 keyA0, u64 keyA1, int M, int N,
-                                                                   int K, int nst, int tiles, PairChainDev d) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int tile = blockIdx.x * 4 + wave;
-    if (tile >= tiles) return;                               // (no barrier in this kernel)
-    const int r = lane & 15, b = lane >> 4;
-    const int m = tile * 16 + r, mc = FULL ? m : min(m, M - 1);
-    const u64* e0row = E0 + (size_t)mc * K;
-    const v4i* bp0 = reinterpret_cast<const v4i*>(planes0) + lane;
-    const v4i* bp1 = reinterpret_cast<const v4i*>(planes1) + lane;
-    v4i acc0[8], acc1[8];
-#pragma unroll
-    for (int s = 0; s < 8; ++s) { acc0[s] = v4i{0, 0, 0, 0}; acc1[s] = v4i{0, 0, 0, 0}; }
-    u64 cur[8];
-    auto load_step = [&](int st, u64 a0[8]) {
-        if (KEVEN) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                int k = st * 32 + 8 * j + 2 * b;
-                if (!FULL) k = min(k, K - 2);
-                const u64x2 x = *reinterpret_cast<const u64x2*>(e0row + k);
-                a0[2 * j] = x.x; a0[2 * j + 1] = x.y;
-            }
-        } else {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) a0[e] = e0row[min(d16_k(st, b, e), K - 1)];
-        }
-    };
-    load_step(0, cur);
-    for (int st = 0; st < nst; ++st) {
-        u64 v[8], w0[8], w1[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = cur[e];
-        if (st + 1 < nst) load_step(st + 1, cur);           // next step's opening is in flight during this step's arithmetic
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const u64 t = ((u64)m * (u64)K + (u64)(st * 32 + 8 * j + 2 * b) + 1ull) * COGNN_GAMMA;
-            w0[2 * j] = cognn_mix64(keyA0 + t); w0[2 * j + 1] = cognn_mix64(keyA0 + t + COGNN_GAMMA);
-            w1[2 * j] = cognn_mix64(keyA1 + t); w1[2 * j + 1] = cognn_mix64(keyA1 + t + COGNN_GAMMA);
-        }
-        if (!FULL) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const u64 keep = (m < M && d16_k(st, b, e) < K) ? ~0ull : 0ull;
-                v[e] &= keep; w0[e] &= keep; w1[e] &= keep;
-            }
-        }
-        uint32_t pe0[8], pe1[8], pm0[8], pm1[8];
-        split4(v, pe0); split4(v + 4, pe1); split4(w0, pm0); split4(w0 + 4, pm1);
-        {
-            v4i bf[8], af[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) { bf[i] = bp0[(size_t)(st * 8 + i) * 64]; af[i] = v4i{(int)pe0[i], (int)pe1[i], (int)pm0[i], (int)pm1[i]}; }
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-#pragma unroll
-                for (int j = 0; j + i < 8; ++j) acc0[i + j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[i], bf[j], acc0[i + j], 0, 0, 0);
-        }
-        split4(w1, pm0); split4(w1 + 4, pm1);
-        {
-            v4i bf[8], af[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) { bf[i] = bp1[(size_t)(st * 8 + i) * 64]; af[i] = v4i{(int)pe0[i], (int)pe1[i], (int)pm0[i], (int)pm1[i]}; }
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-#pragma unroll
-                for (int j = 0; j + i < 8; ++j) acc1[i + j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[i], bf[j], acc1[i + j], 0, 0, 0);
-        }
-    }
-    // the pair chain on the two products (pair_chain.h), element (row, col) = index row N + col of the [M x N] tensors
-    const int col = lane & 15;                               // C/D map of the 16x16 MFMA family: col = lane & 15, row = 4 * (lane >> 4) + reg
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int row = tile * 16 + 4 * b + q;
-        if (!((FULL || row < M) && col < N)) continue;
-        auto combine = [&](const v4i* acc) {
-            const uint32_t hi = (uint32_t)acc[4][q] + ((uint32_t)acc[5][q] << 8) + ((uint32_t)acc[6][q] << 16) + ((uint32_t)acc[7][q] << 24);
-            const long long lo = (long long)acc[0][q] + (long long)acc[1][q] * 256 + (long long)acc[2][q] * 65536 + (long long)acc[3][q] * 16777216;
-            return (u64)lo + ((u64)hi << 32);
-        };
-        u64 v0 = combine(acc0), v1 = combine(acc1);
-        const u64 idx = (u64)row * (u64)N + (u64)col;
-        if (!(d.flags & COGNN_PC_NO_C)) { v0 += cognn_prng(d.keyC0, idx); v1 += d.c1[idx]; }      // TruncOpenAdd: x + C_p
-        pair_trunc(d.tiR, d.tiR0, d.tiRP0, idx, v0, v1);
-        if (d.flags & COGNN_PC_SCALE) pair_scale(d, idx, (u64)row, false, v0, v1);
-        if (d.flags & COGNN_PC_RELU) {
-            const bool pos = pair_relu(d, idx, v0, v1);
-            if (d.mask) d.mask[idx] = pos ? 1 : 0;
-        }
-        if (d.out0) d.out0[idx] = v0;
-        if (d.out1) d.out1[idx] = v1;
-        if (d.flags & COGNN_PC_OPEN_SUM) {
-            if (d.open0) d.open0[idx] = (v0 - cognn_prng(d.open_key0, idx)) + (v1 - cognn_prng(d.open_key1, idx));
-        } else {
-            if (d.open0) d.open0[idx] = v0 - cognn_prng(d.open_key0, idx);
-            if (d.open1) d.open1[idx] = v1 - cognn_prng(d.open_key1, idx);
         }
     }
 }
@@ -1514,51 +1407,6 @@ int cognn_beaver_gemm_close_u64(cognn_ctx* ctx, uint64_t* Z, const uint64_t* E, 
 int cognn_beaver_gemm_fusable(int64_t M, int64_t N, int64_t K, int transA) {
     return (!transA && M >= 256 && N <= kFusedBN && K <= 4096 &&
             (size_t)((K + 15) / 16) * kNnBStage <= ((size_t)M * K + (size_t)K * N) * 8) ? 1 : 0;
-}
-
-int cognn_beaver_gemm_pair_fusable(int64_t M, int64_t N, int64_t K) {
-    // the register-direct N <= 16 kernel without split-K (every wave holds complete sums for its 16 rows)
-    const int64_t tiles = (M + 15) / 16, nst32 = (K + 31) / 32;
-    return (cognn_beaver_gemm_fusable(M, N, K, 0) && N <= 16 && K >= 32 && !(tiles <= 2048 && nst32 >= 4) && M * N < (1ll << 32)) ? 1 : 0;
-}
-
-int cognn_beaver_gemm_pair_chain_u64(cognn_ctx* ctx, const uint64_t* E, const uint64_t* F0, const uint64_t* F1, const cognn_keys* keys, int64_t M,
-                                     int64_t N, int64_t K, uint64_t* scratch0, uint64_t* scratch1, const cognn_pair_chain* chain) {
-    { const int rc_flush_ = cg_flush(ctx); if (rc_flush_) return rc_flush_; }
-    CG_REQUIRE(ctx && E && F0 && keys && scratch0 && scratch1 && chain, "cognn_beaver_gemm_pair_chain_u64: bad arguments");
-    CG_REQUIRE(cognn_beaver_gemm_pair_fusable(M, N, K), "cognn_beaver_gemm_pair_chain_u64: shape %lld x %lld x %lld is not fusable", (long long)M, (long long)N, (long long)K);
-    const cognn_pair_chain& c = *chain;
-    CG_REQUIRE((c.flags & COGNN_PC_TRUNC_IN) && !(c.flags & COGNN_PC_INPUT_OPENED) && !c.mask_in, "cognn_beaver_gemm_pair_chain_u64: the chain must start with the truncation of the product");
-    CG_REQUIRE((c.flags & COGNN_PC_NO_C) || c.c1, "cognn_beaver_gemm_pair_chain_u64: the chain needs side 1's product share");
-    CG_REQUIRE(!(c.flags & COGNN_PC_SCALE) || (c.scale[0] && c.scale[1]), "cognn_beaver_gemm_pair_chain_u64: the chain needs both scale shares");
-    CG_REQUIRE(!(c.flags & COGNN_PC_OPEN_SUM) || !c.open[1], "cognn_beaver_gemm_pair_chain_u64: COGNN_PC_OPEN_SUM writes open[0] only");
-    CG_REQUIRE(c.out[0] || c.out[1] || c.open[0] || c.open[1], "cognn_beaver_gemm_pair_chain_u64: the chain writes nothing");
-    if (M == 0) return 0;
-    const int nst32 = (int)((K + 31) / 32), tiles = (int)((M + 15) / 16);
-    unsigned char* planes[2] = {(unsigned char*)scratch0, (unsigned char*)scratch1};
-    for (int p = 0; p < 2; ++p) {
-        hipLaunchKernelGGL(prep_b_planes_d16_kernel, dim3((unsigned)std::min(nst32, 1024)), dim3(256), 0, ctx->stream, planes[p], (const u64*)F0,
-                           (const u64*)F1, keys->k[p == 0 ? COGNN_SL_B0 : COGNN_SL_B1], p, (int)K, (int)N, nst32, 1);
-        CG_LAUNCH_CHECK();
-    }
-    PairChainDev d;
-    d.x0 = d.x1 = nullptr; d.mask_in = nullptr;
-    d.c1 = (const u64*)c.c1; d.sc0 = (const u64*)c.scale[0]; d.sc1 = (const u64*)c.scale[1];
-    d.out0 = (u64*)c.out[0]; d.out1 = (u64*)c.out[1]; d.open0 = (u64*)c.open[0]; d.open1 = (u64*)c.open[1]; d.mask = c.mask;
-    pair_chain_fill_keys(d, c);
-    d.keyC0 = keys->k[COGNN_SL_C0];
-    d.n = M * N; d.F = (uint32_t)N; d.flags = (uint32_t)c.flags;
-    const bool full16 = (M % 16 == 0) && (K % 32 == 0), keven = (K % 2 == 0);
-    const dim3 grid((unsigned)((tiles + 3) / 4));
-#define CG_D16P_LAUNCH(...)                                                                                                                  \
-    hipLaunchKernelGGL((beaver_gemm_d16_pair_kernel<__VA_ARGS__>), grid, dim3(256), 0, ctx->stream, (const u64*)E, planes[0], planes[1],      \
-                       keys->k[COGNN_SL_A0], keys->k[COGNN_SL_A1], (int)M, (int)N, (int)K, nst32, tiles, d)
-    if (full16) CG_D16P_LAUNCH(true, true);
-    else if (keven) CG_D16P_LAUNCH(false, true);
-    else CG_D16P_LAUNCH(false, false);
-#undef CG_D16P_LAUNCH
-    CG_LAUNCH_CHECK();
-    return 0;
 }
 
 int cognn_beaver_gemm_close_raw_u64(cognn_ctx* ctx, uint64_t* Z, const uint64_t* E, const uint64_t* E1, const uint64_t* F,

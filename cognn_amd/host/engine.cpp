@@ -93,7 +93,6 @@ struct cognn_engine {
     bool retain_offline = false;                    // COGNN_OPT_RETAIN_OFFLINE
     int gemm_lanes = getenv("COGNN_GEMM_LANES") ? atoi(getenv("COGNN_GEMM_LANES")) : 2;   // launch lanes of the per-side products (A/B switch: 1 = one stream)
     bool public_openings = true;                    // COGNN_OPT_PUBLIC_OPENINGS (see pub_open)
-    bool pair_products = getenv("COGNN_PAIR_PRODUCTS") != nullptr;   // fused product + chain launches for co-located pairs (see gemm_stage)
     bool h1e_pairs_summed = false;                  // the co-located pairs' h1E holds E_0 + E_1 (written by a pair chain), not E_p
     bool pair_fusion = true;                        // COGNN_OPT_PAIR_FUSION: co-located share-holders run their two-party steps as pair chains
     bool forward_only = false;                      // COGNN_OPT_FORWARD_ONLY: no backward iteration will follow (inference, -m 2)
@@ -477,49 +476,6 @@ void gemm_stage(cognn_engine* E, int64_t it, XFn X, WFn Wm, SpecFn spec, DstFn d
     // timed as one phase on the engine's stream (the lanes overlap each other): all sides' products of this stage, with their
     // operand preparation (and, for sides whose peer is remote, the truncation opening and the wait for the peer's opening)
     if (E->timing) BE(cognn_timer_begin(E->ctx, T_GEMM));
-    // the pair chain that follows the product of a co-located pair (truncation of the product, + the row scale that consumes it)
-    auto make_chain = [&](Side& s, cognn_pair_chain& c) {
-        Side& t = *s.peer;
-        GemmSpec g = spec(s);
-        c.gemm_keys = gkeys(s, g);
-        c.trunc_in_keys = keys(E, s.owner, it, g.top);
-        if (follow) {
-            c.flags |= COGNN_PC_SCALE;
-            c.scale[0] = s.svec; c.scale[1] = t.svec;
-            c.scale_keys = keys(E, s.owner, it, follow.op);
-            c.scale_trunc_keys = keys(E, s.owner, it, follow.top);
-            c.out[0] = follow.dst(s); c.out[1] = follow.dst(t);
-        } else {
-            c.out[0] = dst(s); c.out[1] = dst(t);
-            if (open_next) {
-                c.open[0] = s.ob[open_next.ob]; c.flags |= COGNN_PC_OPEN_SUM;
-                c.open_key[0] = open_next.key(s); c.open_key[1] = open_next.key(t);
-            }
-        }
-    };
-    auto dealt_c1 = [&](Side& s, const GemmSpec& g, const cognn_keys& k, int64_t elems) -> const u64* {
-        auto f = s.c1.find({it, g.op});
-        if (f == s.c1.end()) {                               // dealer product share not precomputed: do it now
-            u64* c = c1_alloc(E, elems);
-            BE(cognn_dealer_gemm_c1_u64(E->ctx, c, &k, g.M, g.N, g.K, g.transA, s.scratch, s.scratch + g.M * g.K));
-            f = s.c1.emplace(std::make_pair(it, g.op), Side::C1{c, elems}).first;
-        }
-        return f->second.ptr;
-    };
-    // Co-located pair, N <= 16, the opening of X at hand as ONE tensor: both sides' products and their chain can be one launch
-    // (cognn_beaver_gemm_pair_chain_u64) - neither product is written.  Off by default (COGNN_PAIR_PRODUCTS=1 enables it): on
-    // MI355X the launch is bound by the counter-PRNG work of the chain, which two separate products + a chain launch hide under
-    // their memory traffic - config5 6.05 against 5.85 ms per pass, hidden_dim = 16: 2.85 against 2.76.
-    std::vector<char> fused(ns, 0);
-    for (size_t i = 0; i < ns; ++i) {
-        Side& s = E->sides[i];
-        GemmSpec g = spec(s);
-        if (E->pair_products && paired(E, s) && s.p == 0 && g.transA == 0 && (feature || (xsrc != X_OPEN_HERE && E->h1e_pairs_summed)) &&
-            E->be->cognn_beaver_gemm_pair_fusable(g.M, g.N, g.K)) {
-            fused[i] = 1;
-            fused[(size_t)(s.peer - E->sides.data())] = 1;
-        }
-    }
     for_sides(E, false, [&](Side& s, size_t i) {
         GemmSpec g = spec(s);
         cognn_keys k = gkeys(s, g);
@@ -527,26 +483,21 @@ void gemm_stage(cognn_engine* E, int64_t it, XFn X, WFn Wm, SpecFn spec, DstFn d
         const u64* e_own = feature ? s.featSum : h1e_sum ? pair_opening(s, [](Side& x) { return x.h1E; })   // featSum is already the sum of both shares
                                    : xsrc != X_OPEN_HERE ? s.h1E : s.ob[0];
         const u64* e_peer = (feature || h1e_sum) ? nullptr : xsrc != X_OPEN_HERE ? s.h1E_peer : s.ib[0];
+        const u64* c1 = nullptr;
+        if (s.p == 1) {
+            auto f = s.c1.find({it, g.op});
+            if (f == s.c1.end()) {                       // dealer product share not precomputed: do it now
+                u64* c = c1_alloc(E, eo[i]);
+                BE(cognn_dealer_gemm_c1_u64(E->ctx, c, &k, g.M, g.N, g.K, g.transA, s.scratch, s.scratch + g.M * g.K));
+                f = s.c1.emplace(std::make_pair(it, g.op), Side::C1{c, eo[i]}).first;
+            }
+            c1 = f->second.ptr;
+        }
+        // all_raw: fused single-launch product without C_p; C_p joins in the truncation opening below
         // the opened right operand: two shares (ob[1], ib[1]) - or already F itself: derived by both parties (public openings) or
         // written once by the pair chain that produced W
         const bool f_sum = w_opened && (paired(E, s) || w_public);
         const u64* f_own = (w_opened && paired(E, s)) ? pair_opening(s, [](Side& x) { return x.ob[1]; }) : s.ob[1];
-        z[i] = s.zbuf;
-        if (fused[i]) {
-            if (s.p == 1) return;                            // (launched with the owner side)
-            Side& t = *s.peer;
-            cognn_pair_chain c;
-            memset(&c, 0, sizeof(c));
-            c.rows = g.M; c.F = g.N;
-            c.flags = COGNN_PC_TRUNC_IN;
-            c.c1 = dealt_c1(t, g, k, eo[i]);
-            make_chain(s, c);
-            BE(cognn_beaver_gemm_pair_chain_u64(E->ctx, e_own, f_own, f_sum ? nullptr : s.ib[1], &k, g.M, g.N, g.K, s.scratch, t.scratch, &c));
-            if (E->timing) E->algo[T_GEMM] += 2 * 2.0 * 36 * 2 * (double)g.M * g.K * g.N;
-            return;
-        }
-        const u64* c1 = s.p == 1 ? dealt_c1(s, g, k, eo[i]) : nullptr;
-        // all_raw: fused single-launch product without C_p; C_p joins in the truncation opening below
         BE(cognn_beaver_gemm_close2_u64(E->ctx, s.zbuf, e_own, e_peer, f_own, f_sum ? nullptr : s.ib[1], c1, &k, s.p, g.M, g.N,
                                         g.K, g.transA, s.scratch, all_raw ? 1 : 0));
         if (E->timing) E->algo[T_GEMM] += 2.0 * 36 * 2 * (double)g.M * g.K * g.N;
@@ -555,20 +506,34 @@ void gemm_stage(cognn_engine* E, int64_t it, XFn X, WFn Wm, SpecFn spec, DstFn d
             BE(cognn_trunc_open_add_u64(E->ctx, s.ob[2], s.zbuf, c1, &k, &tk, s.p, eo[i]));
         }
         if (s.p == 1 && !paired(E, s)) c1_release(E, s, {it, g.op});   // consumed: the buffer serves a later deal
+        z[i] = s.zbuf;
     }, false, lanes);
     if (E->timing) BE(cognn_timer_end(E->ctx, T_GEMM));
-    // the other co-located pairs: truncation of the product (+ the row scale that follows) as one chain per owner
+    // co-located pairs: truncation of the product (+ the row scale that follows) as one chain per owner
     {
         PairChains pc;
-        for (size_t i = 0; i < ns; ++i) {
-            Side& s = E->sides[i];
-            if (!paired(E, s) || s.p != 0 || fused[i]) continue;
+        for (auto& s : E->sides) {
+            if (!paired(E, s) || s.p != 0) continue;
             Side& t = *s.peer;
             GemmSpec g = spec(s);
             cognn_pair_chain& c = pc.add(s, s.zbuf, t.zbuf, g.M, g.N);
             c.flags = COGNN_PC_TRUNC_IN | (all_raw ? 0 : COGNN_PC_NO_C);
+            c.gemm_keys = gkeys(s, g);
+            c.trunc_in_keys = keys(E, s.owner, it, g.top);
             if (all_raw) c.c1 = t.c1.at({it, g.op}).ptr;
-            make_chain(s, c);
+            if (follow) {
+                c.flags |= COGNN_PC_SCALE;
+                c.scale[0] = s.svec; c.scale[1] = t.svec;
+                c.scale_keys = keys(E, s.owner, it, follow.op);
+                c.scale_trunc_keys = keys(E, s.owner, it, follow.top);
+                c.out[0] = follow.dst(s); c.out[1] = follow.dst(t);
+            } else {
+                c.out[0] = dst(s); c.out[1] = dst(t);
+                if (open_next) {
+                    c.open[0] = s.ob[open_next.ob]; c.flags |= COGNN_PC_OPEN_SUM;
+                    c.open_key[0] = open_next.key(s); c.open_key[1] = open_next.key(t);
+                }
+            }
         }
         pc.launch(E);
         for (auto& s : E->sides)

@@ -238,16 +238,6 @@ typedef struct {
 /* independent chains (the co-located pairs of one protocol phase) are issued as shared launches */
 int cognn_pair_chain_u64(cognn_ctx*, const cognn_pair_chain* chains, int32_t count);
 
-/* Beaver product whose epilogue IS the pair chain (co-located pairs, N <= 16 - the reference's hidden width and every label
- * count): both parties' closes  z_p = [E | A_p] . [B_p + p F ; F]  in one launch (E = the summed opening of X [M x K], F0 (+ F1)
- * = the opening of W [K x N], masks from `keys`) and the chain - COGNN_PC_TRUNC_IN (c1 = side 1's dealt product share),
- * optionally | COGNN_PC_SCALE | COGNN_PC_RELU - on (z_0, z_1) in registers: neither product is written.  chain.x is unused,
- * chain.rows = M, chain.F = N.  Bit-identical to cognn_beaver_gemm_close_raw_u64 for p = 0, 1 followed by cognn_pair_chain_u64.
- * scratch0 / scratch1: ceil(K / 32) * 8 KiB each.  cognn_beaver_gemm_pair_fusable: the shapes it takes (no split-K). */
-int cognn_beaver_gemm_pair_fusable(int64_t M, int64_t N, int64_t K);
-int cognn_beaver_gemm_pair_chain_u64(cognn_ctx*, const uint64_t* E, const uint64_t* F0, const uint64_t* F1, const cognn_keys* keys, int64_t M,
-                                     int64_t N, int64_t K, uint64_t* scratch0, uint64_t* scratch1, const cognn_pair_chain* chain);
-
 /* Gather whose epilogue IS the pair chain (co-located pairs, single process): for every owner, row r of its owner-side segment
  * (first row a_row0) and row r of its co-party-side segment (b_row0) are aggregated by the same lanes -
  *   V_p[r,:] = table[row_p(r),:] + sum_{e in CSR row row_p(r)} table[col[e],:]        (the self row is the base)

@@ -477,22 +477,6 @@ int cognn_pair_chain_u64(cognn_ctx* ctx, const cognn_pair_chain* chains, int32_t
     }
     return 0;
 }
-// the fused product = both parties' raw closes into temporaries, then the pair chain on them
-// (any N <= 16 here: this backend has no kernel constraints, and the host-logic tests reach the engine's fused-product path with
-// their small graphs)
-int cognn_beaver_gemm_pair_fusable(int64_t, int64_t N, int64_t) { return N <= 16 ? 1 : 0; }
-int cognn_beaver_gemm_pair_chain_u64(cognn_ctx* ctx, const uint64_t* E, const uint64_t* F0, const uint64_t* F1, const cognn_keys* keys, int64_t M,
-                                     int64_t N, int64_t K, uint64_t* scratch0, uint64_t*, const cognn_pair_chain* chain) {
-    REQ(E && F0 && keys && chain && (chain->flags & COGNN_PC_TRUNC_IN), "gemm_pair_chain: bad arguments");
-    std::vector<u64> z[2];
-    for (int p = 0; p < 2; ++p) {
-        z[p].resize((size_t)std::max<int64_t>(M * N, 1));
-        if (int rc = cognn_beaver_gemm_close2_u64(ctx, z[p].data(), E, nullptr, F0, F1, nullptr, keys, p, M, N, K, 0, scratch0, 1)) return rc;
-    }
-    cognn_pair_chain ch = *chain;
-    ch.x[0] = z[0].data(); ch.x[1] = z[1].data(); ch.rows = M; ch.F = N; ch.gemm_keys = *keys;
-    return cognn_pair_chain_u64(ctx, &ch, 1);
-}
 // the fused gather = the plain gather of both sides' row segments into temporaries, then the pair chain on them
 int cognn_gather_pair_chain_u64(cognn_ctx* ctx, const uint64_t* table, const uint32_t* rowptr, const uint32_t* col, int64_t F,
                                 const cognn_gather_pair* pairs, int32_t count) {

@@ -85,22 +85,6 @@ def test_whole_epochs_in_one_call_bit_exact(k):
     eng.close()
 
 
-@pytest.mark.parametrize("dims", [(40, 16, 5), (40, 32, 5)])
-@pytest.mark.parametrize("variant", ["optimize-gcn", "optimize-gcn-inference"])
-def test_fused_pair_products_bit_exact(dims, variant, monkeypatch):
-    """>= 256 rows per party: the co-located pairs' N <= 16 products run as cognn_beaver_gemm_pair_chain_u64 (both sides' closes
-    and their chain in one launch) - the layer-0 product with hidden_dim = 16 (cached feature opening), the layer-1 product with
-    hidden_dim = 32 (the opening the ReLU chain left, summed) - every GAS iteration against the oracle."""
-    k = 2
-    monkeypatch.setenv("COGNN_PAIR_PRODUCTS", "1")                       # (off by default: not faster on MI355X, DESIGN.md §5)
-    oracle, eng = _setup(k, 1300, 3000, dims[0], dims[1], dims[2], variant=variant, seed=33)
-    for it in range(6 if variant == "optimize-gcn" else 2):
-        oracle.iteration(it)
-        eng.run(it, it + 1)
-        _compare(oracle, eng, k, it)
-    eng.close()
-
-
 def test_forward_only_inference_pass_matches():
     """COGNN_OPT_FORWARD_ONLY (what bench.py and `gcn-inference-optimize -m 2` set): the prediction layer's shares and metrics are those of
     the full path; a backward iteration is refused."""

@@ -31,7 +31,7 @@ def _run(cfg, world, tmp_path):
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   OMP_NUM_THREADS="1", **cfg.get("env", {}))
+                   OMP_NUM_THREADS="1")
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "multirank_worker.py"), json.dumps(cfg)], env=env))
     for p in procs:
         assert p.wait(timeout=300) == 0
@@ -105,13 +105,6 @@ def test_whole_epochs_per_call(tmp_path):
     for the next product) on one rank and on two."""
     _check(dict(BASE, k=3, iters=12, whole_epochs=True), 1, tmp_path)
     _check(dict(BASE, k=4, iters=12, whole_epochs=True), 2, tmp_path)
-
-
-def test_fused_pair_products_host_logic(tmp_path):
-    """COGNN_PAIR_PRODUCTS=1: the co-located pairs' N <= 16 products go through cognn_beaver_gemm_pair_chain_u64 (product and
-    chain in one call; the plain-C++ backend takes every N <= 16 shape) - one rank, and two ranks with co-located and crossing pairs."""
-    _check(dict(BASE, k=3, iters=12, env={"COGNN_PAIR_PRODUCTS": "1"}), 1, tmp_path)
-    _check(dict(BASE, k=4, iters=6, env={"COGNN_PAIR_PRODUCTS": "1"}), 2, tmp_path)
 
 
 def test_single_rank_host_logic_three_parties(tmp_path):

@@ -218,50 +218,3 @@ def test_gather_with_pair_chain_epilogue_equals_gather_then_chain(ctx, F, relu, 
                 assert np.array_equal(host(bufs[3]), e1 - co.prng_shape(ok[1], e1.shape))
         if not forward_only:
             assert np.array_equal(host(bufs[0]), e0) and np.array_equal(host(bufs[1]), e1)
-
-
-@pytest.mark.parametrize("M,N,K,flags,open_sum", [(4096, 16, 64, TRUNC_IN | SCALE, False), (300, 7, 33, TRUNC_IN, True),
-                                                  (40000, 16, 128, TRUNC_IN | SCALE | RELU, True), (1000, 16, 40, TRUNC_IN, False)])
-def test_beaver_product_with_pair_chain_epilogue(ctx, M, N, K, flags, open_sum):
-    """cognn_beaver_gemm_pair_chain_u64: both parties' closes and the chain on the two products in one launch, against the
-    oracle's beaver_gemm_pair followed by its two-party step functions."""
-    from cognn_amd import capi
-    assert ctx.lib.cognn_beaver_gemm_pair_fusable(M, N, K) == 1
-    rng = np.random.default_rng(M + N + K)
-    X = co.fx_encode(rng.normal(size=(M, K))); W = co.fx_encode(rng.normal(size=(K, N)) * 0.3)
-    X0 = rand_u64(rng, (M, K)); W0 = rand_u64(rng, (K, N))
-    with np.errstate(over="ignore"):
-        X1 = X - X0; W1 = W - W0
-    gk, gkf = _keys(4, 1, 7, co.OP_PS_GEMM)
-    ks = {n: _keys(4, 1, 7, op) for n, op in (("tin", co.OP_PS_GEMM_TRUNC), ("scale", co.OP_PS_SCALE), ("strunc", co.OP_PS_SCALE_TRUNC),
-                                                ("relu", co.OP_AP_RELU))}
-    kf = {n: v[1] for n, v in ks.items()}; kf["gemm"] = gkf
-    with np.errstate(over="ignore"):
-        E = (X0 - co.prng_shape(gkf(co.SL_A0), (M, K))) + (X1 - co.prng_shape(gkf(co.SL_A1), (M, K)))
-        F0 = W0 - co.prng_shape(gkf(co.SL_B0), (K, N)); F1 = W1 - co.prng_shape(gkf(co.SL_B1), (K, N))
-    c1 = dev_empty((M, N)); sa = dev_empty(M * K + K * N); sb = dev_empty(M * K + K * N)
-    ctx.call("cognn_dealer_gemm_c1_u64", ptr(c1), ctypes.byref(gk), M, N, K, 0, ptr(sa), ctypes.c_void_p(sa.data_ptr() + 8 * M * K))
-    s0 = co.normalizer(rng.integers(0, 9, size=M)); s1 = np.zeros(M, dtype=U64)
-    ok0, ok1 = co.stream_key(1, 2, 3, 4, 0), co.stream_key(1, 2, 3, 4, 1)
-    out0, out1, op0, op1 = (dev_empty((M, N)) for _ in range(4))
-    mask = dev_empty((M, N), "u8")
-    c = capi.PairChain()
-    c.c1 = c1.data_ptr(); c.scale[0] = dev(s0).data_ptr(); c.scale[1] = dev(s1).data_ptr()
-    c.out[0] = out0.data_ptr(); c.out[1] = out1.data_ptr(); c.open[0] = op0.data_ptr(); c.open[1] = None if open_sum else op1.data_ptr()
-    c.mask = mask.data_ptr(); c.open_key[0] = ok0; c.open_key[1] = ok1
-    c.trunc_in_keys = ks["tin"][0]; c.scale_keys = ks["scale"][0]; c.scale_trunc_keys = ks["strunc"][0]; c.relu_keys = ks["relu"][0]
-    c.rows = M; c.F = N; c.flags = flags | (OPEN_SUM if open_sum else 0)
-    ctx.call("cognn_beaver_gemm_pair_chain_u64", ptr(dev(E)), ptr(dev(F0)), ptr(dev(F1)), ctypes.byref(gk), M, N, K, ptr(sa), ptr(sb), ctypes.byref(c))
-    z0, z1 = co.beaver_gemm_pair(X0, X1, W0, W1, gkf)              # the products with C_p
-    e0, e1, pos = _expect(flags | NO_C, z0, z1, None, s0, s1, kf)
-    assert np.array_equal(host(out0), e0) and np.array_equal(host(out1), e1)
-    with np.errstate(over="ignore"):
-        if open_sum:
-            assert np.array_equal(host(op0), (e0 - co.prng_shape(ok0, (M, N))) + (e1 - co.prng_shape(ok1, (M, N))))
-        else:
-            assert np.array_equal(host(op0), e0 - co.prng_shape(ok0, (M, N))) and np.array_equal(host(op1), e1 - co.prng_shape(ok1, (M, N)))
-    if flags & RELU:
-        assert np.array_equal(host(mask, np.uint8).astype(bool), pos)
-    assert ctx.lib.cognn_beaver_gemm_pair_fusable(4096, 64, 128) == 0 and ctx.lib.cognn_beaver_gemm_pair_fusable(1354, 16, 1433) == 0   # N > 16; split-K shape
-    with pytest.raises(capi.CognnError, match="not fusable"):
-        ctx.call("cognn_beaver_gemm_pair_chain_u64", ptr(dev(E)), ptr(dev(F0)), None, ctypes.byref(gk), 1354, 16, 1433, ptr(sa), ptr(sb), ctypes.byref(c))
