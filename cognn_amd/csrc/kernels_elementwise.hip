@@ -584,11 +584,13 @@ __global__ __launch_bounds__(kThreads) void pair_chain_kernel(PairBatch b) {
         }
     }
     if (flags & COGNN_PC_SCALE) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const u64 idx = (u64)(i + j);
-            pair_scale(d, idx, (u64)((uint32_t)idx / d.F), (flags & COGNN_PC_INPUT_OPENED) != 0, v0[j], v1[j]);
-        }
+        // i is even: with an even row width both elements lie in one row, whose values are formed once
+        const uint32_t row0 = (uint32_t)i / d.F, row1 = (d.F & 1u) ? (uint32_t)(i + 1) / d.F : row0;
+        const PairRow rw0 = pair_row(d, (u64)row0);
+        PairRow rw1 = rw0;
+        if (row1 != row0 && w == 2) rw1 = pair_row(d, (u64)row1);
+        pair_scale(d, (u64)i, rw0, (flags & COGNN_PC_INPUT_OPENED) != 0, v0[0], v1[0]);
+        pair_scale(d, (u64)i + 1, rw1, (flags & COGNN_PC_INPUT_OPENED) != 0, v0[1], v1[1]);
     }
     if (flags & COGNN_PC_RELU) {
         bool pos[2];

@@ -207,9 +207,11 @@ __device__ __forceinline__ void gather_pair_chain_body(const u64* __restrict__ t
                 const u64 idx = (u64)vr * (u64)F + (u64)off;
                 u64 a[2] = {sum[0].x, sum[0].y}, bb[2] = {sum[1].x, sum[1].y};
                 bool pos[2] = {true, true};
+                PairRow rw = {0, 0, 0};
+                if (d.flags & COGNN_PC_SCALE) rw = pair_row(d, (u64)vr);
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    if (d.flags & COGNN_PC_SCALE) pair_scale(d, idx + j, (u64)vr, false, a[j], bb[j]);
+                    if (d.flags & COGNN_PC_SCALE) pair_scale(d, idx + j, rw, false, a[j], bb[j]);
                     if (d.flags & COGNN_PC_RELU) pos[j] = pair_relu(d, idx + j, a[j], bb[j]);
                 }
                 if ((d.flags & COGNN_PC_RELU) && d.mask) { d.mask[idx] = pos[0] ? 1 : 0; d.mask[idx + 1] = pos[1] ? 1 : 0; }

@@ -434,8 +434,8 @@ void beaver_gemm_ws_kernel(u64* Z, const u64* __restrict__ E0, const u64* __rest
             u64 v_[4], w_[4];                                                                                             \
             v_[0] = s0_[r][0].x + (s1_[r][0].x & e1mask); v_[1] = s0_[r][0].y + (s1_[r][0].y & e1mask);                    \
             v_[2] = s0_[r][1].x + (s1_[r][1].x & e1mask); v_[3] = s0_[r][1].y + (s1_[r][1].y & e1mask);                    \
-            u64 x_ = keyA + ((u64)m_ * (u64)K + (u64)k_ + 1ull) * COGNN_GAMMA;                                            \
-            _Pragma("unroll") for (int j = 0; j < 4; ++j) { w_[j] = (DBG & 2) ? x_ : cognn_mix64(x_); x_ += COGNN_GAMMA; } \
+            const u64 x_ = (u64)m_ * (u64)K + (u64)k_;                                                                    \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) w_[j] = (DBG & 2) ? x_ + j : cognn_prng(keyA, x_ + j);          \
             if (!FULL) {                                                                                                  \
                 _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                           \
                     const u64 keep_ = (m_ < M && k_ + j < K) ? ~0ull : 0ull;                                              \
@@ -598,9 +598,9 @@ __global__ __launch_bounds__(256) void beaver_gemm_d16_kernel(u64* Z, const u64*
         if (st + 1 < st1) load_step(st + 1, cur0, cur1);     // next step's opened shares are in flight during this step's arithmetic
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            u64 x = keyA + ((u64)m * (u64)K + (u64)(st * 32 + 8 * j + 2 * b) + 1ull) * COGNN_GAMMA;
-            w[2 * j] = cognn_mix64(x);
-            w[2 * j + 1] = cognn_mix64(x + COGNN_GAMMA);
+            const u64 x = (u64)m * (u64)K + (u64)(st * 32 + 8 * j + 2 * b);
+            w[2 * j] = cognn_prng(keyA, x);
+            w[2 * j + 1] = cognn_prng(keyA, x + 1);
         }
         if (!FULL) {
 #pragma unroll
@@ -714,9 +714,9 @@ void beaver_gemm_d16n_kernel(u64* Z, const u64* __restrict__ E0, const u64* __re
         if (it + 1 < total) load_step(it + 1);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            u64 x = keyA + ((u64)m * (u64)K + (u64)(st * 32 + 8 * j + 2 * b) + 1ull) * COGNN_GAMMA;
-            w[2 * j] = (DBG & 2) ? x : cognn_mix64(x);
-            w[2 * j + 1] = (DBG & 2) ? x + 1 : cognn_mix64(x + COGNN_GAMMA);
+            const u64 x = (u64)m * (u64)K + (u64)(st * 32 + 8 * j + 2 * b);
+            w[2 * j] = (DBG & 2) ? x : cognn_prng(keyA, x);
+            w[2 * j + 1] = (DBG & 2) ? x + 1 : cognn_prng(keyA, x + 1);
         }
         if (!FULL) {
 #pragma unroll
@@ -960,7 +960,7 @@ void beaver_gemm_tn_ws_kernel(u64* Z, const u64* __restrict__ E0, const u64* __r
         const int mrow = min(m0 + pm, M - 1), ncol = min(pm, N - 1);
         const u64 mkeep = (m0 + pm < M) ? ~0ull : 0ull, nkeep = (pm < N) ? ~0ull : 0ull;
         const int o0 = tn_off(pm, 0, kq), o1 = tn_off(pm, 1, kq);            // segment 0 (E / B_p + pF) and segment 1 (A_p / F) positions
-        const u64 a_step = a_storage ? (u64)M * COGNN_GAMMA : COGNN_GAMMA;
+        const u64 a_step = a_storage ? (u64)M : 1ull;
         u64 a0a[4], a1a[4], fa[4], ga[4], a0b[4], a1b[4], fb[4], gb[4], a0c[4], a1c[4], fc[4], gc[4], a0d[4], a1d[4], fd[4], gd[4];   // four tiles in flight
 #define CG_TN_LOAD(t_, e0_, e1_, f_, g_)                                                                                   \
     do {                                                                                                                  \
@@ -976,15 +976,15 @@ void beaver_gemm_tn_ws_kernel(u64* Z, const u64* __restrict__ E0, const u64* __r
         const int k_ = (st0 + (t_)) * 16 + kq * 4;                                                                        \
         u64 v_[4], w_[4], bp_[4], ff_[4];                                                                                 \
         /* A mask index: logical (m, k) -> m K + k, or storage order k M + m when the operand's untransposed mask is reused */ \
-        u64 xa_ = keyA + ((a_storage ? (u64)k_ * (u64)M + (u64)(m0 + pm) : (u64)(m0 + pm) * (u64)K + (u64)k_) + 1ull) * COGNN_GAMMA; \
-        u64 xb_ = keyB + ((u64)k_ * (u64)N + (u64)pm + 1ull) * COGNN_GAMMA;                                               \
+        u64 xa_ = a_storage ? (u64)k_ * (u64)M + (u64)(m0 + pm) : (u64)(m0 + pm) * (u64)K + (u64)k_;                      \
+        u64 xb_ = (u64)k_ * (u64)N + (u64)pm;                                                                             \
         _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                   \
             const u64 kk_ = (k_ + j < K) ? ~0ull : 0ull;                                                                  \
             v_[j] = (e0_[j] + (e1_[j] & e1mask)) & mkeep & kk_;                                                           \
-            w_[j] = ((DBG & 2) ? xa_ : cognn_mix64(xa_)) & mkeep & kk_;                                                   \
+            w_[j] = ((DBG & 2) ? xa_ : cognn_prng(keyA, xa_)) & mkeep & kk_;                                              \
             ff_[j] = (f_[j] + (g_[j] & f1mask)) & nkeep & kk_;                                                            \
-            bp_[j] = (((DBG & 2) ? xb_ : cognn_mix64(xb_)) & nkeep & kk_) + (p == 1 ? ff_[j] : 0ull);                     \
-            xa_ += a_step; xb_ += (u64)N * COGNN_GAMMA;                                                                   \
+            bp_[j] = (((DBG & 2) ? xb_ : cognn_prng(keyB, xb_)) & nkeep & kk_) + (p == 1 ? ff_[j] : 0ull);                \
+            xa_ += a_step; xb_ += (u64)N;                                                                                 \
         }                                                                                                                 \
         if (DBG & 8) { if ((v_[0] ^ w_[1] ^ bp_[2] ^ ff_[3]) == 0x1234567ull) Z[0] = v_[1] ^ w_[0] ^ bp_[0] ^ ff_[0]; break; } \
         uint32_t pe_[8], pm_[8], pb_[8], pf_[8];                                                                          \
@@ -1110,7 +1110,7 @@ void beaver_gemm_tn_d16_kernel(u64* Z, const u64* __restrict__ E0, const u64* __
                 const int k = st * 32 + bk[q] + j;
                 const u64 keep = (bn[q] < N && k < K) ? ~0ull : 0ull;
                 const u64 f = (TWO ? f0[q][j] + f1[q][j] : f0[q][j]) & keep;
-                v[j] = ((cognn_mix64(keyB + ((u64)k * (u64)N + (u64)bn[q] + 1ull) * COGNN_GAMMA) & keep) + (p == 1 ? f : 0ull));
+                v[j] = ((cognn_prng(keyB, (u64)k * (u64)N + (u64)bn[q]) & keep) + (p == 1 ? f : 0ull));
                 v[2 + j] = f;
             }
             uint32_t pl[8];
@@ -1143,13 +1143,13 @@ void beaver_gemm_tn_d16_kernel(u64* Z, const u64* __restrict__ E0, const u64* __
         }
         if (active) {
             const int k0 = st * 32 + b * 8;
-            u64 x = keyA + ((a_storage ? (u64)k0 * (u64)M + (u64)m : (u64)m * (u64)K + (u64)k0) + 1ull) * COGNN_GAMMA;
-            const u64 xs = a_storage ? (u64)M * COGNN_GAMMA : COGNN_GAMMA;
+            u64 x = a_storage ? (u64)k0 * (u64)M + (u64)m : (u64)m * (u64)K + (u64)k0;
+            const u64 xs = a_storage ? (u64)M : 1ull;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const u64 keep = (mok && k0 + e < K) ? ~0ull : 0ull;
                 v[e] &= keep;
-                w[e] = cognn_mix64(x) & keep;
+                w[e] = cognn_prng(keyA, x) & keep;
                 x += xs;
             }
             uint32_t pe0[8], pe1[8], pm0[8], pm1[8];

@@ -36,12 +36,20 @@ __device__ __forceinline__ void pair_trunc(u64 kR, u64 kR0, u64 kRP0, u64 idx, u
     v0 = ((c0 + c1) >> COGNN_FX_BITS) - (COGNN_TRUNC_OFFSET >> COGNN_FX_BITS) - rp0;     // TruncClose, p = 0
     v1 = 0ull - ((rfull >> COGNN_FX_BITS) - rp0);                                        // TruncClose, p = 1
 }
-// row scale by the shared vector (sc0, sc1) + truncation of element idx (row = idx / F)
-__device__ __forceinline__ void pair_scale(const PairChainDev& d, u64 idx, u64 row, bool opened, u64& v0, u64& v1) {
+// the per-row values of the row scale: the dealer's b shares and the opened g = (s_0 - b_0) + (s_1 - b_1) - once per row, not
+// once per element
+struct PairRow { u64 b0, b1, g; };
+__device__ __forceinline__ PairRow pair_row(const PairChainDev& d, u64 row) {
+    PairRow r;
+    r.b0 = cognn_prng(d.sB0, row); r.b1 = cognn_prng(d.sB1, row);
+    r.g = (d.sc0[row] - r.b0) + (d.sc1[row] - r.b1);                                              // RowscaleOpenG, both sides
+    return r;
+}
+// row scale by the shared vector (sc0, sc1) + truncation of element idx of row `rw`
+__device__ __forceinline__ void pair_scale(const PairChainDev& d, u64 idx, const PairRow& rw, bool opened, u64& v0, u64& v1) {
     const u64 a0 = cognn_prng(d.sA0, idx), a1 = cognn_prng(d.sA1, idx), c0m = cognn_prng(d.sC0, idx);
-    const u64 b0 = cognn_prng(d.sB0, row), b1 = cognn_prng(d.sB1, row);
+    const u64 b0 = rw.b0, b1 = rw.b1, g = rw.g;
     const u64 e = opened ? v0 + v1 : (v0 - a0) + (v1 - a1);                                       // RowscaleOpenE, both sides
-    const u64 g = (d.sc0[row] - b0) + (d.sc1[row] - b1);                                          // RowscaleOpenG, both sides
     const u64 z0 = e * b0 + a0 * g + c0m;                                                         // beaver_mul_b, p = 0
     const u64 c1m = (a0 + a1) * (b0 + b1) - c0m;
     const u64 z1 = e * g + e * b1 + a1 * g + c1m;                                                 // beaver_mul_b, p = 1

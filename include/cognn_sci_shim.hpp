@@ -299,9 +299,14 @@ public:
     static void intoShares(double v, uint64_t& s0, uint64_t& s1) {
         cognn_keys k;
         cognn_make_keys(state().seed, state().tag, 0, cognn_shim::OP_SHARE, &k);
-        // prng(key, idx) = mix64(key + (idx+1)*GAMMA), the definition of cognn_amd/csrc/cognn_spec.h restated for host use
-        uint64_t z = k.k[0] + (state().idx++ + 1) * 0x9E3779B97F4A7C15ull;
-        z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull; z ^= z >> 27; z *= 0x94D049BB133111EBull; z ^= z >> 31;
+        // prng(key, idx) of cognn_amd/csrc/cognn_spec.h restated for host use: four multiply-fold rounds on z = idx ^ key
+        const uint64_t key = k.k[0], hi = 0xFFFFFFFF00000000ull;
+        const uint32_t mul[4] = {0x97D6730Eu, 0xC140D344u, 0xF849CBC2u, 0xEC6F6B54u};
+        uint64_t z = state().idx++ ^ key;
+        for (int i = 0; i < 4; ++i) {
+            z += (uint64_t)(uint32_t)z * mul[i];
+            if (i < 3) z = (z & hi) | (uint32_t)(((uint32_t)z ^ (uint32_t)(z >> 32)) + (i == 1 ? (uint32_t)(key >> 32) : 0u));
+        }
         s1 = z;
         s0 = encodeDoubleAsFixedPoint(v) - s1;
     }

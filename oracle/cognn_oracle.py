@@ -75,11 +75,24 @@ def mix64_np(z):
     return z
 
 
+PRNG_C = (0x97D6730E, 0xC140D344, 0xF849CBC2, 0xEC6F6B54)    # even multipliers: every round is a bijection
+
+
 def prng(key, n, start=0):
-    """prng(key, idx) = mix64(key + (idx+1)*GAMMA), idx = start..start+n-1."""
+    """prng(key, idx), idx = start..start+n-1: four multiply-fold rounds on z = idx ^ key -
+    z += lo32(z) * C_i, then lo32(z) ^= hi32(z) between rounds (the middle fold also adds hi32(key))."""
+    lo_mask, hi_mask = U64(0xFFFFFFFF), U64(0xFFFFFFFF00000000)
     with np.errstate(over="ignore"):
-        idx = np.arange(start + 1, start + n + 1, dtype=U64)
-        return mix64_np(idx * U64(GAMMA) + U64(key))
+        z = np.arange(start, start + n, dtype=U64) ^ U64(key)
+        key_hi = U64(key >> 32)
+        for i, c in enumerate(PRNG_C):
+            z = z + (z & lo_mask) * U64(c)
+            if i < 3:
+                lo = (z & lo_mask) ^ (z >> U64(32))
+                if i == 1:
+                    lo = (lo + key_hi) & lo_mask
+                z = (z & hi_mask) | lo
+        return z
 
 
 def prng_shape(key, shape):
