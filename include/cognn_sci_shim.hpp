@@ -4,9 +4,16 @@
 // (include/ss_vertex_centric_algo_kernel.h) call free functions of libraries that are not in its tree (SCIHarness.h,
 // ObliviousMapper.h, SecureAggregation.h, TaskUtil.h) on nested std::vector<uint64_t> containers.  This header defines
 // those containers as include/task/task.h:237,240,272 does and implements every function the optimize-gcn path calls,
-// with the call-site signatures, on top of the C ABI of libcognn_hip.so (include/cognn_hip.h): upload -> HIP kernels ->
-// download, the two roles of a call meeting through a Channel.  A maintainer compiles gcn.h / ss_...h against this
-// header instead of the absent ones and links -lcognn_hip.
+// with the call-site signatures, on top of the C ABI of libcognn_hip.so (include/cognn_hip.h).  A maintainer compiles
+// gcn.h / ss_...h against this header instead of the absent ones and links -lcognn_hip.
+//
+// Every function exists for TWO container types:
+//   * ShareVecVec (nested host vectors, exactly the reference's type): upload -> HIP kernels -> download per call;
+//   * cognn_shim::DevMat (a [rows x cols] uint64 tensor resident in device memory): no tensor leaves the device - the two
+//     roles of a call hand their openings over device to device (Channel::exchange_device), index structure (oblivious-mapper
+//     positions, aggregation runs, masks, normalisers) is turned into device arrays once and cached per session.
+//   include/cognn_gas_kernel.hpp (the GAS callbacks of ss_...h:78-133 as a class template over the container type) is built on
+//   the second form.
 //
 //   reference call site                                                         here
 //   sci::twoPartyGCNMatMul(A, B, out, coTid, party)            gcn.h:233,665,671,710   Beaver product + truncation
@@ -75,32 +82,47 @@ inline void check(int rc, const char* what) {
 struct Channel {
     virtual ~Channel() {}
     virtual void exchange(const void* send, size_t send_bytes, void* recv, size_t recv_bytes) = 0;
+    // The same round on DEVICE buffers.  Default: staged through host memory (any transport that moves host bytes works);
+    // a transport that can move device memory itself (the in-process pipe below, cognn_exchange.h between GPUs) overrides it.
+    virtual void exchange_device(cognn_ctx* ctx, const void* send_dev, size_t send_bytes, void* recv_dev, size_t recv_bytes) {
+        std::vector<uint8_t> a(send_bytes), b(recv_bytes);
+        if (send_bytes) check(cognn_memcpy_d2h(ctx, a.data(), send_dev, send_bytes), "cognn_memcpy_d2h");
+        exchange(a.data(), send_bytes, b.data(), recv_bytes);
+        if (recv_bytes) check(cognn_memcpy_h2d(ctx, recv_dev, b.data(), recv_bytes), "cognn_memcpy_h2d");
+    }
 };
 
-// Both roles in one process (two threads): a rendezvous in host memory.  The remote case is a Channel over whatever
-// transport the two processes share (the reference's TaskComm / CommSync sockets, or cognn_exchange.h for device buffers).
+// Both roles in one process (two threads): a rendezvous.  Host rounds copy through the sender's buffer, device rounds are one
+// device-to-device copy per side.  The remote case is a Channel over whatever transport the two processes share (the
+// reference's TaskComm / CommSync sockets, or cognn_exchange.h for device buffers).
 class LocalPipe {
 public:
     class End : public Channel {
     public:
         End(LocalPipe* p, int me) : pipe_(p), me_(me) {}
-        void exchange(const void* send, size_t sb, void* recv, size_t rb) override {
-            std::unique_lock<std::mutex> lk(pipe_->m_);
-            pipe_->cv_.wait(lk, [&] { return !pipe_->full_[me_]; });
-            pipe_->buf_[me_].assign((const uint8_t*)send, (const uint8_t*)send + sb);
-            pipe_->full_[me_] = true;
-            pipe_->cv_.notify_all();
-            pipe_->cv_.wait(lk, [&] { return pipe_->full_[1 - me_]; });
-            if (pipe_->buf_[1 - me_].size() != rb) {
-                pipe_->full_[1 - me_] = false;
-                pipe_->cv_.notify_all();
-                throw Error("cognn_shim: the two roles disagree on a message size (protocol calls out of step)");
-            }
-            if (rb) std::memcpy(recv, pipe_->buf_[1 - me_].data(), rb);
-            pipe_->full_[1 - me_] = false;
-            pipe_->cv_.notify_all();
+        void exchange(const void* send, size_t sb, void* recv, size_t rb) override { round(nullptr, send, sb, recv, rb); }
+        void exchange_device(cognn_ctx* ctx, const void* send_dev, size_t sb, void* recv_dev, size_t rb) override {
+            check(cognn_ctx_sync(ctx), "cognn_ctx_sync");            // what is handed over is complete
+            round(ctx, send_dev, sb, recv_dev, rb);
         }
     private:
+        // both sides publish their send buffer, meet, copy the other side's buffer, meet again (then a sender may reuse its buffer)
+        void round(cognn_ctx* ctx, const void* send, size_t sb, void* recv, size_t rb) {
+            LocalPipe& P = *pipe_;
+            std::unique_lock<std::mutex> lk(P.m_);
+            P.ptr_[me_] = send; P.bytes_[me_] = sb;
+            P.meet(lk);
+            const void* theirs = P.ptr_[1 - me_];
+            const bool ok = P.bytes_[1 - me_] == rb;
+            lk.unlock();
+            if (ok && rb) {
+                if (ctx) { check(cognn_memcpy_d2d(ctx, recv, theirs, rb), "cognn_memcpy_d2d"); check(cognn_ctx_sync(ctx), "cognn_ctx_sync"); }
+                else std::memcpy(recv, theirs, rb);
+            }
+            lk.lock();
+            P.meet(lk);
+            if (!ok) throw Error("cognn_shim: the two roles disagree on a message size (protocol calls out of step)");
+        }
         LocalPipe* pipe_;
         int me_;
     };
@@ -108,10 +130,17 @@ public:
     Channel* alice() { return &a_; }
     Channel* bob() { return &b_; }
 private:
+    void meet(std::unique_lock<std::mutex>& lk) {                        // reusable two-party barrier
+        const uint64_t gen = gen_;
+        if (++arrived_ == 2) { arrived_ = 0; ++gen_; cv_.notify_all(); }
+        else cv_.wait(lk, [&] { return gen_ != gen; });
+    }
     std::mutex m_;
     std::condition_variable cv_;
-    std::vector<uint8_t> buf_[2];
-    bool full_[2] = {false, false};
+    const void* ptr_[2] = {nullptr, nullptr};
+    size_t bytes_[2] = {0, 0};
+    int arrived_ = 0;
+    uint64_t gen_ = 0;
     End a_, b_;
 };
 
@@ -126,6 +155,7 @@ public:
     Dev& operator=(const Dev&) = delete;
     uint64_t* u64() const { return (uint64_t*)p_; }
     void* ptr() const { return p_; }
+    cognn_ctx* ctx() const { return ctx_; }
     void up(const void* host) { if (bytes_) check(cognn_memcpy_h2d(ctx_, p_, host, bytes_), "cognn_memcpy_h2d"); }
     void down(void* host) const { if (bytes_) check(cognn_memcpy_d2h(ctx_, host, p_, bytes_), "cognn_memcpy_d2h"); }
     size_t bytes() const { return bytes_; }
@@ -151,33 +181,97 @@ inline void unflatten(const std::vector<uint64_t>& f, size_t rows, size_t cols, 
     out.swap(o);
 }
 
+// ShareVecVec on the device: a flat row-major [rows x cols] uint64 tensor (the a1 row of SURVEY.md §8).  Copies share the
+// buffer (a tensor is never modified once another DevMat may see it: functions that "update in place" rebind to a new buffer).
+class DevMat {
+public:
+    DevMat() {}
+    DevMat(cognn_ctx* c, size_t r, size_t cl) : buf_(std::make_shared<Dev>(c, r * cl)), rows_(r), cols_(cl) {}
+    static DevMat from_host(cognn_ctx* c, const ShareVecVec& v) {
+        size_t r, cl;
+        std::vector<uint64_t> f = flatten(v, &r, &cl);
+        DevMat m(c, r, cl);
+        m.buf_->up(f.data());
+        return m;
+    }
+    void to_host(ShareVecVec& out) const {
+        std::vector<uint64_t> f(elems());
+        if (buf_) buf_->down(f.data());
+        unflatten(f, rows_, cols_, out);
+    }
+    DevMat clone(cognn_ctx* c = nullptr) const {
+        if (!buf_) return DevMat();
+        DevMat m(c ? c : buf_->ctx(), rows_, cols_);
+        check(cognn_memcpy_d2d(m.ctx(), m.u64(), u64(), elems() * 8), "cognn_memcpy_d2d");
+        check(cognn_ctx_sync(m.ctx()), "cognn_ctx_sync");
+        return m;
+    }
+    size_t size() const { return rows_; }                    // number of rows, like ShareVecVec::size()
+    bool empty() const { return rows_ == 0; }
+    size_t rows() const { return rows_; }
+    size_t cols() const { return cols_; }
+    size_t elems() const { return rows_ * cols_; }
+    uint64_t* u64() const { return buf_ ? buf_->u64() : nullptr; }
+    cognn_ctx* ctx() const { return buf_ ? buf_->ctx() : nullptr; }
+    const Dev& dev() const { return *buf_; }
+    Dev& dev() { return *buf_; }
+    bool shared() const { return buf_ && buf_.use_count() > 1; }
+    void clear() { buf_.reset(); rows_ = cols_ = 0; }
+    void swap(DevMat& o) { buf_.swap(o.buf_); std::swap(rows_, o.rows_); std::swap(cols_, o.cols_); }
+private:
+    std::shared_ptr<Dev> buf_;
+    size_t rows_ = 0, cols_ = 0;
+};
+
+// index structure of a row gather (oblivious mapper, aggregation runs, masked add) as device CSR arrays, built once
+struct Plan {
+    std::unique_ptr<Dev> rowptr, col;
+    size_t rows = 0;
+};
+
+inline uint64_t fnv(const void* p, size_t n, uint64_t h = 0xcbf29ce484222325ull) {
+    const uint8_t* b = (const uint8_t*)p;
+    for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 0x100000001b3ull; }
+    return h;
+}
+
 // One role (ALICE = owner share p 0, BOB = co-party share p 1) of one pair.
 struct Session {
     cognn_ctx* ctx = nullptr;
     int p = 0;
     uint64_t seed = 0, owner = 0, counter = 0;
     Channel* ch = nullptr;
+    std::map<uint64_t, std::unique_ptr<Plan>> plans;         // by hash of the index structure (both roles hold the same plans)
+    std::map<uint64_t, std::unique_ptr<Dev>> vectors;        // host side vectors already on the device (normalisers, labels)
 
     cognn_keys keys(int op) const {
         cognn_keys k;
         cognn_make_keys(seed, owner, counter, (uint64_t)op, &k);
         return k;
     }
-    // d2h mine, swap with the other role, h2d theirs
-    void swap_dev(const Dev& mine, Dev& theirs) {
-        std::vector<uint8_t> a(mine.bytes()), b(theirs.bytes());
-        mine.down(a.data());
-        ch->exchange(a.data(), a.size(), b.data(), b.size());
-        theirs.up(b.data());
-    }
+    // one exchange round on device buffers
+    void swap_dev(const Dev& mine, Dev& theirs) { ch->exchange_device(ctx, mine.ptr(), mine.bytes(), theirs.ptr(), theirs.bytes()); }
+    void swap_mat(const DevMat& mine, DevMat& theirs) { ch->exchange_device(ctx, mine.u64(), mine.elems() * 8, theirs.u64(), theirs.elems() * 8); }
     // truncation by 2^f of `x` times the public constant `mul`; mode 1: out = out - result
-    void trunc(Dev& out, const Dev& x, uint64_t mul, int op, int64_t n, int mode = 0) {
+    void trunc(uint64_t* out, const uint64_t* x, uint64_t mul, int op, int64_t n, int mode = 0) {
         cognn_keys tk = keys(op);
         Dev c(ctx, (size_t)n), cp(ctx, (size_t)n);
-        check(cognn_trunc_open_u64(ctx, c.u64(), x.u64(), mul, &tk, p, n), "cognn_trunc_open_u64");
+        check(cognn_trunc_open_u64(ctx, c.u64(), x, mul, &tk, p, n), "cognn_trunc_open_u64");
         swap_dev(c, cp);
-        check(cognn_trunc_close_u64(ctx, out.u64(), p == 0 ? c.u64() : nullptr, p == 0 ? cp.u64() : nullptr, &tk, p, mode, n),
+        check(cognn_trunc_close_u64(ctx, out, p == 0 ? c.u64() : nullptr, p == 0 ? cp.u64() : nullptr, &tk, p, mode, n),
               "cognn_trunc_close_u64");
+        check(cognn_ctx_sync(ctx), "cognn_ctx_sync");        // c / cp are released on return
+    }
+    // a host vector on the device, uploaded once per distinct content
+    const Dev& cached(const void* host, size_t elems, size_t elem_bytes) {
+        const uint64_t h = fnv(host, elems * elem_bytes, 0x9E3779B97F4A7C15ull + elems * 31 + elem_bytes);
+        auto f = vectors.find(h);
+        if (f == vectors.end()) {
+            std::unique_ptr<Dev> d(new Dev(ctx, elems, elem_bytes));
+            d->up(host);
+            f = vectors.emplace(h, std::move(d)).first;
+        }
+        return *f->second;
     }
 };
 
@@ -205,7 +299,10 @@ inline void open_session(uint64_t selfTid, uint64_t coTid, int party, uint64_t s
 inline void close_sessions() {
     Registry& r = Registry::get();
     std::lock_guard<std::mutex> lk(r.m);
-    for (auto& kv : r.sessions) cognn_ctx_destroy(kv.second->ctx);
+    for (auto& kv : r.sessions) {
+        kv.second->plans.clear(); kv.second->vectors.clear();
+        cognn_ctx_destroy(kv.second->ctx);
+    }
     r.sessions.clear();
 }
 inline Session& session(uint64_t coTid, int party) {
@@ -216,64 +313,215 @@ inline Session& session(uint64_t coTid, int party) {
     return *f->second;
 }
 
-// row gather out[r] = sum_{q in rowptr[r]..rowptr[r+1]} table[col[q]] (+ base[r]) through cognn_gather_csr_u64
-inline void gather_rows(Session& s, const ShareVecVec& table, const ShareVecVec* base, const std::vector<uint32_t>& rowptr,
-                        const std::vector<uint32_t>& col, size_t width, ShareVecVec& out) {
-    size_t tr, tc;
-    std::vector<uint64_t> ft = flatten(table, &tr, &tc);
-    if (tr && tc != width) throw Error("cognn_shim: row width mismatch");
-    const size_t rows = rowptr.size() - 1;
-    Dev dt(s.ctx, tr * width), dout(s.ctx, rows * width), drp(s.ctx, rowptr.size(), 4), dcol(s.ctx, col.size(), 4);
-    dt.up(ft.data()); drp.up(rowptr.data()); dcol.up(col.data());
-    std::unique_ptr<Dev> db;
-    if (base) {
-        size_t br, bc;
-        std::vector<uint64_t> fb = flatten(*base, &br, &bc);
-        if (br != rows || (br && bc != width)) throw Error("cognn_shim: base shape mismatch");
-        db.reset(new Dev(s.ctx, br * width));
-        db->up(fb.data());
-    }
-    if (rows && width)
-        check(cognn_gather_csr_u64(s.ctx, dout.u64(), db ? db->u64() : nullptr, dt.u64(), (const uint32_t*)drp.ptr(), (const uint32_t*)dcol.ptr(),
-                                   (int64_t)rows, (int64_t)width), "cognn_gather_csr_u64");
-    std::vector<uint64_t> fo(rows * width);
-    dout.down(fo.data());
-    unflatten(fo, rows, width, out);
+// ---- index plans --------------------------------------------------------------------------------------------------------
+// The client (ALICE) owns the index structure; the server passes placeholders (zero position vectors, ss_...h:1047,1124-1126).
+// Per call the client sends the 64-bit hash of its structure; on a miss - the first use - the structure itself travels, in the
+// clear, and both roles build the same device CSR.  Later calls with the same structure move 16 bytes and no index data.
+enum { PLAN_MAPPER = 1, PLAN_AGGREGATE = 2, PLAN_COND = 3 };
+inline void send_vec(Session& s, std::vector<uint64_t>& v) {  // client -> server
+    uint64_t n = v.size();
+    if (s.p == 0) { s.ch->exchange(&n, 8, nullptr, 0); s.ch->exchange(v.data(), n * 8, nullptr, 0); }
+    else { s.ch->exchange(nullptr, 0, &n, 8); v.resize(n); s.ch->exchange(nullptr, 0, v.data(), n * 8); }
 }
-
-// the position arrays travel from the client to the server in the clear (see header comment)
-inline void share_positions(Session& s, std::vector<uint64_t>& a, std::vector<uint64_t>& b) {
+template <class Build>
+inline const Plan& plan_for(Session& s, int kind, uint64_t flag, std::vector<uint64_t> a, std::vector<uint64_t> b, Build build) {
+    uint64_t msg[2] = {0, flag};
     if (s.p == 0) {
-        uint64_t n[2] = {a.size(), b.size()};
-        s.ch->exchange(n, sizeof(n), nullptr, 0);
-        std::vector<uint64_t> both(a);
-        both.insert(both.end(), b.begin(), b.end());
-        s.ch->exchange(both.data(), both.size() * 8, nullptr, 0);
+        uint64_t h = fnv(a.data(), a.size() * 8, 0xcbf29ce484222325ull ^ (uint64_t)kind * 0x9E3779B97F4A7C15ull ^ flag);
+        h = fnv(b.data(), b.size() * 8, h ^ (a.size() * 0x100000001b3ull));
+        msg[0] = h;
+        s.ch->exchange(msg, 16, nullptr, 0);
     } else {
-        uint64_t n[2];
-        s.ch->exchange(nullptr, 0, n, sizeof(n));
-        std::vector<uint64_t> both(n[0] + n[1]);
-        s.ch->exchange(nullptr, 0, both.data(), both.size() * 8);
-        a.assign(both.begin(), both.begin() + n[0]);
-        b.assign(both.begin() + n[0], both.end());
+        s.ch->exchange(nullptr, 0, msg, 16);
     }
-}
-
-inline void mapper(Session& s, std::vector<uint64_t> srcPos, std::vector<uint64_t> dstPos, const ShareVecVec& src, ShareVecVec& dst,
-                   bool allowMissing) {
-    share_positions(s, srcPos, dstPos);
-    std::map<uint64_t, uint32_t> last;                       // dst[r] = src[last q with srcPos[q] == dstPos[r]]
-    for (size_t q = 0; q < srcPos.size(); ++q) last[srcPos[q]] = (uint32_t)q;
+    auto f = s.plans.find(msg[0]);
+    if (f != s.plans.end()) return *f->second;
+    send_vec(s, a);
+    send_vec(s, b);
     std::vector<uint32_t> rowptr{0}, col;
-    for (uint64_t d : dstPos) {
-        auto f = last.find(d);
-        if (f != last.end()) col.push_back(f->second);
-        else if (!allowMissing) throw Error("cognn_shim: oblivious mapper: destination position missing in the source");
-        rowptr.push_back((uint32_t)col.size());
-    }
-    gather_rows(s, src, nullptr, rowptr, col, src.empty() ? 0 : src[0].size(), dst);
+    build(a, b, msg[1], rowptr, col);
+    std::unique_ptr<Plan> pl(new Plan());
+    pl->rows = rowptr.size() - 1;
+    pl->rowptr.reset(new Dev(s.ctx, rowptr.size(), 4));
+    pl->col.reset(new Dev(s.ctx, col.size(), 4));
+    pl->rowptr->up(rowptr.data());
+    pl->col->up(col.data());
+    return *s.plans.emplace(msg[0], std::move(pl)).first->second;
 }
 
+// out[r] = (base ? base[r] : 0) + sum_{q in rowptr[r]..rowptr[r+1]} table[col[q]]  (cognn_gather_csr_u64)
+inline DevMat gather(Session& s, const DevMat& table, const DevMat* base, const Plan& pl, size_t width) {
+    if (table.rows() && table.cols() != width) throw Error("cognn_shim: row width mismatch");
+    if (base && (base->rows() != pl.rows || (base->rows() && base->cols() != width))) throw Error("cognn_shim: base shape mismatch");
+    DevMat out(s.ctx, pl.rows, width);
+    if (pl.rows && width) {
+        // (an empty table still needs a valid pointer)
+        Dev none(s.ctx, 2);
+        check(cognn_gather_csr_u64(s.ctx, out.u64(), base ? base->u64() : nullptr, table.u64() ? table.u64() : none.u64(), (const uint32_t*)pl.rowptr->ptr(),
+                                   (const uint32_t*)pl.col->ptr(), (int64_t)pl.rows, (int64_t)width), "cognn_gather_csr_u64");
+        check(cognn_ctx_sync(s.ctx), "cognn_ctx_sync");
+    }
+    return out;
+}
+
+// ---- the protocol functions on device tensors ------------------------------------------------------------------------------
+namespace dev {
+
+inline DevMat mapper(Session& s, const std::vector<uint64_t>& srcPos, const std::vector<uint64_t>& dstPos, const DevMat& src, bool allowMissing) {
+    const Plan& pl = plan_for(s, PLAN_MAPPER, allowMissing ? 1 : 0, srcPos, dstPos,
+        [](const std::vector<uint64_t>& sp, const std::vector<uint64_t>& dp, uint64_t allow, std::vector<uint32_t>& rowptr, std::vector<uint32_t>& col) {
+            std::map<uint64_t, uint32_t> last;               // dst[r] = src[last q with srcPos[q] == dstPos[r]]
+            for (size_t q = 0; q < sp.size(); ++q) last[sp[q]] = (uint32_t)q;
+            for (uint64_t d : dp) {
+                auto f = last.find(d);
+                if (f != last.end()) col.push_back(f->second);
+                else if (!allow) throw Error("cognn_shim: oblivious mapper: destination position missing in the source");
+                rowptr.push_back((uint32_t)col.size());
+            }
+        });
+    return gather(s, src, nullptr, pl, src.cols());
+}
+
+// inclusive prefix sum inside each run of equal consecutive positions: row q gathers rows start(q)..q
+inline DevMat aggregate(Session& s, const std::vector<uint64_t>& pos, const DevMat& svv) {
+    const Plan& pl = plan_for(s, PLAN_AGGREGATE, 0, pos, std::vector<uint64_t>(),
+        [](const std::vector<uint64_t>& ps, const std::vector<uint64_t>&, uint64_t, std::vector<uint32_t>& rowptr, std::vector<uint32_t>& col) {
+            size_t start = 0;
+            for (size_t q = 0; q < ps.size(); ++q) {
+                if (q && ps[q] != ps[q - 1]) start = q;
+                for (size_t j = start; j <= q; ++j) col.push_back((uint32_t)j);
+                rowptr.push_back((uint32_t)col.size());
+            }
+        });
+    if (pl.rows != svv.rows()) throw Error("prefix_network_aggregate: one position per row expected");
+    return gather(s, svv, nullptr, pl, svv.cols());
+}
+
+// out = a + (cond ? b : 0) row by row; the condition is the client's (ALICE's) vector
+inline DevMat cond_add(Session& s, const DevMat& a, const DevMat& b, const std::vector<bool>& cond) {
+    if (a.rows() != b.rows() || cond.size() != a.rows()) throw Error("twoPartyGCNCondVectorAddition: shape mismatch");
+    std::vector<uint64_t> c(cond.size());
+    for (size_t r = 0; r < cond.size(); ++r) c[r] = cond[r] ? 1 : 0;
+    const Plan& pl = plan_for(s, PLAN_COND, 0, c, std::vector<uint64_t>(),
+        [](const std::vector<uint64_t>& cs, const std::vector<uint64_t>&, uint64_t, std::vector<uint32_t>& rowptr, std::vector<uint32_t>& col) {
+            for (size_t r = 0; r < cs.size(); ++r) {
+                if (cs[r]) col.push_back((uint32_t)r);
+                rowptr.push_back((uint32_t)col.size());
+            }
+        });
+    return gather(s, b, &a, pl, a.cols());
+}
+
+inline DevMat matmul(Session& s, const DevMat& A, const DevMat& B) {
+    const size_t M = A.rows(), K = A.cols(), N = B.cols();
+    if (K != B.rows()) throw Error("twoPartyGCNMatMul: inner dimensions differ");
+    const int p = s.p;
+    cognn_keys k = s.keys(OP_GEMM);
+    DevMat E(s.ctx, M, K), Ep(s.ctx, M, K), F(s.ctx, K, N), Fp(s.ctx, K, N), Z(s.ctx, M, N), O(s.ctx, M, N);
+    Dev scratch(s.ctx, M * K + K * N);
+    check(cognn_mask_open_u64(s.ctx, E.u64(), A.u64(), k.k[p ? SL_A1 : SL_A0], (int64_t)M, (int64_t)K, 0), "cognn_mask_open_u64");
+    check(cognn_mask_open_u64(s.ctx, F.u64(), B.u64(), k.k[p ? SL_B1 : SL_B0], (int64_t)K, (int64_t)N, 0), "cognn_mask_open_u64");
+    s.swap_mat(E, Ep);                                       // Beaver reveal
+    s.swap_mat(F, Fp);
+    std::unique_ptr<Dev> c1;
+    if (p == 1) {                                            // the dealer's product share (offline phase; dealt in place here)
+        c1.reset(new Dev(s.ctx, M * N));
+        check(cognn_dealer_gemm_c1_u64(s.ctx, c1->u64(), &k, (int64_t)M, (int64_t)N, (int64_t)K, 0, scratch.u64(), scratch.u64() + M * K),
+              "cognn_dealer_gemm_c1_u64");
+    }
+    check(cognn_beaver_gemm_close2_u64(s.ctx, Z.u64(), E.u64(), Ep.u64(), F.u64(), Fp.u64(), c1 ? c1->u64() : nullptr, &k, p, (int64_t)M, (int64_t)N,
+                                       (int64_t)K, 0, scratch.u64(), 0), "cognn_beaver_gemm_close2_u64");
+    s.trunc(O.u64(), Z.u64(), 1, OP_GEMM_TRUNC, (int64_t)(M * N));
+    ++s.counter;
+    return O;
+}
+
+inline DevMat vector_scale(Session& s, const DevMat& in, const std::vector<uint64_t>& rowScale) {
+    const size_t n = in.rows(), F = in.cols();
+    if (rowScale.size() != n) throw Error("twoPartyGCNVectorScale: one scale per row expected");
+    cognn_keys k = s.keys(OP_SCALE), tk = s.keys(OP_SCALE_TRUNC);
+    const Dev& S = s.cached(rowScale.data(), n, 8);
+    DevMat E(s.ctx, n, F), Ep(s.ctx, n, F), c(s.ctx, n, F), cp(s.ctx, n, F), O(s.ctx, n, F);
+    Dev G(s.ctx, n), Gp(s.ctx, n);
+    check(cognn_rowscale_open_u64(s.ctx, E.u64(), G.u64(), in.u64(), S.u64(), &k, s.p, (int64_t)n, (int64_t)F), "cognn_rowscale_open_u64");
+    s.swap_mat(E, Ep);
+    s.swap_dev(G, Gp);
+    check(cognn_rowscale_close_u64(s.ctx, c.u64(), E.u64(), Ep.u64(), G.u64(), Gp.u64(), &k, &tk, s.p, (int64_t)n, (int64_t)F), "cognn_rowscale_close_u64");
+    s.swap_mat(c, cp);
+    check(cognn_trunc_close_u64(s.ctx, O.u64(), s.p == 0 ? c.u64() : nullptr, s.p == 0 ? cp.u64() : nullptr, &tk, s.p, 0, (int64_t)(n * F)),
+          "cognn_trunc_close_u64");
+    check(cognn_ctx_sync(s.ctx), "cognn_ctx_sync");
+    ++s.counter;
+    return O;
+}
+
+// masked-sign ReLU: h (optional) and the public sign mask (optional, 1 byte per element)
+inline void relu_core(Session& s, const DevMat& z, DevMat* h, std::unique_ptr<Dev>* mask) {
+    const size_t n = z.elems();
+    cognn_keys k = s.keys(OP_RELU);
+    Dev E(s.ctx, n), Ep(s.ctx, n), w(s.ctx, n), wp(s.ctx, n);
+    DevMat H(s.ctx, z.rows(), z.cols());
+    std::unique_ptr<Dev> Mk(new Dev(s.ctx, n, 1));
+    check(cognn_relu_open_u64(s.ctx, E.u64(), nullptr, z.u64(), &k, s.p, (int64_t)n), "cognn_relu_open_u64");
+    s.swap_dev(E, Ep);
+    check(cognn_relu_mul_u64(s.ctx, w.u64(), E.u64(), Ep.u64(), nullptr, nullptr, &k, s.p, (int64_t)n), "cognn_relu_mul_u64");
+    s.swap_dev(w, wp);
+    check(cognn_relu_close_u64(s.ctx, H.u64(), (uint8_t*)Mk->ptr(), z.u64(), w.u64(), wp.u64(), (int64_t)n), "cognn_relu_close_u64");
+    check(cognn_ctx_sync(s.ctx), "cognn_ctx_sync");
+    if (h) *h = H;
+    if (mask) *mask = std::move(Mk);
+    ++s.counter;
+}
+
+inline void backward_nn_without_ah(Session& s, const DevMat& in, const DevMat& z, const DevMat& weightT, DevMat& dstVec, DevMat& g, bool isFirstLayer) {
+    if (in.rows() != z.rows() || in.cols() != z.cols()) throw Error("twoPartyGCNBackwardNNWithoutAH: shape mismatch");
+    std::unique_ptr<Dev> mask;
+    relu_core(s, z, nullptr, &mask);                         // 1[z > 0], public
+    DevMat masked(s.ctx, in.rows(), in.cols());
+    check(cognn_mask_select_u64(s.ctx, masked.u64(), in.u64(), (const uint8_t*)mask->ptr(), (int64_t)in.elems()), "cognn_mask_select_u64");
+    check(cognn_ctx_sync(s.ctx), "cognn_ctx_sync");
+    if (!isFirstLayer) g = matmul(s, masked, weightT);       // gradient for the layer below; skipped for the first layer
+    else g.clear();
+    dstVec = masked;
+}
+
+// labels: the owner's class index per row (the one-hot rows of the reference's `label` argument); the co-party passes none
+inline void prediction(Session& s, const DevMat& z, const std::vector<int32_t>& labels, DevMat& p, DevMat& p_minus_y) {
+    const size_t n = z.rows(), L = z.cols();
+    cognn_keys k = s.keys(OP_SOFTMAX);
+    DevMat P(s.ctx, n, L), D(s.ctx, n, L);
+    if (s.p == 0) {                                          // the owner receives the co-party's share of z (it learns p anyway, gcn.h:603-604)
+        DevMat Zp(s.ctx, n, L), PF(s.ctx, n, L);
+        s.ch->exchange_device(s.ctx, nullptr, 0, Zp.u64(), n * L * 8);
+        if (labels.size() != n) throw Error("twoPartyGCNForwardNNPredictionWithoutWeight: one label per row expected");
+        const Dev& Lb = s.cached(labels.data(), n, 4);
+        check(cognn_softmax_u64(s.ctx, P.u64(), D.u64(), PF.u64(), z.u64(), Zp.u64(), (const int32_t*)Lb.ptr(), &k, 0, (int64_t)n, (int64_t)L, (int64_t)n),
+              "cognn_softmax_u64");
+    } else {
+        s.ch->exchange_device(s.ctx, z.u64(), n * L * 8, nullptr, 0);
+        check(cognn_softmax_u64(s.ctx, P.u64(), D.u64(), nullptr, nullptr, nullptr, nullptr, &k, 1, (int64_t)n, (int64_t)L, (int64_t)n), "cognn_softmax_u64");
+    }
+    check(cognn_ctx_sync(s.ctx), "cognn_ctx_sync");
+    p = P; p_minus_y = D;
+    ++s.counter;
+}
+
+inline DevMat matrix_scale(Session& s, const DevMat& m, uint64_t fxScale) {
+    DevMat O(s.ctx, m.rows(), m.cols());
+    s.trunc(O.u64(), m.u64(), fxScale, OP_MSCALE_TRUNC, (int64_t)m.elems());
+    ++s.counter;
+    return O;
+}
+
+inline DevMat apply_gradient(Session& s, const DevMat& W, const DevMat& d, uint64_t fxLr) {
+    if (W.rows() != d.rows() || W.cols() != d.cols()) throw Error("twoPartyGCNApplyGradient: shape mismatch");
+    DevMat O = W.clone(s.ctx);
+    s.trunc(O.u64(), d.u64(), fxLr, OP_LR_TRUNC, (int64_t)W.elems(), 1);       // W -= trunc(lr * d)
+    ++s.counter;
+    return O;
+}
+
+}  // namespace dev
 }  // namespace cognn_shim
 
 // ---- free functions of include/task/task.h:243-249 (defined externally in the reference) --------------------------------
@@ -282,6 +530,14 @@ inline ShareTensor transpose(const ShareTensor& st) {
     ShareTensor t(c, ShareVec(r));
     for (size_t i = 0; i < r; ++i)
         for (size_t j = 0; j < c; ++j) t[j][i] = st[i][j];
+    return t;
+}
+inline cognn_shim::DevMat transpose(const cognn_shim::DevMat& st) {
+    cognn_shim::DevMat t(st.ctx(), st.cols(), st.rows());
+    if (st.elems()) {
+        cognn_shim::check(cognn_transpose_u64(st.ctx(), t.u64(), st.u64(), (int64_t)st.rows(), (int64_t)st.cols()), "cognn_transpose_u64");
+        cognn_shim::check(cognn_ctx_sync(st.ctx()), "cognn_ctx_sync");
+    }
     return t;
 }
 inline ShareVec toShareVec(int hotIndex, int vecSize) {
@@ -317,230 +573,163 @@ private:
 };
 
 // ---- SecureAggregation.h: prefix_network_aggregate (gcn.h:328-335) --------------------------------------------------------
+// (the server passes a zero position vector, ss_...h:1047: it learns the runs from the client)
 enum class AggregationOp { ADD_AGG };
-inline ShareVecVec prefix_network_aggregate(std::vector<uint64_t> pos, const ShareVecVec& svv, AggregationOp, uint64_t coTid, int party, bool) {
+inline cognn_shim::DevMat prefix_network_aggregate(const std::vector<uint64_t>& pos, const cognn_shim::DevMat& svv, AggregationOp, uint64_t coTid, int party, bool) {
     cognn_shim::Session& s = cognn_shim::session(coTid, party);
-    std::vector<uint64_t> none;
-    cognn_shim::share_positions(s, pos, none);               // the server passes a zero vector (ss_...h:1047): it learns the runs here
-    if (pos.size() != svv.size()) throw cognn_shim::Error("prefix_network_aggregate: one position per row expected");
-    // inclusive prefix sum inside each run of equal consecutive positions: row q gathers rows start(q)..q
-    std::vector<uint32_t> rowptr{0}, col;
-    size_t start = 0;
-    for (size_t q = 0; q < pos.size(); ++q) {
-        if (q && pos[q] != pos[q - 1]) start = q;
-        for (size_t j = start; j <= q; ++j) col.push_back((uint32_t)j);
-        rowptr.push_back((uint32_t)col.size());
-    }
+    return cognn_shim::dev::aggregate(s, s.p == 0 ? pos : std::vector<uint64_t>(), svv);
+}
+inline ShareVecVec prefix_network_aggregate(const std::vector<uint64_t>& pos, const ShareVecVec& svv, AggregationOp op, uint64_t coTid, int party, bool b) {
+    cognn_shim::Session& s = cognn_shim::session(coTid, party);
     ShareVecVec out;
-    cognn_shim::gather_rows(s, svv, nullptr, rowptr, col, svv.empty() ? 0 : svv[0].size(), out);
+    prefix_network_aggregate(pos, cognn_shim::DevMat::from_host(s.ctx, svv), op, coTid, party, b).to_host(out);
     return out;
 }
 
 // ---- ObliviousMapper.h (ss_...h:752-763,818,848 client; :1011-1016,1057,1075 server) ---------------------------------------
-inline void client_oblivious_mapper_online(const std::vector<uint64_t>& srcPos, const std::vector<uint64_t>& dstPos, const ShareVecVec& srcSvv,
-                                           ShareVecVec& dstSvv, uint32_t /*plainNumPerOperand*/, uint64_t /*iter*/, uint32_t /*preprocessId*/,
+inline void client_oblivious_mapper_online(const std::vector<uint64_t>& srcPos, const std::vector<uint64_t>& dstPos, const cognn_shim::DevMat& srcSvv,
+                                           cognn_shim::DevMat& dstSvv, uint32_t /*plainNumPerOperand*/, uint64_t /*iter*/, uint32_t /*preprocessId*/,
                                            uint64_t coTid, bool allowMissing = false) {
-    cognn_shim::Session& s = cognn_shim::session(coTid, 1);
-    if (allowMissing) { uint64_t f = 1; s.ch->exchange(&f, 8, nullptr, 0); } else { uint64_t f = 0; s.ch->exchange(&f, 8, nullptr, 0); }
-    cognn_shim::mapper(s, srcPos, dstPos, srcSvv, dstSvv, allowMissing);
+    dstSvv = cognn_shim::dev::mapper(cognn_shim::session(coTid, 1), srcPos, dstPos, srcSvv, allowMissing);
 }
-inline void server_oblivious_mapper_online(const ShareVecVec& srcSvv, ShareVecVec& dstSvv, uint64_t /*iter*/, uint32_t /*preprocessId*/, uint64_t coTid) {
-    cognn_shim::Session& s = cognn_shim::session(coTid, 2);
-    uint64_t f = 0;
-    s.ch->exchange(nullptr, 0, &f, 8);
-    cognn_shim::mapper(s, {}, {}, srcSvv, dstSvv, f != 0);
+inline void server_oblivious_mapper_online(const cognn_shim::DevMat& srcSvv, cognn_shim::DevMat& dstSvv, uint64_t /*iter*/, uint32_t /*preprocessId*/, uint64_t coTid) {
+    dstSvv = cognn_shim::dev::mapper(cognn_shim::session(coTid, 2), {}, {}, srcSvv, false);
+}
+inline void client_oblivious_mapper_online(const std::vector<uint64_t>& srcPos, const std::vector<uint64_t>& dstPos, const ShareVecVec& srcSvv,
+                                           ShareVecVec& dstSvv, uint32_t width, uint64_t iter, uint32_t preprocessId, uint64_t coTid, bool allowMissing = false) {
+    cognn_shim::DevMat d;
+    client_oblivious_mapper_online(srcPos, dstPos, cognn_shim::DevMat::from_host(cognn_shim::session(coTid, 1).ctx, srcSvv), d, width, iter, preprocessId, coTid, allowMissing);
+    d.to_host(dstSvv);
+}
+inline void server_oblivious_mapper_online(const ShareVecVec& srcSvv, ShareVecVec& dstSvv, uint64_t iter, uint32_t preprocessId, uint64_t coTid) {
+    cognn_shim::DevMat d;
+    server_oblivious_mapper_online(cognn_shim::DevMat::from_host(cognn_shim::session(coTid, 2).ctx, srcSvv), d, iter, preprocessId, coTid);
+    d.to_host(dstSvv);
 }
 
 // ---- SCIHarness.h -----------------------------------------------------------------------------------------------------------
 namespace sci {
 enum { ALICE = 1, BOB = 2 };
 using cognn_shim::Dev;
+using cognn_shim::DevMat;
 using cognn_shim::Session;
 using cognn_shim::check;
 
+// -- device tensors ------------------------------------------------------------------------------------------------------
+inline void twoPartyGCNMatMul(const DevMat& A, const DevMat& B, DevMat& out, uint64_t coTid, int party) {
+    out = cognn_shim::dev::matmul(cognn_shim::session(coTid, party), A, B);
+}
+inline void twoPartyGCNVectorScale(const DevMat& in, const std::vector<uint64_t>& rowScale, DevMat& out, bool /*isSigned*/, uint64_t coTid, int party) {
+    out = cognn_shim::dev::vector_scale(cognn_shim::session(coTid, party), in, rowScale);
+}
+// The condition is the client's private input - the server passes a placeholder (zeroIsDummy, ss_...h:1124-1126) - so
+// ALICE's vector is the one both roles apply; here it reaches BOB in the clear.
+inline void twoPartyGCNCondVectorAddition(DevMat& a, DevMat& b, std::vector<bool>& cond, DevMat& out, uint64_t coTid, int party) {
+    out = cognn_shim::dev::cond_add(cognn_shim::session(coTid, party), a, b, cond);
+}
+inline void twoPartyGCNRelu(const DevMat& in, DevMat& out, uint64_t tid, int party) {
+    cognn_shim::dev::relu_core(cognn_shim::session(tid, party), in, &out, nullptr);
+}
+inline void twoPartyGCNBackwardNNWithoutAH(const DevMat& in, const DevMat& z, const DevMat& weightT, DevMat& dstVec, DevMat& g, bool isFirstLayer,
+                                           uint64_t tid, int party) {
+    cognn_shim::dev::backward_nn_without_ah(cognn_shim::session(tid, party), in, z, weightT, dstVec, g, isFirstLayer);
+}
+// `label`: the client's one-hot rows (toShareVec), host side - they are its plaintext; the server passes zero rows
+inline void twoPartyGCNForwardNNPredictionWithoutWeight(const DevMat& z, const ShareVecVec& label, DevMat& p, DevMat& p_minus_y, uint64_t tid, int party) {
+    Session& s = cognn_shim::session(tid, party);
+    std::vector<int32_t> lab;
+    if (s.p == 0) {
+        lab.assign(z.rows(), 0);
+        for (size_t r = 0; r < z.rows() && r < label.size(); ++r)
+            for (size_t j = 0; j < label[r].size(); ++j)
+                if (label[r][j] != 0) lab[r] = (int32_t)j;
+    }
+    cognn_shim::dev::prediction(s, z, lab, p, p_minus_y);
+}
+inline void getPlainShareVecVec(const DevMat& sv, DoubleTensor& plain, uint64_t tid, int party) {
+    Session& s = cognn_shim::session(tid, party);
+    DevMat other(s.ctx, sv.rows(), sv.cols());
+    s.swap_mat(sv, other);
+    check(cognn_add_u64(s.ctx, other.u64(), other.u64(), sv.u64(), (int64_t)sv.elems()), "cognn_add_u64");
+    std::vector<uint64_t> f(sv.elems());
+    other.dev().down(f.data());                              // the revealed values are the only tensor that leaves the device
+    plain.assign(sv.rows(), std::vector<double>(sv.cols()));
+    for (size_t r = 0; r < sv.rows(); ++r)
+        for (size_t j = 0; j < sv.cols(); ++j) plain[r][j] = (double)(int64_t)f[r * sv.cols() + j] / (double)(1ull << SCALER_BIT_LENGTH);
+}
+inline void twoPartyGCNMatrixScale(const DevMat& m, uint64_t fxScale, DevMat& out, uint64_t tid, int party) {
+    out = cognn_shim::dev::matrix_scale(cognn_shim::session(tid, party), m, fxScale);
+}
+inline void twoPartyGCNApplyGradient(const DevMat& W, const DevMat& d, uint64_t fxLr, DevMat& Wout, uint64_t tid, int party) {
+    Wout = cognn_shim::dev::apply_gradient(cognn_shim::session(tid, party), W, d, fxLr);
+}
+inline DevMat plaintext_add_matrix(const DevMat& a, const DevMat& b) {
+    if (a.rows() != b.rows() || a.cols() != b.cols()) throw cognn_shim::Error("plaintext_add_matrix: shape mismatch");
+    DevMat o(a.ctx(), a.rows(), a.cols());
+    if (a.elems()) {
+        check(cognn_add_u64(a.ctx(), o.u64(), a.u64(), b.u64(), (int64_t)a.elems()), "cognn_add_u64");
+        check(cognn_ctx_sync(a.ctx()), "cognn_ctx_sync");
+    }
+    return o;
+}
+inline void plaintext_add_matrix_in_place(DevMat& a, const DevMat& b) { a = plaintext_add_matrix(a, b); }
+
+// -- nested host vectors (the reference's containers): upload, the same device functions, download -------------------------
 inline void twoPartyGCNMatMul(const ShareVecVec& A, const ShareTensor& B, ShareVecVec& out, uint64_t coTid, int party) {
     Session& s = cognn_shim::session(coTid, party);
-    size_t M, K, K2, N;
-    std::vector<uint64_t> fa = cognn_shim::flatten(A, &M, &K), fb = cognn_shim::flatten(B, &K2, &N);
-    if (K != K2) throw cognn_shim::Error("twoPartyGCNMatMul: inner dimensions differ");
-    const int p = s.p;
-    cognn_keys k = s.keys(cognn_shim::OP_GEMM);
-    Dev dA(s.ctx, M * K), dB(s.ctx, K * N), E(s.ctx, M * K), Ep(s.ctx, M * K), F(s.ctx, K * N), Fp(s.ctx, K * N), Z(s.ctx, M * N),
-        scratch(s.ctx, M * K + K * N);
-    dA.up(fa.data()); dB.up(fb.data());
-    check(cognn_mask_open_u64(s.ctx, E.u64(), dA.u64(), k.k[p ? cognn_shim::SL_A1 : cognn_shim::SL_A0], (int64_t)M, (int64_t)K, 0), "cognn_mask_open_u64");
-    check(cognn_mask_open_u64(s.ctx, F.u64(), dB.u64(), k.k[p ? cognn_shim::SL_B1 : cognn_shim::SL_B0], (int64_t)K, (int64_t)N, 0), "cognn_mask_open_u64");
-    s.swap_dev(E, Ep);                                       // Beaver reveal
-    s.swap_dev(F, Fp);
-    check(cognn_add_u64(s.ctx, F.u64(), F.u64(), Fp.u64(), (int64_t)(K * N)), "cognn_add_u64");
-    std::unique_ptr<Dev> c1;
-    if (p == 1) {                                            // the dealer's product share (offline phase; dealt in place here)
-        c1.reset(new Dev(s.ctx, M * N));
-        check(cognn_dealer_gemm_c1_u64(s.ctx, c1->u64(), &k, (int64_t)M, (int64_t)N, (int64_t)K, 0, scratch.u64(), scratch.u64() + M * K),
-              "cognn_dealer_gemm_c1_u64");
-    }
-    check(cognn_beaver_gemm_close_u64(s.ctx, Z.u64(), E.u64(), Ep.u64(), F.u64(), c1 ? c1->u64() : nullptr, &k, p, (int64_t)M, (int64_t)N,
-                                      (int64_t)K, 0, scratch.u64()), "cognn_beaver_gemm_close_u64");
-    Dev O(s.ctx, M * N);
-    s.trunc(O, Z, 1, cognn_shim::OP_GEMM_TRUNC, (int64_t)(M * N));
-    std::vector<uint64_t> fo(M * N);
-    O.down(fo.data());
-    cognn_shim::unflatten(fo, M, N, out);
-    ++s.counter;
+    DevMat o;
+    twoPartyGCNMatMul(DevMat::from_host(s.ctx, A), DevMat::from_host(s.ctx, B), o, coTid, party);
+    o.to_host(out);
 }
-
-inline void twoPartyGCNVectorScale(const ShareVecVec& in, const std::vector<uint64_t>& rowScale, ShareVecVec& out, bool /*isSigned*/, uint64_t coTid,
-                                   int party) {
+inline void twoPartyGCNVectorScale(const ShareVecVec& in, const std::vector<uint64_t>& rowScale, ShareVecVec& out, bool isSigned, uint64_t coTid, int party) {
     Session& s = cognn_shim::session(coTid, party);
-    size_t n, F;
-    std::vector<uint64_t> fi = cognn_shim::flatten(in, &n, &F);
-    if (rowScale.size() != n) throw cognn_shim::Error("twoPartyGCNVectorScale: one scale per row expected");
-    cognn_keys k = s.keys(cognn_shim::OP_SCALE), tk = s.keys(cognn_shim::OP_SCALE_TRUNC);
-    Dev V(s.ctx, n * F), S(s.ctx, n), E(s.ctx, n * F), Ep(s.ctx, n * F), G(s.ctx, n), Gp(s.ctx, n), c(s.ctx, n * F), cp(s.ctx, n * F), O(s.ctx, n * F);
-    V.up(fi.data()); S.up(rowScale.data());
-    check(cognn_rowscale_open_u64(s.ctx, E.u64(), G.u64(), V.u64(), S.u64(), &k, s.p, (int64_t)n, (int64_t)F), "cognn_rowscale_open_u64");
-    s.swap_dev(E, Ep);
-    s.swap_dev(G, Gp);
-    check(cognn_rowscale_close_u64(s.ctx, c.u64(), E.u64(), Ep.u64(), G.u64(), Gp.u64(), &k, &tk, s.p, (int64_t)n, (int64_t)F), "cognn_rowscale_close_u64");
-    s.swap_dev(c, cp);
-    check(cognn_trunc_close_u64(s.ctx, O.u64(), s.p == 0 ? c.u64() : nullptr, s.p == 0 ? cp.u64() : nullptr, &tk, s.p, 0, (int64_t)(n * F)),
-          "cognn_trunc_close_u64");
-    std::vector<uint64_t> fo(n * F);
-    O.down(fo.data());
-    cognn_shim::unflatten(fo, n, F, out);
-    ++s.counter;
+    DevMat o;
+    twoPartyGCNVectorScale(DevMat::from_host(s.ctx, in), rowScale, o, isSigned, coTid, party);
+    o.to_host(out);
 }
-
-// out = a + (cond ? b : 0) row by row.  The condition is the client's private input - the server passes a placeholder
-// (zeroIsDummy, ss_...h:1124-1126) - so ALICE's vector is the one both roles apply; here it reaches BOB in the clear.
 inline void twoPartyGCNCondVectorAddition(ShareVecVec& a, ShareVecVec& b, std::vector<bool>& cond, ShareVecVec& out, uint64_t coTid, int party) {
     Session& s = cognn_shim::session(coTid, party);
-    if (a.size() != b.size() || cond.size() != a.size()) throw cognn_shim::Error("twoPartyGCNCondVectorAddition: shape mismatch");
-    std::vector<uint8_t> c(cond.size());
-    if (s.p == 0) {
-        for (size_t r = 0; r < cond.size(); ++r) c[r] = cond[r] ? 1 : 0;
-        s.ch->exchange(c.data(), c.size(), nullptr, 0);
-    } else {
-        s.ch->exchange(nullptr, 0, c.data(), c.size());
-    }
-    std::vector<uint32_t> rowptr{0}, col;
-    for (size_t r = 0; r < a.size(); ++r) {
-        if (c[r]) col.push_back((uint32_t)r);
-        rowptr.push_back((uint32_t)col.size());
-    }
-    ShareVecVec res;
-    cognn_shim::gather_rows(s, b, &a, rowptr, col, a.empty() ? 0 : a[0].size(), res);
-    out.swap(res);
+    DevMat da = DevMat::from_host(s.ctx, a), db = DevMat::from_host(s.ctx, b), o;
+    twoPartyGCNCondVectorAddition(da, db, cond, o, coTid, party);
+    o.to_host(out);
 }
-
-// masked-sign ReLU; returns the public sign mask through `mask` when asked
-inline void relu_core(Session& s, const std::vector<uint64_t>& fz, size_t n, std::vector<uint64_t>* h, std::vector<uint8_t>* mask) {
-    cognn_keys k = s.keys(cognn_shim::OP_RELU);
-    Dev z(s.ctx, n), E(s.ctx, n), Ep(s.ctx, n), w(s.ctx, n), wp(s.ctx, n), H(s.ctx, n), Mk(s.ctx, n, 1);
-    z.up(fz.data());
-    check(cognn_relu_open_u64(s.ctx, E.u64(), nullptr, z.u64(), &k, s.p, (int64_t)n), "cognn_relu_open_u64");
-    s.swap_dev(E, Ep);
-    check(cognn_relu_mul_u64(s.ctx, w.u64(), E.u64(), Ep.u64(), nullptr, nullptr, &k, s.p, (int64_t)n), "cognn_relu_mul_u64");
-    s.swap_dev(w, wp);
-    check(cognn_relu_close_u64(s.ctx, H.u64(), (uint8_t*)Mk.ptr(), z.u64(), w.u64(), wp.u64(), (int64_t)n), "cognn_relu_close_u64");
-    if (h) { h->resize(n); H.down(h->data()); }
-    if (mask) { mask->resize(n); Mk.down(mask->data()); }
-    ++s.counter;
-}
-
 inline void twoPartyGCNRelu(const ShareVecVec& in, ShareTensor& out, uint64_t tid, int party) {
     Session& s = cognn_shim::session(tid, party);
-    size_t n, F;
-    std::vector<uint64_t> fz = cognn_shim::flatten(in, &n, &F), h;
-    relu_core(s, fz, n * F, &h, nullptr);
-    cognn_shim::unflatten(h, n, F, out);
+    DevMat o;
+    twoPartyGCNRelu(DevMat::from_host(s.ctx, in), o, tid, party);
+    o.to_host(out);
 }
-
 inline void twoPartyGCNBackwardNNWithoutAH(const ShareVecVec& in, const ShareTensor& z, const ShareTensor& weightT, ShareVecVec& dstVec, ShareTensor& g,
                                            bool isFirstLayer, uint64_t tid, int party) {
     Session& s = cognn_shim::session(tid, party);
-    size_t n, F, n2, F2;
-    std::vector<uint64_t> fin = cognn_shim::flatten(in, &n, &F), fz = cognn_shim::flatten(z, &n2, &F2);
-    if (n != n2 || F != F2) throw cognn_shim::Error("twoPartyGCNBackwardNNWithoutAH: shape mismatch");
-    std::vector<uint8_t> mask;
-    relu_core(s, fz, n * F, nullptr, &mask);                 // 1[z > 0], public
-    Dev I(s.ctx, n * F), O(s.ctx, n * F), Mk(s.ctx, n * F, 1);
-    I.up(fin.data()); Mk.up(mask.data());
-    check(cognn_mask_select_u64(s.ctx, O.u64(), I.u64(), (const uint8_t*)Mk.ptr(), (int64_t)(n * F)), "cognn_mask_select_u64");
-    std::vector<uint64_t> fo(n * F);
-    O.down(fo.data());
-    ShareVecVec masked;
-    cognn_shim::unflatten(fo, n, F, masked);
-    if (!isFirstLayer) twoPartyGCNMatMul(masked, weightT, g, tid, party);      // gradient for the layer below; skipped for the first layer
-    else g.clear();
-    dstVec.swap(masked);
+    DevMat d, gg;
+    twoPartyGCNBackwardNNWithoutAH(DevMat::from_host(s.ctx, in), DevMat::from_host(s.ctx, z), DevMat::from_host(s.ctx, weightT), d, gg, isFirstLayer, tid, party);
+    d.to_host(dstVec);
+    if (isFirstLayer) g.clear(); else gg.to_host(g);
 }
-
 inline void twoPartyGCNForwardNNPredictionWithoutWeight(const ShareVecVec& z, const ShareVecVec& label, ShareTensor& p, ShareTensor& p_minus_y,
                                                         uint64_t tid, int party) {
     Session& s = cognn_shim::session(tid, party);
-    size_t n, L;
-    std::vector<uint64_t> fz = cognn_shim::flatten(z, &n, &L);
-    cognn_keys k = s.keys(cognn_shim::OP_SOFTMAX);
-    Dev Z(s.ctx, n * L), Zp(s.ctx, s.p == 0 ? n * L : 0), P(s.ctx, n * L), D(s.ctx, n * L), PF(s.ctx, n * L), Lb(s.ctx, n, 4);
-    Z.up(fz.data());
-    if (s.p == 0) {                                          // the owner receives the co-party's share of z (it learns p anyway, gcn.h:603-604)
-        std::vector<uint64_t> zp(n * L);
-        s.ch->exchange(nullptr, 0, zp.data(), zp.size() * 8);
-        Zp.up(zp.data());
-        std::vector<int32_t> lab(n, 0);
-        for (size_t r = 0; r < n; ++r)
-            for (size_t j = 0; j < L && r < label.size(); ++j)
-                if (label[r][j] != 0) lab[r] = (int32_t)j;
-        Lb.up(lab.data());
-        check(cognn_softmax_u64(s.ctx, P.u64(), D.u64(), PF.u64(), Z.u64(), Zp.u64(), (const int32_t*)Lb.ptr(), &k, 0, (int64_t)n, (int64_t)L, (int64_t)n),
-              "cognn_softmax_u64");
-    } else {
-        s.ch->exchange(fz.data(), fz.size() * 8, nullptr, 0);
-        check(cognn_softmax_u64(s.ctx, P.u64(), D.u64(), nullptr, nullptr, nullptr, nullptr, &k, 1, (int64_t)n, (int64_t)L, (int64_t)n), "cognn_softmax_u64");
-    }
-    std::vector<uint64_t> fp(n * L), fd(n * L);
-    P.down(fp.data()); D.down(fd.data());
-    cognn_shim::unflatten(fp, n, L, p);
-    cognn_shim::unflatten(fd, n, L, p_minus_y);
-    ++s.counter;
+    DevMat dp, dd;
+    twoPartyGCNForwardNNPredictionWithoutWeight(DevMat::from_host(s.ctx, z), label, dp, dd, tid, party);
+    dp.to_host(p); dd.to_host(p_minus_y);
 }
-
 inline void getPlainShareVecVec(const ShareVecVec& sv, DoubleTensor& plain, uint64_t tid, int party) {
     Session& s = cognn_shim::session(tid, party);
-    size_t n, L;
-    std::vector<uint64_t> f = cognn_shim::flatten(sv, &n, &L), o(n * L);
-    s.ch->exchange(f.data(), f.size() * 8, o.data(), o.size() * 8);
-    plain.assign(n, std::vector<double>(L));
-    for (size_t r = 0; r < n; ++r)
-        for (size_t j = 0; j < L; ++j) plain[r][j] = CryptoUtil::mergeShareAsDouble(f[r * L + j], o[r * L + j]);
+    getPlainShareVecVec(DevMat::from_host(s.ctx, sv), plain, tid, party);
 }
-
 inline void twoPartyGCNMatrixScale(const ShareVecVec& m, uint64_t fxScale, ShareVecVec& out, uint64_t tid, int party) {
     Session& s = cognn_shim::session(tid, party);
-    size_t r, c;
-    std::vector<uint64_t> f = cognn_shim::flatten(m, &r, &c);
-    Dev X(s.ctx, r * c), O(s.ctx, r * c);
-    X.up(f.data());
-    s.trunc(O, X, fxScale, cognn_shim::OP_MSCALE_TRUNC, (int64_t)(r * c));
-    O.down(f.data());
-    cognn_shim::unflatten(f, r, c, out);
-    ++s.counter;
+    DevMat o;
+    twoPartyGCNMatrixScale(DevMat::from_host(s.ctx, m), fxScale, o, tid, party);
+    o.to_host(out);
 }
-
 inline void twoPartyGCNApplyGradient(const ShareVecVec& W, const ShareVecVec& d, uint64_t fxLr, ShareVecVec& Wout, uint64_t tid, int party) {
     Session& s = cognn_shim::session(tid, party);
-    size_t r, c, r2, c2;
-    std::vector<uint64_t> fw = cognn_shim::flatten(W, &r, &c), fd = cognn_shim::flatten(d, &r2, &c2);
-    if (r != r2 || c != c2) throw cognn_shim::Error("twoPartyGCNApplyGradient: shape mismatch");
-    Dev Wd(s.ctx, r * c), D(s.ctx, r * c);
-    Wd.up(fw.data()); D.up(fd.data());
-    s.trunc(Wd, D, fxLr, cognn_shim::OP_LR_TRUNC, (int64_t)(r * c), 1);        // W -= trunc(lr * d)
-    Wd.down(fw.data());
-    cognn_shim::unflatten(fw, r, c, Wout);
-    ++s.counter;
+    DevMat o;
+    twoPartyGCNApplyGradient(DevMat::from_host(s.ctx, W), DevMat::from_host(s.ctx, d), fxLr, o, tid, party);
+    o.to_host(Wout);
 }
-
 inline void plaintext_add_matrix_in_place(ShareVecVec& a, const ShareVecVec& b) {
     if (a.size() != b.size()) throw cognn_shim::Error("plaintext_add_matrix_in_place: shape mismatch");
     for (size_t r = 0; r < a.size(); ++r)
@@ -584,4 +773,27 @@ inline size_t count_true(const std::vector<bool>& v) {
 }
 
 }  // namespace sci
+
+// ---- container helpers the callbacks use on either type (include/cognn_gas_kernel.hpp) --------------------------------------
+namespace cognn_shim {
+inline size_t svv_cols(const ShareVecVec& v) { return v.empty() ? 0 : v[0].size(); }
+inline size_t svv_cols(const DevMat& v) { return v.cols(); }
+inline ShareVecVec svv_clone(const ShareVecVec& v) { return v; }
+inline DevMat svv_clone(const DevMat& v) { return v.clone(); }
+// rows [first, rows) <- 0   (gcn.h:639-641)
+inline void svv_zero_rows_from(ShareVecVec& v, size_t first) {
+    for (size_t r = first; r < v.size(); ++r) std::fill(v[r].begin(), v[r].end(), 0);
+}
+inline void svv_zero_rows_from(DevMat& v, size_t first) {
+    if (first >= v.rows() || !v.cols()) return;
+    if (v.shared()) v = v.clone();
+    check(cognn_memset0(v.ctx(), v.u64() + first * v.cols(), (v.rows() - first) * v.cols() * 8), "cognn_memset0");
+    check(cognn_ctx_sync(v.ctx()), "cognn_ctx_sync");
+}
+// host <-> container of the calling role's session
+inline void svv_from_host(Session&, const ShareVecVec& h, ShareVecVec& out) { out = h; }
+inline void svv_from_host(Session& s, const ShareVecVec& h, DevMat& out) { out = DevMat::from_host(s.ctx, h); }
+inline void svv_to_host(const ShareVecVec& v, ShareVecVec& out) { out = v; }
+inline void svv_to_host(const DevMat& v, ShareVecVec& out) { v.to_host(out); }
+}  // namespace cognn_shim
 #endif  // COGNN_SCI_SHIM_HPP_

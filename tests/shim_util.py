@@ -1,6 +1,7 @@
-"""Helpers shared by tests/test_shim_cpu.py and tests/test_shim_gpu.py: build tests/shim_iteration.cpp against
-include/cognn_sci_shim.hpp + libcognn_hip.so with g++, write its input file from the oracle's state, and restate the shim's
-dealer addressing (call counter per session) on top of the oracle so that the outputs can be compared bit for bit."""
+"""Helpers shared by tests/test_shim_cpu.py and tests/test_shim_gpu.py: build tests/gas_epochs.cpp against
+include/cognn_gas_kernel.hpp + include/cognn_sci_shim.hpp + libcognn_hip.so with g++, write its input file from the oracle's
+state, and restate the shim's dealer addressing (call counter per session) on top of the oracle so that the outputs can be
+compared bit for bit."""
 import os
 import struct
 import subprocess
@@ -10,14 +11,14 @@ import numpy as np
 import cognn_oracle as co
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-BIN = os.path.join(ROOT, "tests", "_build", "shim_iteration")
+BIN = os.path.join(ROOT, "tests", "_build", "gas_epochs")
 
 
 def build():
     os.makedirs(os.path.dirname(BIN), exist_ok=True)
-    src = os.path.join(ROOT, "tests", "shim_iteration.cpp")
-    deps = [src, os.path.join(ROOT, "include", "cognn_sci_shim.hpp"), os.path.join(ROOT, "include", "cognn_hip.h"),
-            os.path.join(ROOT, "cognn_amd", "libcognn_hip.so")]
+    src = os.path.join(ROOT, "tests", "gas_epochs.cpp")
+    deps = [src, os.path.join(ROOT, "include", "cognn_gas_kernel.hpp"), os.path.join(ROOT, "include", "cognn_sci_shim.hpp"),
+            os.path.join(ROOT, "include", "cognn_hip.h"), os.path.join(ROOT, "cognn_amd", "libcognn_hip.so")]
     if os.path.exists(BIN) and all(os.path.getmtime(BIN) >= os.path.getmtime(d) for d in deps):
         return BIN
     subprocess.check_call(["g++", "-O1", "-std=c++17", "-Wall", "-Wextra", "-Wno-unused-parameter", "-I" + os.path.join(ROOT, "include"), src,
@@ -26,33 +27,76 @@ def build():
     return BIN
 
 
-# (GAS iteration, engine op id) -> (call number of the owner's session, shim op id): the order in which the callbacks of
-# iterations 0 and 1 reach the protocol functions (gcn.h:233,247,476,549,578)
-SHIM_CALLS = {
-    (0, co.OP_PS_GEMM): (0, 10), (0, co.OP_PS_GEMM_TRUNC): (0, 11),
-    (0, co.OP_GA_SCALE): (1, 12), (0, co.OP_GA_SCALE_TRUNC): (1, 13),
-    (0, co.OP_AP_RELU): (2, 16),
-    (1, co.OP_PS_GEMM): (3, 10), (1, co.OP_PS_GEMM_TRUNC): (3, 11),
-    (1, co.OP_PS_SCALE): (4, 12), (1, co.OP_PS_SCALE_TRUNC): (4, 13),
-    (1, co.OP_GA_SCALE): (5, 12), (1, co.OP_GA_SCALE_TRUNC): (5, 13),
-    (1, co.OP_AP_SOFTMAX): (6, 17),
-}
+# shim op ids (include/cognn_sci_shim.hpp): product, its truncation, row scale, its truncation, ReLU, softmax, MatrixScale, ApplyGradient
+S_GEMM, S_GEMM_T, S_SCALE, S_SCALE_T, S_RELU, S_SOFTMAX, S_MSCALE, S_LR = 10, 11, 12, 13, 16, 17, 20, 21
+
+
+def shim_calls(owner, iters):
+    """(GAS iteration, engine op id) -> (call number of the owner's (owner, co) session, shim op id): the order in which the
+    callbacks of gcn.h reach the protocol functions - PreScatterComp (:233,247), GatherComp (:476), ApplyComp (:549,578,665,671,
+    676,678,705,710,723,730) and, in the session of party 0's pair, the weight-averaging scale (:764)."""
+    m = {}
+    c = 0
+    for it in range(iters):
+        e = it % 6
+        if e in (0, 1):
+            m[(it, co.OP_PS_GEMM)] = (c, S_GEMM); m[(it, co.OP_PS_GEMM_TRUNC)] = (c, S_GEMM_T); c += 1
+            if e == 1:
+                m[(it, co.OP_PS_SCALE)] = (c, S_SCALE); m[(it, co.OP_PS_SCALE_TRUNC)] = (c, S_SCALE_T); c += 1
+            m[(it, co.OP_GA_SCALE)] = (c, S_SCALE); m[(it, co.OP_GA_SCALE_TRUNC)] = (c, S_SCALE_T); c += 1
+            if e == 0:
+                m[(it, co.OP_AP_RELU)] = (c, S_RELU); c += 1
+            else:
+                m[(it, co.OP_AP_SOFTMAX)] = (c, S_SOFTMAX); c += 1
+        elif e == 2:
+            m[(it, co.OP_AP_GEMM)] = (c, S_GEMM); m[(it, co.OP_AP_GEMM_TRUNC)] = (c, S_GEMM_T); c += 1
+        elif e == 4:
+            c += 1                                           # twoPartyGCNBackwardNNWithoutAH: the sign protocol on z (its result is public)
+        else:                                                # e in (3, 5)
+            m[(it, co.OP_PS_SCALE)] = (c, S_SCALE); m[(it, co.OP_PS_SCALE_TRUNC)] = (c, S_SCALE_T); c += 1
+            if e == 3:
+                m[(it, co.OP_GA_SCALE)] = (c, S_SCALE); m[(it, co.OP_GA_SCALE_TRUNC)] = (c, S_SCALE_T); c += 1
+            m[(it, co.OP_AP_GEMM)] = (c, S_GEMM); m[(it, co.OP_AP_GEMM_TRUNC)] = (c, S_GEMM_T); c += 1
+            m[(it, co.OP_AP_GSCALE_TRUNC)] = (c, S_MSCALE); c += 1
+            m[(it, co.OP_AP_LR_TRUNC)] = (c, S_LR); c += 1
+            if owner == 0:
+                m[(it, co.OP_WAVG_TRUNC)] = (c, S_MSCALE); c += 1
+    return m
 
 
 class ShimKeyedOracle(co.OracleEngine):
     """The oracle with the shim's dealer addressing: call number c of owner P draws from (seed, P, c, shim op)."""
+    MAX_ITERS = 24
 
     def key_of(self, owner, it, op):
-        c, sop = SHIM_CALLS[(it, op)]
+        if owner == co.OWNER_WAVG:                           # twoPartyGCNMatrixScale(..., 1 - tileIndex, tileIndex + 1): the pair of party 0
+            owner = 0
+        if not hasattr(self, "_calls"):
+            self._calls = {}
+        if owner not in self._calls:
+            self._calls[owner] = shim_calls(owner, self.MAX_ITERS)
+        c, sop = self._calls[owner][(it, op)]
         return lambda slot: co.stream_key(self.seed, owner, c, sop, slot)
 
+    # the masks of a product's operands do not survive its truncation (the truncated shares depend on the exact product and on
+    # the truncation streams only), so the engine's mask reuse and the shim's fresh masks give the same bits
     def key_of_feature_gemm(self, owner, it):
         return self.key_of(owner, it, co.OP_PS_GEMM)
+
+    def key_of_feature_wgrad(self, owner, it):
+        return self.key_of(owner, it, co.OP_AP_GEMM)
+
+    def key_of_hidden_wgrad(self, owner, it, it_fwd):
+        return self.key_of(owner, it, co.OP_AP_GEMM)
 
 
 def _vec(f, a):
     a = np.ascontiguousarray(np.asarray(a, dtype=np.uint64))
     f.write(struct.pack("<Q", a.size)); f.write(a.tobytes())
+
+
+def _real(f, x):
+    f.write(struct.pack("<Q", 1)); f.write(struct.pack("<d", float(x)))
 
 
 def _mat(f, m):
@@ -61,26 +105,30 @@ def _mat(f, m):
 
 
 def write_input(path, o, iters):
-    """State of a freshly started 2-party OracleEngine in the order tests/shim_iteration.cpp reads it."""
-    assert o.k == 2
+    """State of a freshly started k-party OracleEngine in the order tests/gas_epochs.cpp reads it."""
+    k = o.k
+    p = o.param
     with open(path, "wb") as f:
-        _vec(f, [o.seed]); _vec(f, [iters])
-        for t in range(2):
+        _vec(f, [k]); _vec(f, [o.seed]); _vec(f, [iters])
+        _vec(f, [p.input_dim]); _vec(f, [p.hidden_dim]); _vec(f, [p.num_labels])
+        _real(f, p.learning_rate); _real(f, p.train_ratio); _real(f, p.val_ratio); _real(f, p.test_ratio)
+        for t in range(k):
             gs = o.states[t]
-            n = len(gs.localVertexPos)
-            _vec(f, gs.localVertexPos); _vec(f, gs.localVertexInDeg); _vec(f, gs.labels); _vec(f, [int(n * o.param.train_ratio)])
-            for j in range(2):
+            _vec(f, gs.localVertexPos); _vec(f, gs.localVertexInDeg); _vec(f, gs.labels); _vec(f, [int(b) for b in gs.isLocalVertexBorder])
+            for j in range(k):
                 _vec(f, gs.updateSrcVertexPos[j]); _vec(f, gs.updateDstVertexPos[j]); _vec(f, gs.remoteMirrorVertexPos[j])
                 _vec(f, [int(b) for b in gs.isGatherDstVertexDummy[j]])
             _mat(f, gs.localVertexSvv)
-            _mat(f, gs.remoteVertexSvvs[1 - t])
+            for j in range(k):
+                if j != t:
+                    _mat(f, gs.remoteVertexSvvs[j])
             for l in range(2):
                 _mat(f, gs.localWeight[l])
             for l in range(2):
                 _mat(f, gs.remoteWeight[l])
 
 
-def read_output(path, iters):
+def read_output(path, k, iters):
     data = open(path, "rb").read()
     pos = 0
 
@@ -89,7 +137,12 @@ def read_output(path, iters):
         r, c = struct.unpack_from("<QQ", data, pos); pos += 16
         a = np.frombuffer(data, dtype=np.uint64, count=r * c, offset=pos).reshape(r, c); pos += 8 * r * c
         return a
-    per_iter = [[(mat(), mat()) for _ in range(2)] for _ in range(iters)]
-    probs = [mat() for _ in range(2)]
+    per_iter = [[(mat(), mat()) for _ in range(k)] for _ in range(iters)]
+    weights = [[(mat(), mat()) for _ in range(2)] for _ in range(k)]          # [party][layer] = (local, remote)
+    probs = []
+    metrics = []
+    for _ in range(k):
+        probs.append(mat())
+        metrics.append(mat().reshape(-1).astype(np.int64) / 1e6)
     assert pos == len(data)
-    return per_iter, probs
+    return per_iter, weights, probs, metrics

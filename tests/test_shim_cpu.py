@@ -1,4 +1,4 @@
-"""The drop-in shim (include/cognn_sci_shim.hpp) builds with plain g++ against the C ABI, and a program using it fails loudly
+"""The drop-in headers (include/cognn_sci_shim.hpp, include/cognn_gas_kernel.hpp) build with plain g++ against the C ABI, and a program using them fails loudly
 - not silently on some CPU path - when there is no HIP device."""
 import subprocess
 
@@ -21,7 +21,7 @@ def test_shim_program_builds_and_refuses_to_run_without_a_gpu(tmp_path):
     o = shim_util.ShimKeyedOracle(2, src, dst, [v % 2 for v in range(V)], feats, labels,
                                   co.GnnParam(num_labels=3, input_dim=6, hidden_dim=4, num_samples=V), seed=5)
     shim_util.write_input(tmp_path / "in.bin", o, 2)
-    r = subprocess.run([exe, str(tmp_path / "in.bin"), str(tmp_path / "out.bin")], capture_output=True, text=True, timeout=60)
+    r = subprocess.run([exe, "device", str(tmp_path / "in.bin"), str(tmp_path / "out.bin")], capture_output=True, text=True, timeout=60)
     assert r.returncode != 0 and "no HIP device" in r.stderr
 
 
