@@ -111,17 +111,23 @@ int cognn_rccl_rendezvous_tcp(const char* addr, int port, int rank, int world, d
         }
         timeval tv; tv.tv_sec = 1; tv.tv_usec = 0;
         setsockopt(ls, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof(tv));    // accept() wakes up once a second to check the deadline
+        // A stray or garbled connection (port scanner, a client that dies mid-handshake) is dropped and accepting goes on until
+        // the deadline; a rank is counted once however often it connects (a retry gets the id again).
+        std::vector<char> seen((size_t)world, 0);
         for (int served = 0; served < world - 1;) {
             int c = accept(ls, nullptr, nullptr);
             if (c < 0) {
                 if (std::chrono::steady_clock::now() > deadline) { close(ls); return xerr("cognn_rccl_rendezvous_tcp: %d of %d ranks connected before the timeout", served, world - 1); }
                 continue;
             }
+            timeval ctv; ctv.tv_sec = 10; ctv.tv_usec = 0;          // the accepted socket inherits the listener's 1 s: too short for a slow client
+            setsockopt(c, SOL_SOCKET, SO_RCVTIMEO, &ctv, sizeof(ctv));
+            setsockopt(c, SOL_SOCKET, SO_SNDTIMEO, &ctv, sizeof(ctv));
             int32_t peer = -1;
             const int bad = read_all(c, &peer, sizeof(peer)) || peer <= 0 || peer >= world || write_all(c, id128, COGNN_RCCL_ID_BYTES);
             close(c);
-            if (bad) { close(ls); return xerr("cognn_rccl_rendezvous_tcp: hand-shake with a client failed"); }
-            ++served;
+            if (bad) continue;
+            if (!seen[(size_t)peer]) { seen[(size_t)peer] = 1; ++served; }
         }
         close(ls);
         return 0;
@@ -206,10 +212,10 @@ int cognn_rccl_exchange_begin(void* user, const cognn_xfer* xfers, int32_t n) {
         const cognn_xfer& t = xfers[i];
         ncclResult_t r = t.is_send ? ncclSend(t.ptr, (size_t)t.bytes, ncclChar, t.peer, x->comm, x->comm_stream)
                                    : ncclRecv(t.ptr, (size_t)t.bytes, ncclChar, t.peer, x->comm, x->comm_stream);
-        if (r != ncclSuccess) { (void)ncclGroupEnd(); return xerr("cognn_rccl_exchange_begin: %s failed: %s", t.is_send ? "ncclSend" : "ncclRecv", ncclGetErrorString(r)); }
+        if (r != ncclSuccess) { (void)ncclGroupEnd(); x->spare.push_back(tm); return xerr("cognn_rccl_exchange_begin: %s failed: %s", t.is_send ? "ncclSend" : "ncclRecv", ncclGetErrorString(r)); }
         (t.is_send ? x->sent : x->received) += t.bytes;
     }
-    X_NCCL(ncclGroupEnd());
+    { const ncclResult_t ge = ncclGroupEnd(); if (ge != ncclSuccess) { x->spare.push_back(tm); return xerr("cognn_rccl_exchange_begin: ncclGroupEnd failed: %s", ncclGetErrorString(ge)); } }
     X_HIP(hipEventRecord(tm.second, x->comm_stream));
     x->timing.push_back(tm);
     // ... and whoever consumes a received buffer (or overwrites a sent one) waits for this event on the compute stream

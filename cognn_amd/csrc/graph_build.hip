@@ -55,10 +55,20 @@ __device__ __forceinline__ uint32_t row_order_key(uint32_t c) {
     c ^= c >> 16; c *= 0x7feb352du; c ^= c >> 15; c *= 0x846ca68bu; c ^= c >> 16;
     return c;
 }
-__global__ __launch_bounds__(256) void row_order_kernel(const uint32_t* __restrict__ rowptr, uint32_t* col, int64_t rows) {
+__device__ __forceinline__ unsigned long long row_order_full_key(uint32_t c) { return ((unsigned long long)row_order_key(c) << 32) | c; }
+// Rows of up to kSmallRow entries: one thread each, insertion sort.  Longer rows (hubs of a skewed graph: a single lane would
+// run O(d^2) dependent loads) are only listed here and sorted by a whole workgroup each in row_order_big_kernel.
+constexpr uint32_t kSmallRow = 64;
+__global__ __launch_bounds__(256) void row_order_kernel(const uint32_t* __restrict__ rowptr, uint32_t* col, int64_t rows, uint32_t* big_rows,
+                                                         uint32_t* big_count, uint32_t big_cap) {
     const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (r >= rows) return;
     const uint32_t b = rowptr[r], e = rowptr[r + 1];
+    if (e - b > kSmallRow) {
+        const uint32_t slot = atomicAdd(big_count, 1u);
+        if (slot < big_cap) big_rows[slot] = (uint32_t)r;    // (cap = entries / kSmallRow + 1: cannot overflow)
+        return;
+    }
     for (uint32_t i = b + 1; i < e; ++i) {                   // insertion sort (rows hold about average-degree entries)
         const uint32_t c = col[i], kc = row_order_key(c);
         uint32_t j = i;
@@ -68,6 +78,38 @@ __global__ __launch_bounds__(256) void row_order_kernel(const uint32_t* __restri
             col[j] = p; --j;
         }
         col[j] = c;
+    }
+}
+// One workgroup per long row: bitonic network with all comparators ascending (positions beyond the row count as +infinity,
+// so comparators that reach them are skipped), in LDS when the row fits, in place in global memory otherwise.
+constexpr uint32_t kLdsRow = 8192;
+__global__ __launch_bounds__(256) void row_order_big_kernel(const uint32_t* __restrict__ rowptr, uint32_t* col, const uint32_t* __restrict__ big_rows,
+                                                             const uint32_t* __restrict__ big_count, uint32_t big_cap) {
+    __shared__ uint32_t s_col[kLdsRow];
+    const uint32_t nbig = min(*big_count, big_cap);
+    for (uint32_t w = blockIdx.x; w < nbig; w += gridDim.x) {
+        const uint32_t r = big_rows[w];
+        const uint32_t b = rowptr[r], n = rowptr[r + 1] - b;
+        uint32_t* a = col + b;
+        const bool lds = n <= kLdsRow;
+        __syncthreads();
+        if (lds) { for (uint32_t i = threadIdx.x; i < n; i += 256) s_col[i] = a[i]; a = s_col; }
+        __syncthreads();
+        uint32_t np2 = 1;
+        while (np2 < n) np2 <<= 1;
+        for (uint32_t k = 2; k <= np2; k <<= 1) {
+            for (uint32_t j = k >> 1, first = 1; j > 0; j >>= 1, first = 0) {
+                for (uint32_t i = threadIdx.x; i < np2; i += 256) {
+                    const uint32_t l = first ? (i ^ (k - 1)) : (i ^ j);
+                    if (l > i && l < n) {
+                        const uint32_t x = a[i], y = a[l];
+                        if (row_order_full_key(x) > row_order_full_key(y)) { a[i] = y; a[l] = x; }
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        if (lds) for (uint32_t i = threadIdx.x; i < n; i += 256) col[b + i] = s_col[i];
     }
 }
 
@@ -120,8 +162,17 @@ extern "C" int cognn_graph_build_colocated(cognn_ctx* ctx, int64_t V, int64_t E,
         hipLaunchKernelGGL(edge_pass_kernel<true>, dim3(blocks), dim3(256), 0, ctx->stream, src, dst, E, (int)undirected, V, L, (uint32_t*)nullptr,
                            (uint32_t*)nullptr, (uint8_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)rowptr, cursor, col, bad);
     }
-    if (total > 0 && table_rows > 0)
-        hipLaunchKernelGGL(row_order_kernel, dim3((unsigned)((table_rows + 255) / 256)), dim3(256), 0, ctx->stream, (const uint32_t*)rowptr, col, table_rows);
+    uint32_t* big = nullptr;                                  // [1 + cap]: count, then the rows longer than kSmallRow
+    if (total > 0 && table_rows > 0) {
+        const uint32_t big_cap = (uint32_t)(2 * total / kSmallRow + 1);
+        hipError_t be = hipMalloc((void**)&big, ((size_t)big_cap + 1) * 4);
+        if (be != hipSuccess) { (void)hipFree(tmp); return cognn_set_error("cognn_graph_build_colocated: %s", hipGetErrorString(be)); }
+        (void)hipMemsetAsync(big, 0, 4, ctx->stream);
+        hipLaunchKernelGGL(row_order_kernel, dim3((unsigned)((table_rows + 255) / 256)), dim3(256), 0, ctx->stream, (const uint32_t*)rowptr, col, table_rows,
+                           big + 1, big, big_cap);
+        hipLaunchKernelGGL(row_order_big_kernel, dim3((unsigned)std::min<uint32_t>(big_cap, 2048u)), dim3(256), 0, ctx->stream, (const uint32_t*)rowptr, col,
+                           (const uint32_t*)(big + 1), (const uint32_t*)big, big_cap);
+    }
     if (V > 0)
         hipLaunchKernelGGL(dummy_rule_kernel, dim3((unsigned)((V + 255) / 256)), dim3(256), 0, ctx->stream, V, local_in, true_in_deg, in_deg, out_deg,
                            self_dummy);
@@ -129,6 +180,7 @@ extern "C" int cognn_graph_build_colocated(cognn_ctx* ctx, int64_t V, int64_t E,
     hipError_t ce = hipMemcpyAsync(&host_bad, bad, sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
     if (ce == hipSuccess) ce = hipStreamSynchronize(ctx->stream);
     (void)hipFree(tmp);
+    if (big) (void)hipFree(big);
     if (ce != hipSuccess) return cognn_set_error("cognn_graph_build_colocated: %s", hipGetErrorString(ce));
     CG_LAUNCH_CHECK();
     CG_REQUIRE(!host_bad, "edge list: vertex id out of range");

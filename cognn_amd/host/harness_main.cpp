@@ -77,12 +77,19 @@ void printHelp(const char* prog) {
               << "\t-h                    Print this help message.\n";
 }
 
+// One log per hosted party: the party named by -i goes to stdout (the launcher redirects it into gcn_test_<dataset>_<i>.log,
+// tmp_run_cluster.py:146); when a rank hosts several parties and COGNN_LOG_PREFIX is set, every other hosted party p gets
+// <prefix><p>.log with the same lines and its own metrics, so that the reference's one-log-per-party layout is complete.
+struct PartyLog { int party; FILE* f; };
+std::vector<PartyLog> g_logs{{0, stdout}};
+#define LOGF(...) do { for (auto& L_ : g_logs) fprintf(L_.f, __VA_ARGS__); } while (0)
+
 void print_duration(std::chrono::high_resolution_clock::time_point t0, const char* tag) {
     const double sec = std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - t0).count();
-    printf("::%s took %lf seconds\n", tag, sec);
+    LOGF("::%s took %lf seconds\n", tag, sec);
 }
 
-void print_seconds(double sec, const char* tag) { printf("::%s took %lf seconds\n", tag, sec); }
+void print_seconds(double sec, const char* tag) { LOGF("::%s took %lf seconds\n", tag, sec); }
 
 // mkdir -p without a shell (the setting string comes from the command line)
 bool make_dirs(const std::string& path) {
@@ -163,6 +170,16 @@ int main(int argc, char* argv[]) {
     if (rank < 0 || rank >= world) { std::cerr << "Rank out of range." << std::endl; return -1; }
     const int device = world > 1 ? env_int("LOCAL_RANK", rank) : 0;
     if (world > 1 && ((int)tileIndex < rank * perRank || (int)tileIndex >= (rank + 1) * perRank)) tileIndex = (size_t)(rank * perRank);
+    g_logs[0].party = (int)tileIndex;
+    if (const char* prefix = getenv("COGNN_LOG_PREFIX")) {
+        for (int p = rank * perRank; p < (rank + 1) * perRank; ++p) {
+            if (p == (int)tileIndex) continue;
+            const std::string path = std::string(prefix) + std::to_string(p) + ".log";
+            FILE* f = fopen(path.c_str(), "w");
+            if (!f) { std::cerr << "cannot write " << path << std::endl; return -1; }
+            g_logs.push_back(PartyLog{p, f});
+        }
+    }
     try {
         auto t_pre = std::chrono::high_resolution_clock::now();
         std::vector<int32_t> part;
@@ -234,10 +251,11 @@ int main(int argc, char* argv[]) {
         }
         for (int p = rank * perRank; p < (rank + 1) * perRank; ++p)
             if (cognn_engine_set_party_data(e, p, feats[p].data(), labels[p].data())) { std::cerr << cognn_engine_last_error() << std::endl; return -1; }
-        std::cout << "Graph loaded from " << edgelistFile << " and " << partitionFile << " with " << graphTileCount << " graph tiles, into "
-                  << threadCount << " tiles. Treated as " << (undirected ? "undirected" : "directed") << " graph.Current tile is the No."
-                  << tileIndex << " tile." << std::endl;
-        std::cout << tileIndex << " Initialize graph algo kernel" << std::endl;
+        for (auto& L : g_logs) {
+            fprintf(L.f, "Graph loaded from %s and %s with %zu graph tiles, into %zu tiles. Treated as %s graph.Current tile is the No.%d tile.\n",
+                    edgelistFile.c_str(), partitionFile.c_str(), (size_t)graphTileCount, (size_t)threadCount, undirected ? "undirected" : "directed", L.party);
+            fprintf(L.f, "%d Initialize graph algo kernel\n", L.party);
+        }
         if (cognn_engine_start(e)) { std::cerr << cognn_engine_last_error() << std::endl; return -1; }
         print_duration(t_pre, "preprocess");
         // Offline phase and its cache: ./preprocess/<setting>/ is written by a run without -n and reused by `-n 1`
@@ -268,14 +286,14 @@ int main(int argc, char* argv[]) {
             if (cognn_engine_sync(e)) return false;
             if (it0 == 0) {
                 if (!noPreprocess) print_duration(t_om, "preprocess_OM");
-                else std::cout << tileIndex << " Reused " << reused << " offline products from " << cacheDir << std::endl;
+                else for (auto& L : g_logs) fprintf(L.f, "%d Reused %lld offline products from %s\n", L.party, (long long)reused, cacheDir.c_str());
             }
             return true;
         };
-        std::cout << tileIndex << " Begin algo kernel iteration" << std::endl;
+        for (auto& L : g_logs) fprintf(L.f, "%d Begin algo kernel iteration\n", L.party);
         for (uint64_t it = 0; it < maxIters; ++it) {
             if (it % (uint64_t)epoch == 0 && !deal_epoch(it)) { std::cerr << cognn_engine_last_error() << std::endl; return -1; }
-            printf("tid-> %lld, iteration-> %lld\n", (long long)tileIndex, (long long)it);
+            for (auto& L : g_logs) fprintf(L.f, "tid-> %lld, iteration-> %lld\n", (long long)L.party, (long long)it);
             auto t_it = std::chrono::high_resolution_clock::now();
             if (cognn_engine_run(e, (int64_t)it, (int64_t)it + 1) || cognn_engine_sync(e)) { std::cerr << cognn_engine_last_error() << std::endl; return -1; }
             const int ei = (int)(it % epoch);
@@ -297,30 +315,33 @@ int main(int argc, char* argv[]) {
                 print_seconds(ph[2], "Gather_computation");
             }
             if (ei == gp.num_layers - 1) {                                         // prediction layer: gcn.h:619-632
-                double m[8];
-                if (cognn_engine_get_metrics(e, (int32_t)tileIndex, m)) { std::cerr << cognn_engine_last_error() << std::endl; return -1; }
-                printf("--------\n");
-                printf("cross-entropy-loss = %lf\n", m[5]);
-                // sci::accuracy reports per cent (README.md:226-236: "full set accuracy = 19.188192" = 104 of 542 vertices)
-                printf("full set accuracy = %lf\n", 100.0 * m[0]);
-                printf("training set accuracy = %lf\n", 100.0 * m[1]);
-                printf("border training set accuracy = %lf\n", 100.0 * m[2]);
-                printf("test set accuracy = %lf\n", 100.0 * m[3]);
-                printf("border test set accuracy = %lf\n", 100.0 * m[4]);
-                printf("the number of vertices is %lu, the number of border vertices is %lu\n", (unsigned long)m[6], (unsigned long)m[7]);
+                for (auto& L : g_logs) {
+                    double m[8];
+                    if (cognn_engine_get_metrics(e, (int32_t)L.party, m)) { std::cerr << cognn_engine_last_error() << std::endl; return -1; }
+                    fprintf(L.f, "--------\n");
+                    fprintf(L.f, "cross-entropy-loss = %lf\n", m[5]);
+                    // sci::accuracy reports per cent (README.md:226-236: "full set accuracy = 19.188192" = 104 of 542 vertices)
+                    fprintf(L.f, "full set accuracy = %lf\n", 100.0 * m[0]);
+                    fprintf(L.f, "training set accuracy = %lf\n", 100.0 * m[1]);
+                    fprintf(L.f, "border training set accuracy = %lf\n", 100.0 * m[2]);
+                    fprintf(L.f, "test set accuracy = %lf\n", 100.0 * m[3]);
+                    fprintf(L.f, "border test set accuracy = %lf\n", 100.0 * m[4]);
+                    fprintf(L.f, "the number of vertices is %lu, the number of border vertices is %lu\n", (unsigned long)m[6], (unsigned long)m[7]);
+                }
             }
             if (!applyOnly) print_seconds(ph[3] + ph[4], "Apply_computation");     // incl. weight averaging (inside ApplyComp, gcn.h:747-802)
             print_duration(t_it, "iteration");
         }
-        std::cout << tileIndex << " Finish algo kernel" << std::endl;
+        for (auto& L : g_logs) fprintf(L.f, "%d Finish algo kernel\n", L.party);
 #ifndef COGNN_NO_RCCL
         if (xch) {                                               // sendFinish / recvFinish (ss_...h:270-272)
             int64_t rounds = 0, sent = 0, recvd = 0;
             double comm_ms = 0;
             cognn_rccl_exchange_stats(xch, &rounds, &sent, &recvd);
             cognn_rccl_exchange_time(xch, &comm_ms);
-            printf("%zu exchange rounds %lld, sent %.2fMB, received %.2fMB, %.3f ms on the communication stream\n", tileIndex, (long long)rounds,
-                   sent / 1048576.0, recvd / 1048576.0, comm_ms);
+            for (auto& L : g_logs)
+                fprintf(L.f, "%d exchange rounds %lld, sent %.2fMB, received %.2fMB, %.3f ms on the communication stream\n", L.party, (long long)rounds,
+                        sent / 1048576.0, recvd / 1048576.0, comm_ms);
             if (cognn_rccl_exchange_barrier(xch)) std::cerr << cognn_exchange_last_error() << std::endl;
         }
         cognn_engine_destroy(e);
@@ -332,5 +353,6 @@ int main(int argc, char* argv[]) {
         std::cerr << ex.what() << std::endl;
         return -1;
     }
+    for (size_t i = 1; i < g_logs.size(); ++i) fclose(g_logs[i].f);
     return 0;
 }

@@ -134,13 +134,47 @@ int run(uint64_t k, uint64_t seed, uint64_t iters, const cognn_gas::GNNParam& pa
     return 0;
 }
 
+// onAlgoKernelStart alone (gcn.h:819-887): plain feature rows and load-time in-degrees in, the shares it deals out
+int run_start(Reader& in, const char* out_path) {
+    using namespace cognn_gas;
+    const uint64_t k = in.one(), seed = in.one();
+    GNNParam param;
+    param.input_dim = (uint32_t)in.one(); param.hidden_dim = (uint32_t)in.one(); param.num_labels = (uint32_t)in.one();
+    FILE* out = fopen(out_path, "wb");
+    if (!out) throw std::runtime_error("cannot open output");
+    cognn_shim::LocalPipe pipe;
+    GCNEdgeCentricAlgoKernel<cognn_shim::DevMat> kernel(param);
+    kernel.sharingSeed = seed;
+    for (uint64_t t = 0; t < k; ++t) {
+        const uint64_t n = in.one();
+        std::vector<std::vector<double>> feat(n, std::vector<double>(param.input_dim));
+        for (auto& row : feat) for (auto& v : row) v = in.real();
+        std::vector<uint64_t> deg = in.vec();
+        cognn_shim::self_tid() = t;
+        cognn_shim::open_session(t, (t + 1) % k, sci::ALICE, seed, pipe.alice());
+        GraphSummary<cognn_shim::DevMat> gs;
+        gs.init(k, t, param.num_layers);
+        ShareVecVec second;
+        std::vector<ShareTensor> secondW;
+        kernel.onAlgoKernelStart(gs, feat, deg, second, secondW);
+        ShareVecVec h;
+        gs.localVertexSvv.to_host(h); put(out, h);
+        put(out, second);
+        for (uint32_t l = 0; l < 2; ++l) { gs.localWeight[l].to_host(h); put(out, h); put(out, secondW[l]); }
+    }
+    fclose(out);
+    cognn_shim::close_sessions();
+    return 0;
+}
+
 }  // namespace
 
 int main(int argc, char** argv) {
-    if (argc < 4) { fprintf(stderr, "usage: %s <device|host> <input> <output>\n", argv[0]); return 2; }
+    if (argc < 4) { fprintf(stderr, "usage: %s <device|host|start> <input> <output>\n", argv[0]); return 2; }
     try {
         Reader in{fopen(argv[2], "rb")};
         if (!in.f) throw std::runtime_error("cannot open input");
+        if (std::string(argv[1]) == "start") return run_start(in, argv[3]);
         const uint64_t k = in.one(), seed = in.one(), iters = in.one();
         cognn_gas::GNNParam param;
         param.input_dim = (uint32_t)in.one(); param.hidden_dim = (uint32_t)in.one(); param.num_labels = (uint32_t)in.one();

@@ -81,6 +81,50 @@ def test_device_graph_build_matches_oracle_preprocess(ctx, k, V, Eu, undirected,
         assert sorted(cl[rp[r]:rp[r + 1]].tolist()) == sorted(want[r]), r
 
 
+def test_device_graph_build_orders_hub_rows_like_short_ones(ctx):
+    """A skewed graph: two hubs (degree ~3000 and ~12000: the LDS and the in-place sort of row_order_big_kernel) among
+    low-degree vertices.  Every CSR row - hub or not - holds the expected multiset in the one fixed order (ascending by the
+    hash of the source row), so the build is deterministic and no single lane walks a hub row."""
+    rng = np.random.default_rng(5)
+    k, V = 4, 20000
+    hubs = {7: 3000, 1234: 12000}
+    src = [rng.integers(0, V, size=30000)]; dst = [rng.integers(0, V, size=30000)]
+    for h, d in hubs.items():
+        src.append(rng.integers(0, V, size=d)); dst.append(np.full(d, h))
+    src = np.concatenate(src).astype(np.int64); dst = np.concatenate(dst).astype(np.int64)
+    part = (np.arange(V) % k).astype(np.int32)
+    row_of, a_off, b_off, rows = _layout(k, part)
+    E = len(src)
+    bufs = {}
+    for run in range(2):
+        rowptr = dev_empty(rows + 1, "u32"); col = dev_empty(2 * E, "u32")
+        tin, din, dout = dev_empty(V, "u32"), dev_empty(V, "u32"), dev_empty(V, "u32")
+        border, dummy = dev_empty(V, "u8"), dev_empty(V, "u8")
+        ctx.call("cognn_graph_build_colocated", V, E, 0, ptr(dev(src)), ptr(dev(dst)), ptr(dev(part)), ptr(dev(row_of.view(np.int32))), ptr(dev(a_off)),
+                 ptr(dev(b_off)), rows, ptr(rowptr), ptr(col), ptr(tin), ptr(din), ptr(dout), ptr(border), ptr(dummy), ptr(dev_empty(V + 2 * rows + 2, "u32")))
+        bufs[run] = (host(rowptr, np.uint32).copy(), host(col, np.uint32).copy())
+    rp, cl = bufs[0]
+    assert np.array_equal(rp, bufs[1][0]) and np.array_equal(cl, bufs[1][1]), "two builds of the same edge list differ"
+    want = [[] for _ in range(rows)]
+    A = lambda v: int(a_off[part[v]] + row_of[v]); B = lambda v: int(b_off[part[v]] + row_of[v])
+    for u, v in zip(src, dst):
+        same = part[u] == part[v]
+        want[A(v)].append(A(u) if same else B(u)); want[B(v)].append(B(u) if same else A(u))
+
+    def key(c):
+        c = np.uint32(c)
+        with np.errstate(over="ignore"):
+            c ^= c >> np.uint32(16); c *= np.uint32(0x7feb352d); c ^= c >> np.uint32(15); c *= np.uint32(0x846ca68b); c ^= c >> np.uint32(16)
+        return int(c)
+    for h in hubs:
+        for r in (A(h), B(h)):
+            got = cl[rp[r]:rp[r + 1]].tolist()
+            assert len(got) >= hubs[h] and got == sorted(want[r], key=lambda c: (key(c), c)), "hub row %d" % r
+    for r in range(0, rows, 97):
+        got = cl[rp[r]:rp[r + 1]].tolist()
+        assert got == sorted(want[r], key=lambda c: (key(c), c)), r
+
+
 def test_device_graph_build_rejects_bad_vertex_ids(ctx):
     from cognn_amd import capi
     V, k = 10, 2

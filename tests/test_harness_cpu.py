@@ -72,6 +72,31 @@ def test_cli_runs_reference_formats_and_matches_oracle(tmp_path):
     assert [int(x) for x in nv[0]] == [want[0]["n"], want[0]["n_border"]]
 
 
+def test_one_log_per_hosted_party(tmp_path):
+    """COGNN_LOG_PREFIX (set by tools/run_cluster.py for C++ ranks): a process that hosts several parties writes the log of every
+    hosted party - the one named by -i to stdout, the others to <prefix><party>.log - each with its own party's metrics, so the
+    reference's one-log-per-party layout (tmp_run_cluster.py:146) is complete when parties > ranks."""
+    k, V, Eu, in_dim, lab, hid = 3, 45, 100, 6, 3, 4
+    src, dst, feats, labels = _write_inputs(tmp_path, k, V, Eu, in_dim, lab, hid)
+    setting = "three-on-one"
+    cmd = [BIN, "-t", str(k), "-g", str(k), "-i", "1", "-m", "2", "-p", "1", "-s", setting, "-r", "1",
+           str(tmp_path / "edges.txt"), str(tmp_path / "vertices.txt"), str(tmp_path / "part.txt"), str(tmp_path / "out.txt"),
+           str(tmp_path / "config.txt")]
+    env = dict(os.environ, COGNN_LOG_PREFIX=str(tmp_path / "gcn_test_x_"))
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=120, cwd=tmp_path, env=env)
+    assert res.returncode == 0, res.stderr
+    p = co.GnnParam(num_labels=lab, input_dim=in_dim, hidden_dim=hid, num_samples=V, learning_rate=0.5)
+    o = co.OracleEngine(k, src, dst, [v % k for v in range(V)], feats, labels, p, seed=_fnv1a(setting))
+    o.run(2)
+    texts = {1: res.stdout, 0: (tmp_path / "gcn_test_x_0.log").read_text(), 2: (tmp_path / "gcn_test_x_2.log").read_text()}
+    assert not (tmp_path / "gcn_test_x_1.log").exists()
+    for party, text in texts.items():
+        want = [m for m in o.metrics if m["party"] == party][0]
+        assert abs(float(re.findall(r"cross-entropy-loss = ([0-9.]+)", text)[0]) - want["loss"]) < 1e-5
+        assert len(re.findall(r"::iteration took [0-9.]+ seconds", text)) == 2 and "::premerging took" in text
+        assert "tid-> %d, iteration-> 1" % party in text and "%d Finish algo kernel" % party in text
+
+
 def test_cli_argument_errors(tmp_path):
     r = subprocess.run([BIN, "-h"], capture_output=True, text=True)
     assert r.returncode != 0 and "Usage" in r.stderr

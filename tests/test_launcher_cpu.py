@@ -129,6 +129,41 @@ def test_rank_killed_by_signal_fails_the_launch(tmp_path):
     assert res.returncode == 124
 
 
+def test_sigterm_to_the_launcher_ends_its_ranks(tmp_path):
+    """The outer driver times the launcher out with SIGTERM: no rank may outlive it (a rank blocked in ncclRecv would hold its
+    GPU until its own timeout)."""
+    import signal
+    import time
+    hang = tmp_path / "hanging_worker.py"
+    hang.write_text("import os, sys, time\n"
+                    "open(os.path.join(%r, 'pid_' + os.environ['RANK']), 'w').write(str(os.getpid()))\n"
+                    "time.sleep(600)\n" % str(tmp_path))
+    data, logs = tmp_path / "data", tmp_path / "log"
+    cmd = LAUNCH + ["--dataset", "cora_small", "--parties", "2", "--gpus", "2", "--iterations", "2", "--data-dir", str(data),
+                    "--log-dir", str(logs), "--synthetic", "--backend", "gloo", "--worker", str(hang)]
+    launcher = subprocess.Popen(cmd, cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    deadline = time.monotonic() + 60
+    while time.monotonic() < deadline and not all((tmp_path / ("pid_%d" % r)).exists() and (tmp_path / ("pid_%d" % r)).read_text() for r in range(2)):
+        time.sleep(0.1)
+    pids = [int((tmp_path / ("pid_%d" % r)).read_text()) for r in range(2)]
+    launcher.send_signal(signal.SIGTERM)
+    assert launcher.wait(timeout=30) == 143
+
+    def alive(pid):
+        try:
+            os.kill(pid, 0)
+        except ProcessLookupError:
+            return False
+        try:                                                 # (a zombie still answers signal 0)
+            return open("/proc/%d/stat" % pid).read().split(")")[-1].split()[0] != "Z"
+        except OSError:
+            return False
+    t_end = time.monotonic() + 10
+    while time.monotonic() < t_end and any(alive(p) for p in pids):
+        time.sleep(0.1)
+    assert not any(alive(p) for p in pids), "ranks survived the launcher"
+
+
 @pytest.mark.gpu
 def test_launcher_runs_the_cpp_binary_on_the_gpu(tmp_path):
     """--gpus 1 without --worker: bin/gcn-optimize (no Python in the run) once per party log, all parties co-located on the GPU."""

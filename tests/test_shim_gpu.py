@@ -69,3 +69,45 @@ def test_device_mode_at_a_wider_shape_and_four_parties(tmp_path):
 
 def test_forward_iterations_on_host_vectors_at_the_round_2_shapes(tmp_path):
     run_case(tmp_path, "host", 2, 90, 100, 33, 16, 7, 2)
+
+
+def test_on_algo_kernel_start_deals_the_oracles_shares(tmp_path):
+    """onAlgoKernelStart (gcn.h:819-887): features * (inDeg + 1)^-1/2 in double, Glorot weights from srand(42), both split with
+    CryptoUtil::intoShares - the owner's feature share is the oracle's, bit for bit; the weights reconstruct to the libc fixture."""
+    import struct
+    exe = shim_util.build()
+    k, V, in_dim, hid, lab, seed = 2, 30, 9, 5, 3, 0xC06A11
+    src, dst = co.synth_graph(V, 50, 2)
+    feats, labels = co.synth_features(V, in_dim, lab, 4, density=0.3)
+    p = co.GnnParam(num_labels=lab, input_dim=in_dim, hidden_dim=hid, num_samples=V)
+    o = co.OracleEngine(k, src, dst, [v % k for v in range(V)], feats, labels, p, seed=seed)
+    with open(tmp_path / "in.bin", "wb") as f:
+        for v in (k, seed, in_dim, hid, lab):
+            shim_util._vec(f, [v])
+        for t in range(k):
+            gs = o.states[t]
+            vids = gs.localVertexPos
+            shim_util._vec(f, [len(vids)])
+            for v in vids:
+                for x in np.asarray(feats)[v]:
+                    shim_util._real(f, x)
+            shim_util._vec(f, [gs.true_in_deg[v] for v in vids])
+    r = subprocess.run([exe, "start", str(tmp_path / "in.bin"), str(tmp_path / "out.bin")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    data = open(tmp_path / "out.bin", "rb").read()
+    pos = 0
+
+    def mat():
+        nonlocal pos
+        rr, c = struct.unpack_from("<QQ", data, pos); pos += 16
+        a = np.frombuffer(data, dtype=np.uint64, count=rr * c, offset=pos).reshape(rr, c); pos += 8 * rr * c
+        return a
+    w_plain = [co.fx_encode(co.init_weight(in_dim, hid)), co.fx_encode(co.init_weight(hid, lab))]
+    for t in range(k):
+        s0, s1 = mat(), mat()
+        assert np.array_equal(s0, o.states[t].localVertexSvvBackup) and np.array_equal(s1, o.states[t].featShare1)
+        for l in range(2):
+            w0, w1 = mat(), mat()
+            with np.errstate(over="ignore"):
+                assert np.array_equal(w0 + w1, w_plain[l])
+    assert pos == len(data)

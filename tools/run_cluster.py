@@ -75,35 +75,55 @@ def write_synthetic(data_dir, dataset, parties, kind="p", seed=1):
                 "learning_rate : %s\ntrain_ratio : %s\nval_ratio : %s\ntest_ratio : %s" % (lab, in_dim, hid, V, len(src), lr, tr, va, te))
 
 
+LIVE = []                                                     # every child that may still run (the SIGTERM handler ends them)
+
+
+def spawn(cmd, **kw):
+    p = subprocess.Popen(cmd, **kw)
+    LIVE.append(p)
+    return p
+
+
+def end_children(procs):
+    """terminate(), then kill() after 5 s: a rank blocked in ncclRecv never exits by itself."""
+    procs = [p for p in procs if p.poll() is None]
+    for p in procs:
+        p.terminate()
+    t_end = time.monotonic() + 5
+    for p in procs:
+        try:
+            p.wait(max(0.0, t_end - time.monotonic()))
+        except subprocess.TimeoutExpired:
+            p.kill()
+            p.wait()
+
+
 def wait_all(procs, timeout):
     """Waits for every child; on the first failure (non-zero exit or death by signal) or on timeout the others are terminated,
-    then killed.  Returns 0 only if all exited with 0; a signal -N maps to 128 + N."""
+    then killed - and so they are when the launcher itself is interrupted.  Returns 0 only if all exited with 0; a signal -N
+    maps to 128 + N."""
     deadline = time.monotonic() + timeout
     rc = 0
     live = list(procs)
-    while live and rc == 0:
-        for p in list(live):
-            r = p.poll()
-            if r is None:
-                continue
-            live.remove(p)
-            if r != 0:
-                rc = 128 - r if r < 0 else r
-        if rc == 0 and live:
-            if time.monotonic() > deadline:
-                rc = 124
-                break
-            time.sleep(0.05)
-    if live:                                                  # a rank died or the run timed out: its peers would block in recv forever
-        for p in live:
-            p.terminate()
-        t_end = time.monotonic() + 5
-        for p in live:
-            try:
-                p.wait(max(0.0, t_end - time.monotonic()))
-            except subprocess.TimeoutExpired:
-                p.kill()
-                p.wait()
+    try:
+        while live and rc == 0:
+            for p in list(live):
+                r = p.poll()
+                if r is None:
+                    continue
+                live.remove(p)
+                if r != 0:
+                    rc = 128 - r if r < 0 else r
+            if rc == 0 and live:
+                if time.monotonic() > deadline:
+                    rc = 124
+                    break
+                time.sleep(0.05)
+    finally:                                                  # a rank died, the run timed out or the launcher is going down: the
+        end_children(live)                                    # peers would block in recv (and hold their GPUs) forever
+        for p in procs:
+            if p in LIVE:
+                LIVE.remove(p)
     return rc
 
 
@@ -132,7 +152,7 @@ def run_one(executable, dataset, parties, iterations, setting, data_dir, log_dir
             cmd = [exe] + common + ["-i", str(i)] + files
             print(" ".join(cmd), flush=True)
             with open(log_name(i), "w") as lf:
-                rc = rc or wait_all([subprocess.Popen(cmd, stdout=lf)], timeout)   # sequential: they share the one GPU
+                rc = rc or wait_all([spawn(cmd, stdout=lf)], timeout)   # sequential: they share the one GPU
         return rc
     if parties % gpus:
         raise SystemExit("the %d parties must divide evenly over %d ranks" % (parties, gpus))
@@ -142,16 +162,17 @@ def run_one(executable, dataset, parties, iterations, setting, data_dir, log_dir
     for r in range(gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
-        if worker is None:                                    # C++ rank: prints the log of its first hosted party
+        if worker is None:                                    # C++ rank: its first hosted party's log on stdout, the others' through COGNN_LOG_PREFIX
             cmd = [exe] + common + ["-c", "1", "-i", str(r * per)] + files
             lf = open(log_name(r * per), "w")
             logs.append(lf)
-            procs.append(subprocess.Popen(cmd, env=env, stdout=lf))
+            env["COGNN_LOG_PREFIX"] = os.path.join(log_dir, "gcn_test_%s_" % dataset)
+            procs.append(spawn(cmd, env=env, stdout=lf))
         else:                                                 # Python rank (cognn_amd.worker or a test wrapper of it): one log per hosted party
             variant = "optimize-gcn-inference" if "inference" in executable else "optimize-gcn"
             head = [sys.executable] + (["-m", worker] if not worker.endswith(".py") else [worker])
             cmd = head + common + ["--variant", variant, "--backend", backend, "--log-dir", log_dir, "--log-prefix", "gcn_test_%s_" % dataset] + files
-            procs.append(subprocess.Popen(cmd, env=env))
+            procs.append(spawn(cmd, env=env))
         print("RANK=%d " % r + " ".join(cmd), flush=True)
     rc = wait_all(procs, timeout)
     for lf in logs:
@@ -230,6 +251,11 @@ def main():
                    no_preprocess=a.no_preprocess, worker=a.worker, backend=a.backend, timeout=a.timeout)
 
 
+def on_sigterm(*_):
+    end_children(list(LIVE))                                  # no rank outlives the launcher
+    sys.exit(143)
+
+
 if __name__ == "__main__":
-    signal.signal(signal.SIGTERM, lambda *_: sys.exit(143))
+    signal.signal(signal.SIGTERM, on_sigterm)
     sys.exit(main())
