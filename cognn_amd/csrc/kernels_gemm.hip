@@ -15,6 +15,7 @@
 #include "common.h"
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
 #include "../../include/cognn_hip.h"
 
 namespace {
@@ -761,6 +762,166 @@ void beaver_gemm_d16n_kernel(u64* Z, const u64* __restrict__ E0, const u64* __re
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 const int col = t * 16 + (lane & 15);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int row = tile * 16 + 4 * b + q;
+                    const uint32_t hi = (uint32_t)acc[t][4][q] + ((uint32_t)acc[t][5][q] << 8) + ((uint32_t)acc[t][6][q] << 16) + ((uint32_t)acc[t][7][q] << 24);
+                    const long long lo = (long long)acc[t][0][q] + (long long)acc[t][1][q] * 256 + (long long)acc[t][2][q] * 65536 +
+                                         (long long)acc[t][3][q] * 16777216;
+                    if ((FULL || row < M) && col < N) Z[(size_t)row * N + col] = (u64)lo + ((u64)hi << 32);
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// The register-direct scheme as ONE grouped launch for all products of a protocol phase (cognn_beaver_gemm_close_group_u64):
+// up to 16 jobs of the same (N, K) - the hosted sides' PreScatter / Apply products.  A workgroup serves one job: it builds the
+// job's B fragments ([B_p + p F | F] limb planes in MFMA slot order - what prep_b_planes_d16_kernel wrote to HBM for the
+// per-job kernels) straight into LDS in its prologue, then its waves walk the job's 16-row tiles as beaver_gemm_d16n_kernel
+// does.  One launch instead of 2 x 16 (preparation + product per side), no plane scratch, and the launches' 16 separate tails
+// become one.  WAVES = 8 (two waves per SIMD, LDS-bound occupancy) for NT >= 2, 4 for NT = 1 (several workgroups per CU).
+// ------------------------------------------------------------------------------------------
+constexpr int kGroupMax = 16;
+struct GemmGroupJob {
+    u64* Z; const u64* E0; const u64* E1; const u64* F0; const u64* F1;
+    u64 keyA, keyB;
+    int p, M, tiles, wg_end;                                 // wg_end: exclusive prefix of the workgroups assigned to the jobs
+};
+struct GemmGroup {
+    GemmGroupJob j[kGroupMax];
+    int count, N, K, nst;
+};
+template <int NT, int WAVES, bool FULL, bool KEVEN>
+__global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(2, NT == 1 ? 4 : 2)))
+void beaver_gemm_group_kernel(GemmGroup g) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int kThreadsG = WAVES * 64;
+    int job = 0;
+    while (job < g.count - 1 && (int)blockIdx.x >= g.j[job].wg_end) ++job;
+    const GemmGroupJob& J = g.j[job];
+    const int wg0 = job ? g.j[job - 1].wg_end : 0, nwg = J.wg_end - wg0, wgi = (int)blockIdx.x - wg0;
+    const int N = g.N, K = g.K, nst = g.nst, M = J.M, tiles = J.tiles, p = J.p;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    {   // B fragments of every K step: one task per (k step, column tile, lane, 4-slot quad); quads 0,1: E segment (B_p + pF),
+        // quads 2,3: mask segment (F); image: [k step][column tile][plane][lane][16 B]
+        const u64* __restrict__ F0 = J.F0;
+        const u64* __restrict__ F1 = J.F1;
+        const u64 keyB = J.keyB;
+        const int total = nst * NT * 256;
+        for (int t = threadIdx.x; t < total; t += kThreadsG) {
+            const int q = t & 3, l = (t >> 2) & 63, sn = t >> 8;
+            const int nt = sn % NT, st = sn / NT;
+            const int n = nt * 16 + (l & 15), b = l >> 4, seg = q >> 1;
+            u64 v[4];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const int k = d16_k(st, b, (q & 1) * 4 + jj);
+                u64 x = 0;
+                if (k < K && n < N) {
+                    const u64 f = F0[(size_t)k * N + n] + (F1 ? F1[(size_t)k * N + n] : 0ull);
+                    x = seg == 0 ? cognn_prng(keyB, (u64)k * (u64)N + (u64)n) + (p == 1 ? f : 0ull) : f;
+                }
+                v[jj] = x;
+            }
+            uint32_t pl[8];
+            split4(v, pl);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) *reinterpret_cast<uint32_t*>(smem + (size_t)sn * kD16Stage + (i * 64 + l) * 16 + q * 4) = pl[i];
+        }
+    }
+    __syncthreads();
+    const int r = lane & 15, b = lane >> 4;
+    const u64* __restrict__ E0 = J.E0;
+    const u64* __restrict__ E1 = J.E1;
+    u64* __restrict__ Z = J.Z;
+    const u64 keyA = J.keyA;
+    const bool two = E1 != nullptr;                         // (uniform) the opened value arrives as two shares, summed here
+    const v4i* bp = reinterpret_cast<const v4i*>(smem) + lane;
+    const int wid = wgi * WAVES + wave, nw = nwg * WAVES;
+    const int my_tiles = (tiles - wid + nw - 1) / nw;
+    const int total = my_tiles * nst;                      // flattened (row tile, K step) space of this wave
+    if (total <= 0) return;                                // (after the only barrier)
+    u64 nx0[8], nx1[8];
+    auto load_step = [&](int it) {
+        const int tile = wid + (it / nst) * nw, st = it % nst;
+        const int mc = FULL ? tile * 16 + r : min(tile * 16 + r, M - 1);
+        const u64* e0row = E0 + (size_t)mc * K;
+        if (KEVEN) {
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                int k = st * 32 + 8 * jj + 2 * b;
+                if (!FULL) k = min(k, K - 2);
+                const u64x2 x = *reinterpret_cast<const u64x2*>(e0row + k);
+                nx0[2 * jj] = x.x; nx0[2 * jj + 1] = x.y;
+            }
+            if (two) {
+                const u64* e1row = E1 + (size_t)mc * K;
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    int k = st * 32 + 8 * jj + 2 * b;
+                    if (!FULL) k = min(k, K - 2);
+                    const u64x2 y = *reinterpret_cast<const u64x2*>(e1row + k);
+                    nx1[2 * jj] = y.x; nx1[2 * jj + 1] = y.y;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int k = min(d16_k(st, b, e), K - 1);
+                nx0[e] = e0row[k];
+                nx1[e] = two ? E1[(size_t)mc * K + k] : 0ull;
+            }
+        }
+    };
+    load_step(0);
+    v4i acc[NT][8];
+    for (int it = 0; it < total; ++it) {
+        const int tile = wid + (it / nst) * nw, st = it % nst;
+        const int m = tile * 16 + r;
+        if (st == 0) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int s2 = 0; s2 < 8; ++s2) acc[t][s2] = v4i{0, 0, 0, 0};
+        }
+        u64 v[8], w[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = two ? nx0[e] + nx1[e] : nx0[e];
+        if (it + 1 < total) load_step(it + 1);             // the next step's opened shares are in flight during this step's arithmetic
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const u64 x = (u64)m * (u64)K + (u64)(st * 32 + 8 * jj + 2 * b);
+            w[2 * jj] = cognn_prng(keyA, x);
+            w[2 * jj + 1] = cognn_prng(keyA, x + 1);
+        }
+        if (!FULL) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const u64 keep = (m < M && d16_k(st, b, e) < K) ? ~0ull : 0ull;
+                v[e] &= keep; w[e] &= keep;
+            }
+        }
+        uint32_t pe0[8], pe1[8], pm0[8], pm1[8];
+        split4(v, pe0); split4(v + 4, pe1); split4(w, pm0); split4(w + 4, pm1);
+        v4i af[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) af[i] = v4i{(int)pe0[i], (int)pe1[i], (int)pm0[i], (int)pm1[i]};
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            v4i bf[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) bf[i] = bp[(size_t)((st * NT + t) * 8 + i) * 64];
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int jj = 0; jj + i < 8; ++jj) acc[t][i + jj] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[i], bf[jj], acc[t][i + jj], 0, 0, 0);
+        }
+        if (st == nst - 1) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int col = t * 16 + (lane & 15);        // C/D map of the 16x16 MFMA family: col = lane & 15, row = 4 * (lane >> 4) + reg
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int row = tile * 16 + 4 * b + q;
@@ -1597,3 +1758,88 @@ int beaver_close_impl(cognn_ctx* ctx, uint64_t* Z, const uint64_t* E, const uint
     return F1 ? gemm_dispatch(ctx, (u64*)Z, Ap, nullptr, (const u64*)F1, M, N, K, transA, 1) : 0;   // A_p.(F0 + F1) by linearity
 }
 }  // namespace
+
+// ---- grouped launch of one phase's products ------------------------------------------------------------------------------
+namespace {
+template <int NT, int WAVES>
+int launch_group(cognn_ctx* ctx, const GemmGroup& g, int wgs, size_t lds, bool full, bool keven) {
+#define CG_GROUP_LAUNCH(FULL_, KEVEN_)                                                                                           \
+    do {                                                                                                                          \
+        CG_HIP(hipFuncSetAttribute((const void*)beaver_gemm_group_kernel<NT, WAVES, FULL_, KEVEN_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL((beaver_gemm_group_kernel<NT, WAVES, FULL_, KEVEN_>), dim3((unsigned)wgs), dim3(WAVES * 64), lds, ctx->stream, g);             \
+    } while (0)
+    if (full) CG_GROUP_LAUNCH(true, true);
+    else if (keven) CG_GROUP_LAUNCH(false, true);
+    else CG_GROUP_LAUNCH(false, false);
+#undef CG_GROUP_LAUNCH
+    CG_LAUNCH_CHECK();
+    return 0;
+}
+}  // namespace
+
+extern "C" int cognn_beaver_gemm_close_group_u64(cognn_ctx* ctx, const cognn_gemm_job* jobs, int32_t count, int64_t N, int64_t K, int raw) {
+    { const int rc_flush_ = cg_flush(ctx); if (rc_flush_) return rc_flush_; }
+    CG_REQUIRE(ctx && (count == 0 || jobs) && count >= 0 && count <= kGroupMax, "cognn_beaver_gemm_close_group_u64: bad arguments");
+    CG_REQUIRE(N > 0 && K > 0 && N < (1ll << 31) && K < (1ll << 31), "cognn_beaver_gemm_close_group_u64: bad shape");
+    int64_t tiles_all = 0;
+    bool full = (K % 32 == 0), aligned = true;
+    for (int32_t j = 0; j < count; ++j) {
+        const cognn_gemm_job& J = jobs[j];
+        CG_REQUIRE(J.Z && J.E0 && J.F0 && J.scratch && (J.p == 0 || J.p == 1) && J.M >= 0 && J.M < (1ll << 31), "cognn_beaver_gemm_close_group_u64: job %d is malformed", j);
+        CG_REQUIRE(raw || J.p == 0 || J.c1, "cognn_beaver_gemm_close_group_u64: job %d: p=1 needs the dealer share c1", j);
+        tiles_all += (J.M + 15) / 16;
+        full = full && (J.M % 16 == 0);
+        aligned = aligned && cg_aligned16(J.E0) && (!J.E1 || cg_aligned16(J.E1)) && cg_aligned16(J.Z);
+    }
+    const int nst = (int)((K + 31) / 32), NT = (int)((N + 15) / 16);
+    const size_t lds = (size_t)nst * NT * kD16Stage;
+    static const bool no_group = getenv("COGNN_GEMM_NO_GROUP") != nullptr;   // A/B switch: job by job through the per-side kernels
+    // enough row tiles to fill the chip without splitting K (the per-job path has split-K kernels for the dataset-sized shapes)
+    const bool grouped = !no_group && count > 0 && N <= kFusedBN && K >= 32 && lds <= 128 * 1024 && tiles_all >= 2048 && aligned;
+    if (!grouped) {
+        for (int32_t j = 0; j < count; ++j) {
+            const cognn_gemm_job& J = jobs[j];
+            const int rc = cognn_beaver_gemm_close2_u64(ctx, J.Z, J.E0, J.E1, J.F0, J.F1, J.c1, &J.keys, J.p, J.M, N, K, 0, J.scratch, raw);
+            if (rc) return rc;
+        }
+        return 0;
+    }
+    GemmGroup g;
+    memset(&g, 0, sizeof(g));
+    g.count = 0; g.N = (int)N; g.K = (int)K; g.nst = nst;
+    // workgroups: NT >= 2: one 8-wave workgroup per CU; NT = 1: 4-wave workgroups, several per CU.  Shared out over the jobs in
+    // proportion to their row tiles (at least one each).
+    const int waves = NT == 1 ? 4 : 8;
+    const int budget = NT == 1 ? 768 : 256;                  // resident workgroups: 3 (146 registers) x 256 CUs / 1 x 256
+    int wg_end = 0;
+    for (int32_t j = 0; j < count; ++j) {
+        const cognn_gemm_job& J = jobs[j];
+        const int tiles = (int)((J.M + 15) / 16);
+        if (tiles == 0) continue;
+        GemmGroupJob& d = g.j[g.count++];
+        d.Z = (u64*)J.Z; d.E0 = (const u64*)J.E0; d.E1 = (const u64*)J.E1; d.F0 = (const u64*)J.F0; d.F1 = (const u64*)J.F1;
+        d.keyA = J.keys.k[J.p == 0 ? COGNN_SL_A0 : COGNN_SL_A1]; d.keyB = J.keys.k[J.p == 0 ? COGNN_SL_B0 : COGNN_SL_B1];
+        d.p = J.p; d.M = (int)J.M; d.tiles = tiles;
+        int share = (int)(((int64_t)budget * tiles + tiles_all - 1) / tiles_all);
+        share = std::max(1, std::min(share, (tiles + waves - 1) / waves));
+        wg_end += share;
+        d.wg_end = wg_end;
+    }
+    if (g.count == 0) return 0;
+    const bool keven = (K % 2 == 0);
+    int rc;
+    if (NT == 1) rc = launch_group<1, 4>(ctx, g, wg_end, lds, full, keven);
+    else if (NT == 2) rc = launch_group<2, 8>(ctx, g, wg_end, lds, full, keven);
+    else if (NT == 3) rc = launch_group<3, 8>(ctx, g, wg_end, lds, full, keven);
+    else rc = launch_group<4, 8>(ctx, g, wg_end, lds, full, keven);
+    if (rc || raw) return rc;
+    for (int32_t j = 0; j < count; ++j) {                      // C_p joins here when the caller did not ask for the raw product
+        const cognn_gemm_job& J = jobs[j];
+        const int64_t n = J.M * N;
+        if (n <= 0) continue;
+        hipLaunchKernelGGL(add_cp_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 8192)), dim3(256), 0, ctx->stream, (u64*)J.Z, (const u64*)J.c1,
+                           J.keys.k[COGNN_SL_C0], J.p, n);
+        CG_LAUNCH_CHECK();
+    }
+    return 0;
+}

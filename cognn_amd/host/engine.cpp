@@ -92,6 +92,7 @@ struct cognn_engine {
     std::map<int64_t, std::vector<u64*>> c1_pool;   // released product-share buffers by element count, reused by later deals
     bool retain_offline = false;                    // COGNN_OPT_RETAIN_OFFLINE
     int gemm_lanes = getenv("COGNN_GEMM_LANES") ? atoi(getenv("COGNN_GEMM_LANES")) : 2;   // launch lanes of the per-side products (A/B switch: 1 = one stream)
+    bool gemm_group = !getenv("COGNN_GEMM_PER_SIDE");       // one grouped launch per phase (A/B switch: the per-side launch sequences)
     bool public_openings = true;                    // COGNN_OPT_PUBLIC_OPENINGS (see pub_open)
     bool h1e_pairs_summed = false;                  // the co-located pairs' h1E holds E_0 + E_1 (written by a pair chain), not E_p
     bool pair_fusion = true;                        // COGNN_OPT_PAIR_FUSION: co-located share-holders run their two-party steps as pair chains
@@ -476,6 +477,54 @@ void gemm_stage(cognn_engine* E, int64_t it, XFn X, WFn Wm, SpecFn spec, DstFn d
     // timed as one phase on the engine's stream (the lanes overlap each other): all sides' products of this stage, with their
     // operand preparation (and, for sides whose peer is remote, the truncation opening and the wait for the peer's opening)
     if (E->timing) BE(cognn_timer_begin(E->ctx, T_GEMM));
+    // The sides' products of this phase as ONE grouped launch (cognn_beaver_gemm_close_group_u64: every workgroup builds its job's
+    // weight planes in its prologue): possible when all of them are raw fusable products of one (N, K) - the PreScatter products
+    // and g = (p - y) . W^T.  First the sides whose peer is hosted here, then - once their openings have arrived - the others.
+    bool same_nk = true;
+    for (auto& s : E->sides) { GemmSpec g = spec(s); same_nk = same_nk && g.N == g0.N && g.K == g0.K && g.transA == 0; }
+    const bool grouped = all_raw && same_nk && ns <= 16 && E->gemm_group;
+    if (grouped) {
+        for (int pass = 0; pass < 2; ++pass) {
+            if (pass == 1) exchange_wait(E);
+            std::vector<cognn_gemm_job> jobs;
+            std::vector<size_t> idx;
+            for (size_t i = 0; i < ns; ++i) {
+                Side& s = E->sides[i];
+                if ((s.peer != nullptr) != (pass == 0)) continue;
+                GemmSpec g = spec(s);
+                cognn_keys k = gkeys(s, g);
+                const bool h1e_sum = xsrc != X_OPEN_HERE && paired(E, s) && E->h1e_pairs_summed;
+                cognn_gemm_job J;
+                memset(&J, 0, sizeof(J));
+                J.E0 = feature ? s.featSum : h1e_sum ? pair_opening(s, [](Side& x) { return x.h1E; }) : xsrc != X_OPEN_HERE ? s.h1E : s.ob[0];
+                J.E1 = (feature || h1e_sum) ? nullptr : xsrc != X_OPEN_HERE ? s.h1E_peer : s.ib[0];
+                if (s.p == 1 && !s.c1.count({it, g.op})) {            // dealer product share not precomputed: do it now
+                    u64* c = c1_alloc(E, eo[i]);
+                    BE(cognn_dealer_gemm_c1_u64(E->ctx, c, &k, g.M, g.N, g.K, g.transA, s.scratch, s.scratch + g.M * g.K));
+                    s.c1.emplace(std::make_pair(it, g.op), Side::C1{c, eo[i]});
+                }
+                const bool f_sum = w_opened && (paired(E, s) || w_public);
+                J.F0 = (w_opened && paired(E, s)) ? pair_opening(s, [](Side& x) { return x.ob[1]; }) : s.ob[1];
+                J.F1 = f_sum ? nullptr : s.ib[1];
+                J.Z = s.zbuf; J.keys = k; J.p = s.p; J.M = g.M; J.scratch = s.scratch;
+                jobs.push_back(J); idx.push_back(i);
+                if (E->timing) E->algo[T_GEMM] += 2.0 * 36 * 2 * (double)g.M * g.K * g.N;
+                z[i] = s.zbuf;
+            }
+            if (jobs.empty()) continue;
+            BE(cognn_beaver_gemm_close_group_u64(E->ctx, jobs.data(), (int32_t)jobs.size(), g0.N, g0.K, 1));
+            Batch batch(E);                                    // the truncation openings of the sides outside pair chains: one launch
+            for (size_t i : idx) {
+                Side& s = E->sides[i];
+                if (paired(E, s)) continue;
+                GemmSpec g = spec(s);
+                cognn_keys k = gkeys(s, g), tk = keys(E, s.owner, it, g.top);
+                BE(cognn_trunc_open_add_u64(E->ctx, s.ob[2], s.zbuf, s.p == 1 ? s.c1.at({it, g.op}).ptr : nullptr, &k, &tk, s.p, eo[i]));
+            }
+        }
+        for (auto& s : E->sides)
+            if (s.p == 1 && !paired(E, s)) c1_release(E, s, {it, spec(s).op});   // consumed: the buffer serves a later deal
+    } else
     for_sides(E, false, [&](Side& s, size_t i) {
         GemmSpec g = spec(s);
         cognn_keys k = gkeys(s, g);

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define COGNN_ABI_VERSION 2
+#define COGNN_ABI_VERSION 3
 #define COGNN_NUM_SLOTS 11
 
 typedef struct cognn_ctx cognn_ctx;
@@ -128,6 +128,24 @@ int cognn_beaver_gemm_close_raw_u64(cognn_ctx*, uint64_t* Z, const uint64_t* E0,
 int cognn_beaver_gemm_close2_u64(cognn_ctx*, uint64_t* Z, const uint64_t* E0, const uint64_t* E1, const uint64_t* F0, const uint64_t* F1,
                                  const uint64_t* c1, const cognn_keys* keys, int p, int64_t M, int64_t N, int64_t K, int transA,
                                  uint64_t* scratch, int raw);
+
+/* The products of ONE protocol phase - every hosted side's PreScatter / Apply product (gcn.h:233,665) - as one grouped launch:
+ * each job is one cognn_beaver_gemm_close2_u64 call (NN; raw != 0: without C_p).  When all jobs share (N, K), N <= 64 and
+ * there are enough row tiles to fill the chip, a single persistent kernel runs them all: every workgroup serves one job,
+ * builds that job's weight-operand limb planes ([B_p + p F | F] in MFMA fragment order) in LDS in its prologue - no
+ * separate preparation launch, no plane scratch in HBM - and walks the job's row tiles.  Other shapes run job by job through
+ * cognn_beaver_gemm_close2_u64 (same results either way).  count <= 16. */
+typedef struct {
+    uint64_t* Z;
+    const uint64_t* E0; const uint64_t* E1;      /* opened left operand [M x K]: one pre-summed tensor or two shares (E1 may be NULL) */
+    const uint64_t* F0; const uint64_t* F1;      /* opened right operand [K x N], likewise */
+    const uint64_t* c1;                          /* dealt product share (p == 1, raw == 0) */
+    cognn_keys keys;
+    int32_t p;
+    int64_t M;
+    uint64_t* scratch;                           /* M x K + K x N u64: used by the per-job fallback only */
+} cognn_gemm_job;
+int cognn_beaver_gemm_close_group_u64(cognn_ctx*, const cognn_gemm_job* jobs, int32_t count, int64_t N, int64_t K, int raw);
 
 /* ---- truncation by 2^16 (implicit in every sci:: fixed-point op) ------------------------- */
 /* c_p = mul * x_p + r_p (+2^61 if p==0) */

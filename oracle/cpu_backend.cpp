@@ -237,6 +237,13 @@ int cognn_beaver_gemm_close2_u64(cognn_ctx* c, uint64_t* Z, const uint64_t* E0, 
     return raw ? cognn_beaver_gemm_close_raw_u64(c, Z, E0, E1, f.data(), keys, p, M, N, K, scratch)
                : cognn_beaver_gemm_close_u64(c, Z, E0, E1, f.data(), c1, keys, p, M, N, K, transA, scratch);
 }
+int cognn_beaver_gemm_close_group_u64(cognn_ctx* c, const cognn_gemm_job* jobs, int32_t count, int64_t N, int64_t K, int raw) {
+    for (int32_t j = 0; j < count; ++j) {
+        const cognn_gemm_job& J = jobs[j];
+        if (cognn_beaver_gemm_close2_u64(c, J.Z, J.E0, J.E1, J.F0, J.F1, J.c1, &J.keys, J.p, J.M, N, K, 0, J.scratch, raw)) return 1;
+    }
+    return 0;
+}
 int cognn_trunc_open_add_u64(cognn_ctx*, uint64_t* c, const uint64_t* x, const uint64_t* c1, const cognn_keys* gkeys,
                              const cognn_keys* tkeys, int p, int64_t n) {
     const cognn_opkeys tk = K(tkeys);

@@ -40,7 +40,7 @@ def test_binding_covers_every_declared_symbol(lib):
 
 
 def test_abi_version_and_loud_failure_without_gpu(lib):
-    assert lib.cognn_abi_version() == 2
+    assert lib.cognn_abi_version() == 3
     import torch
     if torch.cuda.is_available():
         pytest.skip("GPU present")
