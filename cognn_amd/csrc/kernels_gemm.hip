@@ -786,6 +786,7 @@ void beaver_gemm_d16n_kernel(u64* Z, const u64* __restrict__ E0, const u64* __re
 constexpr int kGroupMax = 16;
 struct GemmGroupJob {
     u64* Z; const u64* E0; const u64* E1; const u64* F0; const u64* F1;
+    const u64x2* Epl;                                        // PRE: the opened left operand already in fragment order (presplit_e_kernel)
     u64 keyA, keyB;
     int p, M, tiles, wg_end;                                 // wg_end: exclusive prefix of the workgroups assigned to the jobs
 };
@@ -793,7 +794,38 @@ struct GemmGroup {
     GemmGroupJob j[kGroupMax];
     int count, N, K, nst;
 };
-template <int NT, int WAVES, bool FULL, bool KEVEN>
+// The E halves of the A fragments ([tile][k step][16-byte piece j][lane]: piece j of a lane = plane words (pe0[2j], pe1[2j],
+// pe0[2j+1], pe1[2j+1]) of beaver_gemm_group_kernel) of an opened operand that is used many times - the constant feature opening
+// of the layer-0 product: the same bytes as the operand itself (8 per element, rows padded to 16, K to 32), limb-split and
+// byte-transposed once instead of in every pass.
+__global__ __launch_bounds__(256) void presplit_e_kernel(u64x2* out, const u64* __restrict__ E0, const u64* __restrict__ E1, int M, int K, int nst, int tiles) {
+    const int64_t total = (int64_t)tiles * nst * 64;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+        const int lane = (int)(t & 63);
+        const int64_t ts = t >> 6;
+        const int st = (int)(ts % nst), tile = (int)(ts / nst);
+        const int r = lane & 15, b = lane >> 4, m = tile * 16 + r;
+        u64 v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = d16_k(st, b, e);
+            const bool ok = m < M && k < K;
+            const size_t o = (size_t)min(m, M - 1) * K + min(k, K - 1);
+            v[e] = ok ? E0[o] + (E1 ? E1[o] : 0ull) : 0ull;
+        }
+        uint32_t pe0[8], pe1[8];
+        split4(v, pe0); split4(v + 4, pe1);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            u64x2 w;
+            w.x = (u64)pe0[2 * j] | ((u64)pe1[2 * j] << 32);
+            w.y = (u64)pe0[2 * j + 1] | ((u64)pe1[2 * j + 1] << 32);
+            out[((ts * 4 + j) << 6) + lane] = w;
+        }
+    }
+}
+
+template <int NT, int WAVES, bool FULL, bool KEVEN, bool PRE = false>
 __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(2, NT == 1 ? 4 : 2)))
 void beaver_gemm_group_kernel(GemmGroup g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -843,9 +875,16 @@ void beaver_gemm_group_kernel(GemmGroup g) {
     const int my_tiles = (tiles - wid + nw - 1) / nw;
     const int total = my_tiles * nst;                      // flattened (row tile, K step) space of this wave
     if (total <= 0) return;                                // (after the only barrier)
-    u64 nx0[8], nx1[8];
+    u64 nx0[8], nx1[PRE ? 1 : 8];
+    const u64x2* __restrict__ Epl = J.Epl;
     auto load_step = [&](int it) {
         const int tile = wid + (it / nst) * nw, st = it % nst;
+        if (PRE) {                                           // fragment-ordered image: four coalesced 16-byte pieces
+            const u64x2* src = Epl + (((size_t)tile * nst + st) * 4 << 6) + lane;
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) { const u64x2 x = src[jj << 6]; nx0[2 * jj] = x.x; nx0[2 * jj + 1] = x.y; }
+            return;
+        }
         const int mc = FULL ? tile * 16 + r : min(tile * 16 + r, M - 1);
         const u64* e0row = E0 + (size_t)mc * K;
         if (KEVEN) {
@@ -888,7 +927,7 @@ void beaver_gemm_group_kernel(GemmGroup g) {
         }
         u64 v[8], w[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = two ? nx0[e] + nx1[e] : nx0[e];
+        for (int e = 0; e < 8; ++e) v[e] = (!PRE && two) ? nx0[e] + nx1[PRE ? 0 : e] : nx0[e];
         if (it + 1 < total) load_step(it + 1);             // the next step's opened shares are in flight during this step's arithmetic
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
@@ -900,11 +939,18 @@ void beaver_gemm_group_kernel(GemmGroup g) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const u64 keep = (m < M && d16_k(st, b, e) < K) ? ~0ull : 0ull;
-                v[e] &= keep; w[e] &= keep;
+                if (!PRE) v[e] &= keep;                      // (the image is zero-padded)
+                w[e] &= keep;
             }
         }
         uint32_t pe0[8], pe1[8], pm0[8], pm1[8];
-        split4(v, pe0); split4(v + 4, pe1); split4(w, pm0); split4(w + 4, pm1);
+        if (PRE) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { pe0[i] = (uint32_t)v[i]; pe1[i] = (uint32_t)(v[i] >> 32); }
+        } else {
+            split4(v, pe0); split4(v + 4, pe1);
+        }
+        split4(w, pm0); split4(w + 4, pm1);
         v4i af[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) af[i] = v4i{(int)pe0[i], (int)pe1[i], (int)pm0[i], (int)pm1[i]};
@@ -1762,13 +1808,14 @@ int beaver_close_impl(cognn_ctx* ctx, uint64_t* Z, const uint64_t* E, const uint
 // ---- grouped launch of one phase's products ------------------------------------------------------------------------------
 namespace {
 template <int NT, int WAVES>
-int launch_group(cognn_ctx* ctx, const GemmGroup& g, int wgs, size_t lds, bool full, bool keven) {
-#define CG_GROUP_LAUNCH(FULL_, KEVEN_)                                                                                           \
+int launch_group(cognn_ctx* ctx, const GemmGroup& g, int wgs, size_t lds, bool full, bool keven, bool pre) {
+#define CG_GROUP_LAUNCH(...)                                                                                                     \
     do {                                                                                                                          \
-        CG_HIP(hipFuncSetAttribute((const void*)beaver_gemm_group_kernel<NT, WAVES, FULL_, KEVEN_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        hipLaunchKernelGGL((beaver_gemm_group_kernel<NT, WAVES, FULL_, KEVEN_>), dim3((unsigned)wgs), dim3(WAVES * 64), lds, ctx->stream, g);             \
+        CG_HIP(hipFuncSetAttribute((const void*)beaver_gemm_group_kernel<NT, WAVES, __VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL((beaver_gemm_group_kernel<NT, WAVES, __VA_ARGS__>), dim3((unsigned)wgs), dim3(WAVES * 64), lds, ctx->stream, g);             \
     } while (0)
-    if (full) CG_GROUP_LAUNCH(true, true);
+    if (pre) { if (full) CG_GROUP_LAUNCH(true, true, true); else CG_GROUP_LAUNCH(false, true, true); }
+    else if (full) CG_GROUP_LAUNCH(true, true);
     else if (keven) CG_GROUP_LAUNCH(false, true);
     else CG_GROUP_LAUNCH(false, false);
 #undef CG_GROUP_LAUNCH
@@ -1783,8 +1830,10 @@ extern "C" int cognn_beaver_gemm_close_group_u64(cognn_ctx* ctx, const cognn_gem
     CG_REQUIRE(N > 0 && K > 0 && N < (1ll << 31) && K < (1ll << 31), "cognn_beaver_gemm_close_group_u64: bad shape");
     int64_t tiles_all = 0;
     bool full = (K % 32 == 0), aligned = true;
+    int npre = 0;
     for (int32_t j = 0; j < count; ++j) {
         const cognn_gemm_job& J = jobs[j];
+        if (J.E_presplit) ++npre;
         CG_REQUIRE(J.Z && J.E0 && J.F0 && J.scratch && (J.p == 0 || J.p == 1) && J.M >= 0 && J.M < (1ll << 31), "cognn_beaver_gemm_close_group_u64: job %d is malformed", j);
         CG_REQUIRE(raw || J.p == 0 || J.c1, "cognn_beaver_gemm_close_group_u64: job %d: p=1 needs the dealer share c1", j);
         tiles_all += (J.M + 15) / 16;
@@ -1795,7 +1844,8 @@ extern "C" int cognn_beaver_gemm_close_group_u64(cognn_ctx* ctx, const cognn_gem
     const size_t lds = (size_t)nst * NT * kD16Stage;
     static const bool no_group = getenv("COGNN_GEMM_NO_GROUP") != nullptr;   // A/B switch: job by job through the per-side kernels
     // enough row tiles to fill the chip without splitting K (the per-job path has split-K kernels for the dataset-sized shapes)
-    const bool grouped = !no_group && count > 0 && N <= kFusedBN && K >= 32 && lds <= 128 * 1024 && tiles_all >= 2048 && aligned;
+    const bool pre = npre == count && count > 0;             // every job brings its fragment-ordered image (else none is used)
+    const bool grouped = !no_group && count > 0 && N <= kFusedBN && K >= 16 && lds <= 128 * 1024 && tiles_all >= 2048 && aligned;
     if (!grouped) {
         for (int32_t j = 0; j < count; ++j) {
             const cognn_gemm_job& J = jobs[j];
@@ -1810,7 +1860,7 @@ extern "C" int cognn_beaver_gemm_close_group_u64(cognn_ctx* ctx, const cognn_gem
     // workgroups: NT >= 2: one 8-wave workgroup per CU; NT = 1: 4-wave workgroups, several per CU.  Shared out over the jobs in
     // proportion to their row tiles (at least one each).
     const int waves = NT == 1 ? 4 : 8;
-    const int budget = NT == 1 ? 768 : 256;                  // resident workgroups: 3 (146 registers) x 256 CUs / 1 x 256
+    const int budget = NT == 1 ? (pre ? 1024 : 768) : 256;   // resident workgroups: 4 (126 registers, fragment-ordered operand) or 3 (146) x 256 CUs / 1 x 256
     int wg_end = 0;
     for (int32_t j = 0; j < count; ++j) {
         const cognn_gemm_job& J = jobs[j];
@@ -1818,6 +1868,7 @@ extern "C" int cognn_beaver_gemm_close_group_u64(cognn_ctx* ctx, const cognn_gem
         if (tiles == 0) continue;
         GemmGroupJob& d = g.j[g.count++];
         d.Z = (u64*)J.Z; d.E0 = (const u64*)J.E0; d.E1 = (const u64*)J.E1; d.F0 = (const u64*)J.F0; d.F1 = (const u64*)J.F1;
+        d.Epl = pre ? (const u64x2*)J.E_presplit : nullptr;
         d.keyA = J.keys.k[J.p == 0 ? COGNN_SL_A0 : COGNN_SL_A1]; d.keyB = J.keys.k[J.p == 0 ? COGNN_SL_B0 : COGNN_SL_B1];
         d.p = J.p; d.M = (int)J.M; d.tiles = tiles;
         int share = (int)(((int64_t)budget * tiles + tiles_all - 1) / tiles_all);
@@ -1828,10 +1879,10 @@ extern "C" int cognn_beaver_gemm_close_group_u64(cognn_ctx* ctx, const cognn_gem
     if (g.count == 0) return 0;
     const bool keven = (K % 2 == 0);
     int rc;
-    if (NT == 1) rc = launch_group<1, 4>(ctx, g, wg_end, lds, full, keven);
-    else if (NT == 2) rc = launch_group<2, 8>(ctx, g, wg_end, lds, full, keven);
-    else if (NT == 3) rc = launch_group<3, 8>(ctx, g, wg_end, lds, full, keven);
-    else rc = launch_group<4, 8>(ctx, g, wg_end, lds, full, keven);
+    if (NT == 1) rc = launch_group<1, 4>(ctx, g, wg_end, lds, full, keven, pre);
+    else if (NT == 2) rc = launch_group<2, 8>(ctx, g, wg_end, lds, full, keven, pre);
+    else if (NT == 3) rc = launch_group<3, 8>(ctx, g, wg_end, lds, full, keven, pre);
+    else rc = launch_group<4, 8>(ctx, g, wg_end, lds, full, keven, pre);
     if (rc || raw) return rc;
     for (int32_t j = 0; j < count; ++j) {                      // C_p joins here when the caller did not ask for the raw product
         const cognn_gemm_job& J = jobs[j];
@@ -1841,5 +1892,21 @@ extern "C" int cognn_beaver_gemm_close_group_u64(cognn_ctx* ctx, const cognn_gem
                            J.keys.k[COGNN_SL_C0], J.p, n);
         CG_LAUNCH_CHECK();
     }
+    return 0;
+}
+
+// the fragment-ordered image of an opened operand for cognn_beaver_gemm_close_group_u64 (cognn_gemm_job::E_presplit)
+extern "C" int64_t cognn_gemm_presplit_bytes(int64_t M, int64_t K) {
+    return ((M + 15) / 16) * ((K + 31) / 32) * 64 * 64;
+}
+extern "C" int cognn_gemm_presplit_u64(cognn_ctx* ctx, void* image, const uint64_t* E0, const uint64_t* E1, int64_t M, int64_t K) {
+    { const int rc_flush_ = cg_flush(ctx); if (rc_flush_) return rc_flush_; }
+    CG_REQUIRE(ctx && image && E0 && M >= 0 && K > 0 && M < (1ll << 31) && K < (1ll << 31) && cg_aligned16(image), "cognn_gemm_presplit_u64: bad arguments");
+    if (M == 0) return 0;
+    const int nst = (int)((K + 31) / 32), tiles = (int)((M + 15) / 16);
+    const int64_t total = (int64_t)tiles * nst * 64;
+    hipLaunchKernelGGL(presplit_e_kernel, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 1 << 16)), dim3(256), 0, ctx->stream, (u64x2*)image,
+                       (const u64*)E0, (const u64*)E1, (int)M, (int)K, nst, tiles);
+    CG_LAUNCH_CHECK();
     return 0;
 }

@@ -48,6 +48,7 @@ struct Side {
     u64* featE = nullptr;          // E_p = feat_p - A_p of the layer-0 product, opened once (fixed-operand mask reuse)
     u64* featE_peer = nullptr;     // the peer's opening (alias when co-located)
     const u64* featSum = nullptr;  // E = E_0 + E_1 of that product, summed once in start() (one copy per co-located pair)
+    const void* featPl = nullptr;  // the same opening limb-split in MFMA fragment order (cognn_gemm_presplit_u64), for the grouped forward product
     u64* h1E = nullptr;            // E_p = h_p - A_p of the layer-1 forward product (written by the ReLU close); kept for the epoch:
     u64* h1E_peer = nullptr;       // the layer-1 weight gradient h^T.g reuses mask and opening (alias when co-located)
     const uint8_t* cur_mask = nullptr;   // co-located pairs, between the backward ReLU' and the row scale that consumes it: the tensor is
@@ -93,6 +94,7 @@ struct cognn_engine {
     bool retain_offline = false;                    // COGNN_OPT_RETAIN_OFFLINE
     int gemm_lanes = getenv("COGNN_GEMM_LANES") ? atoi(getenv("COGNN_GEMM_LANES")) : 2;   // launch lanes of the per-side products (A/B switch: 1 = one stream)
     bool gemm_group = !getenv("COGNN_GEMM_PER_SIDE");       // one grouped launch per phase (A/B switch: the per-side launch sequences)
+    bool gemm_presplit = !getenv("COGNN_GEMM_NO_PRESPLIT"); // the constant feature opening kept in MFMA fragment order (A/B switch)
     bool public_openings = true;                    // COGNN_OPT_PUBLIC_OPENINGS (see pub_open)
     bool h1e_pairs_summed = false;                  // the co-located pairs' h1E holds E_0 + E_1 (written by a pair chain), not E_p
     bool pair_fusion = true;                        // COGNN_OPT_PAIR_FUSION: co-located share-holders run their two-party steps as pair chains
@@ -507,6 +509,7 @@ void gemm_stage(cognn_engine* E, int64_t it, XFn X, WFn Wm, SpecFn spec, DstFn d
                 J.F0 = (w_opened && paired(E, s)) ? pair_opening(s, [](Side& x) { return x.ob[1]; }) : s.ob[1];
                 J.F1 = f_sum ? nullptr : s.ib[1];
                 J.Z = s.zbuf; J.keys = k; J.p = s.p; J.M = g.M; J.scratch = s.scratch;
+                if (feature) J.E_presplit = s.featPl;
                 jobs.push_back(J); idx.push_back(i);
                 if (E->timing) E->algo[T_GEMM] += 2.0 * 36 * 2 * (double)g.M * g.K * g.N;
                 z[i] = s.zbuf;
@@ -1533,6 +1536,18 @@ void start(cognn_engine* E) {
         BE(cognn_add_u64(E->ctx, s.featE, s.featE, s.featE_peer, (int64_t)s.n * in));
     }
     for (auto& s : E->sides) s.featSum = (s.peer && s.p == 1) ? s.peer->featE : s.featE;
+    // ... and, for the grouped layer-0 product, once more in the order its A fragments have (same size, no split in the K loop)
+    if (E->gemm_group && E->gemm_presplit) {
+        for (auto& s : E->sides) {
+            if (s.peer && s.p == 1) continue;
+            const int64_t bytes = E->be->cognn_gemm_presplit_bytes((int64_t)s.n, in);
+            if (bytes <= 0) continue;
+            void* img = dalloc<unsigned char>(E, (size_t)bytes);
+            BE(cognn_gemm_presplit_u64(E->ctx, img, s.featSum, nullptr, (int64_t)s.n, in));
+            s.featPl = img;
+        }
+        for (auto& s : E->sides) if (s.peer && s.p == 1) s.featPl = s.peer->featPl;
+    }
     BE(cognn_ctx_sync(E->ctx));
     E->started = true;
 }

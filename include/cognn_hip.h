@@ -144,8 +144,15 @@ typedef struct {
     int32_t p;
     int64_t M;
     uint64_t* scratch;                           /* M x K + K x N u64: used by the per-job fallback only */
+    const void* E_presplit;                      /* optional: E0 + E1 already limb-split in MFMA fragment order (cognn_gemm_presplit_u64);
+                                                  * used by the grouped kernel when EVERY job of the call brings one */
 } cognn_gemm_job;
 int cognn_beaver_gemm_close_group_u64(cognn_ctx*, const cognn_gemm_job* jobs, int32_t count, int64_t N, int64_t K, int raw);
+/* An opened left operand that many products reuse - the constant input-feature opening of the layer-0 product (gcn.h:233 in
+ * every epoch) - limb-split and byte-transposed ONCE into the order the grouped kernel's A fragments have: the same 8 bytes per
+ * element (rows padded to 16, K to 32), so a pass reads as many bytes as before and skips the split.  image: _bytes(M, K) bytes. */
+int64_t cognn_gemm_presplit_bytes(int64_t M, int64_t K);
+int cognn_gemm_presplit_u64(cognn_ctx*, void* image, const uint64_t* E0, const uint64_t* E1, int64_t M, int64_t K);
 
 /* ---- truncation by 2^16 (implicit in every sci:: fixed-point op) ------------------------- */
 /* c_p = mul * x_p + r_p (+2^61 if p==0) */

@@ -439,6 +439,61 @@ def test_beaver_gemm_pair(ctx, M, N, K, transA):
         assert np.array_equal(host(Zs), (z0, z1)[p])
 
 
+@pytest.mark.parametrize("N,K,Ms,two,presplit", [(64, 128, (16384, 16400, 4096), False, False), (64, 128, (16384, 16384), False, True),
+                                                   (16, 64, (20000, 12000, 800), True, False), (16, 16, (32768,), False, False),
+                                                   (33, 70, (16390, 16390), False, True), (48, 35, (17000, 16000), True, False),
+                                                   (7, 16, (270, 300), False, False)])
+def test_beaver_gemm_group(ctx, N, K, Ms, two, presplit):
+    """cognn_beaver_gemm_close_group_u64: the products of a phase as one grouped launch (weight planes built in the kernel's
+    prologue; optionally the left operand pre-split in fragment order) against the oracle's Beaver product, job by job - jobs
+    of different row counts, both share indices, ragged shapes, and a set too small for the grouped kernel (per-job path)."""
+    from cognn_amd import capi
+    rng = np.random.default_rng(N * 7 + K)
+    jobs = (capi.GemmJob * (2 * len(Ms)))()
+    keep, want, c1s = [], [], []
+    for q, M in enumerate(Ms):
+        X0 = rand_u64(rng, (M, K)); X1 = rand_u64(rng, (M, K)); W0 = rand_u64(rng, (K, N)); W1 = rand_u64(rng, (K, N))
+        k, kf = keys_of(11, q, 4, co.OP_PS_GEMM)
+        E = [dev_empty((M, K)) for _ in range(2)]; Fm = [dev_empty((K, N)) for _ in range(2)]
+        for p, (xp, wp) in enumerate(((X0, W0), (X1, W1))):
+            ctx.call("cognn_mask_open_u64", ptr(E[p]), ptr(dev(xp)), ctypes.c_uint64(kf(co.SL_A0 + p)), M, K, 0)
+            ctx.call("cognn_mask_open_u64", ptr(Fm[p]), ptr(dev(wp)), ctypes.c_uint64(kf(co.SL_B0 + p)), K, N, 0)
+        Es = dev_empty((M, K)); Fs = dev_empty((K, N))
+        ctx.call("cognn_add_u64", ptr(Es), ptr(E[0]), ptr(E[1]), M * K)
+        ctx.call("cognn_add_u64", ptr(Fs), ptr(Fm[0]), ptr(Fm[1]), K * N)
+        c1 = dev_empty((M, N)); sa = dev_empty(M * K + K * N)
+        ctx.call("cognn_dealer_gemm_c1_u64", ptr(c1), ctypes.byref(k), M, N, K, 0, ptr(sa), ctypes.c_void_p(sa.data_ptr() + 8 * M * K))
+        img = None
+        if presplit:
+            img = dev_empty(capi.load().cognn_gemm_presplit_bytes(M, K) // 8)
+            ctx.call("cognn_gemm_presplit_u64", ptr(img), ptr(E[0]), ptr(E[1]), M, K)
+        z0, z1 = co.beaver_gemm_pair(X0, X1, W0, W1, kf)
+        for p in range(2):
+            J = jobs[2 * q + p]
+            Z = dev_empty((M, N)); scr = dev_empty(M * K + K * N)
+            J.Z = Z.data_ptr()
+            if two:
+                J.E0, J.E1, J.F0, J.F1 = E[p].data_ptr(), E[1 - p].data_ptr(), Fm[p].data_ptr(), Fm[1 - p].data_ptr()
+            else:
+                J.E0, J.E1, J.F0, J.F1 = Es.data_ptr(), None, Fs.data_ptr(), None
+            J.c1 = c1.data_ptr() if p == 1 else None
+            J.keys = k; J.p = p; J.M = M; J.scratch = scr.data_ptr()
+            J.E_presplit = img.data_ptr() if img is not None else None
+            keep += [Z, scr]; want.append((Z, (z0, z1)[p]))
+        keep += [E, Fm, Es, Fs, c1, sa, img]
+        c1s.append(c1)
+    ctx.call("cognn_beaver_gemm_close_group_u64", jobs, len(jobs), N, K, 0)
+    for Z, w in want:
+        assert np.array_equal(host(Z), w)
+    # raw: the same without C_p (the engine's form: C_p joins in the truncation opening)
+    ctx.call("cognn_beaver_gemm_close_group_u64", jobs, len(jobs), N, K, 1)
+    for q, M in enumerate(Ms):
+        k, kf = keys_of(11, q, 4, co.OP_PS_GEMM)
+        with np.errstate(over="ignore"):
+            assert np.array_equal(host(want[2 * q][0]) + co.prng_shape(kf(co.SL_C0), (M, N)), want[2 * q][1])
+            assert np.array_equal(host(want[2 * q + 1][0]) + host(c1s[q]), want[2 * q + 1][1])
+
+
 def test_gather_csr_open_epilogue(ctx):
     """Gather whose output rows inside given segments are the Beaver opening V - prng(key, local index)."""
     rng = np.random.default_rng(77)
