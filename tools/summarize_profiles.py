@@ -36,7 +36,14 @@ def counters(path_glob):
 def main():
     src, prefix = sys.argv[1], sys.argv[2]
     workloads = sys.argv[3:] or sorted(os.listdir(src))
-    pmc = {"method": __doc__.split("usage")[0].strip().split("\n", 3)[-1].strip()}
+    import subprocess
+    try:
+        head = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+    except OSError:
+        head = ""
+    # "build": what the passes were collected on - the tag of the gpurun directory and the commit checked out when the raw
+    # outputs were reduced (the builder's PMC pass, not a measurement of whoever reads the number later)
+    pmc = {"method": __doc__.split("usage")[0].strip().split("\n", 3)[-1].strip(), "build": {"tag": os.path.basename(os.path.normpath(src)), "git_head": head}}
     for wl in workloads:
         d = os.path.join(src, wl)
         if not os.path.isdir(d):
