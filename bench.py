@@ -121,7 +121,7 @@ def cpu_baseline(args, wl):
                       "in=%d hid=%d labels=%d, %.2f s" % (k, variant, lv2, le2, in_dim, hid, lab, dt)}
 
 
-def cross_path_check(eng, Engine, k, src, dst, part, param, variant, iters, in_dim, lab):
+def cross_path_check(eng, Engine, k, src, dst, part, param, variant, iters, in_dim, lab, passes):
     """After the timed region (N = 1): the shares the bench's own sequence left behind - forward-only stores, retained offline
     products, the pass replayed warmup + steps times - must equal, bit for bit and for every party, those of a fresh engine
     that runs the pass once the plain way; for an inference pass the revealed rows must also be probability vectors.  (Parity
@@ -133,6 +133,8 @@ def cross_path_check(eng, Engine, k, src, dst, part, param, variant, iters, in_d
         for P in range(k):
             for sd in (0, 1):
                 h.update(np.ascontiguousarray(e.shares(P, sd)).tobytes())
+                for layer in (0, 1):                        # (a training epoch ends with an empty vertex tensor: the weights carry the result)
+                    h.update(np.ascontiguousarray(e.weight(P, sd, layer)).tobytes())
         return h.hexdigest()
     t0 = time.perf_counter()
     d_bench = digest(eng)
@@ -142,9 +144,11 @@ def cross_path_check(eng, Engine, k, src, dst, part, param, variant, iters, in_d
         rng = np.random.default_rng(0xC06A12 + P)
         ref.set_party_data(P, (rng.random((len(vids), in_dim)) < 0.01).astype(np.float64), rng.integers(0, lab, size=len(vids)))
     ref.start()
-    ref.run(0, iters)
+    for _ in range(passes if "inference" not in variant else 1):   # a training pass updates the weights: as many passes as the bench ran
+        ref.run(0, iters)
     d_plain = digest(ref)
-    res = {"what": "sha256 over every party's two shares: the bench sequence (forward-only / retained products / replays) vs one plain pass on a fresh engine",
+    res = {"what": "sha256 over every party's two vertex-tensor shares and weight shares: the bench sequence (forward-only / retained products / "
+                   "replays) vs the plain sequence on a fresh engine",
            "cross_path_identical": d_bench == d_plain, "digest": d_bench}
     if "inference" in variant:
         a = ref.shares(0, 0); b = ref.shares(0, 1)
@@ -314,7 +318,7 @@ def main():
                            "GBps_while_communicating": ((x1["bytes_sent"] - x0["bytes_sent"]) / 1e9) / max((x1["comm_ms"] - x0["comm_ms"]) / 1e3, 1e-12),
                            "transport": "native RCCL p2p groups on a communication stream (csrc/exchange_rccl.hip)"}
     if not args.no_check and world == 1:
-        out["check"] = cross_path_check(eng, Engine, k, src, dst, part, param, variant, iters, in_dim, lab)
+        out["check"] = cross_path_check(eng, Engine, k, src, dst, part, param, variant, iters, in_dim, lab, args.warmup + args.steps)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args, wl)
     elif rank == 0:

@@ -33,7 +33,14 @@ def main():
     eng = Engine(k, src, dst, part, gp, seed=cfg["seed"], variant=cfg["variant"], rank=rank, world=world, stream=0)
     # asynchronous exchange (begin / wait) unless the case asks for the blocking callback
     mk = cdist.make_exchange if cfg.get("blocking_exchange") else cdist.make_exchange_async
-    eng.set_exchange(mk(torch.device("cuda", 0), host_staged=True) if hip else mk(torch.device("cpu")))
+    hostile_stats = None
+    if cfg.get("hostile"):                                 # late, poisoned, shuffled delivery (tests/hostile_transport.py; CPU backend only)
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import hostile_transport
+        fns, hostile_stats = hostile_transport.make_hostile_exchange(cfg["hostile"], skip_waits=cfg.get("hostile_skip_waits", 0))
+        eng.set_exchange(fns)
+    else:
+        eng.set_exchange(mk(torch.device("cuda", 0), host_staged=True) if hip else mk(torch.device("cpu")))
     eng.set_global_data(feats, labels)
     eng.start()
     if cfg.get("exchanged_openings"):                      # every opening travels as two shares (COGNN_OPT_PUBLIC_OPENINGS off)
@@ -55,6 +62,8 @@ def main():
                 out["it%d_o%d_s1" % (it, o)] = eng.shares(o, 1)
                 for l in range(2):
                     out["it%d_o%d_s1_w%d" % (it, o, l)] = eng.weight(o, 1, l)
+    if hostile_stats is not None:
+        out["hostile_rounds"] = np.array([hostile_stats["rounds"], hostile_stats["max_inflight"]])
     np.savez(cfg["out"] + ".rank%d.npz" % rank, **out)
     eng.close()
     dist.destroy_process_group()

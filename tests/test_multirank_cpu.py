@@ -39,6 +39,9 @@ def _run(cfg, world, tmp_path):
     for r in range(world):
         with np.load(cfg["out"] + ".rank%d.npz" % r) as z:
             for key in z.files:
+                if key == "hostile_rounds":
+                    got.setdefault("hostile_rounds", []).append(z[key])
+                    continue
                 assert key not in got
                 got[key] = z[key]
     return got
@@ -110,3 +113,20 @@ def test_whole_epochs_per_call(tmp_path):
 def test_single_rank_host_logic_three_parties(tmp_path):
     """world == 1 through the same worker: the engine's co-located path (in-device hand-off) on the CPU backend."""
     _check(dict(BASE, k=3, iters=12), 1, tmp_path)
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+@pytest.mark.parametrize("k,world,variant,iters,extra", [(4, 2, "optimize-gcn", 6, {}), (4, 4, "optimize-gcn", 6, {}), (4, 4, "optimize-gcn-inference", 2, {}),
+                                                        (4, 2, "optimize-gcn", 6, {"exchanged_openings": True}), (6, 2, "optimize-gcn", 12, {"whole_epochs": True})])
+def test_hostile_transport(tmp_path, seed, k, world, variant, iters, extra):
+    """Late reads of the outboxes, poisoned inboxes until wait(), rounds and messages completed in shuffled order
+    (tests/hostile_transport.py): every exchange_wait the engine owes - before it overwrites a buffer it handed to a round,
+    before it reads a received one, with two rounds in flight during the message passing - is exercised at world 2 and 4."""
+    _check(dict(BASE, k=k, variant=variant, iters=iters, hostile=seed, **extra), world, tmp_path)
+
+
+def test_hostile_transport_detects_a_missing_wait(tmp_path):
+    """The transport's own sensitivity: when the first wait() completes nothing (= the engine consumed a round it never waited
+    for), the poisoned inboxes reach the arithmetic and the shares no longer match the oracle."""
+    with pytest.raises(AssertionError):
+        _check(dict(BASE, k=4, variant="optimize-gcn-inference", iters=2, hostile=1, hostile_skip_waits=1), 2, tmp_path)
