@@ -166,6 +166,44 @@ def cross_path_check(eng, Engine, k, src, dst, part, param, variant, iters, in_d
     return res
 
 
+def dealer_streams_leg(eng, torch, args, iters, k, digest_before):
+    """The same pass with the dealer values of the co-located pairs' chains and the A masks of the grouped products READ from
+    HBM (COGNN_OPT_DEALER_STREAMS) instead of regenerated in registers: what the online phase costs when the offline phase hands
+    each party its correlations in memory, as the reference's does (README.md:215-216).  Extra keys only: the headline stays the
+    in-register form.  The first passes deal (materialise) the values; the timed ones read them."""
+    import hashlib
+    mem0 = eng.memory()[1]
+    eng.dealer_streams(True)
+    for _ in range(2):
+        eng.run(0, iters)
+    eng.enable_timing(True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        eng.run(0, iters)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    n_agg, ms_agg, bytes_agg = eng.timing(0)
+    n_gemm, ms_gemm, ops_gemm = eng.timing(2)
+    eng.enable_timing(False)
+    res = {"what": "dealer values of the pair chains (truncations, row scales, ReLUs, openings: what each party receives) and the A masks of the "
+                   "grouped products read from HBM instead of regenerated from the counter PRNG; same shares",
+           "ms_per_step": dt / args.steps * 1e3, "dealt_GB_resident": (eng.memory()[1] - mem0) / 1e9,
+           "gather_avg_ms": ms_agg / max(n_agg, 1), "gather_bytes_per_launch_incl_dealt": bytes_agg / max(n_agg, 1),
+           "gather_GBps_incl_dealt": (bytes_agg / 1e9) / (ms_agg / 1e3) if ms_agg > 0 else None,
+           "beaver_gemm_avg_ms_per_phase": ms_gemm / max(n_gemm, 1)}
+    if digest_before is not None:
+        h = hashlib.sha256()
+        for P in range(k):
+            for sd in (0, 1):
+                h.update(np.ascontiguousarray(eng.shares(P, sd)).tobytes())
+                for layer in (0, 1):
+                    h.update(np.ascontiguousarray(eng.weight(P, sd, layer)).tobytes())
+        res["shares_identical_to_in_register_form"] = (h.hexdigest() == digest_before) if "inference" in WORKLOADS[args.workload][6] else None
+    eng.dealer_streams(False)
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -174,6 +212,7 @@ def main():
     ap.add_argument("--workload", default="config5", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true", help="skip the cross-path verification after the timed region")
+    ap.add_argument("--no-dealer-streams", action="store_true", help="skip the extra timing of the dealt (memory-streamed dealer) form")
     args = ap.parse_args()
 
     import torch
@@ -319,6 +358,8 @@ def main():
                            "transport": "native RCCL p2p groups on a communication stream (csrc/exchange_rccl.hip)"}
     if not args.no_check and world == 1:
         out["check"] = cross_path_check(eng, Engine, k, src, dst, part, param, variant, iters, in_dim, lab, args.warmup + args.steps)
+    if world == 1 and not args.no_dealer_streams:
+        out["dealer_streams"] = dealer_streams_leg(eng, torch, args, iters, k, out.get("check", {}).get("digest"))
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args, wl)
     elif rank == 0:

@@ -28,7 +28,7 @@ class PairChain(ctypes.Structure):
     _fields_ = [("x", ctypes.c_void_p * 2), ("c1", ctypes.c_void_p), ("scale", ctypes.c_void_p * 2), ("out", ctypes.c_void_p * 2),
                 ("open", ctypes.c_void_p * 2), ("mask", ctypes.c_void_p), ("open_key", ctypes.c_uint64 * 2),
                 ("gemm_keys", Keys), ("trunc_in_keys", Keys), ("scale_keys", Keys), ("scale_trunc_keys", Keys), ("relu_keys", Keys),
-                ("rows", ctypes.c_int64), ("F", ctypes.c_int64), ("flags", ctypes.c_int32), ("mask_in", ctypes.c_void_p)]
+                ("rows", ctypes.c_int64), ("F", ctypes.c_int64), ("flags", ctypes.c_int32), ("mask_in", ctypes.c_void_p), ("dealt", ctypes.c_void_p)]
 
 
 PC_TRUNC_IN, PC_SCALE, PC_RELU, PC_INPUT_OPENED, PC_NO_C, PC_OPEN_SUM = 1, 2, 4, 8, 16, 32
@@ -50,7 +50,7 @@ class GemmJob(ctypes.Structure):
     """cognn_gemm_job (include/cognn_hip.h)."""
     _fields_ = [("Z", ctypes.c_void_p), ("E0", ctypes.c_void_p), ("E1", ctypes.c_void_p), ("F0", ctypes.c_void_p), ("F1", ctypes.c_void_p),
                 ("c1", ctypes.c_void_p), ("keys", Keys), ("p", ctypes.c_int32), ("M", ctypes.c_int64), ("scratch", ctypes.c_void_p),
-                ("E_presplit", ctypes.c_void_p)]
+                ("E_presplit", ctypes.c_void_p), ("A_dealt", ctypes.c_void_p)]
 
 
 class CognnError(RuntimeError):
@@ -118,6 +118,8 @@ _SIGNATURES = {
     "cognn_softmax_u64": (_I, [_P, _P, _P, _P, _P, _P, _P, _KP, _I, _L, _L, _L]),
     "cognn_metrics_q16": (_I, [_P, _P, _P, _P, _L, _L, _L, _L, _P, _P]),
     "cognn_pair_chain_u64": (_I, [_P, ctypes.POINTER(PairChain), ctypes.c_int32]),
+    "cognn_pair_chain_dealt_slots": (_L, [ctypes.c_int32, ctypes.c_int32]),
+    "cognn_pair_chain_deal_u64": (_I, [_P, ctypes.POINTER(PairChain), _P]),
     "cognn_softmax_jobs_u64": (_I, [_P, ctypes.POINTER(SoftmaxJob), ctypes.c_int32, _L]),
     "cognn_gather_pair_chain_u64": (_I, [_P, _P, _P, _P, _L, ctypes.POINTER(GatherPair), ctypes.c_int32]),
     "cognn_graph_build_colocated": (_I, [_P, _L, _L, ctypes.c_int32] + [_P] * 6 + [_L] + [_P] * 8),

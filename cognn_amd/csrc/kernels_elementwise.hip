@@ -5,6 +5,7 @@
 // CryptoUtil::intoShares (gcn.h:70); definitions in DESIGN.md §3.
 #include "common.h"
 #include <algorithm>
+#include <cstring>
 #include "../../include/cognn_hip.h"
 #include "pair_chain.h"
 
@@ -556,6 +557,7 @@ struct PairBatch {
     unsigned blk_end[kPairBatchMax];
     int count;
 };
+template <bool STREAM>   // STREAM: every chain of the batch brings its dealt slab (pair_chain.h)
 __global__ __launch_bounds__(kThreads) void pair_chain_kernel(PairBatch b) {
     const unsigned blk = blockIdx.x;
     int seg = 0;
@@ -566,6 +568,7 @@ __global__ __launch_bounds__(kThreads) void pair_chain_kernel(PairBatch b) {
     if (i >= d.n) return;
     const int w = (i + 1 < d.n) ? 2 : 1;
     const uint32_t flags = d.flags;
+    const PcSlotBase SB = pc_slot_base(flags, d.open0 != nullptr || d.open1 != nullptr);
     u64 v0[2], v1[2];
     ld2(d.x0, i, w, v0); ld2(d.x1, i, w, v1);
     if (d.mask_in) {                                         // MaskSelect on both sides' inputs
@@ -579,8 +582,8 @@ __global__ __launch_bounds__(kThreads) void pair_chain_kernel(PairBatch b) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const u64 idx = (u64)(i + j);
-            if (addc) { v0[j] += cognn_prng(d.keyC0, idx); v1[j] += cc[j]; }     // TruncOpenAdd: x + C_p
-            pair_trunc(d.tiR, d.tiR0, d.tiRP0, idx, v0[j], v1[j]);
+            if (addc) { v0[j] += STREAM ? d.slab[(u64)(SB.ti + PCS_TI_C0) * (u64)d.n + idx] : cognn_prng(d.keyC0, idx); v1[j] += cc[j]; }     // TruncOpenAdd: x + C_p
+            if (j < w) pair_trunc<STREAM>(d, SB.ti + PCS_TI_R0, d.tiR, d.tiR0, d.tiRP0, idx, v0[j], v1[j]);
         }
     }
     if (flags & COGNN_PC_SCALE) {
@@ -589,27 +592,33 @@ __global__ __launch_bounds__(kThreads) void pair_chain_kernel(PairBatch b) {
         const PairRow rw0 = pair_row(d, (u64)row0);
         PairRow rw1 = rw0;
         if (row1 != row0 && w == 2) rw1 = pair_row(d, (u64)row1);
-        pair_scale(d, (u64)i, rw0, (flags & COGNN_PC_INPUT_OPENED) != 0, v0[0], v1[0]);
-        pair_scale(d, (u64)i + 1, rw1, (flags & COGNN_PC_INPUT_OPENED) != 0, v0[1], v1[1]);
+        pair_scale<STREAM>(d, SB.sc, (u64)i, rw0, (flags & COGNN_PC_INPUT_OPENED) != 0, v0[0], v1[0]);
+        if (w == 2) pair_scale<STREAM>(d, SB.sc, (u64)i + 1, rw1, (flags & COGNN_PC_INPUT_OPENED) != 0, v0[1], v1[1]);
     }
     if (flags & COGNN_PC_RELU) {
         bool pos[2];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) pos[j] = pair_relu(d, (u64)(i + j), v0[j], v1[j]);
+        for (int j = 0; j < 2; ++j) pos[j] = (j < w) ? pair_relu<STREAM>(d, SB.re, (u64)(i + j), v0[j], v1[j]) : false;
         if (d.mask) { d.mask[i] = pos[0] ? 1 : 0; if (w == 2) d.mask[i + 1] = pos[1] ? 1 : 0; }
     }
     if (d.out0) st2(d.out0, i, w, v0);
     if (d.out1) st2(d.out1, i, w, v1);
-    if (d.flags & COGNN_PC_OPEN_SUM) {
-        if (d.open0) {
-            u64 e[2];
-            for (int j = 0; j < 2; ++j) e[j] = (v0[j] - cognn_prng(d.open_key0, (u64)(i + j))) + (v1[j] - cognn_prng(d.open_key1, (u64)(i + j)));
-            st2(d.open0, i, w, e);
+    if (d.open0 || d.open1) {
+        u64 a0[2] = {0, 0}, a1[2] = {0, 0};
+        for (int j = 0; j < w; ++j) pair_open_masks<STREAM>(d, SB.op, (u64)(i + j), a0[j], a1[j]);
+        if (d.flags & COGNN_PC_OPEN_SUM) {
+            if (d.open0) { u64 e[2] = {(v0[0] - a0[0]) + (v1[0] - a1[0]), (v0[1] - a0[1]) + (v1[1] - a1[1])}; st2(d.open0, i, w, e); }
+            return;
         }
-        return;
+        if (d.open0) { u64 e[2] = {v0[0] - a0[0], v0[1] - a0[1]}; st2(d.open0, i, w, e); }
+        if (d.open1) { u64 e[2] = {v1[0] - a1[0], v1[1] - a1[1]}; st2(d.open1, i, w, e); }
     }
-    if (d.open0) { u64 e[2] = {v0[0] - cognn_prng(d.open_key0, (u64)i), v0[1] - cognn_prng(d.open_key0, (u64)i + 1)}; st2(d.open0, i, w, e); }
-    if (d.open1) { u64 e[2] = {v1[0] - cognn_prng(d.open_key1, (u64)i), v1[1] - cognn_prng(d.open_key1, (u64)i + 1)}; st2(d.open1, i, w, e); }
+}
+// the offline phase of one chain: its dealt slab (cognn_pair_chain_deal_u64)
+__global__ __launch_bounds__(kThreads) void pair_chain_deal_kernel(PairChainDev d, u64* slab, int has_open) {
+    const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (i >= d.n) return;
+    pair_deal_element(d, slab, (u64)i, (u64)((uint32_t)i / d.F), has_open != 0);
 }
 
 inline cognn_opkeys K(const cognn_keys* k) {
@@ -803,9 +812,13 @@ int cognn_pair_chain_u64(cognn_ctx* ctx, const cognn_pair_chain* chains, int32_t
     CG_REQUIRE(ctx && (count == 0 || chains) && count >= 0, "cognn_pair_chain_u64: bad arguments");
     PairBatch b;
     b.count = 0;
+    int nstream = 0;
+    for (int32_t c = 0; c < count; ++c) if (chains[c].dealt) ++nstream;
+    CG_REQUIRE(nstream == 0 || nstream == count, "cognn_pair_chain_u64: either every chain of a call brings its dealt values or none does");
     auto launch = [&]() -> int {
         if (b.count == 0) return 0;
-        hipLaunchKernelGGL(pair_chain_kernel, dim3(b.blk_end[b.count - 1]), dim3(kThreads), 0, ctx->stream, b);
+        if (nstream) hipLaunchKernelGGL(pair_chain_kernel<true>, dim3(b.blk_end[b.count - 1]), dim3(kThreads), 0, ctx->stream, b);
+        else hipLaunchKernelGGL(pair_chain_kernel<false>, dim3(b.blk_end[b.count - 1]), dim3(kThreads), 0, ctx->stream, b);
         b.count = 0;
         CG_LAUNCH_CHECK();
         return 0;
@@ -831,6 +844,7 @@ int cognn_pair_chain_u64(cognn_ctx* ctx, const cognn_pair_chain* chains, int32_t
         CG_REQUIRE(!s.mask_in || !(fl & COGNN_PC_INPUT_OPENED), "cognn_pair_chain_u64: chain %d: mask_in needs plain input shares", c);
         pair_chain_fill_keys(d, s);
         d.n = n; d.F = (uint32_t)std::max<int64_t>(s.F, 1); d.flags = (uint32_t)fl;
+        d.slab = (const u64*)s.dealt;
         const int64_t pairs = (n + 1) / 2;
         const unsigned blocks = (unsigned)((pairs + kThreads - 1) / kThreads);
         const unsigned base = b.count ? b.blk_end[b.count - 1] : 0u;
@@ -840,6 +854,25 @@ int cognn_pair_chain_u64(cognn_ctx* ctx, const cognn_pair_chain* chains, int32_t
         if (++b.count == kPairBatchMax) { const int rc = launch(); if (rc) return rc; }
     }
     return launch();
+}
+
+int64_t cognn_pair_chain_dealt_slots(int32_t flags, int32_t has_open) {
+    return (int64_t)pc_slot_base((uint32_t)flags, has_open != 0).total;
+}
+int cognn_pair_chain_deal_u64(cognn_ctx* ctx, const cognn_pair_chain* chain, uint64_t* dealt) {
+    { const int rc_flush_ = cg_flush(ctx); if (rc_flush_) return rc_flush_; }
+    CG_REQUIRE(ctx && chain && dealt && al(dealt), "cognn_pair_chain_deal_u64: bad arguments");
+    const int64_t n = chain->rows * chain->F;
+    CG_REQUIRE(chain->rows >= 0 && chain->F >= 0 && n < (1ll << 32), "cognn_pair_chain_deal_u64: tensor too large");
+    if (n == 0) return 0;
+    PairChainDev d;
+    memset(&d, 0, sizeof(d));
+    pair_chain_fill_keys(d, *chain);
+    d.n = n; d.F = (uint32_t)std::max<int64_t>(chain->F, 1); d.flags = (uint32_t)chain->flags;
+    hipLaunchKernelGGL(pair_chain_deal_kernel, dim3((unsigned)((n + kThreads - 1) / kThreads)), dim3(kThreads), 0, ctx->stream, d, (u64*)dealt,
+                       (chain->open[0] || chain->open[1]) ? 1 : 0);
+    CG_LAUNCH_CHECK();
+    return 0;
 }
 
 int cognn_transpose_u64(cognn_ctx* ctx, uint64_t* out, const uint64_t* in, int64_t rows, int64_t cols) {

@@ -148,7 +148,7 @@ struct GatherPairBatch {
     GatherPairSeg s[kGatherPairsMax];
     int count;
 };
-template <int LPR>
+template <int LPR, bool STREAM>
 __device__ __forceinline__ void gather_pair_chain_body(const u64* __restrict__ table, const uint32_t* __restrict__ rowptr,
                                                        const uint32_t* __restrict__ col, int F, int ntiles, const GatherPairBatch& b,
                                                        uint32_t (&s_rp)[2][kPairTile + 1], uint32_t (&s_col)[2][kPairColCap]) {
@@ -208,37 +208,38 @@ __device__ __forceinline__ void gather_pair_chain_body(const u64* __restrict__ t
                 u64 a[2] = {sum[0].x, sum[0].y}, bb[2] = {sum[1].x, sum[1].y};
                 bool pos[2] = {true, true};
                 PairRow rw = {0, 0, 0};
+                const PcSlotBase SB = pc_slot_base(d.flags, d.open0 != nullptr || d.open1 != nullptr);
                 if (d.flags & COGNN_PC_SCALE) rw = pair_row(d, (u64)vr);
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    if (d.flags & COGNN_PC_SCALE) pair_scale(d, idx + j, rw, false, a[j], bb[j]);
-                    if (d.flags & COGNN_PC_RELU) pos[j] = pair_relu(d, idx + j, a[j], bb[j]);
+                    if (d.flags & COGNN_PC_SCALE) pair_scale<STREAM>(d, SB.sc, idx + j, rw, false, a[j], bb[j]);
+                    if (d.flags & COGNN_PC_RELU) pos[j] = pair_relu<STREAM>(d, SB.re, idx + j, a[j], bb[j]);
                 }
                 if ((d.flags & COGNN_PC_RELU) && d.mask) { d.mask[idx] = pos[0] ? 1 : 0; d.mask[idx + 1] = pos[1] ? 1 : 0; }
                 if (d.out0) { u64x2 t; t.x = a[0]; t.y = a[1]; *reinterpret_cast<u64x2*>(d.out0 + idx) = t; }
                 if (d.out1) { u64x2 t; t.x = bb[0]; t.y = bb[1]; *reinterpret_cast<u64x2*>(d.out1 + idx) = t; }
-                if (d.flags & COGNN_PC_OPEN_SUM) {
-                    if (d.open0) {
-                        u64x2 t;
-                        t.x = (a[0] - cognn_prng(d.open_key0, idx)) + (bb[0] - cognn_prng(d.open_key1, idx));
-                        t.y = (a[1] - cognn_prng(d.open_key0, idx + 1)) + (bb[1] - cognn_prng(d.open_key1, idx + 1));
-                        *reinterpret_cast<u64x2*>(d.open0 + idx) = t;
+                if (d.open0 || d.open1) {
+                    u64 m0[2], m1[2];
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) pair_open_masks<STREAM>(d, SB.op, idx + j, m0[j], m1[j]);
+                    if (d.flags & COGNN_PC_OPEN_SUM) {
+                        if (d.open0) { u64x2 t; t.x = (a[0] - m0[0]) + (bb[0] - m1[0]); t.y = (a[1] - m0[1]) + (bb[1] - m1[1]); *reinterpret_cast<u64x2*>(d.open0 + idx) = t; }
+                    } else {
+                        if (d.open0) { u64x2 t; t.x = a[0] - m0[0]; t.y = a[1] - m0[1]; *reinterpret_cast<u64x2*>(d.open0 + idx) = t; }
+                        if (d.open1) { u64x2 t; t.x = bb[0] - m1[0]; t.y = bb[1] - m1[1]; *reinterpret_cast<u64x2*>(d.open1 + idx) = t; }
                     }
-                } else {
-                    if (d.open0) { u64x2 t; t.x = a[0] - cognn_prng(d.open_key0, idx); t.y = a[1] - cognn_prng(d.open_key0, idx + 1); *reinterpret_cast<u64x2*>(d.open0 + idx) = t; }
-                    if (d.open1) { u64x2 t; t.x = bb[0] - cognn_prng(d.open_key1, idx); t.y = bb[1] - cognn_prng(d.open_key1, idx + 1); *reinterpret_cast<u64x2*>(d.open1 + idx) = t; }
                 }
             }
         }
     }
 }
 
-template <int LPR>
+template <int LPR, bool STREAM>   // STREAM: every pair brings the dealt slab of its chain (pair_chain.h)
 __global__ __launch_bounds__(kThreads) void gather_pair_chain_kernel(const u64* __restrict__ table, const uint32_t* __restrict__ rowptr,
                                                                       const uint32_t* __restrict__ col, int F, int ntiles, GatherPairBatch b) {
     __shared__ uint32_t s_rp[2][kPairTile + 1];
     __shared__ uint32_t s_col[2][kPairColCap];
-    gather_pair_chain_body<LPR>(table, rowptr, col, F, ntiles, b, s_rp, s_col);
+    gather_pair_chain_body<LPR, STREAM>(table, rowptr, col, F, ntiles, b, s_rp, s_col);
 }
 // Grid of the gather kernels: one workgroup per tile up to this cap (the kernels keep their grid-stride loop).  Measured on
 // MI355X (config5, fused F = 64 launch): persistent grids lose to the hardware dispatcher - 1792 workgroups (one per slot)
@@ -340,7 +341,7 @@ int cognn_gather_pair_chain_u64(cognn_ctx* ctx, const uint64_t* table, const uin
     CG_REQUIRE(F > 0 && F % 2 == 0 && F < (1 << 20) && cg_aligned16(table), "cognn_gather_pair_chain_u64: F must be even and the table 16-byte aligned");
     GatherPairBatch b;
     b.count = 0;
-    int ntiles = 0;
+    int ntiles = 0, nstream = 0;
     for (int32_t c = 0; c < count; ++c) {
         const cognn_gather_pair& p = pairs[c];
         const cognn_pair_chain& s = p.chain;
@@ -359,6 +360,8 @@ int cognn_gather_pair_chain_u64(cognn_ctx* ctx, const uint64_t* table, const uin
         d.out0 = (u64*)s.out[0]; d.out1 = (u64*)s.out[1]; d.open0 = (u64*)s.open[0]; d.open1 = (u64*)s.open[1]; d.mask = s.mask;
         pair_chain_fill_keys(d, s);
         d.n = s.rows * F; d.F = (uint32_t)F; d.flags = (uint32_t)fl;
+        d.slab = (const u64*)s.dealt;
+        if (d.slab) ++nstream;
         g.a_row0 = (int)p.a_row0; g.b_row0 = (int)p.b_row0; g.rows = (int)s.rows;
         ntiles += (int)((s.rows + kPairTile - 1) / kPairTile);
         g.tile_end = ntiles;
@@ -367,7 +370,12 @@ int cognn_gather_pair_chain_u64(cognn_ctx* ctx, const uint64_t* table, const uin
     if (ntiles == 0) return 0;
     const int lpr = pick_lpr((int)(F / 2));
     dim3 grid((unsigned)gather_grid(ntiles)), block(kThreads);
-#define CG_GP_CASE(L) case L: hipLaunchKernelGGL((gather_pair_chain_kernel<L>), grid, block, 0, ctx->stream, (const u64*)table, rowptr, col, (int)F, ntiles, b); break;
+    CG_REQUIRE(nstream == 0 || nstream == b.count, "cognn_gather_pair_chain_u64: either every pair brings its dealt values or none does");
+#define CG_GP_CASE(L)                                                                                                                              \
+    case L:                                                                                                                                        \
+        if (nstream) hipLaunchKernelGGL((gather_pair_chain_kernel<L, true>), grid, block, 0, ctx->stream, (const u64*)table, rowptr, col, (int)F, ntiles, b); \
+        else hipLaunchKernelGGL((gather_pair_chain_kernel<L, false>), grid, block, 0, ctx->stream, (const u64*)table, rowptr, col, (int)F, ntiles, b);        \
+        break;
     switch (lpr) {
         CG_GP_CASE(1) CG_GP_CASE(2) CG_GP_CASE(4) CG_GP_CASE(8) CG_GP_CASE(16) CG_GP_CASE(32) CG_GP_CASE(64)
         default: return cognn_set_error("gather_pair_chain: bad lanes-per-row %d", lpr);

@@ -787,6 +787,7 @@ constexpr int kGroupMax = 16;
 struct GemmGroupJob {
     u64* Z; const u64* E0; const u64* E1; const u64* F0; const u64* F1;
     const u64x2* Epl;                                        // PRE: the opened left operand already in fragment order (presplit_e_kernel)
+    const u64* Amask;                                        // the party's mask A_p as dealt [M x K] (COGNN_OPT_DEALER_STREAMS): read, not regenerated
     u64 keyA, keyB;
     int p, M, tiles, wg_end;                                 // wg_end: exclusive prefix of the workgroups assigned to the jobs
 };
@@ -869,6 +870,7 @@ void beaver_gemm_group_kernel(GemmGroup g) {
     const u64* __restrict__ E1 = J.E1;
     u64* __restrict__ Z = J.Z;
     const u64 keyA = J.keyA;
+    const u64* __restrict__ Amask = J.Amask;
     const bool two = E1 != nullptr;                         // (uniform) the opened value arrives as two shares, summed here
     const v4i* bp = reinterpret_cast<const v4i*>(smem) + lane;
     const int wid = wgi * WAVES + wave, nw = nwg * WAVES;
@@ -932,8 +934,14 @@ void beaver_gemm_group_kernel(GemmGroup g) {
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
             const u64 x = (u64)m * (u64)K + (u64)(st * 32 + 8 * jj + 2 * b);
-            w[2 * jj] = cognn_prng(keyA, x);
-            w[2 * jj + 1] = cognn_prng(keyA, x + 1);
+            if (Amask) {                                     // (uniform) dealt mask: a memory stream instead of the counter PRNG
+                const size_t xc = FULL ? (size_t)x : (size_t)min((u64)x, (u64)M * (u64)K - 2);
+                if (KEVEN) { const u64x2 t = *reinterpret_cast<const u64x2*>(Amask + xc); w[2 * jj] = t.x; w[2 * jj + 1] = t.y; }
+                else { w[2 * jj] = Amask[xc]; w[2 * jj + 1] = Amask[xc + 1]; }
+            } else {
+                w[2 * jj] = cognn_prng(keyA, x);
+                w[2 * jj + 1] = cognn_prng(keyA, x + 1);
+            }
         }
         if (!FULL) {
 #pragma unroll
@@ -1869,6 +1877,7 @@ extern "C" int cognn_beaver_gemm_close_group_u64(cognn_ctx* ctx, const cognn_gem
         GemmGroupJob& d = g.j[g.count++];
         d.Z = (u64*)J.Z; d.E0 = (const u64*)J.E0; d.E1 = (const u64*)J.E1; d.F0 = (const u64*)J.F0; d.F1 = (const u64*)J.F1;
         d.Epl = pre ? (const u64x2*)J.E_presplit : nullptr;
+        d.Amask = (const u64*)J.A_dealt;
         d.keyA = J.keys.k[J.p == 0 ? COGNN_SL_A0 : COGNN_SL_A1]; d.keyB = J.keys.k[J.p == 0 ? COGNN_SL_B0 : COGNN_SL_B1];
         d.p = J.p; d.M = (int)J.M; d.tiles = tiles;
         int share = (int)(((int64_t)budget * tiles + tiles_all - 1) / tiles_all);

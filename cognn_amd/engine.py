@@ -142,6 +142,11 @@ class Engine:
         """Promise that no backward iteration follows (inference): stores that only the backward pass reads are skipped."""
         _check(self.lib.cognn_engine_set_option(self.h, 3, int(on)))
 
+    def dealer_streams(self, on=True):
+        """Measurement mode (needs retain_offline): the co-located pairs' dealer values are materialised in HBM at first use and
+        read from there instead of being regenerated from the counter PRNG (cognn_engine.h: COGNN_OPT_DEALER_STREAMS)."""
+        _check(self.lib.cognn_engine_set_option(self.h, 5, int(on)))
+
     def public_openings(self, on=True):
         """Share-holders outside pair chains derive the opening that follows a truncation themselves (default) instead of
         exchanging it as two shares (cognn_engine.h: COGNN_OPT_PUBLIC_OPENINGS)."""

@@ -99,6 +99,9 @@ struct cognn_engine {
     bool h1e_pairs_summed = false;                  // the co-located pairs' h1E holds E_0 + E_1 (written by a pair chain), not E_p
     bool pair_fusion = true;                        // COGNN_OPT_PAIR_FUSION: co-located share-holders run their two-party steps as pair chains
     bool forward_only = false;                      // COGNN_OPT_FORWARD_ONLY: no backward iteration will follow (inference, -m 2)
+    bool dealer_streams = false;                    // COGNN_OPT_DEALER_STREAMS: dealt values of the pair chains / grouped products read from HBM
+    std::map<std::tuple<int, int64_t, int>, u64*> dealt;   // (owner, iteration, place) -> slab, filled at first use, kept (retain_offline)
+    int64_t dealt_bytes = 0;
     double phase_s[6] = {0, 0, 0, 0, 0, 0};         // cognn_engine_get_phase_seconds
     int64_t rounds = 0;                             // exchange rounds started (all iterations)
     cognn_exchange_fn xfn = nullptr;
@@ -352,6 +355,35 @@ struct PairChains {
         v.clear();
     }
 };
+// COGNN_OPT_DEALER_STREAMS: the dealt slab of a chain / the dealt A mask of a product, materialised at first use
+enum { DEAL_GEMM_CHAIN = 0, DEAL_SCALE_CHAIN = 1, DEAL_GATHER_CHAIN = 2, DEAL_RELU_CHAIN = 3, DEAL_GEMM_A0 = 4, DEAL_GEMM_A1 = 5 };
+bool streams_on(const cognn_engine* E) { return E->dealer_streams && E->retain_offline; }
+void attach_dealt(cognn_engine* E, cognn_pair_chain& c, int owner, int64_t it, int place) {
+    if (!streams_on(E)) return;
+    const int64_t slots = E->be->cognn_pair_chain_dealt_slots(c.flags, (c.open[0] || c.open[1]) ? 1 : 0);
+    if (slots <= 0 || c.rows * c.F <= 0) return;
+    auto key = std::make_tuple(owner, it, place);
+    auto f = E->dealt.find(key);
+    if (f == E->dealt.end()) {
+        u64* slab = dalloc<u64>(E, (size_t)(slots * c.rows * c.F));
+        E->dealt_bytes += slots * c.rows * c.F * 8;
+        BE(cognn_pair_chain_deal_u64(E->ctx, &c, slab));
+        f = E->dealt.emplace(key, slab).first;
+    }
+    c.dealt = f->second;
+}
+const u64* dealt_mask(cognn_engine* E, int owner, int64_t it, int place, u64 key, int64_t elems) {
+    if (!streams_on(E) || elems <= 0) return nullptr;
+    auto k = std::make_tuple(owner, it, place);
+    auto f = E->dealt.find(k);
+    if (f == E->dealt.end()) {
+        u64* m = dalloc<u64>(E, (size_t)elems);
+        E->dealt_bytes += elems * 8;
+        BE(cognn_prng_fill_u64(E->ctx, m, key, elems));
+        f = E->dealt.emplace(k, m).first;
+    }
+    return f->second;
+}
 // what follows a Beaver product on the same tensor (PreScatterComp: product, then row scale, gcn.h:233-254)
 struct FollowScale {
     int op = 0, top = 0;
@@ -510,6 +542,7 @@ void gemm_stage(cognn_engine* E, int64_t it, XFn X, WFn Wm, SpecFn spec, DstFn d
                 J.F1 = f_sum ? nullptr : s.ib[1];
                 J.Z = s.zbuf; J.keys = k; J.p = s.p; J.M = g.M; J.scratch = s.scratch;
                 if (feature) J.E_presplit = s.featPl;
+                J.A_dealt = dealt_mask(E, s.owner, it, s.p == 0 ? DEAL_GEMM_A0 : DEAL_GEMM_A1, k.k[s.p == 0 ? COGNN_SL_A0 : COGNN_SL_A1], g.M * g.K);
                 jobs.push_back(J); idx.push_back(i);
                 if (E->timing) E->algo[T_GEMM] += 2.0 * 36 * 2 * (double)g.M * g.K * g.N;
                 z[i] = s.zbuf;
@@ -586,7 +619,9 @@ void gemm_stage(cognn_engine* E, int64_t it, XFn X, WFn Wm, SpecFn spec, DstFn d
                     c.open_key[0] = open_next.key(s); c.open_key[1] = open_next.key(t);
                 }
             }
+            attach_dealt(E, c, s.owner, it, DEAL_GEMM_CHAIN);
         }
+        if (streams_on(E)) { bool all = true; for (auto& c : pc.v) all = all && c.dealt; if (!all) for (auto& c : pc.v) c.dealt = nullptr; }
         pc.launch(E);
         for (auto& s : E->sides)
             if (paired(E, s) && s.p == 1) c1_release(E, s, {it, spec(s).op});
@@ -895,8 +930,11 @@ void message_passing_fused(cognn_engine* E, int F, int64_t it, bool scale, bool 
         }
         const double elems = (double)s.n * F;
         out_bytes += 8.0 * elems * ((c.out[0] ? 2 : 0) + (c.open[0] ? ((c.flags & COGNN_PC_OPEN_SUM) ? 1 : 2) : 0)) + (c.mask ? elems : 0.0);
+        attach_dealt(E, c, s.owner, it, DEAL_GATHER_CHAIN);
+        if (c.dealt) out_bytes += 8.0 * elems * (double)E->be->cognn_pair_chain_dealt_slots(c.flags, c.open[0] ? 1 : 0);   // the dealt values it reads
         gp.push_back(g);
     }
+    if (streams_on(E)) { bool all = true; for (auto& g : gp) all = all && g.chain.dealt; if (!all) for (auto& g : gp) g.chain.dealt = nullptr; }
     if (E->timing) BE(cognn_timer_begin(E->ctx, T_AGG));
     BE(cognn_gather_pair_chain_u64(E->ctx, E->table, E->agg_rowptr, E->agg_col, F, gp.data(), (int32_t)gp.size()));
     if (E->timing) {
@@ -1776,6 +1814,7 @@ int cognn_engine_set_option(cognn_engine* E, int32_t option, int64_t value) {
         else if (option == COGNN_OPT_PAIR_FUSION) E->pair_fusion = value != 0;
         else if (option == COGNN_OPT_FORWARD_ONLY) E->forward_only = value != 0;
         else if (option == COGNN_OPT_PUBLIC_OPENINGS) E->public_openings = value != 0;
+        else if (option == COGNN_OPT_DEALER_STREAMS) E->dealer_streams = value != 0;
         else throw EngineError("cognn_engine_set_option: unknown option");
     });
 }

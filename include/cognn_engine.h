@@ -89,8 +89,16 @@ int cognn_engine_offline(cognn_engine* e, int64_t iter_begin, int64_t iter_end);
  * fusion is off) close a truncation from both opened values and derive the opening of the op that consumes the result
  * themselves (cognn_trunc_close_pub_u64), so the exchange round that carried that opening - and the co-party's reveal of z
  * before the softmax - disappears: 3 of the 17 rounds and 15 % of the bytes of an inference pass.  0: every opening is
- * exchanged as two shares.  Shares and metrics are bit-identical either way. */
-enum { COGNN_OPT_RETAIN_OFFLINE = 1, COGNN_OPT_PAIR_FUSION = 2, COGNN_OPT_FORWARD_ONLY = 3, COGNN_OPT_PUBLIC_OPENINGS = 4 };
+ * exchanged as two shares.  Shares and metrics are bit-identical either way.
+ * COGNN_OPT_DEALER_STREAMS (default 0; needs COGNN_OPT_RETAIN_OFFLINE): the dealt form of the online phase.  By default
+ * every dealer value is regenerated in registers from the counter PRNG (0 HBM bytes).  The reference's online phase instead
+ * consumes correlations its offline phase wrote to memory (README.md:215-216, ss_...h:536-610).  With this option the masks of
+ * the co-located pairs' chains (cognn_pair_chain_deal_u64: what each party receives for the truncations, row scales, ReLUs and
+ * openings) and the A masks of the grouped products are materialised in HBM the first time an iteration runs and READ from
+ * there afterwards: +8 bytes per dealt value, shares bit-identical.  A measurement mode (bench.py reports it beside the
+ * headline): the per-side kernels of multi-rank runs and the weight-sized operands keep regenerating theirs. */
+enum { COGNN_OPT_RETAIN_OFFLINE = 1, COGNN_OPT_PAIR_FUSION = 2, COGNN_OPT_FORWARD_ONLY = 3, COGNN_OPT_PUBLIC_OPENINGS = 4,
+       COGNN_OPT_DEALER_STREAMS = 5 };
 int cognn_engine_set_option(cognn_engine* e, int32_t option, int64_t value);
 /* Offline-phase cache on disk, the counterpart of the reference's preprocess/<setting>/ directory reused with `-n 1`
  * (include/harness.h:140-146, README.md:215-216): save writes every dealt product share currently held on this rank to

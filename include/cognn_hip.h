@@ -146,6 +146,8 @@ typedef struct {
     uint64_t* scratch;                           /* M x K + K x N u64: used by the per-job fallback only */
     const void* E_presplit;                      /* optional: E0 + E1 already limb-split in MFMA fragment order (cognn_gemm_presplit_u64);
                                                   * used by the grouped kernel when EVERY job of the call brings one */
+    const uint64_t* A_dealt;                     /* optional (COGNN_OPT_DEALER_STREAMS): this party's mask A_p [M x K] as dealt (cognn_prng_fill_u64
+                                                  * with its A key): read instead of regenerated (grouped kernel only) */
 } cognn_gemm_job;
 int cognn_beaver_gemm_close_group_u64(cognn_ctx*, const cognn_gemm_job* jobs, int32_t count, int64_t N, int64_t K, int raw);
 /* An opened left operand that many products reuse - the constant input-feature opening of the layer-0 product (gcn.h:233 in
@@ -259,7 +261,17 @@ typedef struct {
     int32_t flags;
     const uint8_t* mask_in;      /* optional: x_p is taken as mask_in[i] ? x_p[i] : 0 - the backward ReLU' (cognn_mask_select_u64 with the public
                                   * sign mask, gcn.h:702-708) folded into the chain that consumes its result; not with COGNN_PC_INPUT_OPENED */
+    const uint64_t* dealt;       /* optional (COGNN_OPT_DEALER_STREAMS): the chain's per-element dealer values as the offline phase hands them to
+                                  * the two parties, [slot][rows x F] (cognn_pair_chain_deal_u64): read instead of regenerated from the counter
+                                  * PRNG - identical results, +8 bytes of HBM traffic per slot and element */
 } cognn_pair_chain;
+/* The dealt form of one chain (README.md:215-216, ss_...h:536-610: the reference's online phase consumes preprocessed correlations
+ * from memory): per element, in this order, the slots the chain's steps use -
+ *   COGNN_PC_TRUNC_IN: C_0, r_0, r_1, r'_0, r'_1;  COGNN_PC_SCALE: a_0, a_1, c_0, c_1, r_0, r_1, r'_0, r'_1 (b_p: one value per row,
+ *   regenerated);  COGNN_PC_RELU: a_0, a_1, b_0, b_1, c_0, c_1, g;  an opening (open[0] or open[1] set): a_0, a_1.
+ * _slots: their number; _deal fills `dealt` (slots x rows x F u64) from the chain's keys. */
+int64_t cognn_pair_chain_dealt_slots(int32_t flags, int32_t has_open);
+int cognn_pair_chain_deal_u64(cognn_ctx*, const cognn_pair_chain* chain, uint64_t* dealt);
 /* independent chains (the co-located pairs of one protocol phase) are issued as shared launches */
 int cognn_pair_chain_u64(cognn_ctx*, const cognn_pair_chain* chains, int32_t count);
 

@@ -237,6 +237,8 @@ int cognn_beaver_gemm_close2_u64(cognn_ctx* c, uint64_t* Z, const uint64_t* E0, 
     return raw ? cognn_beaver_gemm_close_raw_u64(c, Z, E0, E1, f.data(), keys, p, M, N, K, scratch)
                : cognn_beaver_gemm_close_u64(c, Z, E0, E1, f.data(), c1, keys, p, M, N, K, transA, scratch);
 }
+int64_t cognn_pair_chain_dealt_slots(int32_t, int32_t) { return 0; }     // the CPU stand-in regenerates every dealer value
+int cognn_pair_chain_deal_u64(cognn_ctx*, const cognn_pair_chain*, uint64_t*) { return 0; }
 int64_t cognn_gemm_presplit_bytes(int64_t, int64_t) { return 0; }      // the CPU stand-in has no fragment-ordered form
 int cognn_gemm_presplit_u64(cognn_ctx*, void*, const uint64_t*, const uint64_t*, int64_t, int64_t) { return 0; }
 int cognn_beaver_gemm_close_group_u64(cognn_ctx* c, const cognn_gemm_job* jobs, int32_t count, int64_t N, int64_t K, int raw) {

@@ -80,6 +80,25 @@ def test_pair_chain_matches_the_two_party_oracle(ctx, flags, rows, F):
     with np.errstate(over="ignore"):
         assert np.array_equal(host(op0), e0 - co.prng_shape(ok0, shape))
         assert np.array_equal(host(op1), e1 - co.prng_shape(ok1, shape))
+    # the dealt form (COGNN_OPT_DEALER_STREAMS): the same chain with its dealer values read from a slab instead of regenerated
+    if not flags & OPENED:
+        lib = capi.load()
+        slots = lib.cognn_pair_chain_dealt_slots(flags, 1)
+        assert slots == (5 if flags & TRUNC_IN else 0) + (8 if flags & SCALE else 0) + (7 if flags & RELU else 0) + 2
+        slab = dev_empty(slots * rows * F)
+        ctx.call("cognn_pair_chain_deal_u64", ctypes.byref(c), ptr(slab))
+        d0, d1, dp0, dp1 = (dev_empty(shape) for _ in range(4))
+        dmask = dev_empty(shape, "u8")
+        c.out[0] = d0.data_ptr(); c.out[1] = d1.data_ptr(); c.open[0] = dp0.data_ptr(); c.open[1] = dp1.data_ptr(); c.mask = dmask.data_ptr()
+        c.dealt = slab.data_ptr()
+        ctx.call("cognn_pair_chain_u64", ctypes.byref(c), 1)
+        assert np.array_equal(host(d0), e0) and np.array_equal(host(d1), e1)
+        assert np.array_equal(host(dp0), host(op0)) and np.array_equal(host(dp1), host(op1))
+        if flags & RELU:
+            assert np.array_equal(host(dmask, np.uint8), host(mask, np.uint8))
+        c.dealt = None
+        c.out[0] = out0.data_ptr(); c.out[1] = out1.data_ptr(); c.open[0] = op0.data_ptr(); c.open[1] = op1.data_ptr(); c.mask = mask.data_ptr()
+    with np.errstate(over="ignore"):
         # COGNN_PC_OPEN_SUM: one tensor, the opening as both parties hold it after the exchange
         c.open[0] = op0.data_ptr(); c.open[1] = None; c.flags = flags | OPEN_SUM
         c.out[0] = None; c.out[1] = None

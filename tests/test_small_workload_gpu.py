@@ -66,3 +66,11 @@ def test_small_workload_matches_the_oracle_on_every_row(hid):
     for P in range(k):
         assert np.array_equal(b.shares(P, 0), want[-1][P][0]) and np.array_equal(b.shares(P, 1), want[-1][P][1]), "bench sequence, party %d" % P
     b.close()
+    # the dealt form of the online phase: the same sequence with the pairs' dealer values read from HBM (COGNN_OPT_DEALER_STREAMS)
+    d = engine()
+    d.retain_offline(True); d.forward_only(True); d.dealer_streams(True); d.offline(0, iters)
+    for _ in range(2):                                       # first pass deals, second reads what the first dealt
+        d.run(0, iters)
+    for P in range(k):
+        assert np.array_equal(d.shares(P, 0), want[-1][P][0]) and np.array_equal(d.shares(P, 1), want[-1][P][1]), "dealer streams, party %d" % P
+    d.close()
