@@ -213,6 +213,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true", help="skip the cross-path verification after the timed region")
     ap.add_argument("--no-dealer-streams", action="store_true", help="skip the extra timing of the dealt (memory-streamed dealer) form")
+    ap.add_argument("--graph", action="store_true", help="training workloads: replay the recorded epoch (hipGraph, COGNN_OPT_GRAPH_EPOCHS) instead of launching every kernel")
     args = ap.parse_args()
 
     import torch
@@ -268,6 +269,11 @@ def main():
     eng.retain_offline(True)                  # every step replays the same iterations: keep their dealt product shares
     if "inference" in variant:
         eng.forward_only(True)                # -m 2: the hidden activation and the ReLU sign mask have no reader
+    # measured (MI355X, ROCm 7.2): replaying a recorded epoch is NOT faster than launching its kernels - Cora 0.43 vs 0.45 ms, CiteSeer 0.64 vs
+    # 0.54, PubMed 0.80 vs 0.69, config5-train 15.1 vs 13.0 - a serial chain of dependent dispatches costs the same either way; opt-in only
+    recorded = world == 1 and "inference" not in variant and iters % 6 == 0 and args.graph
+    if recorded:
+        eng.graph_epochs(True)                # a training epoch per step: recorded once (hipGraph), replayed (COGNN_OPT_GRAPH_EPOCHS)
     eng.offline(0, iters)
     torch.cuda.synchronize()
     offline_ms = (time.perf_counter() - t_off) * 1e3
@@ -281,9 +287,11 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    n_warm = max(args.warmup, 2) if recorded else args.warmup   # (recorded epochs: one eager, one while recording)
+    for _ in range(n_warm):
         eng.run(0, iters)
-    eng.enable_timing(True)
+    if not recorded:
+        eng.enable_timing(True)               # (per-kernel HIP-event timers would break up the recorded epoch)
     x0 = xch.stats() if xch else None
     barrier()
     t0 = time.perf_counter()
@@ -348,6 +356,7 @@ def main():
                                           "i8_TOPs": (ops_gemm / 1e12) / (ms_gemm / 1e3) if ms_gemm > 0 else None,
                                           "frac_of_5000_TOPs": ((ops_gemm / 1e12) / (ms_gemm / 1e3) / 5000.0) if ms_gemm > 0 else None}},
         "graph": wlinfo,
+        "launch": "recorded epoch replayed (hipGraph)" if recorded else "one launch per kernel",
     }
     if xch:                                   # rank 0's share of the exchange: rounds and bytes per step (all ranks are symmetric up to the partition)
         out["exchange"] = {"rounds_per_step": (x1["rounds"] - x0["rounds"]) / args.steps,
@@ -357,8 +366,8 @@ def main():
                            "GBps_while_communicating": ((x1["bytes_sent"] - x0["bytes_sent"]) / 1e9) / max((x1["comm_ms"] - x0["comm_ms"]) / 1e3, 1e-12),
                            "transport": "native RCCL p2p groups on a communication stream (csrc/exchange_rccl.hip)"}
     if not args.no_check and world == 1:
-        out["check"] = cross_path_check(eng, Engine, k, src, dst, part, param, variant, iters, in_dim, lab, args.warmup + args.steps)
-    if world == 1 and not args.no_dealer_streams:
+        out["check"] = cross_path_check(eng, Engine, k, src, dst, part, param, variant, iters, in_dim, lab, n_warm + args.steps)
+    if world == 1 and not args.no_dealer_streams and not recorded:
         out["dealer_streams"] = dealer_streams_leg(eng, torch, args, iters, k, out.get("check", {}).get("digest"))
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args, wl)

@@ -75,6 +75,12 @@ _SIGNATURES = {
     "cognn_lane_begin": (_I, [_P, ctypes.c_int32]),
     "cognn_lane_select": (_I, [_P, ctypes.c_int32]),
     "cognn_lane_end": (_I, [_P]),
+    "cognn_set_epoch_salt": (_I, [_P, _U]),
+    "cognn_ctx_use_private_stream": (_I, [_P]),
+    "cognn_graph_capture_begin": (_I, [_P]),
+    "cognn_graph_capture_end": (_I, [_P, ctypes.POINTER(_P)]),
+    "cognn_graph_launch": (_I, [_P, _P]),
+    "cognn_graph_destroy": (_I, [_P, _P]),
     "cognn_malloc": (_I, [_P, ctypes.POINTER(_P), ctypes.c_size_t]),
     "cognn_free": (_I, [_P, _P]),
     "cognn_memcpy_h2d": (_I, [_P, _P, _P, ctypes.c_size_t]),

@@ -13,6 +13,15 @@ int cognn_set_error(const char* fmt, ...) {
     return 1;
 }
 
+void* cg_salt_symbol_kernels_elementwise();
+void* cg_salt_symbol_kernels_gather();
+void* cg_salt_symbol_kernels_gemm();
+namespace {
+__global__ void salt_set_kernel(unsigned long long* a, unsigned long long* b, unsigned long long* c, unsigned long long v) {
+    if (threadIdx.x == 0) { *a = v; *b = v; *c = v; }
+}
+}  // namespace
+
 extern "C" {
 
 int cognn_abi_version(void) { return COGNN_ABI_VERSION; }
@@ -181,6 +190,64 @@ int cognn_timer_reset(cognn_ctx* ctx) {
         for (auto& ev : ctx->open_begin[k]) (void)hipEventDestroy(ev);
         ctx->open_begin[k].clear();
     }
+    return 0;
+}
+int cognn_set_epoch_salt(cognn_ctx* ctx, uint64_t salt) {
+    { const int rc_flush_ = cg_flush(ctx); if (rc_flush_) return rc_flush_; }
+    CG_REQUIRE(ctx, "cognn_set_epoch_salt: null ctx");
+    if (!ctx->salt_sym[0]) {
+        ctx->salt_sym[0] = (unsigned long long*)cg_salt_symbol_kernels_elementwise();
+        ctx->salt_sym[1] = (unsigned long long*)cg_salt_symbol_kernels_gather();
+        ctx->salt_sym[2] = (unsigned long long*)cg_salt_symbol_kernels_gemm();
+        CG_REQUIRE(ctx->salt_sym[0] && ctx->salt_sym[1] && ctx->salt_sym[2], "cognn_set_epoch_salt: cannot resolve the salt symbols");
+    }
+    hipLaunchKernelGGL(salt_set_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->salt_sym[0], ctx->salt_sym[1], ctx->salt_sym[2], (unsigned long long)salt);
+    CG_LAUNCH_CHECK();
+    return 0;
+}
+// ---- a recorded sequence of launches (hipGraph): the engine records one epoch and replays it (COGNN_OPT_GRAPH_EPOCHS) ----------
+int cognn_ctx_use_private_stream(cognn_ctx* ctx) {
+    { const int rc_flush_ = cg_flush(ctx); if (rc_flush_) return rc_flush_; }
+    CG_REQUIRE(ctx && !ctx->lanes_active && !ctx->capturing, "cognn_ctx_use_private_stream: bad state");
+    if (ctx->own_stream) return 0;
+    CG_HIP(hipStreamSynchronize(ctx->stream));                 // everything issued so far on the caller's stream is done
+    hipStream_t st;
+    CG_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));   // (the legacy default stream cannot be captured)
+    ctx->stream = st;
+    ctx->own_stream = true;
+    return 0;
+}
+int cognn_graph_capture_begin(cognn_ctx* ctx) {
+    { const int rc_flush_ = cg_flush(ctx); if (rc_flush_) return rc_flush_; }
+    CG_REQUIRE(ctx && ctx->own_stream && !ctx->capturing && !ctx->lanes_active, "cognn_graph_capture_begin: needs a private stream (cognn_ctx_use_private_stream) and no open lanes");
+    CG_HIP(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+    ctx->capturing = true;
+    return 0;
+}
+int cognn_graph_capture_end(cognn_ctx* ctx, void** exec_out) {
+    CG_REQUIRE(ctx && ctx->capturing && exec_out, "cognn_graph_capture_end: not capturing");
+    const int rc_flush = cg_flush(ctx);
+    hipGraph_t graph = nullptr;
+    const hipError_t e = hipStreamEndCapture(ctx->stream, &graph);
+    ctx->capturing = false;
+    if (rc_flush) { if (graph) (void)hipGraphDestroy(graph); return rc_flush; }
+    if (e != hipSuccess || !graph) return cognn_set_error("cognn_graph_capture_end: hipStreamEndCapture failed: %s", hipGetErrorString(e));
+    hipGraphExec_t exec = nullptr;
+    const hipError_t ie = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (ie != hipSuccess) return cognn_set_error("cognn_graph_capture_end: hipGraphInstantiate failed: %s", hipGetErrorString(ie));
+    *exec_out = (void*)exec;
+    return 0;
+}
+int cognn_graph_launch(cognn_ctx* ctx, void* exec) {
+    { const int rc_flush_ = cg_flush(ctx); if (rc_flush_) return rc_flush_; }
+    CG_REQUIRE(ctx && exec && !ctx->capturing, "cognn_graph_launch: bad arguments");
+    CG_HIP(hipGraphLaunch((hipGraphExec_t)exec, ctx->stream));
+    return 0;
+}
+int cognn_graph_destroy(cognn_ctx* ctx, void* exec) {
+    CG_REQUIRE(ctx, "cognn_graph_destroy: null ctx");
+    if (exec) { (void)hipStreamSynchronize(ctx->stream); CG_HIP(hipGraphExecDestroy((hipGraphExec_t)exec)); }
     return 0;
 }
 void cognn_make_keys(uint64_t seed, uint64_t owner, uint64_t iter, uint64_t op, cognn_keys* out) {

@@ -62,7 +62,27 @@ COGNN_HD uint64_t cognn_prng_z(uint64_t z, uint32_t key_hi) {
     z += (uint64_t)(uint32_t)z * COGNN_PRNG_C3;
     return z;
 }
+/* Epoch salt.  The engine addresses a dealer stream by (seed, owner, GAS iteration, op, slot); the iteration enters in two
+ * parts: its position inside the epoch goes through the key derivation (cognn_stream_key with iter % epoch), the epoch number
+ * is ADDED to the 64-bit stream key as epoch * COGNN_GAMMA - here, where the stream is evaluated.  Kernel arguments therefore
+ * do not change from one epoch to the next, which is what lets a recorded epoch (hipGraph) be replayed: the salt lives in
+ * device memory (one uniform scalar load and add per stream, no vector work) and is set between replays
+ * (cognn_set_epoch_salt).  It is 0 unless the engine sets it, so every other user of the C ABI sees prng(key, idx) as defined
+ * above.  The plain-C++ backend of the tests keeps its copy in cognn_host_salt. */
+#if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
+static __constant__ uint64_t cognn_epoch_salt_dev;
+#define COGNN_SALT cognn_epoch_salt_dev
+#elif defined(__HIPCC__)
+static __constant__ uint64_t cognn_epoch_salt_dev;          /* host pass: the shadow of the device symbol (address taken by the setter) */
+#define COGNN_SALT 0ull
+#elif defined(COGNN_HOST_SALT)
+extern uint64_t cognn_host_salt;
+#define COGNN_SALT cognn_host_salt
+#else
+#define COGNN_SALT 0ull
+#endif
 COGNN_HD uint64_t cognn_prng(uint64_t key, uint64_t idx) {
+    key += COGNN_SALT;
     return cognn_prng_z(idx ^ key, (uint32_t)(key >> 32));
 }
 COGNN_HD uint64_t cognn_derive(uint64_t key, uint64_t tag) {

@@ -30,6 +30,8 @@ struct cognn_ctx {
     std::vector<char> lane_used;
     hipEvent_t lane_fork = nullptr;
     int lanes_active = 0;
+    unsigned long long* salt_sym[3] = {nullptr, nullptr, nullptr};   // the kernel translation units' copies of the epoch salt (cognn_spec.h)
+    bool capturing = false;                                          // between cognn_graph_capture_begin / _end
 };
 // launches whatever is queued (every non-element-wise entry point calls it first, so stream order is preserved)
 static inline int cg_flush(cognn_ctx* ctx) { return (ctx && ctx->pending.flush) ? ctx->pending.flush(ctx) : 0; }

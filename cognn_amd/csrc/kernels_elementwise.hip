@@ -886,3 +886,9 @@ int cognn_transpose_u64(cognn_ctx* ctx, uint64_t* out, const uint64_t* in, int64
 }
 
 }  // extern "C"
+
+// device address of this translation unit's copy of the epoch salt (cognn_spec.h), for cognn_set_epoch_salt
+void* cg_salt_symbol_kernels_elementwise() {
+    void* p = nullptr;
+    return hipGetSymbolAddress(&p, HIP_SYMBOL(cognn_epoch_salt_dev)) == hipSuccess ? p : nullptr;
+}

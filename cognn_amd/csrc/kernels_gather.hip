@@ -397,3 +397,9 @@ int cognn_scatter_add_rows_u64(cognn_ctx* ctx, uint64_t* v, const uint64_t* part
 }
 
 }  // extern "C"
+
+// device address of this translation unit's copy of the epoch salt (cognn_spec.h), for cognn_set_epoch_salt
+void* cg_salt_symbol_kernels_gather() {
+    void* p = nullptr;
+    return hipGetSymbolAddress(&p, HIP_SYMBOL(cognn_epoch_salt_dev)) == hipSuccess ? p : nullptr;
+}

@@ -1919,3 +1919,9 @@ extern "C" int cognn_gemm_presplit_u64(cognn_ctx* ctx, void* image, const uint64
     CG_LAUNCH_CHECK();
     return 0;
 }
+
+// device address of this translation unit's copy of the epoch salt (cognn_spec.h), for cognn_set_epoch_salt
+void* cg_salt_symbol_kernels_gemm() {
+    void* p = nullptr;
+    return hipGetSymbolAddress(&p, HIP_SYMBOL(cognn_epoch_salt_dev)) == hipSuccess ? p : nullptr;
+}

@@ -147,6 +147,10 @@ class Engine:
         read from there instead of being regenerated from the counter PRNG (cognn_engine.h: COGNN_OPT_DEALER_STREAMS)."""
         _check(self.lib.cognn_engine_set_option(self.h, 5, int(on)))
 
+    def graph_epochs(self, on=True):
+        """Whole epochs per run() call are recorded once (hipGraph) and replayed (cognn_engine.h: COGNN_OPT_GRAPH_EPOCHS)."""
+        _check(self.lib.cognn_engine_set_option(self.h, 6, int(on)))
+
     def public_openings(self, on=True):
         """Share-holders outside pair chains derive the opening that follows a truncation themselves (default) instead of
         exchanging it as two shares (cognn_engine.h: COGNN_OPT_PUBLIC_OPENINGS)."""

@@ -99,6 +99,11 @@ struct cognn_engine {
     bool h1e_pairs_summed = false;                  // the co-located pairs' h1E holds E_0 + E_1 (written by a pair chain), not E_p
     bool pair_fusion = true;                        // COGNN_OPT_PAIR_FUSION: co-located share-holders run their two-party steps as pair chains
     bool forward_only = false;                      // COGNN_OPT_FORWARD_ONLY: no backward iteration will follow (inference, -m 2)
+    bool graph_epochs = false;                      // COGNN_OPT_GRAPH_EPOCHS: whole epochs are recorded once (hipGraph) and replayed
+    bool graph_warm = false, graph_unsupported = false;
+    void* graph_exec = nullptr;
+    int64_t graph_epoch = -1;                       // the epoch the recorded graph was captured in (retained products are tied to it)
+    u64 salt_now = 0;                               // the epoch salt currently set on the device (cognn_set_epoch_salt)
     bool dealer_streams = false;                    // COGNN_OPT_DEALER_STREAMS: dealt values of the pair chains / grouped products read from HBM
     std::map<std::tuple<int, int64_t, int>, u64*> dealt;   // (owner, iteration, place) -> slab, filled at first use, kept (retain_offline)
     int64_t dealt_bytes = 0;
@@ -196,23 +201,40 @@ T* upload(cognn_engine* E, const std::vector<T>& v) {
     return d;
 }
 
+// A dealer stream of GAS iteration `it` is addressed by (seed, owner, it % epoch, op, slot) through the key derivation and by the
+// epoch number through the salt that the device adds to every key (cognn_spec.h): the arguments of an epoch's kernels do not
+// depend on the epoch, so a recorded epoch can be replayed.
+int epoch_len(const cognn_engine* E) { return 3 * E->cfg.num_layers; }
 cognn_keys keys(cognn_engine* E, u64 owner, int64_t it, int op) {
     cognn_keys k;
-    cognn_opkeys o = cognn_make_opkeys(E->cfg.seed, owner, (u64)it, (u64)op);
+    cognn_opkeys o = cognn_make_opkeys(E->cfg.seed, owner, (u64)(it % epoch_len(E)), (u64)op);
     for (int i = 0; i < COGNN_SL_COUNT; ++i) k.k[i] = o.k[i];
     return k;
 }
+void set_salt_value(cognn_engine* E, u64 salt) {
+    if (E->salt_now == salt) return;
+    BE(cognn_set_epoch_salt(E->ctx, salt));
+    E->salt_now = salt;
+}
+void set_salt(cognn_engine* E, int64_t it) { set_salt_value(E, (u64)(it / epoch_len(E)) * COGNN_GAMMA); }
 // layer-0 PreScatter product: the feature operand's mask A is dealt once (iteration 0), B and C per iteration
 // (op = COGNN_OP_PS_GEMM for the forward product, COGNN_OP_AP_GEMM for the layer-0 weight gradient on the transposed features)
+// Default: the mask is the one of iteration 0 in EVERY epoch - the device adds the current epoch's salt to whatever key it is
+// given, so the salt is taken off here.  With recorded epochs (COGNN_OPT_GRAPH_EPOCHS) kernel arguments must not depend on the
+// epoch: the mask is then dealt per epoch (salted like every other stream) and the opening is renewed at the first iteration of
+// each epoch (open_features).  The shares after the product's truncation are the same either way: they depend on the exact
+// product and on the truncation's streams, not on how the operands were masked.
 cognn_keys feature_gemm_keys(cognn_engine* E, u64 owner, int64_t it, int op = COGNN_OP_PS_GEMM) {
     cognn_keys k = keys(E, owner, it, op), k0 = keys(E, owner, 0, COGNN_OP_PS_GEMM);
-    k.k[COGNN_SL_A0] = k0.k[COGNN_SL_A0];
-    k.k[COGNN_SL_A1] = k0.k[COGNN_SL_A1];
+    const u64 off = E->graph_epochs ? 0 : E->salt_now;
+    k.k[COGNN_SL_A0] = k0.k[COGNN_SL_A0] - off;
+    k.k[COGNN_SL_A1] = k0.k[COGNN_SL_A1] - off;
     return k;
 }
 
 struct GemmSpec;
 cognn_keys gemm_keys(cognn_engine* E, Side& s, int64_t it, const GemmSpec& g);
+void open_features(cognn_engine* E);
 
 u64 fx_llround(double x) { return (u64)(long long)llround(x * (double)COGNN_FX_ONE); }
 u64 fx_trunc(double x) { return (u64)(x * (double)COGNN_FX_ONE); }   // static_cast as in gcn.h:676,678,764
@@ -507,7 +529,7 @@ void gemm_stage(cognn_engine* E, int64_t it, XFn X, WFn Wm, SpecFn spec, DstFn d
         dealt = dealt && (s.p != 1 || s.c1.count({it, g.op}));
         large = large || g.M * g.K * g.N >= (1ll << 27);
     }
-    const int lanes = (dealt && large && E->gemm_lanes > 1 && ns > 1) ? E->gemm_lanes : 0;
+    const int lanes = (dealt && large && E->gemm_lanes > 1 && ns > 1 && !E->graph_epochs) ? E->gemm_lanes : 0;   // (no auxiliary streams inside a recording)
     // timed as one phase on the engine's stream (the lanes overlap each other): all sides' products of this stage, with their
     // operand preparation (and, for sides whose peer is remote, the truncation opening and the wait for the peer's opening)
     if (E->timing) BE(cognn_timer_begin(E->ctx, T_GEMM));
@@ -1099,8 +1121,10 @@ void run_iteration(cognn_engine* E, int64_t it) {
     const IterInfo I = iter_info(E, it);
     if (E->forward_only && !I.fwd) throw EngineError("engine: COGNN_OPT_FORWARD_ONLY is set but a backward iteration was requested");
     bool relu_opened = false, wgrad_w_opened = false, relu_pairs_done = false, gather_chain_fused = false, z_revealed = false;
+    set_salt(E, it);                                       // (a launch only when the epoch changes: never inside a recorded epoch)
     if (I.e == 0) {                                        // ss_...h:695, 938: back to the input features
         for (auto& s : E->sides) { s.cur = s.feat; s.curF = E->in(); s.cur_mask = nullptr; }
+        if (E->graph_epochs) open_features(E);             // this epoch's feature mask (feature_gemm_keys)
     }
     // a deferred ReLU' selection is consumed by the backward PreScatter row scale of the co-located pairs; anybody else gets the
     // selected tensor
@@ -1228,7 +1252,10 @@ bool gemm_of_iteration(cognn_engine* E, Side& s, int64_t it, GemmSpec& g) {
 
 // dealer phase: product shares of every Beaver GEMM in [it0,it1)
 void run_offline(cognn_engine* E, int64_t it0, int64_t it1) {
-    for (int64_t it = it0; it < it1; ++it)
+    // recorded epochs deal their product shares inside the recording (on demand), unless the caller replays ONE epoch and keeps them
+    if (E->graph_epochs && !E->retain_offline) return;
+    for (int64_t it = it0; it < it1; ++it) {
+        set_salt(E, it);
         for (auto& s : E->sides) {
             GemmSpec g;
             if (s.p != 1 || !gemm_of_iteration(E, s, it, g) || s.c1.count({it, g.op})) continue;
@@ -1237,6 +1264,35 @@ void run_offline(cognn_engine* E, int64_t it0, int64_t it1) {
             BE(cognn_dealer_gemm_c1_u64(E->ctx, c, &k, g.M, g.N, g.K, g.transA, s.scratch, s.scratch + g.M * g.K));
             s.c1[{it, g.op}] = Side::C1{c, g.M * g.N};
         }
+    }
+    set_salt_value(E, 0);
+}
+
+// One whole epoch [it, it + epoch) of a single-process run as a recorded launch sequence (COGNN_OPT_GRAPH_EPOCHS): the first
+// epoch runs eagerly (allocations, pools and kernel attributes settle), the second is recorded while it is issued, every later
+// one is the same recording replayed under its own epoch salt - dataset-sized graphs spend their epoch in launch overhead
+// (about 100 launches of a few microseconds of work each).
+void run_epoch(cognn_engine* E, int64_t it) {
+    const int ep = epoch_len(E);
+    auto eager = [&] { for (int j = 0; j < ep; ++j) { run_iteration(E, it + j); exchange_wait(E); } };
+    set_salt(E, it);
+    if (!E->graph_warm || E->graph_unsupported) { eager(); E->graph_warm = true; return; }
+    if (E->graph_exec && E->retain_offline && E->graph_epoch != it / ep) { eager(); return; }   // retained products belong to the epoch they were dealt in
+    if (!E->graph_exec) {
+        if (E->be->cognn_graph_capture_begin(E->ctx) != 0) { E->graph_unsupported = true; eager(); return; }
+        void* exec = nullptr;
+        try {
+            for (int j = 0; j < ep; ++j) run_iteration(E, it + j);
+        } catch (...) {
+            E->be->cognn_graph_capture_end(E->ctx, &exec);
+            if (exec) E->be->cognn_graph_destroy(E->ctx, exec);
+            throw;
+        }
+        BE(cognn_graph_capture_end(E->ctx, &exec));
+        E->graph_exec = exec;
+        E->graph_epoch = it / ep;
+    }
+    BE(cognn_graph_launch(E->ctx, E->graph_exec));
 }
 
 // identifies the run a cached product share belongs to: parties, ranks, variant, dimensions, graph size, rows of the owner
@@ -1519,6 +1575,43 @@ std::vector<double> glorot(int d0, int d1) {               // gcn.h:838-852, lib
     return w;
 }
 
+// The layer-0 product's feature opening E_p = X_p - A_p (fixed-operand mask reuse): opened, exchanged and summed
+// once in start() - or, with recorded epochs, at the first iteration of every epoch with that epoch's mask.
+void open_features(cognn_engine* E) {
+    const int in = E->in();
+    for (auto& s : E->sides) {
+        cognn_keys fk = feature_gemm_keys(E, s.owner, 0);
+        BE(cognn_mask_open_u64(E->ctx, s.featE, s.feat, fk.k[s.p == 0 ? COGNN_SL_A0 : COGNN_SL_A1], (int64_t)s.n, in, 0));
+    }
+    {
+        XList xl;
+        for (auto& s : E->sides) {
+            if (s.peer) continue;
+            xl.send(s.peer_rank, s.featE, (int64_t)s.n * in * 8);
+            xl.recv(s.peer_rank, s.featE_peer, (int64_t)s.n * in * 8);
+        }
+        run_exchange_sync(E, xl);
+    }
+    // E = E_0 + E_1: summed once (in place; a co-located pair shares the owner side's copy, so its two GEMMs read the same
+    // 8*n*in bytes)
+    for (auto& s : E->sides) {
+        if (s.peer && s.p == 1) continue;
+        BE(cognn_add_u64(E->ctx, s.featE, s.featE, s.featE_peer, (int64_t)s.n * in));
+    }
+    for (auto& s : E->sides) s.featSum = (s.peer && s.p == 1) ? s.peer->featE : s.featE;
+    // ... and, for the grouped layer-0 product, once more in the order its A fragments have (same size, no split in the K loop)
+    if (E->gemm_group && E->gemm_presplit) {
+        for (auto& s : E->sides) {
+            if (s.peer && s.p == 1) continue;
+            const int64_t bytes = E->be->cognn_gemm_presplit_bytes((int64_t)s.n, in);
+            if (bytes <= 0) continue;
+            if (!s.featPl) s.featPl = dalloc<unsigned char>(E, (size_t)bytes);
+            BE(cognn_gemm_presplit_u64(E->ctx, (void*)s.featPl, s.featSum, nullptr, (int64_t)s.n, in));
+        }
+        for (auto& s : E->sides) if (s.peer && s.p == 1) s.featPl = s.peer->featPl;
+    }
+}
+
 void start(cognn_engine* E) {
     const int in = E->in(), hid = E->hid(), lab = E->lab();
     if (E->w0.empty()) { E->w0 = glorot(in, hid); E->w1 = glorot(hid, lab); }
@@ -1554,38 +1647,8 @@ void start(cognn_engine* E) {
             BE(cognn_share_split_u64(E->ctx, dW[l], wkey, s.p == 0 ? s.W[l] : nullptr, s.p == 1 ? s.W[l] : nullptr, elems));
         }
         s.cur = s.feat; s.curF = in;
-        // the layer-0 product's feature opening E_p = X_p - A_p, once for all epochs
-        cognn_keys fk = feature_gemm_keys(E, s.owner, 0);
-        BE(cognn_mask_open_u64(E->ctx, s.featE, s.feat, fk.k[s.p == 0 ? COGNN_SL_A0 : COGNN_SL_A1], (int64_t)n, in, 0));
     }
-    {
-        XList xl;
-        for (auto& s : E->sides) {
-            if (s.peer) continue;
-            xl.send(s.peer_rank, s.featE, (int64_t)s.n * in * 8);
-            xl.recv(s.peer_rank, s.featE_peer, (int64_t)s.n * in * 8);
-        }
-        run_exchange_sync(E, xl);
-    }
-    // E = E_0 + E_1 is constant over the whole run: sum it once (in place; a co-located pair shares the owner side's copy, so
-    // its two GEMMs read the same 8*n*in bytes)
-    for (auto& s : E->sides) {
-        if (s.peer && s.p == 1) continue;
-        BE(cognn_add_u64(E->ctx, s.featE, s.featE, s.featE_peer, (int64_t)s.n * in));
-    }
-    for (auto& s : E->sides) s.featSum = (s.peer && s.p == 1) ? s.peer->featE : s.featE;
-    // ... and, for the grouped layer-0 product, once more in the order its A fragments have (same size, no split in the K loop)
-    if (E->gemm_group && E->gemm_presplit) {
-        for (auto& s : E->sides) {
-            if (s.peer && s.p == 1) continue;
-            const int64_t bytes = E->be->cognn_gemm_presplit_bytes((int64_t)s.n, in);
-            if (bytes <= 0) continue;
-            void* img = dalloc<unsigned char>(E, (size_t)bytes);
-            BE(cognn_gemm_presplit_u64(E->ctx, img, s.featSum, nullptr, (int64_t)s.n, in));
-            s.featPl = img;
-        }
-        for (auto& s : E->sides) if (s.peer && s.p == 1) s.featPl = s.peer->featPl;
-    }
+    open_features(E);
     BE(cognn_ctx_sync(E->ctx));
     E->started = true;
 }
@@ -1648,6 +1711,8 @@ int cognn_engine_create(const cognn_engine_config* cfg, int64_t V, int64_t Ecoun
 int cognn_engine_destroy(cognn_engine* E) {
     if (!E) return 0;
     if (E->ctx) {
+        if (E->graph_exec) E->be->cognn_graph_destroy(E->ctx, E->graph_exec);
+        if (E->salt_now) E->be->cognn_set_epoch_salt(E->ctx, 0);
         for (void* p : E->allocs) E->be->cognn_free(E->ctx, p);
         E->be->cognn_ctx_destroy(E->ctx);
     }
@@ -1778,7 +1843,14 @@ int cognn_engine_offline_load(cognn_engine* E, const char* dir, int64_t it0, int
 int cognn_engine_run(cognn_engine* E, int64_t it0, int64_t it1) {
     return guard([&] {
         if (!E || !E->started) throw EngineError("cognn_engine_run: engine not started");
+        const int ep = epoch_len(E);
+        struct SaltReset { cognn_engine* E; ~SaltReset() { if (E->salt_now) { E->be->cognn_set_epoch_salt(E->ctx, 0); E->salt_now = 0; } } } salt_reset{E};
         for (int64_t it = it0; it < it1; ++it) {
+            if (E->graph_epochs && E->world == 1 && !E->cfg.verbose && !E->timing && it % ep == 0 && it + ep <= it1) {
+                run_epoch(E, it);
+                it += ep - 1;
+                continue;
+            }
             const int64_t rounds0 = E->rounds;
             double before[5] = {0, 0, 0, 0, 0};
             int64_t nl;
@@ -1815,6 +1887,11 @@ int cognn_engine_set_option(cognn_engine* E, int32_t option, int64_t value) {
         else if (option == COGNN_OPT_FORWARD_ONLY) E->forward_only = value != 0;
         else if (option == COGNN_OPT_PUBLIC_OPENINGS) E->public_openings = value != 0;
         else if (option == COGNN_OPT_DEALER_STREAMS) E->dealer_streams = value != 0;
+        else if (option == COGNN_OPT_GRAPH_EPOCHS) {
+            if (value != 0 && !E->graph_epochs) BE(cognn_ctx_use_private_stream(E->ctx));   // (the caller's stream may be the default stream, which cannot record)
+            if (E->graph_exec) { E->be->cognn_graph_destroy(E->ctx, E->graph_exec); E->graph_exec = nullptr; }
+            E->graph_epochs = value != 0; E->graph_warm = false;
+        }
         else throw EngineError("cognn_engine_set_option: unknown option");
     });
 }

@@ -96,9 +96,15 @@ int cognn_engine_offline(cognn_engine* e, int64_t iter_begin, int64_t iter_end);
  * the co-located pairs' chains (cognn_pair_chain_deal_u64: what each party receives for the truncations, row scales, ReLUs and
  * openings) and the A masks of the grouped products are materialised in HBM the first time an iteration runs and READ from
  * there afterwards: +8 bytes per dealt value, shares bit-identical.  A measurement mode (bench.py reports it beside the
- * headline): the per-side kernels of multi-rank runs and the weight-sized operands keep regenerating theirs. */
+ * headline): the per-side kernels of multi-rank runs and the weight-sized operands keep regenerating theirs.
+ * COGNN_OPT_GRAPH_EPOCHS (default 0; single process): cognn_engine_run calls that cover whole epochs (first iteration a multiple
+ * of the epoch length) run each such epoch as ONE recorded launch sequence (hipGraph): the first epoch eagerly, the second while
+ * it is recorded, every later one as a replay under its own epoch salt (cognn_set_epoch_salt) - dataset-sized graphs spend
+ * their epoch in launch overhead.  The engine moves to a private stream, deals product shares inside the recording (the
+ * offline call becomes a no-op unless COGNN_OPT_RETAIN_OFFLINE keeps one epoch's products for replays of that epoch) and
+ * renews the feature opening every epoch.  Shares, weights and metrics are bit-identical to the eager run. */
 enum { COGNN_OPT_RETAIN_OFFLINE = 1, COGNN_OPT_PAIR_FUSION = 2, COGNN_OPT_FORWARD_ONLY = 3, COGNN_OPT_PUBLIC_OPENINGS = 4,
-       COGNN_OPT_DEALER_STREAMS = 5 };
+       COGNN_OPT_DEALER_STREAMS = 5, COGNN_OPT_GRAPH_EPOCHS = 6 };
 int cognn_engine_set_option(cognn_engine* e, int32_t option, int64_t value);
 /* Offline-phase cache on disk, the counterpart of the reference's preprocess/<setting>/ directory reused with `-n 1`
  * (include/harness.h:140-146, README.md:215-216): save writes every dealt product share currently held on this rank to

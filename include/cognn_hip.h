@@ -60,6 +60,19 @@ int cognn_memcpy_h2d(cognn_ctx* ctx, void* dst, const void* src, size_t bytes);
 int cognn_memcpy_d2h(cognn_ctx* ctx, void* dst, const void* src, size_t bytes);
 int cognn_memcpy_d2d(cognn_ctx* ctx, void* dst, const void* src, size_t bytes);
 int cognn_memset0(cognn_ctx* ctx, void* dst, size_t bytes);
+/* The epoch salt (cognn_amd/csrc/cognn_spec.h): every stream evaluated on the device is addressed by key + salt.  0 unless set;
+ * the engine sets it to epoch * 0x9E3779B97F4A7C15 around the iterations of an epoch (and back to 0), so that the kernel
+ * arguments of an epoch do not depend on the epoch number.  Stream-ordered on the context's stream. */
+int cognn_set_epoch_salt(cognn_ctx*, uint64_t salt);
+/* Recording and replaying a launch sequence (hipGraph).  capture_begin / capture_end bracket calls of this ABI on the context's
+ * stream - which must be a private one: cognn_ctx_create_private, or cognn_ctx_use_private_stream on a context created on the
+ * caller's stream - that are recorded instead of executed (no allocation, no synchronising call in between); the handle is
+ * replayed with cognn_graph_launch any number of times. */
+int cognn_ctx_use_private_stream(cognn_ctx*);
+int cognn_graph_capture_begin(cognn_ctx*);
+int cognn_graph_capture_end(cognn_ctx*, void** exec);
+int cognn_graph_launch(cognn_ctx*, void* exec);
+int cognn_graph_destroy(cognn_ctx*, void* exec);
 /* derive the slot keys of one dealer op instance (host-side helper) */
 void cognn_make_keys(uint64_t seed, uint64_t owner, uint64_t iter, uint64_t op, cognn_keys* out);
 

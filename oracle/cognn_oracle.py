@@ -505,23 +505,27 @@ class OracleEngine:
         return (P + 1) % self.k
 
     def key_of(self, owner, it, op):
-        return lambda slot: stream_key(self.seed, owner, it, op, slot)
+        """The stream key of GAS iteration `it`: the position inside the epoch goes through the key derivation, the epoch number
+        is added to the key as epoch * GAMMA (the epoch salt, cognn_spec.h / DESIGN.md §3.2)."""
+        ep = self.epoch_len()
+        return lambda slot: (stream_key(self.seed, owner, it % ep, op, slot) + (it // ep) * GAMMA) & MASK64
 
     def key_of_feature_gemm(self, owner, it):
         """Layer-0 PreScatter product X.W0: X (the input features) is the same tensor in every epoch, so its Beaver mask A
         is dealt once (iteration 0) and E = X - A is opened once; W0's mask B and the product share C stay per-iteration
         (fixed-operand mask reuse)."""
-        return lambda slot: stream_key(self.seed, owner, 0 if slot in (SL_A0, SL_A1) else it, OP_PS_GEMM, slot)
+        return lambda slot: (stream_key(self.seed, owner, 0, OP_PS_GEMM, slot) if slot in (SL_A0, SL_A1)
+                             else self.key_of(owner, it, OP_PS_GEMM)(slot))
 
     def key_of_feature_wgrad(self, owner, it):
         """Layer-0 weight gradient X^T.g (gcn.h:710): the left operand is the same feature tensor, transposed, so it keeps the
         A mask of key_of_feature_gemm (indexed in storage order); B and C come from this iteration's OP_AP_GEMM streams."""
         return lambda slot: (stream_key(self.seed, owner, 0, OP_PS_GEMM, slot) if slot in (SL_A0, SL_A1)
-                             else stream_key(self.seed, owner, it, OP_AP_GEMM, slot))
+                             else self.key_of(owner, it, OP_AP_GEMM)(slot))
 
     def key_of_hidden_wgrad(self, owner, it, it_fwd):
-        return lambda slot: (stream_key(self.seed, owner, it_fwd, OP_PS_GEMM, slot) if slot in (SL_A0, SL_A1)
-                             else stream_key(self.seed, owner, it, OP_AP_GEMM, slot))
+        return lambda slot: (self.key_of(owner, it_fwd, OP_PS_GEMM)(slot) if slot in (SL_A0, SL_A1)
+                             else self.key_of(owner, it, OP_AP_GEMM)(slot))
 
     # -- onAlgoKernelStart (gcn.h:854-887) + share distribution (ss_...h:205-232) ------------
     def _start(self, features, labels, weights):

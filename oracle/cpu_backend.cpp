@@ -15,8 +15,11 @@
 #include <cstring>
 #include <vector>
 
+#define COGNN_HOST_SALT                                     /* cognn_prng adds cognn_host_salt (the epoch salt of cognn_spec.h) */
 #include "../cognn_amd/csrc/cognn_spec.h"
 #include "../cognn_amd/host/backend.h"
+
+uint64_t cognn_host_salt = 0;
 
 // OpenMP over loops whose iterations are independent (bench.py's cpu_baseline uses all host cores; tests run with 1 thread)
 #define CG_PAR _Pragma("omp parallel for schedule(static)")
@@ -237,6 +240,12 @@ int cognn_beaver_gemm_close2_u64(cognn_ctx* c, uint64_t* Z, const uint64_t* E0, 
     return raw ? cognn_beaver_gemm_close_raw_u64(c, Z, E0, E1, f.data(), keys, p, M, N, K, scratch)
                : cognn_beaver_gemm_close_u64(c, Z, E0, E1, f.data(), c1, keys, p, M, N, K, transA, scratch);
 }
+int cognn_set_epoch_salt(cognn_ctx*, uint64_t salt) { cognn_host_salt = salt; return 0; }
+int cognn_ctx_use_private_stream(cognn_ctx*) { return 0; }
+int cognn_graph_capture_begin(cognn_ctx*) { return fail("the CPU stand-in records no launch graphs"); }
+int cognn_graph_capture_end(cognn_ctx*, void**) { return fail("the CPU stand-in records no launch graphs"); }
+int cognn_graph_launch(cognn_ctx*, void*) { return fail("the CPU stand-in records no launch graphs"); }
+int cognn_graph_destroy(cognn_ctx*, void*) { return 0; }
 int64_t cognn_pair_chain_dealt_slots(int32_t, int32_t) { return 0; }     // the CPU stand-in regenerates every dealer value
 int cognn_pair_chain_deal_u64(cognn_ctx*, const cognn_pair_chain*, uint64_t*) { return 0; }
 int64_t cognn_gemm_presplit_bytes(int64_t, int64_t) { return 0; }      // the CPU stand-in has no fragment-ordered form

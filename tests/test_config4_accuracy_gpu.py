@@ -31,8 +31,10 @@ SHAPES = {
 }
 
 
+@pytest.mark.parametrize("recorded", [False, True])
 @pytest.mark.parametrize("shape", ["pubmed-4p", "cora-2p", "citeseer-2p"])
-def test_dataset_shaped_90_epochs_track_plaintext(shape):
+def test_dataset_shaped_90_epochs_track_plaintext(shape, recorded):
+    """recorded: every epoch is one cognn_engine_run call under COGNN_OPT_GRAPH_EPOCHS (epoch 1 eager, epoch 2 recorded, 88 replays)."""
     from cognn_amd.engine import Engine, GnnParam
     k, V, E, in_dim, lab, lr, ratios, planted, min_acc = SHAPES[shape]
     src, dst, feats, labels = co.synth_planted(V, E // 2, in_dim, lab, 3, **planted)
@@ -44,6 +46,8 @@ def test_dataset_shaped_90_epochs_track_plaintext(shape):
     eng = Engine(k, src, dst, part, GnnParam(**kw), seed=0xC06A11)
     eng.set_global_data(feats, labels)
     eng.start()
+    if recorded:
+        eng.graph_epochs(True)
     epochs = 90
     TOL_LOSS, TOL_ACC = TOL[shape]
     worst = {"loss": 0.0, "acc": 0.0}
@@ -51,10 +55,13 @@ def test_dataset_shaped_90_epochs_track_plaintext(shape):
     mem = None
     for ep in range(epochs):
         eng.offline(6 * ep, 6 * ep + 6)
+        if recorded:
+            eng.run(6 * ep, 6 * ep + 6)
         for it in range(6 * ep, 6 * ep + 6):
             plain.iteration(it)
-            eng.run(it, it + 1)
-            if it % 6 == 1:
+            if not recorded:
+                eng.run(it, it + 1)
+            if it % 6 == 1:                                  # (the prediction layer's metrics stay readable until the next one)
                 row = []
                 for P in range(k):
                     m = eng.metrics(P)

@@ -64,6 +64,41 @@ def test_training_two_epochs_bit_exact(k, pair_fusion):
     eng.close()
 
 
+@pytest.mark.parametrize("k,V,Eu,in_dim,hid,lab", [(2, 70, 170, 20, 8, 4), (3, 120, 400, 33, 16, 7), (8, 400, 1500, 24, 16, 6)])
+def test_recorded_epochs_bit_exact(k, V, Eu, in_dim, hid, lab):
+    """COGNN_OPT_GRAPH_EPOCHS: epoch 0 runs eagerly, epoch 1 while it is recorded (hipGraph), epochs 2-4 as replays of that
+    recording under their own epoch salt; also several epochs per call.  Shares, weights and metrics after every epoch are the
+    oracle's - whose feature mask is the one of iteration 0 in every epoch while the recorded epochs renew theirs: the truncated
+    product does not depend on it."""
+    oracle, eng = _setup(k, V, Eu, in_dim, hid, lab, seed=33)
+    eng.graph_epochs(True)
+
+    def check(ep):
+        _compare(oracle, eng, k, 6 * ep + 5)
+        for P in range(k):
+            m = eng.metrics(P)
+            om = [x for x in oracle.metrics if x["party"] == P and x["iter"] == 6 * ep + 1][0]
+            for key in ("full", "train", "border_train", "test", "border_test"):
+                assert abs(m[key] - om[key]) < 1e-12, (ep, key, m, om)
+            assert abs(m["loss"] - om["loss"]) < 1e-9
+    for ep in range(3):
+        for it in range(6 * ep, 6 * ep + 6):
+            oracle.iteration(it)
+        eng.offline(6 * ep, 6 * ep + 6)                       # (a no-op here: a recorded epoch deals inside the recording)
+        eng.run(6 * ep, 6 * ep + 6)
+        check(ep)
+    for it in range(18, 30):                                  # two epochs in one call
+        oracle.iteration(it)
+    eng.run(18, 30)
+    check(4)
+    # an iteration-by-iteration stretch afterwards (eager) continues from the replayed state
+    for it in range(30, 36):
+        oracle.iteration(it)
+        eng.run(it, it + 1)
+        _compare(oracle, eng, k, it)
+    eng.close()
+
+
 @pytest.mark.parametrize("k", [2, 3])
 def test_whole_epochs_in_one_call_bit_exact(k):
     """cognn_engine_run over whole epochs without reading anything in between: the paths that only exist across GAS iterations
