@@ -1259,19 +1259,17 @@ void beaver_gemm_tn_ws_kernel(u64* Z, const u64* __restrict__ E0, const u64* __r
 // NT = ceil(N / 16) column tiles per wave (one B image of NT x 8 KiB per K step), WAVES row tiles per workgroup: <1, 4> for
 // N <= 16, <NT, 8> for 16 < N <= 64 (128 x 64 output block, as many accumulator registers as beaver_gemm_d16n_kernel).
 template <int NT, int WAVES, bool TWO>   // TWO: an operand may arrive as two shares (E1 / F1 given); false saves the second stream's registers
-__global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(2, (NT == 1 && !TWO) ? 3 : 2)))
-void beaver_gemm_tn_d16_kernel(u64* Z, const u64* __restrict__ E0, const u64* __restrict__ E1, const u64* __restrict__ F,
-                               const u64* __restrict__ F1, u64 keyA, u64 keyB, int p, int M, int N, int K, int nst, int ksteps, int mtiles,
-                               int a_storage) {
+__device__ __forceinline__ void tn_d16_body(u64* Z, const u64* __restrict__ E0, const u64* __restrict__ E1, const u64* __restrict__ F,
+                                            const u64* __restrict__ F1, u64 keyA, u64 keyB, int p, int M, int N, int K, int nst, int ksteps, int mtiles,
+                                            int a_storage, int bx, int by, unsigned char* sB) {
     constexpr int kThreadsTn = WAVES * 64;
     constexpr int kImage = NT * kD16Stage;                   // B fragments of one K step: [column tile][plane][lane][16 B]
     constexpr int kTasks = 256 * NT;                         // (column, lane block, entry pair) triples of one K step
     constexpr int TPT = (kTasks + kThreadsTn - 1) / kThreadsTn;
-    extern __shared__ __attribute__((aligned(16))) unsigned char sB[];   // two images
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int st0 = (int)blockIdx.y * ksteps, st1 = min(nst, st0 + ksteps);
+    const int st0 = by * ksteps, st1 = min(nst, st0 + ksteps);
     if (st0 >= st1) return;                                  // (uniform over the workgroup)
-    const int tile = (int)blockIdx.x * WAVES + wave;
+    const int tile = bx * WAVES + wave;
     const bool active = tile < mtiles;                       // wave-uniform: waves beyond M still help to build the B fragments
     const int r = lane & 15, b = lane >> 4;
     const int m = tile * 16 + r, mc = min(m, M - 1);
@@ -1398,6 +1396,46 @@ void beaver_gemm_tn_d16_kernel(u64* Z, const u64* __restrict__ E0, const u64* __
             if (row < M && col < N) atomicAdd((unsigned long long*)&Z[(size_t)row * N + col], (u64)lo + ((u64)hi << 32));
         }
     }
+}
+
+template <int NT, int WAVES, bool TWO>
+__global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(2, (NT == 1 && !TWO) ? 3 : 2)))
+void beaver_gemm_tn_d16_kernel(u64* Z, const u64* __restrict__ E0, const u64* __restrict__ E1, const u64* __restrict__ F,
+                               const u64* __restrict__ F1, u64 keyA, u64 keyB, int p, int M, int N, int K, int nst, int ksteps, int mtiles,
+                               int a_storage) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char sB[];   // two images
+    tn_d16_body<NT, WAVES, TWO>(Z, E0, E1, F, F1, keyA, keyB, p, M, N, K, nst, ksteps, mtiles, a_storage, (int)blockIdx.x, (int)blockIdx.y, sB);
+}
+
+// The weight-gradient products of ONE phase - every hosted side's d = h_t^T . in (gcn.h:671,710) - as one launch
+// (cognn_beaver_gemm_close_group_tn_u64): the jobs share M and N, each has its own K (the rows of its party).  A workgroup
+// serves (job, block of row tiles, K range); with all sides in one launch a K range is 16 times longer than when every side
+// fills the chip alone, so the prologue and the uint64 atomics of a workgroup are paid 16 times less often.  Z holds zeros
+// on entry (zero_jobs_kernel): the products are raw, C_p joins in the consumer's truncation opening.
+struct GemmTnJob {
+    u64* Z; const u64* E0; const u64* E1; const u64* F; const u64* F1;
+    u64 keyA, keyB;
+    int p, K, nst, ksteps, splits, a_storage, wg_end;
+};
+struct GemmTnGroup {
+    GemmTnJob j[kGroupMax];
+    int count, M, N, mtiles, gx;
+};
+template <int NT, int WAVES, bool TWO>
+__global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(2, (NT == 1 && !TWO) ? 3 : 2)))
+void beaver_gemm_tn_group_kernel(GemmTnGroup g) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char sB[];
+    int job = 0;
+    while (job < g.count - 1 && (int)blockIdx.x >= g.j[job].wg_end) ++job;
+    const GemmTnJob& J = g.j[job];
+    const int w = (int)blockIdx.x - (job ? g.j[job - 1].wg_end : 0);
+    tn_d16_body<NT, WAVES, TWO>(J.Z, J.E0, J.E1, J.F, J.F1, J.keyA, J.keyB, J.p, g.M, g.N, J.K, J.nst, J.ksteps, g.mtiles, J.a_storage, w % g.gx, w / g.gx, sB);
+}
+struct ZeroJobs { u64* p[kGroupMax]; unsigned n[kGroupMax]; int count; };
+__global__ __launch_bounds__(256) void zero_jobs_kernel(ZeroJobs z) {
+    u64* p = z.p[blockIdx.y];
+    const unsigned n = z.n[blockIdx.y];
+    for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) p[i] = 0ull;
 }
 
 int launch_tn_d16(cognn_ctx* ctx, u64* Z, const u64* E0, const u64* E1, const u64* F, const u64* F1, u64 keyA, u64 keyB, int p, int64_t M,
@@ -1901,6 +1939,77 @@ extern "C" int cognn_beaver_gemm_close_group_u64(cognn_ctx* ctx, const cognn_gem
                            J.keys.k[COGNN_SL_C0], J.p, n);
         CG_LAUNCH_CHECK();
     }
+    return 0;
+}
+
+// ---- grouped launch of one phase's weight-gradient products (A stored transposed, K = #vertices of the job's party) ----------
+extern "C" int cognn_beaver_gemm_tn_groupable(int64_t M, int64_t N, int64_t K, int two_share_operands) {
+    // the shapes the register-direct TN kernel serves (beaver_close_impl): N <= 16 any operand form; 16 < N <= 48 likewise; N <= 64
+    // with single-stream operands (four column tiles with a second stream do not fit the register file)
+    return (N >= 1 && N <= kFusedBN && K >= 256 && M >= 1 && M * N <= (1ll << 22) && (N <= 48 || !two_share_operands)) ? 1 : 0;
+}
+extern "C" int cognn_beaver_gemm_close_group_tn_u64(cognn_ctx* ctx, const cognn_gemm_job* jobs, int32_t count, int64_t M, int64_t N, int storage_order_mask) {
+    { const int rc_flush_ = cg_flush(ctx); if (rc_flush_) return rc_flush_; }
+    CG_REQUIRE(ctx && (count == 0 || jobs) && count >= 0 && count <= kGroupMax, "cognn_beaver_gemm_close_group_tn_u64: bad arguments");
+    CG_REQUIRE(M > 0 && N > 0 && M < (1ll << 31) && N <= kFusedBN, "cognn_beaver_gemm_close_group_tn_u64: bad shape");
+    bool two = false;
+    for (int32_t j = 0; j < count; ++j) {
+        const cognn_gemm_job& J = jobs[j];
+        CG_REQUIRE(J.Z && J.E0 && J.F0 && (J.p == 0 || J.p == 1) && J.K >= 0 && J.K < (1ll << 31), "cognn_beaver_gemm_close_group_tn_u64: job %d is malformed", j);
+        two = two || J.E1 || J.F1;
+    }
+    for (int32_t j = 0; j < count; ++j)
+        CG_REQUIRE(jobs[j].K == 0 || cognn_beaver_gemm_tn_groupable(M, N, jobs[j].K, two ? 1 : 0),
+                   "cognn_beaver_gemm_close_group_tn_u64: job %d: shape %lld x %lld x %lld is not served by the grouped kernel (cognn_beaver_gemm_tn_groupable)",
+                   j, (long long)M, (long long)N, (long long)jobs[j].K);
+    const int NT = (int)((N + 15) / 16), waves = NT == 1 ? 4 : 8;
+    const int mtiles = (int)((M + 15) / 16), gx = (mtiles + waves - 1) / waves;
+    GemmTnGroup g;
+    ZeroJobs z;
+    memset(&g, 0, sizeof(g)); memset(&z, 0, sizeof(z));
+    g.M = (int)M; g.N = (int)N; g.mtiles = mtiles; g.gx = gx;
+    int live = 0;
+    for (int32_t j = 0; j < count; ++j) if (jobs[j].K > 0) ++live;
+    // resident workgroups (launch_tn_d16): two (single-stream N <= 16: three) waves per SIMD; shared out evenly over the jobs
+    const int budget = NT == 1 ? (two ? 512 : 768) : 256;
+    int wg_end = 0;
+    unsigned zmax = 0;
+    for (int32_t j = 0; j < count; ++j) {
+        const cognn_gemm_job& J = jobs[j];
+        z.p[z.count] = (u64*)J.Z; z.n[z.count] = (unsigned)(M * N); zmax = std::max(zmax, z.n[z.count]); ++z.count;
+        if (J.K <= 0) continue;
+        GemmTnJob& d = g.j[g.count++];
+        d.Z = (u64*)J.Z; d.E0 = (const u64*)J.E0; d.E1 = (const u64*)J.E1; d.F = (const u64*)J.F0; d.F1 = (const u64*)J.F1;
+        d.keyA = J.keys.k[J.p == 0 ? COGNN_SL_A0 : COGNN_SL_A1]; d.keyB = J.keys.k[J.p == 0 ? COGNN_SL_B0 : COGNN_SL_B1];
+        d.p = J.p; d.K = (int)J.K; d.nst = (int)((J.K + 31) / 32); d.a_storage = storage_order_mask ? 1 : 0;
+        int splits = std::max(1, std::min(d.nst, (budget / std::max(live, 1) + gx - 1) / gx));
+        d.ksteps = (d.nst + splits - 1) / splits;
+        d.splits = (d.nst + d.ksteps - 1) / d.ksteps;
+        wg_end += gx * d.splits;
+        d.wg_end = wg_end;
+    }
+    if (z.count) {
+        hipLaunchKernelGGL(zero_jobs_kernel, dim3((zmax + 255) / 256 > 64 ? 64u : (zmax + 255) / 256, (unsigned)z.count), dim3(256), 0, ctx->stream, z);
+        CG_LAUNCH_CHECK();
+    }
+    if (g.count == 0) return 0;
+    const size_t lds = 2 * (size_t)NT * kD16Stage;
+#define CG_TNG_LAUNCH(NT_, W_)                                                                                                           \
+    do {                                                                                                                                  \
+        if (two) {                                                                                                                        \
+            CG_HIP(hipFuncSetAttribute((const void*)beaver_gemm_tn_group_kernel<NT_, W_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            hipLaunchKernelGGL((beaver_gemm_tn_group_kernel<NT_, W_, true>), dim3((unsigned)wg_end), dim3(W_ * 64), lds, ctx->stream, g);              \
+        } else {                                                                                                                          \
+            CG_HIP(hipFuncSetAttribute((const void*)beaver_gemm_tn_group_kernel<NT_, W_, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            hipLaunchKernelGGL((beaver_gemm_tn_group_kernel<NT_, W_, false>), dim3((unsigned)wg_end), dim3(W_ * 64), lds, ctx->stream, g);             \
+        }                                                                                                                                 \
+    } while (0)
+    if (NT == 1) CG_TNG_LAUNCH(1, 4);
+    else if (NT == 2) CG_TNG_LAUNCH(2, 8);
+    else if (NT == 3) CG_TNG_LAUNCH(3, 8);
+    else CG_TNG_LAUNCH(4, 8);
+#undef CG_TNG_LAUNCH
+    CG_LAUNCH_CHECK();
     return 0;
 }
 

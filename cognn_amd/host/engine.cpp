@@ -519,6 +519,23 @@ void gemm_stage(cognn_engine* E, int64_t it, XFn X, WFn Wm, SpecFn spec, DstFn d
     GemmSpec g0 = spec(E->sides[0]);
     bool all_raw = true;
     for (auto& s : E->sides) { GemmSpec g = spec(s); all_raw = all_raw && E->be->cognn_beaver_gemm_fusable(g.M, g.N, g.K, g.transA); }
+    // weight gradients (A stored transposed, K = rows of the side's party): one grouped launch of raw products when every side's
+    // shape is served by the register-direct TN kernel (cognn_beaver_gemm_close_group_tn_u64)
+    bool tn_group = E->gemm_group && ns <= 16 && g0.transA != 0;
+    if (tn_group) {
+        bool two = false;
+        for (auto& s : E->sides) {                          // does any side pass an operand as two shares (E1 / F1, see the jobs below)?
+            const bool h1e_sum = xsrc != X_OPEN_HERE && paired(E, s) && E->h1e_pairs_summed;
+            const bool e_two = !(feature || h1e_sum), f_two = !(w_opened && (paired(E, s) || w_public));
+            two = two || e_two || f_two;
+        }
+        for (auto& s : E->sides) {
+            GemmSpec g = spec(s);
+            tn_group = tn_group && g.transA == g0.transA && g.M == g0.M && g.N == g0.N &&
+                       (g.K == 0 || E->be->cognn_beaver_gemm_tn_groupable(g.M, g.N, g.K, two ? 1 : 0));
+        }
+        if (tn_group) all_raw = true;                       // C_p joins in the truncation opening / the pair chain, as for the NN products
+    }
     // every side's product is its own launch sequence (operand planes, product, truncation opening) on its own buffers: two
     // launch lanes, so that one side's start-up runs in the drain of another's - unless a product share still has to be dealt
     // here (its buffer comes from a pool that the releases below feed)
@@ -538,7 +555,7 @@ void gemm_stage(cognn_engine* E, int64_t it, XFn X, WFn Wm, SpecFn spec, DstFn d
     // and g = (p - y) . W^T.  First the sides whose peer is hosted here, then - once their openings have arrived - the others.
     bool same_nk = true;
     for (auto& s : E->sides) { GemmSpec g = spec(s); same_nk = same_nk && g.N == g0.N && g.K == g0.K && g.transA == 0; }
-    const bool grouped = all_raw && same_nk && ns <= 16 && E->gemm_group;
+    const bool grouped = tn_group || (all_raw && same_nk && ns <= 16 && E->gemm_group);
     if (grouped) {
         for (int pass = 0; pass < 2; ++pass) {
             if (pass == 1) exchange_wait(E);
@@ -562,15 +579,16 @@ void gemm_stage(cognn_engine* E, int64_t it, XFn X, WFn Wm, SpecFn spec, DstFn d
                 const bool f_sum = w_opened && (paired(E, s) || w_public);
                 J.F0 = (w_opened && paired(E, s)) ? pair_opening(s, [](Side& x) { return x.ob[1]; }) : s.ob[1];
                 J.F1 = f_sum ? nullptr : s.ib[1];
-                J.Z = s.zbuf; J.keys = k; J.p = s.p; J.M = g.M; J.scratch = s.scratch;
-                if (feature) J.E_presplit = s.featPl;
-                J.A_dealt = dealt_mask(E, s.owner, it, s.p == 0 ? DEAL_GEMM_A0 : DEAL_GEMM_A1, k.k[s.p == 0 ? COGNN_SL_A0 : COGNN_SL_A1], g.M * g.K);
+                J.Z = s.zbuf; J.keys = k; J.p = s.p; J.M = g.M; J.K = g.K; J.scratch = s.scratch;
+                if (g.feature == 1) J.E_presplit = s.featPl;
+                if (!tn_group) J.A_dealt = dealt_mask(E, s.owner, it, s.p == 0 ? DEAL_GEMM_A0 : DEAL_GEMM_A1, k.k[s.p == 0 ? COGNN_SL_A0 : COGNN_SL_A1], g.M * g.K);
                 jobs.push_back(J); idx.push_back(i);
                 if (E->timing) E->algo[T_GEMM] += 2.0 * 36 * 2 * (double)g.M * g.K * g.N;
                 z[i] = s.zbuf;
             }
             if (jobs.empty()) continue;
-            BE(cognn_beaver_gemm_close_group_u64(E->ctx, jobs.data(), (int32_t)jobs.size(), g0.N, g0.K, 1));
+            if (tn_group) BE(cognn_beaver_gemm_close_group_tn_u64(E->ctx, jobs.data(), (int32_t)jobs.size(), g0.M, g0.N, g0.transA == 2 ? 1 : 0));
+            else BE(cognn_beaver_gemm_close_group_u64(E->ctx, jobs.data(), (int32_t)jobs.size(), g0.N, g0.K, 1));
             Batch batch(E);                                    // the truncation openings of the sides outside pair chains: one launch
             for (size_t i : idx) {
                 Side& s = E->sides[i];

@@ -161,8 +161,16 @@ typedef struct {
                                                   * used by the grouped kernel when EVERY job of the call brings one */
     const uint64_t* A_dealt;                     /* optional (COGNN_OPT_DEALER_STREAMS): this party's mask A_p [M x K] as dealt (cognn_prng_fill_u64
                                                   * with its A key): read instead of regenerated (grouped kernel only) */
+    int64_t K;                                   /* cognn_beaver_gemm_close_group_tn_u64 only: the job's inner dimension (rows of its party) */
 } cognn_gemm_job;
 int cognn_beaver_gemm_close_group_u64(cognn_ctx*, const cognn_gemm_job* jobs, int32_t count, int64_t N, int64_t K, int raw);
+/* The weight-gradient products of one phase, d = h_t^T . in of every hosted side (gcn.h:671,710), as one launch: logical A [M x K]
+ * stored [K x M] (E0 / E1), F0 / F1 [K x N]; M and N are common, K is per job (job.K: the rows of the job's party; job.M is
+ * unused).  RAW products (without C_p: the consumer's truncation opening adds it) into Z, which the call zeroes first.
+ * storage_order_mask != 0: the A mask streams are indexed by the storage element (k, m) (transA = 2 of the per-job calls).
+ * Only shapes with cognn_beaver_gemm_tn_groupable(M, N, K, two_share_operands) != 0 (two_share_operands: any job passes E1 or F1). */
+int cognn_beaver_gemm_tn_groupable(int64_t M, int64_t N, int64_t K, int two_share_operands);
+int cognn_beaver_gemm_close_group_tn_u64(cognn_ctx*, const cognn_gemm_job* jobs, int32_t count, int64_t M, int64_t N, int storage_order_mask);
 /* An opened left operand that many products reuse - the constant input-feature opening of the layer-0 product (gcn.h:233 in
  * every epoch) - limb-split and byte-transposed ONCE into the order the grouped kernel's A fragments have: the same 8 bytes per
  * element (rows padded to 16, K to 32), so a pass reads as many bytes as before and skips the split.  image: _bytes(M, K) bytes. */
