@@ -790,10 +790,12 @@ struct GemmGroupJob {
     const u64* Amask;                                        // the party's mask A_p as dealt [M x K] (COGNN_OPT_DEALER_STREAMS): read, not regenerated
     u64 keyA, keyB;
     int p, M, tiles, wg_end;                                 // wg_end: exclusive prefix of the workgroups assigned to the jobs
+    int ngroups;                                             // SPLITK: workgroups per K range (the job has ngroups x splits workgroups)
 };
 struct GemmGroup {
     GemmGroupJob j[kGroupMax];
     int count, N, K, nst;
+    int ksteps;                                              // SPLITK: K steps per workgroup (its B fragments fit LDS); Z holds zeros on entry
 };
 // The E halves of the A fragments ([tile][k step][16-byte piece j][lane]: piece j of a lane = plane words (pe0[2j], pe1[2j],
 // pe0[2j+1], pe1[2j+1]) of beaver_gemm_group_kernel) of an opened operand that is used many times - the constant feature opening
@@ -826,7 +828,10 @@ __global__ __launch_bounds__(256) void presplit_e_kernel(u64x2* out, const u64* 
     }
 }
 
-template <int NT, int WAVES, bool FULL, bool KEVEN, bool PRE = false>
+// SPLITK (few row tiles, long K: the dataset-sized graphs - Cora's 1354 x 1433): a workgroup serves (job, group of row tiles,
+// K range of g.ksteps steps), builds the B fragments of its K range only and adds its partial tiles into the zeroed Z with
+// uint64 atomics (exact: integer adds commute).
+template <int NT, int WAVES, bool FULL, bool KEVEN, bool PRE = false, bool SPLITK = false>
 __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(2, NT == 1 ? 4 : 2)))
 void beaver_gemm_group_kernel(GemmGroup g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -834,8 +839,11 @@ void beaver_gemm_group_kernel(GemmGroup g) {
     int job = 0;
     while (job < g.count - 1 && (int)blockIdx.x >= g.j[job].wg_end) ++job;
     const GemmGroupJob& J = g.j[job];
-    const int wg0 = job ? g.j[job - 1].wg_end : 0, nwg = J.wg_end - wg0, wgi = (int)blockIdx.x - wg0;
-    const int N = g.N, K = g.K, nst = g.nst, M = J.M, tiles = J.tiles, p = J.p;
+    const int wg0 = job ? g.j[job - 1].wg_end : 0;
+    const int nwg = SPLITK ? J.ngroups : J.wg_end - wg0, wgi = SPLITK ? ((int)blockIdx.x - wg0) % J.ngroups : (int)blockIdx.x - wg0;
+    const int N = g.N, K = g.K, M = J.M, tiles = J.tiles, p = J.p;
+    const int st_lo = SPLITK ? (((int)blockIdx.x - wg0) / J.ngroups) * g.ksteps : 0;       // first K step of this workgroup
+    const int nst = SPLITK ? min(g.nst, st_lo + g.ksteps) - st_lo : g.nst;                  // its number of K steps
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     {   // B fragments of every K step: one task per (k step, column tile, lane, 4-slot quad); quads 0,1: E segment (B_p + pF),
         // quads 2,3: mask segment (F); image: [k step][column tile][plane][lane][16 B]
@@ -845,7 +853,7 @@ void beaver_gemm_group_kernel(GemmGroup g) {
         const int total = nst * NT * 256;
         for (int t = threadIdx.x; t < total; t += kThreadsG) {
             const int q = t & 3, l = (t >> 2) & 63, sn = t >> 8;
-            const int nt = sn % NT, st = sn / NT;
+            const int nt = sn % NT, st = st_lo + sn / NT;
             const int n = nt * 16 + (l & 15), b = l >> 4, seg = q >> 1;
             u64 v[4];
 #pragma unroll
@@ -880,9 +888,9 @@ void beaver_gemm_group_kernel(GemmGroup g) {
     u64 nx0[8], nx1[PRE ? 1 : 8];
     const u64x2* __restrict__ Epl = J.Epl;
     auto load_step = [&](int it) {
-        const int tile = wid + (it / nst) * nw, st = it % nst;
+        const int tile = wid + (it / nst) * nw, st = st_lo + it % nst;
         if (PRE) {                                           // fragment-ordered image: four coalesced 16-byte pieces
-            const u64x2* src = Epl + (((size_t)tile * nst + st) * 4 << 6) + lane;
+            const u64x2* src = Epl + (((size_t)tile * g.nst + st) * 4 << 6) + lane;
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) { const u64x2 x = src[jj << 6]; nx0[2 * jj] = x.x; nx0[2 * jj + 1] = x.y; }
             return;
@@ -919,9 +927,9 @@ void beaver_gemm_group_kernel(GemmGroup g) {
     load_step(0);
     v4i acc[NT][8];
     for (int it = 0; it < total; ++it) {
-        const int tile = wid + (it / nst) * nw, st = it % nst;
+        const int tile = wid + (it / nst) * nw, ls = it % nst, st = st_lo + ls;   // ls: step inside this workgroup's K range (its LDS image)
         const int m = tile * 16 + r;
-        if (st == 0) {
+        if (ls == 0) {
 #pragma unroll
             for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -966,13 +974,13 @@ void beaver_gemm_group_kernel(GemmGroup g) {
         for (int t = 0; t < NT; ++t) {
             v4i bf[8];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) bf[i] = bp[(size_t)((st * NT + t) * 8 + i) * 64];
+            for (int i = 0; i < 8; ++i) bf[i] = bp[(size_t)((ls * NT + t) * 8 + i) * 64];
 #pragma unroll
             for (int i = 0; i < 8; ++i)
 #pragma unroll
                 for (int jj = 0; jj + i < 8; ++jj) acc[t][i + jj] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[i], bf[jj], acc[t][i + jj], 0, 0, 0);
         }
-        if (st == nst - 1) {
+        if (ls == nst - 1) {
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 const int col = t * 16 + (lane & 15);        // C/D map of the 16x16 MFMA family: col = lane & 15, row = 4 * (lane >> 4) + reg
@@ -982,7 +990,10 @@ void beaver_gemm_group_kernel(GemmGroup g) {
                     const uint32_t hi = (uint32_t)acc[t][4][q] + ((uint32_t)acc[t][5][q] << 8) + ((uint32_t)acc[t][6][q] << 16) + ((uint32_t)acc[t][7][q] << 24);
                     const long long lo = (long long)acc[t][0][q] + (long long)acc[t][1][q] * 256 + (long long)acc[t][2][q] * 65536 +
                                          (long long)acc[t][3][q] * 16777216;
-                    if ((FULL || row < M) && col < N) Z[(size_t)row * N + col] = (u64)lo + ((u64)hi << 32);
+                    if ((FULL || row < M) && col < N) {
+                        if (SPLITK) atomicAdd((unsigned long long*)&Z[(size_t)row * N + col], (u64)lo + ((u64)hi << 32));
+                        else Z[(size_t)row * N + col] = (u64)lo + ((u64)hi << 32);
+                    }
                 }
             }
         }
@@ -1854,13 +1865,18 @@ int beaver_close_impl(cognn_ctx* ctx, uint64_t* Z, const uint64_t* E, const uint
 // ---- grouped launch of one phase's products ------------------------------------------------------------------------------
 namespace {
 template <int NT, int WAVES>
-int launch_group(cognn_ctx* ctx, const GemmGroup& g, int wgs, size_t lds, bool full, bool keven, bool pre) {
+int launch_group(cognn_ctx* ctx, const GemmGroup& g, int wgs, size_t lds, bool full, bool keven, bool pre, bool splitk) {
 #define CG_GROUP_LAUNCH(...)                                                                                                     \
     do {                                                                                                                          \
         CG_HIP(hipFuncSetAttribute((const void*)beaver_gemm_group_kernel<NT, WAVES, __VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
         hipLaunchKernelGGL((beaver_gemm_group_kernel<NT, WAVES, __VA_ARGS__>), dim3((unsigned)wgs), dim3(WAVES * 64), lds, ctx->stream, g);             \
     } while (0)
-    if (pre) { if (full) CG_GROUP_LAUNCH(true, true, true); else CG_GROUP_LAUNCH(false, true, true); }
+    if (splitk) {
+        if (pre) CG_GROUP_LAUNCH(false, true, true, true);
+        else if (keven) CG_GROUP_LAUNCH(false, true, false, true);
+        else CG_GROUP_LAUNCH(false, false, false, true);
+    }
+    else if (pre) { if (full) CG_GROUP_LAUNCH(true, true, true); else CG_GROUP_LAUNCH(false, true, true); }
     else if (full) CG_GROUP_LAUNCH(true, true);
     else if (keven) CG_GROUP_LAUNCH(false, true);
     else CG_GROUP_LAUNCH(false, false);
@@ -1887,11 +1903,14 @@ extern "C" int cognn_beaver_gemm_close_group_u64(cognn_ctx* ctx, const cognn_gem
         aligned = aligned && cg_aligned16(J.E0) && (!J.E1 || cg_aligned16(J.E1)) && cg_aligned16(J.Z);
     }
     const int nst = (int)((K + 31) / 32), NT = (int)((N + 15) / 16);
-    const size_t lds = (size_t)nst * NT * kD16Stage;
+    const size_t lds_all = (size_t)nst * NT * kD16Stage;
     static const bool no_group = getenv("COGNN_GEMM_NO_GROUP") != nullptr;   // A/B switch: job by job through the per-side kernels
-    // enough row tiles to fill the chip without splitting K (the per-job path has split-K kernels for the dataset-sized shapes)
-    const bool pre = npre == count && count > 0;             // every job brings its fragment-ordered image (else none is used)
-    const bool grouped = !no_group && count > 0 && N <= kFusedBN && K >= 16 && lds <= 128 * 1024 && tiles_all >= 2048 && aligned;
+    const bool pre = npre == count && count > 0 && (K % 2 == 0);   // every job brings its fragment-ordered image (else none is used)
+    // Either every workgroup keeps the B fragments of ALL K steps in LDS and walks whole rows (enough row tiles to fill the chip),
+    // or - few row tiles, or a K too long for LDS: the dataset-sized graphs - workgroups take K ranges and add partial tiles
+    // into the zeroed outputs (split K).
+    const bool whole_k = lds_all <= 128 * 1024 && tiles_all >= 2048;
+    const bool grouped = !no_group && count > 0 && N <= kFusedBN && K >= 4 && aligned && tiles_all > 0;
     if (!grouped) {
         for (int32_t j = 0; j < count; ++j) {
             const cognn_gemm_job& J = jobs[j];
@@ -1907,7 +1926,21 @@ extern "C" int cognn_beaver_gemm_close_group_u64(cognn_ctx* ctx, const cognn_gem
     // proportion to their row tiles (at least one each).
     const int waves = NT == 1 ? 4 : 8;
     const int budget = NT == 1 ? (pre ? 1024 : 768) : 256;   // resident workgroups: 4 (126 registers, fragment-ordered operand) or 3 (146) x 256 CUs / 1 x 256
+    int64_t groups_all = 0;
+    for (int32_t j = 0; j < count; ++j) groups_all += ((jobs[j].M + 15) / 16 + waves - 1) / waves;
+    int ksteps = nst;
+    if (!whole_k) {
+        const int ksteps_max = std::max(1, (int)((128 * 1024) / ((size_t)NT * kD16Stage)));
+        const int want_splits = (int)std::max<int64_t>(1, (2 * budget + groups_all - 1) / groups_all);   // about two waves of workgroups
+        ksteps = std::min(ksteps_max, std::max(std::min(2, nst), (nst + want_splits - 1) / want_splits));
+    }
+    const int splits = (nst + ksteps - 1) / ksteps;
+    g.ksteps = ksteps;
+    const size_t lds = (size_t)ksteps * NT * kD16Stage;
     int wg_end = 0;
+    ZeroJobs z;
+    memset(&z, 0, sizeof(z));
+    unsigned zmax = 0;
     for (int32_t j = 0; j < count; ++j) {
         const cognn_gemm_job& J = jobs[j];
         const int tiles = (int)((J.M + 15) / 16);
@@ -1918,18 +1951,30 @@ extern "C" int cognn_beaver_gemm_close_group_u64(cognn_ctx* ctx, const cognn_gem
         d.Amask = (const u64*)J.A_dealt;
         d.keyA = J.keys.k[J.p == 0 ? COGNN_SL_A0 : COGNN_SL_A1]; d.keyB = J.keys.k[J.p == 0 ? COGNN_SL_B0 : COGNN_SL_B1];
         d.p = J.p; d.M = (int)J.M; d.tiles = tiles;
-        int share = (int)(((int64_t)budget * tiles + tiles_all - 1) / tiles_all);
-        share = std::max(1, std::min(share, (tiles + waves - 1) / waves));
-        wg_end += share;
+        if (whole_k) {
+            int share = (int)(((int64_t)budget * tiles + tiles_all - 1) / tiles_all);
+            share = std::max(1, std::min(share, (tiles + waves - 1) / waves));
+            d.ngroups = share;
+            wg_end += share;
+        } else {
+            d.ngroups = (tiles + waves - 1) / waves;           // one row tile per wave and K range
+            wg_end += d.ngroups * splits;
+            z.p[z.count] = (u64*)J.Z; z.n[z.count] = (unsigned)(J.M * N); zmax = std::max(zmax, z.n[z.count]); ++z.count;
+            CG_REQUIRE(J.M * N < (1ll << 32), "cognn_beaver_gemm_close_group_u64: job %d: output too large for the split-K form", j);
+        }
         d.wg_end = wg_end;
     }
     if (g.count == 0) return 0;
+    if (z.count) {
+        hipLaunchKernelGGL(zero_jobs_kernel, dim3(std::min(256u, (zmax + 255) / 256), (unsigned)z.count), dim3(256), 0, ctx->stream, z);
+        CG_LAUNCH_CHECK();
+    }
     const bool keven = (K % 2 == 0);
     int rc;
-    if (NT == 1) rc = launch_group<1, 4>(ctx, g, wg_end, lds, full, keven, pre);
-    else if (NT == 2) rc = launch_group<2, 8>(ctx, g, wg_end, lds, full, keven, pre);
-    else if (NT == 3) rc = launch_group<3, 8>(ctx, g, wg_end, lds, full, keven, pre);
-    else rc = launch_group<4, 8>(ctx, g, wg_end, lds, full, keven, pre);
+    if (NT == 1) rc = launch_group<1, 4>(ctx, g, wg_end, lds, full, keven, pre, !whole_k);
+    else if (NT == 2) rc = launch_group<2, 8>(ctx, g, wg_end, lds, full, keven, pre, !whole_k);
+    else if (NT == 3) rc = launch_group<3, 8>(ctx, g, wg_end, lds, full, keven, pre, !whole_k);
+    else rc = launch_group<4, 8>(ctx, g, wg_end, lds, full, keven, pre, !whole_k);
     if (rc || raw) return rc;
     for (int32_t j = 0; j < count; ++j) {                      // C_p joins here when the caller did not ask for the raw product
         const cognn_gemm_job& J = jobs[j];
