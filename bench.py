@@ -63,11 +63,15 @@ def message_widths(variant, iters, hid, lab):
     return sum(w[i % 6] for i in range(iters))
 
 
-def _cpu_engine_run(wl, shift, threads, steps):
-    """One child process of oracle/cpu_engine_bench.py (plain-C++ reference backend under the same engine host code)."""
+def _cpu_engine_run(wl, shift, threads, steps, exact=None):
+    """One child process of oracle/cpu_engine_bench.py (plain-C++ reference backend under the same engine host code).
+    exact = (V, directed E): that size instead of the workload's power-of-two size scaled down by 2^shift."""
     import subprocess
     k, lv, le, in_dim, hid, lab, variant, iters = wl
-    lv2, le2 = max(lv - shift, 8), max(le - shift, 10)
+    if exact:
+        lv2, le2 = "=%d" % exact[0], "=%d" % exact[1]
+    else:
+        lv2, le2 = max(lv - shift, 8), max(le - shift, 10)
     env = dict(os.environ, OMP_NUM_THREADS=str(threads), HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "cpu_engine_bench.py"), str(k), str(lv2), str(le2), str(in_dim),
                           str(hid), str(lab), variant, str(iters), str(steps)], env=env, capture_output=True, text=True, timeout=600)
@@ -92,6 +96,16 @@ def cpu_baseline(args, wl):
         except (OSError, ValueError):
             pass
         cores = min(cores, 16)                              # a one-GPU box's CPU share is 16 cores; more threads only oversubscribe
+        if args.workload in DATASET_VE:                     # dataset-shaped epochs are small: the CPU runs the whole workload
+            ve = DATASET_VE[args.workload]
+            dt_all, edges_all, _, _ = _cpu_engine_run(wl, 0, cores, 5, exact=ve)
+            dt_1, edges_1, _, _ = _cpu_engine_run(wl, 0, 1, 3, exact=ve)
+            return {"value": edges_all * widths / dt_all, "unit": "edges*feat/s", "cores": cores, "kind": "port",
+                    "value_1core": edges_1 * widths / dt_1, "seconds_per_epoch": dt_all, "seconds_per_epoch_1core": dt_1,
+                    "sample": "engine host code on the plain-C++ reference backend (oracle/cpu_backend.cpp, OpenMP, per-side loops): the whole "
+                              "workload (%d-party %s epoch, %d vertices / %d directed edges, in=%d hid=%d labels=%d): %.3f s per epoch on %d "
+                              "threads, %.3f s on 1 (medians of 5 and 3 timed epochs after a warm-up epoch; dealer phase outside the timed region)"
+                              % (k, variant, ve[0], ve[1], in_dim, hid, lab, dt_all, cores, dt_1)}
         dt_all, edges_all, lva, lea = _cpu_engine_run(wl, 2, cores, 5)      # median of 5 passes
         dt_1, edges_1, lv1, le1 = _cpu_engine_run(wl, 4, 1, 3)              # median of 3 passes
         return {"value": edges_all * widths / dt_all, "unit": "edges*feat/s", "cores": cores, "kind": "port",
@@ -104,6 +118,8 @@ def cpu_baseline(args, wl):
         sys.stderr.write("cpu_baseline: C++ reference backend unavailable (%r), using the numpy oracle\n" % (ex,))
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import cognn_oracle as co
+    if args.workload in DATASET_VE:
+        return None                                         # (the numpy oracle at dataset size takes minutes per epoch)
     lv2, le2 = max(lv - 4, 8), max(le - 4, 10)
     V, Eu = 1 << lv2, 1 << (le2 - 1)
     src, dst = co.synth_graph(V, Eu, 0xC06A11)

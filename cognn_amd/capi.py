@@ -31,7 +31,13 @@ class PairChain(ctypes.Structure):
                 ("rows", ctypes.c_int64), ("F", ctypes.c_int64), ("flags", ctypes.c_int32), ("mask_in", ctypes.c_void_p), ("dealt", ctypes.c_void_p)]
 
 
-PC_TRUNC_IN, PC_SCALE, PC_RELU, PC_INPUT_OPENED, PC_NO_C, PC_OPEN_SUM = 1, 2, 4, 8, 16, 32
+PC_TRUNC_IN, PC_SCALE, PC_RELU, PC_INPUT_OPENED, PC_NO_C, PC_OPEN_SUM, WU_SWAP = 1, 2, 4, 8, 16, 32, 64
+
+
+class PairWUpdate(ctypes.Structure):
+    """cognn_pair_wupdate (include/cognn_hip.h)."""
+    _fields_ = [("z", ctypes.c_void_p * 2), ("c1", ctypes.c_void_p), ("W", ctypes.c_void_p * 2), ("gemm_keys", Keys),
+                ("trunc_keys", Keys * 4), ("mul", ctypes.c_uint64 * 3), ("n", ctypes.c_int64), ("flags", ctypes.c_int32)]
 
 
 class GatherPair(ctypes.Structure):
@@ -126,6 +132,7 @@ _SIGNATURES = {
     "cognn_softmax_u64": (_I, [_P, _P, _P, _P, _P, _P, _P, _KP, _I, _L, _L, _L]),
     "cognn_metrics_q16": (_I, [_P, _P, _P, _P, _L, _L, _L, _L, _P, _P]),
     "cognn_pair_chain_u64": (_I, [_P, ctypes.POINTER(PairChain), ctypes.c_int32]),
+    "cognn_pair_weight_update_u64": (_I, [_P, ctypes.POINTER(PairWUpdate), ctypes.c_int32, ctypes.POINTER(Keys), ctypes.c_uint64, ctypes.c_int32]),
     "cognn_pair_chain_dealt_slots": (_L, [ctypes.c_int32, ctypes.c_int32]),
     "cognn_pair_chain_deal_u64": (_I, [_P, ctypes.POINTER(PairChain), _P]),
     "cognn_softmax_jobs_u64": (_I, [_P, ctypes.POINTER(SoftmaxJob), ctypes.c_int32, _L]),

@@ -132,6 +132,14 @@ struct MaskOpen {       // E = X - prng(key, logical idx)
     u64* E; const u64* X; u64 key; int64_t rows, cols; int transposed;
     __device__ void operator()(int64_t i, int w) const {
         u64 x[2], e[2];
+        if (transposed == 3) {             // X stored [cols x rows], E written in logical [rows x cols] order (a small weight matrix)
+            for (int j = 0; j < w; ++j) {
+                const u64 idx = (u64)(i + j), m = idx / (u64)cols, k = idx % (u64)cols;
+                e[j] = X[k * (u64)rows + m] - cognn_prng(key, idx);
+            }
+            st2(E, i, w, e);
+            return;
+        }
         ld2(X, i, w, x);
         for (int j = 0; j < 2; ++j) {
             u64 idx = (u64)(i + j);
@@ -621,6 +629,87 @@ __global__ __launch_bounds__(kThreads) void pair_chain_deal_kernel(PairChainDev 
     pair_deal_element(d, slab, (u64)i, (u64)((uint32_t)i / d.F), has_open != 0);
 }
 
+// ---- weight update of co-located pairs (cognn_pair_weight_update_u64) -----------------------------------------------------
+struct PairWUpdateDev {
+    const u64* z0; const u64* z1; const u64* c1; u64* W0; u64* W1;
+    u64 keyC0;
+    u64 kR[4], kR0[4], kRP0[4];      // the three truncation streams of: product, gradient scale, learning rate, post scale
+    u64 mul[3];
+    int64_t n; int addc; int swap;
+};
+constexpr int kWUpdateMax = 16;
+struct PairWUpdateBatch {
+    PairWUpdateDev d[kWUpdateMax];
+    unsigned blk_end[kWUpdateMax];
+    int count;
+    u64 aR, aR0, aRP0, amul;         // averaging form: the truncation streams and multiplier of the 1/k scale (amul = 0: none)
+};
+__device__ __forceinline__ void trunc2(u64 kR, u64 kR0, u64 kRP0, u64 idx, u64& v0, u64& v1) {
+    PairChainDev none;                                       // (the PRNG form of pair_trunc reads nothing from the chain)
+    none.slab = nullptr; none.n = 0;
+    pair_trunc<false>(none, 0, kR, kR0, kRP0, idx, v0, v1);
+}
+// new weight shares of one pair for elements i, i + 1
+__device__ __forceinline__ void wupdate_pair(const PairWUpdateDev& d, int64_t i, int w, u64* w0, u64* w1) {
+    u64 v0[2], v1[2], cc[2] = {0, 0};
+    ld2(d.z0, i, w, v0); ld2(d.z1, i, w, v1);
+    ld2(d.W0, i, w, w0); ld2(d.W1, i, w, w1);
+    if (d.addc) ld2(d.c1, i, w, cc);
+    for (int j = 0; j < w; ++j) {
+        const u64 idx = (u64)(i + j);
+        if (d.addc) { v0[j] += cognn_prng(d.keyC0, idx); v1[j] += cc[j]; }                      // TruncOpenAdd: x + C_p
+        trunc2(d.kR[0], d.kR0[0], d.kRP0[0], idx, v0[j], v1[j]);                                // d = h_t^T . in
+        v0[j] *= d.mul[0]; v1[j] *= d.mul[0];
+        trunc2(d.kR[1], d.kR0[1], d.kRP0[1], idx, v0[j], v1[j]);                                // d / |train|
+        v0[j] *= d.mul[1]; v1[j] *= d.mul[1];
+        trunc2(d.kR[2], d.kR0[2], d.kRP0[2], idx, v0[j], v1[j]);                                // lr . d
+        w0[j] -= v0[j]; w1[j] -= v1[j];                                                         // TruncClose, mode 1
+        if (d.mul[2]) {
+            w0[j] *= d.mul[2]; w1[j] *= d.mul[2];
+            trunc2(d.kR[3], d.kR0[3], d.kRP0[3], idx, w0[j], w1[j]);                            // W / k (inference variant)
+        }
+    }
+}
+// independent pairs: one segment of the grid each
+__global__ __launch_bounds__(kThreads) void pair_wupdate_kernel(PairWUpdateBatch b) {
+    const unsigned blk = blockIdx.x;
+    int seg = 0;
+    while (seg < b.count - 1 && blk >= b.blk_end[seg]) ++seg;
+    const PairWUpdateDev& d = b.d[seg];
+    const unsigned blk0 = seg ? b.blk_end[seg - 1] : 0u;
+    const int64_t i = 2 * ((int64_t)(blk - blk0) * kThreads + threadIdx.x);
+    if (i >= d.n) return;
+    const int w = (i + 1 < d.n) ? 2 : 1;
+    u64 w0[2], w1[2];
+    wupdate_pair(d, i, w, w0, w1);
+    st2(d.W0, i, w, w0); st2(d.W1, i, w, w1);
+}
+// every party's pair is here: update + the weight average of gcn.h:753-778 (sum of one share of every party's weights on party 0,
+// of the other on party 1, the 1/k scale between those two, redistribution) element by element
+__global__ __launch_bounds__(kThreads) void pair_wupdate_avg_kernel(PairWUpdateBatch b) {
+    const int64_t n = b.d[0].n;
+    const int64_t i = 2 * ((int64_t)blockIdx.x * kThreads + threadIdx.x);
+    if (i >= n) return;
+    const int w = (i + 1 < n) ? 2 : 1;
+    u64 s0[2] = {0, 0}, s1[2] = {0, 0};
+    for (int c = 0; c < b.count; ++c) {
+        u64 w0[2] = {0, 0}, w1[2] = {0, 0};
+        wupdate_pair(b.d[c], i, w, w0, w1);
+        const bool sw = b.d[c].swap != 0;
+        for (int j = 0; j < 2; ++j) { s0[j] += sw ? w1[j] : w0[j]; s1[j] += sw ? w0[j] : w1[j]; }
+    }
+    if (b.amul)
+        for (int j = 0; j < w; ++j) {
+            s0[j] *= b.amul; s1[j] *= b.amul;
+            trunc2(b.aR, b.aR0, b.aRP0, (u64)(i + j), s0[j], s1[j]);
+        }
+    for (int c = 0; c < b.count; ++c) {
+        const bool sw = b.d[c].swap != 0;
+        st2(sw ? b.d[c].W1 : b.d[c].W0, i, w, s0);
+        st2(sw ? b.d[c].W0 : b.d[c].W1, i, w, s1);
+    }
+}
+
 inline cognn_opkeys K(const cognn_keys* k) {
     cognn_opkeys r;
     for (int i = 0; i < COGNN_SL_COUNT; ++i) r.k[i] = k->k[i];
@@ -856,6 +945,49 @@ int cognn_pair_chain_u64(cognn_ctx* ctx, const cognn_pair_chain* chains, int32_t
     return launch();
 }
 
+int cognn_pair_weight_update_u64(cognn_ctx* ctx, const cognn_pair_wupdate* jobs, int32_t count, const cognn_keys* avg_keys, uint64_t avg_mul,
+                                 int32_t average) {
+    CG_REQUIRE(ctx && (count == 0 || jobs) && count >= 0, "cognn_pair_weight_update_u64: bad arguments");
+    CG_REQUIRE(!average || (count >= 1 && count <= kWUpdateMax && (avg_mul == 0 || avg_keys)),
+               "cognn_pair_weight_update_u64: the averaging form takes 1..%d pairs (and the keys of its scale)", kWUpdateMax);
+    int rc;
+    if ((rc = cg_flush(ctx))) return rc;
+    PairWUpdateBatch b; b.count = 0; b.amul = 0; b.aR = b.aR0 = b.aRP0 = 0;
+    auto flush = [&]() {
+        if (!b.count) return;
+        hipLaunchKernelGGL(pair_wupdate_kernel, dim3(b.blk_end[b.count - 1]), dim3(kThreads), 0, ctx->stream, b);
+        b.count = 0;
+    };
+    for (int c = 0; c < count; ++c) {
+        const cognn_pair_wupdate& s = jobs[c];
+        CG_REQUIRE(s.n >= 0 && s.n < (1ll << 32), "cognn_pair_weight_update_u64: job %d: matrix too large", c);
+        CG_REQUIRE(!average || (s.n == jobs[0].n && s.n > 0), "cognn_pair_weight_update_u64: job %d: the averaged matrices must have one (non-zero) size", c);
+        if (s.n == 0) continue;
+        const bool addc = !(s.flags & COGNN_PC_NO_C);
+        CG_REQUIRE(s.z[0] && s.z[1] && s.W[0] && s.W[1] && al(s.z[0]) && al(s.z[1]) && al(s.W[0]) && al(s.W[1]) && al(s.c1),
+                   "cognn_pair_weight_update_u64: job %d: null or misaligned tensor", c);
+        CG_REQUIRE(!addc || s.c1, "cognn_pair_weight_update_u64: job %d needs side 1's product share", c);
+        CG_REQUIRE(s.W[0] != s.W[1], "cognn_pair_weight_update_u64: job %d: the two sides share a weight buffer", c);
+        PairWUpdateDev& d = b.d[b.count];
+        d.z0 = (const u64*)s.z[0]; d.z1 = (const u64*)s.z[1]; d.c1 = (const u64*)s.c1; d.W0 = (u64*)s.W[0]; d.W1 = (u64*)s.W[1];
+        d.keyC0 = s.gemm_keys.k[COGNN_SL_C0];
+        for (int t = 0; t < 4; ++t) {
+            d.kR[t] = s.trunc_keys[t].k[COGNN_SL_R]; d.kR0[t] = s.trunc_keys[t].k[COGNN_SL_R0]; d.kRP0[t] = s.trunc_keys[t].k[COGNN_SL_RP0];
+        }
+        for (int t = 0; t < 3; ++t) d.mul[t] = s.mul[t];
+        d.n = s.n; d.addc = addc ? 1 : 0; d.swap = (s.flags & COGNN_WU_SWAP) ? 1 : 0;
+        const unsigned blocks = (unsigned)(((s.n + 1) / 2 + kThreads - 1) / kThreads);
+        b.blk_end[b.count] = (b.count ? b.blk_end[b.count - 1] : 0u) + blocks;
+        ++b.count;
+        if (!average && b.count == kWUpdateMax) flush();
+    }
+    if (average) {
+        if (avg_mul) { b.amul = avg_mul; b.aR = avg_keys->k[COGNN_SL_R]; b.aR0 = avg_keys->k[COGNN_SL_R0]; b.aRP0 = avg_keys->k[COGNN_SL_RP0]; }
+        hipLaunchKernelGGL(pair_wupdate_avg_kernel, dim3(b.blk_end[0]), dim3(kThreads), 0, ctx->stream, b);
+    } else flush();
+    CG_LAUNCH_CHECK();
+    return 0;
+}
 int64_t cognn_pair_chain_dealt_slots(int32_t flags, int32_t has_open) {
     return (int64_t)pc_slot_base((uint32_t)flags, has_open != 0).total;
 }

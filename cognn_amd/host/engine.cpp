@@ -54,7 +54,6 @@ struct Side {
     const uint8_t* cur_mask = nullptr;   // co-located pairs, between the backward ReLU' and the row scale that consumes it: the tensor is
                                          // cur (.) cur_mask, the selection rides in that row scale's pair chain (apply_cur_mask otherwise)
     u64* W[2] = {nullptr, nullptr};
-    u64* WT = nullptr;             // transposed W1 scratch [lab x hid]
     u64* h1 = nullptr;             // h_t of layer 1 [n x hid]   (vertexInterData["h_t"], gcn.h:230-231)
     u64* g = nullptr;              // vertexInterData["g"] [n x hid]
     uint8_t* relu_mask = nullptr;  // public sign of z[0] (revealed by the masked-sign ReLU)
@@ -94,6 +93,7 @@ struct cognn_engine {
     bool retain_offline = false;                    // COGNN_OPT_RETAIN_OFFLINE
     int gemm_lanes = getenv("COGNN_GEMM_LANES") ? atoi(getenv("COGNN_GEMM_LANES")) : 2;   // launch lanes of the per-side products (A/B switch: 1 = one stream)
     bool gemm_group = !getenv("COGNN_GEMM_PER_SIDE");       // one grouped launch per phase (A/B switch: the per-side launch sequences)
+    bool wupdate_fusion = !getenv("COGNN_NO_WUPDATE_FUSION"); // co-located pairs: weight update (+ average) as one pass (A/B switch)
     bool gemm_presplit = !getenv("COGNN_GEMM_NO_PRESPLIT"); // the constant feature opening kept in MFMA fragment order (A/B switch)
     bool public_openings = true;                    // COGNN_OPT_PUBLIC_OPENINGS (see pub_open)
     bool h1e_pairs_summed = false;                  // the co-located pairs' h1E holds E_0 + E_1 (written by a pair chain), not E_p
@@ -311,6 +311,7 @@ struct GemmSpec {            // logical Z[MxN] = X[MxK] . Wm[KxN]
     int xsrc = 0;            // where the opening of X comes from: X_OPEN_HERE, X_H1E_FRESH (written by the ReLU close of the previous
                              // iteration, still to be exchanged), X_H1E_REUSE (the layer-1 forward opening, exchanged two iterations ago)
     int64_t akey_it = -1;    // iteration whose COGNN_OP_PS_GEMM A streams mask X (X_H1E_REUSE); -1: this product's own streams
+    int transB = 0;          // Wm(side) is stored [N x K] (a weight matrix used transposed, gcn.h:648): its opening reads it across
 };
 enum { X_OPEN_HERE = 0, X_H1E_FRESH = 1, X_H1E_REUSE = 2 };
 
@@ -416,16 +417,16 @@ struct FollowScale {
 // truncation of every side's `x` (elems) scaled by `mul`; result written/applied to dst(side)
 template <class DstFn>
 void trunc_stage(cognn_engine* E, int64_t it, int op, u64 mul, const std::vector<u64*>& x, const std::vector<int64_t>& elems,
-                 DstFn dst, int mode, u64 owner_override = ~0ull) {
+                 DstFn dst, int mode, u64 owner_override = ~0ull, bool skip_paired = false) {
     for_sides(E, true, [&](Side& s, size_t i) {
         cognn_keys k = keys(E, owner_override == ~0ull ? (u64)s.owner : owner_override, it, op);
         BE(cognn_trunc_open_u64(E->ctx, s.ob[2], x[i], mul, &k, s.p, elems[i]));
-    });
+    }, skip_paired);
     exchange_ob(E, 2, elems);
     for_sides(E, true, [&](Side& s, size_t i) {
         cognn_keys k = keys(E, owner_override == ~0ull ? (u64)s.owner : owner_override, it, op);
         BE(cognn_trunc_close_u64(E->ctx, dst(s), s.p == 0 ? s.ob[2] : nullptr, s.p == 0 ? s.ib[2] : nullptr, &k, s.p, mode, elems[i]));
-    });
+    }, skip_paired);
 }
 
 // dealer streams of a Beaver product: its own (owner, iteration, op) streams, except that a reused operand keeps the A streams
@@ -477,9 +478,12 @@ void trunc_close_all(cognn_engine* E, int64_t it, int top, DstFn dst, const std:
 }
 
 // Beaver GEMM for every side: X(side), Wm(side) -> truncated product written to dst(side)
+// pairs_raw: the co-located pairs' product shares stay in zbuf as the product kernels left them - the caller's chain consumes them
+// (weight_update_chain); returns whether those are raw products (C_p still to be added)
 template <class XFn, class WFn, class SpecFn, class DstFn>
-void gemm_stage(cognn_engine* E, int64_t it, XFn X, WFn Wm, SpecFn spec, DstFn dst, bool x_opened = false,
-                const OpenNext& open_next = OpenNext(), bool w_opened = false, const FollowScale& follow = FollowScale()) {
+bool gemm_stage(cognn_engine* E, int64_t it, XFn X, WFn Wm, SpecFn spec, DstFn dst, bool x_opened = false,
+                const OpenNext& open_next = OpenNext(), bool w_opened = false, const FollowScale& follow = FollowScale(),
+                bool pairs_raw = false) {
     // follow (co-located pairs only): the row scale that consumes the product joins the pair chain; the caller's rowscale_stage
     // then handles the other sides
     // w_opened: ob[1] already holds F_p = W_p - B_p (written by the truncation close that produced W)
@@ -493,7 +497,7 @@ void gemm_stage(cognn_engine* E, int64_t it, XFn X, WFn Wm, SpecFn spec, DstFn d
         cognn_keys k = gkeys(s, g);
         if (xsrc == X_OPEN_HERE && !feature)
             BE(cognn_mask_open_u64(E->ctx, s.ob[0], X(s), k.k[s.p == 0 ? COGNN_SL_A0 : COGNN_SL_A1], g.M, g.K, g.transA));
-        if (!w_opened) BE(cognn_mask_open_u64(E->ctx, s.ob[1], Wm(s), k.k[s.p == 0 ? COGNN_SL_B0 : COGNN_SL_B1], g.K, g.N, 0));
+        if (!w_opened) BE(cognn_mask_open_u64(E->ctx, s.ob[1], Wm(s), k.k[s.p == 0 ? COGNN_SL_B0 : COGNN_SL_B1], g.K, g.N, g.transB ? 3 : 0));
         e0[i] = g.M * g.K; e1[i] = g.K * g.N; eo[i] = g.M * g.N;
     });
     const bool w_public = w_opened && E->public_openings;   // ob[1] holds F itself on the sides outside pair chains: nothing to exchange
@@ -635,7 +639,7 @@ void gemm_stage(cognn_engine* E, int64_t it, XFn X, WFn Wm, SpecFn spec, DstFn d
     }, false, lanes);
     if (E->timing) BE(cognn_timer_end(E->ctx, T_GEMM));
     // co-located pairs: truncation of the product (+ the row scale that follows) as one chain per owner
-    {
+    if (!pairs_raw) {
         PairChains pc;
         for (auto& s : E->sides) {
             if (!paired(E, s) || s.p != 0) continue;
@@ -675,6 +679,7 @@ void gemm_stage(cognn_engine* E, int64_t it, XFn X, WFn Wm, SpecFn spec, DstFn d
     }
     exchange_ob(E, 2, eo);
     trunc_close_all(E, it, g0.top, dst, eo, open_next, true);
+    return all_raw;
 }
 
 // row scale by the (owner-known) normaliser followed by truncation; x(side) [n x F] -> dst(side)
@@ -1108,31 +1113,68 @@ GemmSpec wgrad_spec(cognn_engine* E, Side& s, int layer, int64_t it) {
     return g;
 }
 
-void weight_update_chain(cognn_engine* E, int64_t it, int layer) {
+// pairs_fused: the co-located pairs' products are still in zbuf (gemm_stage, pairs_raw): product truncation, both scales and the
+// update run as one pass per pair (cognn_pair_weight_update_u64) - and, when every party's pair is hosted here, the weight
+// average too (returns true: weight_average has been done)
+bool weight_update_chain(cognn_engine* E, int64_t it, int layer, bool pairs_fused, bool raw) {
     // d (in side.small[0]) -> *1/trainSetSize -> W -= lr*d   (gcn.h:673-678, 720-730)
     const int64_t elems = layer == 0 ? (int64_t)E->in() * E->hid() : (int64_t)E->hid() * E->lab();
+    const u64 lr = fx_trunc(E->cfg.learning_rate);
+    const bool inference = E->cfg.variant == COGNN_VARIANT_OPTIMIZE_GCN_INFERENCE;
+    auto gscale = [&](Side& s) {                           // gradient scale: per-owner constant
+        const int64_t train = (int64_t)((double)s.n * E->cfg.train_ratio);
+        return train > 0 ? fx_trunc(1.0 / (double)train) : (u64)0;
+    };
+    bool averaged = false;
+    if (pairs_fused) {
+        std::vector<cognn_pair_wupdate> jobs;
+        bool all = true;
+        for (auto& s : E->sides) {
+            if (!paired(E, s)) { all = false; continue; }
+            if (s.p != 0) continue;
+            Side& t = *s.peer;
+            cognn_pair_wupdate J;
+            memset(&J, 0, sizeof(J));
+            GemmSpec g = wgrad_spec(E, s, layer, it);
+            J.z[0] = s.zbuf; J.z[1] = t.zbuf; J.W[0] = s.W[layer]; J.W[1] = t.W[layer];
+            if (raw) J.c1 = t.c1.at({it, g.op}).ptr;
+            J.gemm_keys = gemm_keys(E, s, it, g);
+            J.trunc_keys[0] = keys(E, s.owner, it, g.top);
+            J.trunc_keys[1] = keys(E, s.owner, it, COGNN_OP_AP_GSCALE_TRUNC);
+            J.trunc_keys[2] = keys(E, s.owner, it, COGNN_OP_AP_LR_TRUNC);
+            J.trunc_keys[3] = keys(E, s.owner, it, COGNN_OP_WAVG_TRUNC);
+            J.mul[0] = gscale(s); J.mul[1] = lr; J.mul[2] = inference ? fx_trunc(1.0 / E->k) : 0;   // optimize-gcn-inference/gcn.h:680-681,732-733
+            J.n = elems;
+            J.flags = (raw ? 0 : COGNN_PC_NO_C) | (s.owner == 0 ? 0 : COGNN_WU_SWAP);   // owner 0 keeps (s0, s1); owners >= 1 keep (s1, s0)
+            jobs.push_back(J);
+        }
+        averaged = all && E->world == 1 && jobs.size() <= 16 && elems > 0;
+        cognn_keys ak = keys(E, COGNN_OWNER_WAVG, it, COGNN_OP_WAVG_TRUNC);
+        const u64 amul = E->cfg.variant == COGNN_VARIANT_OPTIMIZE_GCN ? fx_trunc(1.0 / E->k) : 0;   // twoPartyGCNMatrixScale between parties 0 and 1 (gcn.h:763-764)
+        BE(cognn_pair_weight_update_u64(E->ctx, jobs.data(), (int32_t)jobs.size(), &ak, averaged ? amul : 0, averaged ? 1 : 0));
+        for (auto& s : E->sides)
+            if (paired(E, s) && s.p == 1) c1_release(E, s, {it, wgrad_spec(E, s, layer, it).op});
+        if (all) return averaged;
+    }
     std::vector<u64*> d, d2;
     std::vector<int64_t> el;
     for (auto& s : E->sides) { d.push_back(s.small[0]); d2.push_back(s.small[1]); el.push_back(elems); }
-    // gradient scale: per-owner constant, so the stage runs per side with its own multiplier
     for_sides(E, true, [&](Side& s, size_t i) {
-        const int64_t train = (int64_t)((double)s.n * E->cfg.train_ratio);
-        const u64 gs = train > 0 ? fx_trunc(1.0 / (double)train) : 0;
         cognn_keys k = keys(E, s.owner, it, COGNN_OP_AP_GSCALE_TRUNC);
-        BE(cognn_trunc_open_u64(E->ctx, s.ob[2], d[i], gs, &k, s.p, elems));
-    });
+        BE(cognn_trunc_open_u64(E->ctx, s.ob[2], d[i], gscale(s), &k, s.p, elems));
+    }, pairs_fused);
     exchange_ob(E, 2, el);
     for_sides(E, true, [&](Side& s, size_t i) {
         cognn_keys k = keys(E, s.owner, it, COGNN_OP_AP_GSCALE_TRUNC);
         BE(cognn_trunc_close_u64(E->ctx, d2[i], s.p == 0 ? s.ob[2] : nullptr, s.p == 0 ? s.ib[2] : nullptr, &k, s.p, 0, elems));
-    });
-    const u64 lr = fx_trunc(E->cfg.learning_rate);
-    trunc_stage(E, it, COGNN_OP_AP_LR_TRUNC, lr, d2, el, [&](Side& s) { return s.W[layer]; }, 1);
-    if (E->cfg.variant == COGNN_VARIANT_OPTIMIZE_GCN_INFERENCE) {   // optimize-gcn-inference/gcn.h:680-681,732-733
+    }, pairs_fused);
+    trunc_stage(E, it, COGNN_OP_AP_LR_TRUNC, lr, d2, el, [&](Side& s) { return s.W[layer]; }, 1, ~0ull, pairs_fused);
+    if (inference) {                                       // optimize-gcn-inference/gcn.h:680-681,732-733
         std::vector<u64*> w;
         for (auto& s : E->sides) w.push_back(s.W[layer]);
-        trunc_stage(E, it, COGNN_OP_WAVG_TRUNC, fx_trunc(1.0 / E->k), w, el, [&](Side& s) { return s.W[layer]; }, 0);
+        trunc_stage(E, it, COGNN_OP_WAVG_TRUNC, fx_trunc(1.0 / E->k), w, el, [&](Side& s) { return s.W[layer]; }, 0, ~0ull, pairs_fused);
     }
+    return false;
 }
 
 void run_iteration(cognn_engine* E, int64_t it) {
@@ -1225,9 +1267,9 @@ void run_iteration(cognn_engine* E, int64_t it) {
     const bool first_of_two = ((I.e - I.f) % 2 == 0);
     if (first_of_two) {
         if (I.layer == I.f - 1) {                          // g = (p-y) . W1^T, out = in  (gcn.h:664-669)
-            for (auto& s : E->sides) BE(cognn_transpose_u64(E->ctx, s.WT, s.W[1], E->hid(), E->lab()));
-            gemm_stage(E, it, [&](Side& s) { return s.cur; }, [&](Side& s) { return s.WT; },
-                       [&](Side& s) { return GemmSpec{s.n, E->hid(), E->lab(), 0, COGNN_OP_AP_GEMM, COGNN_OP_AP_GEMM_TRUNC}; },
+            // (W1 is read across by the opening of the right operand: no transposed copy)
+            gemm_stage(E, it, [&](Side& s) { return s.cur; }, [&](Side& s) { return s.W[1]; },
+                       [&](Side& s) { GemmSpec g{s.n, E->hid(), E->lab(), 0, COGNN_OP_AP_GEMM, COGNN_OP_AP_GEMM_TRUNC}; g.transB = 1; return g; },
                        [&](Side& s) { return s.g; });
         } else {                                           // out = in * 1[z>0]  (gcn.h:702-708; g' skipped for layer 0)
             Batch batch(E);
@@ -1242,17 +1284,18 @@ void run_iteration(cognn_engine* E, int64_t it) {
         return;
     }
     // d = h_t^T . in ; scale ; W -= lr d ; out = g  (gcn.h:671-684, 710-736)
-    gemm_stage(E, it, [&](Side& s) { return I.layer == 0 ? s.feat : s.h1; }, [&](Side& s) { return s.cur; },
-               [&](Side& s) { return wgrad_spec(E, s, I.layer, it); },
-               [&](Side& s) { return s.small[0]; }, false, OpenNext(), wgrad_w_opened);
-    weight_update_chain(E, it, I.layer);
+    const bool pairs_fused = E->pair_fusion && E->wupdate_fusion && !streams_on(E);
+    const bool raw = gemm_stage(E, it, [&](Side& s) { return I.layer == 0 ? s.feat : s.h1; }, [&](Side& s) { return s.cur; },
+                                [&](Side& s) { return wgrad_spec(E, s, I.layer, it); },
+                                [&](Side& s) { return s.small[0]; }, false, OpenNext(), wgrad_w_opened, FollowScale(), pairs_fused);
+    const bool averaged = weight_update_chain(E, it, I.layer, pairs_fused, raw);
     for (auto& s : E->sides) {
         if (I.layer == I.f - 1) { s.cur = s.g; s.curF = E->hid(); }
         else { s.curF = 0; }                               // vertexInterData["g"] is empty for the first layer
     }
     ph_ap.end();
     Phase ph_wa(E, T_PH_WAVG);
-    weight_average(E, it, I.layer);
+    if (!averaged) weight_average(E, it, I.layer);
     exchange_wait(E);
 }
 
@@ -1553,7 +1596,6 @@ void alloc_sides(cognn_engine* E) {
         s.featE = dalloc<u64>(E, n * in);
         s.W[0] = dalloc<u64>(E, (size_t)in * hid);
         s.W[1] = dalloc<u64>(E, (size_t)hid * lab);
-        s.WT = dalloc<u64>(E, (size_t)hid * lab);
         s.h1 = dalloc<u64>(E, n * hid);
         s.h1E = dalloc<u64>(E, n * hid);
         s.g = dalloc<u64>(E, n * hid);

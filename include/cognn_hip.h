@@ -296,6 +296,32 @@ int cognn_pair_chain_deal_u64(cognn_ctx*, const cognn_pair_chain* chain, uint64_
 /* independent chains (the co-located pairs of one protocol phase) are issued as shared launches */
 int cognn_pair_chain_u64(cognn_ctx*, const cognn_pair_chain* chains, int32_t count);
 
+/* The weight update of ApplyComp's second backward iteration (gcn.h:671-684, 710-736; optimize-gcn-inference/gcn.h:680-681,
+ * 732-733) for a co-located pair, as one pass over the (small) weight matrix: with d_p = z_p (+ C_p unless COGNN_PC_NO_C) the
+ * weight-gradient product shares,
+ *   d = trunc(d; trunc_keys[0]);  d = trunc(d * mul[0]; trunc_keys[1]);  u = trunc(d * mul[1]; trunc_keys[2]);  W -= u;
+ *   mul[2] != 0:  W = trunc(W * mul[2]; trunc_keys[3])
+ * where trunc(v; k) is cognn_trunc_open[_add]_u64 on both sides + exchange + cognn_trunc_close_u64 on both sides, evaluated for
+ * both sides by one thread (same dealer streams, same formulas: bit-identical to that sequence).  Jobs of one call (the pairs
+ * of a GAS iteration) share a launch.
+ * average != 0 (every party's pair is hosted by the caller; count <= 16, one n): the weight average that follows (gcn.h:753-778) in
+ * the same pass - sum_0 = sum over jobs of W[swap ? 1 : 0], sum_1 = of the other share (owner 0 keeps (s0, s1), owners >= 1
+ * (s1, s0): COGNN_WU_SWAP); avg_mul != 0: (sum_0, sum_1) = trunc(sum * avg_mul; avg_keys) between parties 0 and 1; every job's
+ * W[swap ? 1 : 0] = sum_0 and its other share = sum_1.  Bit-identical to cognn_sum_u64 x 2, the truncation and cognn_fanout_u64 x 2. */
+enum { COGNN_WU_SWAP = 64 };
+typedef struct {
+    const uint64_t* z[2];        /* the two sides' product shares [n] */
+    const uint64_t* c1;          /* side 1's dealt product share (flags without COGNN_PC_NO_C) */
+    uint64_t* W[2];              /* the two sides' weight shares [n], updated in place */
+    cognn_keys gemm_keys;        /* C_0 stream of the product */
+    cognn_keys trunc_keys[4];
+    uint64_t mul[3];             /* gradient scale 1/|train|, learning rate, post scale (0: none) - Q16 */
+    int64_t n;
+    int32_t flags;               /* COGNN_PC_NO_C, COGNN_WU_SWAP */
+} cognn_pair_wupdate;
+int cognn_pair_weight_update_u64(cognn_ctx*, const cognn_pair_wupdate* jobs, int32_t count, const cognn_keys* avg_keys, uint64_t avg_mul,
+                                 int32_t average);
+
 /* Gather whose epilogue IS the pair chain (co-located pairs, single process): for every owner, row r of its owner-side segment
  * (first row a_row0) and row r of its co-party-side segment (b_row0) are aggregated by the same lanes -
  *   V_p[r,:] = table[row_p(r),:] + sum_{e in CSR row row_p(r)} table[col[e],:]        (the self row is the base)

@@ -160,6 +160,10 @@ int cognn_ring_gemm_u64(cognn_ctx*, uint64_t* C, const uint64_t* A, const uint64
     return 0;
 }
 int cognn_mask_open_u64(cognn_ctx*, uint64_t* E, const uint64_t* X, uint64_t key, int64_t rows, int64_t cols, int tr) {
+    if (tr == 3) {                                         // X stored [cols x rows], E in logical order
+        for (int64_t i = 0; i < rows * cols; ++i) E[i] = X[(i % cols) * rows + i / cols] - cognn_prng(key, (u64)i);
+        return 0;
+    }
     CG_PAR
     for (int64_t i = 0; i < rows * cols; ++i) E[i] = X[i] - cognn_prng(key, lidx(i, rows, cols, tr));
     return 0;
@@ -500,6 +504,62 @@ int cognn_pair_chain_u64(cognn_ctx* ctx, const cognn_pair_chain* chains, int32_t
     return 0;
 }
 // the fused gather = the plain gather of both sides' row segments into temporaries, then the pair chain on them
+// the per-side sequence the fused kernel replaces, call by call
+int cognn_pair_weight_update_u64(cognn_ctx* ctx, const cognn_pair_wupdate* jobs, int32_t count, const cognn_keys* avg_keys, uint64_t avg_mul,
+                                 int32_t average) {
+    REQ(!average || (count >= 1 && count <= 16), "pair_weight_update: the averaging form takes 1..16 pairs");
+    for (int32_t j = 0; j < count; ++j) {
+        const cognn_pair_wupdate& s = jobs[j];
+        const int64_t n = s.n;
+        if (n == 0) continue;
+        REQ(s.z[0] && s.z[1] && s.W[0] && s.W[1], "pair_weight_update: null tensor");
+        std::vector<u64> c0(n), c1(n), d0(n), d1(n);
+        if (s.flags & COGNN_PC_NO_C) {
+            cognn_trunc_open_u64(ctx, c0.data(), s.z[0], 1, &s.trunc_keys[0], 0, n);
+            cognn_trunc_open_u64(ctx, c1.data(), s.z[1], 1, &s.trunc_keys[0], 1, n);
+        } else {
+            REQ(s.c1, "pair_weight_update: side 1's product share is missing");
+            cognn_trunc_open_add_u64(ctx, c0.data(), s.z[0], nullptr, &s.gemm_keys, &s.trunc_keys[0], 0, n);
+            cognn_trunc_open_add_u64(ctx, c1.data(), s.z[1], s.c1, &s.gemm_keys, &s.trunc_keys[0], 1, n);
+        }
+        cognn_trunc_close_u64(ctx, d0.data(), c0.data(), c1.data(), &s.trunc_keys[0], 0, 0, n);
+        cognn_trunc_close_u64(ctx, d1.data(), nullptr, nullptr, &s.trunc_keys[0], 1, 0, n);
+        for (int t = 1; t <= 2; ++t) {
+            cognn_trunc_open_u64(ctx, c0.data(), d0.data(), s.mul[t - 1], &s.trunc_keys[t], 0, n);
+            cognn_trunc_open_u64(ctx, c1.data(), d1.data(), s.mul[t - 1], &s.trunc_keys[t], 1, n);
+            const int mode = t == 2 ? 1 : 0;
+            cognn_trunc_close_u64(ctx, mode ? s.W[0] : d0.data(), c0.data(), c1.data(), &s.trunc_keys[t], 0, mode, n);
+            cognn_trunc_close_u64(ctx, mode ? s.W[1] : d1.data(), nullptr, nullptr, &s.trunc_keys[t], 1, mode, n);
+        }
+        if (s.mul[2]) {
+            cognn_trunc_open_u64(ctx, c0.data(), s.W[0], s.mul[2], &s.trunc_keys[3], 0, n);
+            cognn_trunc_open_u64(ctx, c1.data(), s.W[1], s.mul[2], &s.trunc_keys[3], 1, n);
+            cognn_trunc_close_u64(ctx, s.W[0], c0.data(), c1.data(), &s.trunc_keys[3], 0, 0, n);
+            cognn_trunc_close_u64(ctx, s.W[1], nullptr, nullptr, &s.trunc_keys[3], 1, 0, n);
+        }
+    }
+    if (average) {                                         // cognn_sum_u64 x 2, the 1/k truncation, cognn_fanout_u64 x 2
+        const int64_t n = jobs[0].n;
+        std::vector<u64> s0(n, 0), s1(n, 0), c0(n), c1(n);
+        for (int32_t j = 0; j < count; ++j) {
+            REQ(jobs[j].n == n, "pair_weight_update: the averaged matrices must have one size");
+            const int sw = (jobs[j].flags & COGNN_WU_SWAP) ? 1 : 0;
+            for (int64_t i = 0; i < n; ++i) { s0[i] += jobs[j].W[sw][i]; s1[i] += jobs[j].W[1 - sw][i]; }
+        }
+        if (avg_mul) {
+            REQ(avg_keys, "pair_weight_update: the scale's keys are missing");
+            cognn_trunc_open_u64(ctx, c0.data(), s0.data(), avg_mul, avg_keys, 0, n);
+            cognn_trunc_open_u64(ctx, c1.data(), s1.data(), avg_mul, avg_keys, 1, n);
+            cognn_trunc_close_u64(ctx, s0.data(), c0.data(), c1.data(), avg_keys, 0, 0, n);
+            cognn_trunc_close_u64(ctx, s1.data(), nullptr, nullptr, avg_keys, 1, 0, n);
+        }
+        for (int32_t j = 0; j < count; ++j) {
+            const int sw = (jobs[j].flags & COGNN_WU_SWAP) ? 1 : 0;
+            memcpy(jobs[j].W[sw], s0.data(), (size_t)n * 8); memcpy(jobs[j].W[1 - sw], s1.data(), (size_t)n * 8);
+        }
+    }
+    return 0;
+}
 int cognn_gather_pair_chain_u64(cognn_ctx* ctx, const uint64_t* table, const uint32_t* rowptr, const uint32_t* col, int64_t F,
                                 const cognn_gather_pair* pairs, int32_t count) {
     for (int32_t c = 0; c < count; ++c) {

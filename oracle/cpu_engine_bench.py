@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """TEST INFRASTRUCTURE (bench.py's cpu_baseline leg only): times the engine's host code linked against the plain-C++
 reference backend (oracle/libcognn_engine_cpu.so, OpenMP over the independent loop iterations) on a synthetic workload and
-prints one JSON line.  Usage: cpu_engine_bench.py K LOG2_V LOG2_E IN HID LAB VARIANT ITERS STEPS"""
+prints one JSON line.  Usage: cpu_engine_bench.py K LOG2_V LOG2_E IN HID LAB VARIANT ITERS STEPS
+(LOG2_V / LOG2_E written as =N give the exact vertex / directed-edge count instead of a power of two)"""
 import json
 import os
 import sys
@@ -14,14 +15,15 @@ import numpy as np  # noqa: E402
 
 
 def main():
-    k, lv, le, in_dim, hid, lab = (int(x) for x in sys.argv[1:7])
+    k, in_dim, hid, lab = int(sys.argv[1]), int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6])
+    size = lambda a: int(a[1:]) if a.startswith("=") else 1 << int(a)
     variant, iters, steps = sys.argv[7], int(sys.argv[8]), int(sys.argv[9])
     import cognn_oracle as co
     from cognn_amd import capi
     capi.LIB_PATH = os.path.join(ROOT, "oracle", "libcognn_engine_cpu.so")   # test infrastructure: the plain-C++ reference backend
     capi.load()
     from cognn_amd.engine import Engine, GnnParam
-    V, Eu = 1 << lv, 1 << (le - 1)
+    V, Eu = size(sys.argv[2]), size(sys.argv[3]) // 2
     src, dst = co.synth_graph(V, Eu, 0xC06A11)
     part = (np.arange(V) % k).astype(np.int32)
     gp = GnnParam(num_labels=lab, input_dim=in_dim, hidden_dim=hid, num_samples=V, num_edges=len(src))

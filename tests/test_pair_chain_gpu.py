@@ -237,3 +237,70 @@ def test_gather_with_pair_chain_epilogue_equals_gather_then_chain(ctx, F, relu, 
                 assert np.array_equal(host(bufs[3]), e1 - co.prng_shape(ok[1], e1.shape))
         if not forward_only:
             assert np.array_equal(host(bufs[0]), e0) and np.array_equal(host(bufs[1]), e1)
+
+
+@pytest.mark.parametrize("n", [1, 7, 16 * 7, 1433 * 16 + 1])
+@pytest.mark.parametrize("pairs,average,avg_scale,post,raw", [(1, 0, 0, 0, 1), (3, 0, 0, 1, 0), (2, 1, 1, 0, 1), (5, 1, 0, 1, 1), (16, 1, 1, 0, 0)])
+def test_pair_weight_update_matches_the_two_party_oracle(ctx, n, pairs, average, avg_scale, post, raw):
+    """cognn_pair_weight_update_u64 (product truncation, gradient scale, learning rate, update, optional 1/k scale, optional
+    weight average with its scale) against the oracle's truncation pairs chained the way the reference's ApplyComp + weight
+    average do (gcn.h:671-684, 710-736, 753-778)."""
+    from cognn_amd import capi
+    rng = np.random.default_rng(n * 31 + pairs * 7 + average + 2 * post + 4 * raw)
+    seed, it = 77, 5
+    jobs = (capi.PairWUpdate * pairs)()
+    exp, Wd = [], []
+    gs = [int(co.fx_encode_trunc(1.0 / (40 + 3 * o))) for o in range(pairs)]
+    lr, ws = int(co.fx_encode_trunc(0.5)), int(co.fx_encode_trunc(1.0 / pairs))
+    with np.errstate(over="ignore"):
+        for o in range(pairs):
+            val = rng.integers(-(1 << 44), 1 << 44, size=n).astype(np.int64).astype(U64)       # Q32 product of Q16 values
+            z1 = rand_u64(rng, n); z0 = val - z1
+            c1 = rand_u64(rng, n) >> U64(30)
+            wv = rng.integers(-(1 << 20), 1 << 20, size=n).astype(np.int64).astype(U64)
+            w1 = rand_u64(rng, n); w0 = wv - w1
+            ks = [_keys(seed, o, it, op) for op in (co.OP_AP_GEMM, co.OP_AP_GEMM_TRUNC, co.OP_AP_GSCALE_TRUNC, co.OP_AP_LR_TRUNC, co.OP_WAVG_TRUNC)]
+            J = jobs[o]
+            W0d, W1d = dev(w0), dev(w1)
+            Wd.append((W0d, W1d))
+            J.z[0] = dev(z0).data_ptr(); J.z[1] = dev(z1).data_ptr(); J.c1 = dev(c1).data_ptr()
+            J.W[0] = W0d.data_ptr(); J.W[1] = W1d.data_ptr()
+            J.gemm_keys = ks[0][0]
+            for t in range(4):
+                J.trunc_keys[t] = ks[1 + t][0]
+            J.mul[0] = gs[o]; J.mul[1] = lr; J.mul[2] = ws if post else 0
+            J.n = n; J.flags = (0 if raw else NO_C) | (capi.WU_SWAP if o >= 1 else 0)
+            d0, d1 = (z0 + co.prng_shape(ks[0][1](co.SL_C0), (n,)), z1 + c1) if raw else (z0, z1)
+            d0, d1 = co.trunc_pair(d0, d1, ks[1][1])
+            d0, d1 = co.const_scale_trunc_pair(d0, d1, gs[o], ks[2][1])
+            u0, u1 = co.const_scale_trunc_pair(d0, d1, lr, ks[3][1])
+            n0, n1 = w0 - u0, w1 - u1
+            if post:
+                n0, n1 = co.const_scale_trunc_pair(n0, n1, ws, ks[4][1])
+            exp.append((n0, n1))
+        ak = _keys(seed, co.OWNER_WAVG, it, co.OP_WAVG_TRUNC)
+        if average:
+            s0 = np.zeros(n, dtype=U64); s1 = np.zeros(n, dtype=U64)
+            for o in range(pairs):
+                s0 = s0 + exp[o][0 if o == 0 else 1]; s1 = s1 + exp[o][1 if o == 0 else 0]
+            if avg_scale:
+                s0, s1 = co.const_scale_trunc_pair(s0, s1, ws, ak[1])
+            exp = [((s0, s1) if o == 0 else (s1, s0)) for o in range(pairs)]
+    ctx.call("cognn_pair_weight_update_u64", jobs, pairs, ctypes.byref(ak[0]), ws if (average and avg_scale) else 0, average)
+    ctx.sync()
+    for o in range(pairs):
+        assert np.array_equal(host(Wd[o][0]), exp[o][0]) and np.array_equal(host(Wd[o][1]), exp[o][1]), o
+
+
+@pytest.mark.parametrize("rows,cols", [(7, 16), (16, 64), (3, 5), (1, 1)])
+def test_mask_open_reads_a_transposed_weight_matrix(ctx, rows, cols):
+    """transposed = 3: X is stored [cols x rows], the opening is written in logical [rows x cols] order (W1^T of gcn.h:648,665
+    without the transposed copy)."""
+    rng = np.random.default_rng(rows * 17 + cols)
+    X = rand_u64(rng, (cols, rows))
+    key = co.stream_key(3, 1, 4, co.OP_AP_GEMM, co.SL_B0)
+    E = dev_empty((rows, cols))
+    ctx.call("cognn_mask_open_u64", ptr(E), ptr(dev(X)), ctypes.c_uint64(key), rows, cols, 3)
+    ctx.sync()
+    with np.errstate(over="ignore"):
+        assert np.array_equal(host(E), X.T - co.prng_shape(key, (rows, cols)))
