@@ -78,6 +78,8 @@ _SIGNATURES = {
     "cognn_ctx_sync": (_I, [_P]),
     "cognn_batch_begin": (_I, [_P]),
     "cognn_batch_end": (_I, [_P]),
+    "cognn_ctx_set_chunk": (_I, [_P, ctypes.c_int32, ctypes.c_int32]),
+    "cognn_chunk_range": (None, [_L, ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(_L), ctypes.POINTER(_L)]),
     "cognn_lane_begin": (_I, [_P, ctypes.c_int32]),
     "cognn_lane_select": (_I, [_P, ctypes.c_int32]),
     "cognn_lane_end": (_I, [_P]),

@@ -112,7 +112,17 @@ int cognn_batch_begin(cognn_ctx* ctx) {
 }
 int cognn_batch_end(cognn_ctx* ctx) {
     CG_REQUIRE(ctx && ctx->batch_depth > 0, "cognn_batch_end: no open batch");
-    return --ctx->batch_depth == 0 ? cg_flush(ctx) : 0;
+    return --ctx->batch_depth == 0 ? cg_flush_pending(ctx) : 0;
+}
+void cognn_chunk_range(int64_t n, int32_t c, int32_t C, int64_t* lo, int64_t* hi) {
+    if (C <= 1) { *lo = 0; *hi = n; return; }
+    *lo = (n * c / C) & ~(int64_t)1;
+    *hi = (c + 1 == C) ? n : ((n * (c + 1) / C) & ~(int64_t)1);
+}
+int cognn_ctx_set_chunk(cognn_ctx* ctx, int32_t c, int32_t C) {
+    CG_REQUIRE(ctx && ((C <= 1 && c == 0) || (C >= 2 && C <= 64 && c >= 0 && c < C)), "cognn_ctx_set_chunk: chunk %d of %d", (int)c, (int)C);
+    ctx->chunk_c = C <= 1 ? 0 : c; ctx->chunk_C = C <= 1 ? 1 : C;     // (queued calls keep the window they were issued under)
+    return 0;
 }
 int cognn_malloc(cognn_ctx* ctx, void** ptr, size_t bytes) {
     CG_REQUIRE(ctx && ptr, "cognn_malloc: null argument");

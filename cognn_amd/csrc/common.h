@@ -32,11 +32,16 @@ struct cognn_ctx {
     int lanes_active = 0;
     unsigned long long* salt_sym[3] = {nullptr, nullptr, nullptr};   // the kernel translation units' copies of the epoch salt (cognn_spec.h)
     bool capturing = false;                                          // between cognn_graph_capture_begin / _end
+    int chunk_c = 0, chunk_C = 1;                                    // chunk window of the element-wise entry points (cognn_ctx_set_chunk)
 };
-// launches whatever is queued (every non-element-wise entry point calls it first, so stream order is preserved)
-static inline int cg_flush(cognn_ctx* ctx) { return (ctx && ctx->pending.flush) ? ctx->pending.flush(ctx) : 0; }
-
 int cognn_set_error(const char* fmt, ...);
+// launches whatever is queued
+static inline int cg_flush_pending(cognn_ctx* ctx) { return (ctx && ctx->pending.flush) ? ctx->pending.flush(ctx) : 0; }
+// ... as every entry point other than the element-wise ones does first, so that stream order is preserved; those take no chunk window
+static inline int cg_flush(cognn_ctx* ctx) {
+    if (ctx && ctx->chunk_C > 1) return cognn_set_error("a chunk window is set (cognn_ctx_set_chunk): only the element-wise entry points may be called");
+    return cg_flush_pending(ctx);
+}
 
 #define CG_HIP(expr)                                                                          \
     do {                                                                                      \

@@ -49,6 +49,11 @@ struct cognn_rccl_exchange {
     hipStream_t comm_stream = nullptr;  // owned
     hipEvent_t ready = nullptr;         // compute -> comm: the round's send buffers are written
     hipEvent_t done = nullptr;          // comm -> compute: the messages of the newest round (and, in stream order, all before) have arrived
+    // ... and one event per round, in a ring: a consumer of round r waits for r only while r + 1.. are still in flight
+    // (cognn_rccl_exchange_wait_round; a slot that has been reused since belongs to a LATER round, which over-waits, never under-waits)
+    static constexpr int kRing = 64;
+    hipEvent_t done_ring[kRing] = {};
+    int64_t round_base = 0;             // rounds begun before the engine's numbering started (cognn_engine_set_exchange_rccl)
     // every round is bracketed by a pair of timing events on the communication stream: its duration there is the time the
     // p2p group took (cognn_rccl_exchange_time)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> timing, spare;
@@ -177,6 +182,7 @@ int cognn_rccl_exchange_destroy(cognn_rccl_exchange* x) {
     if (x->comm) (void)ncclCommDestroy(x->comm);
     if (x->ready) (void)hipEventDestroy(x->ready);
     if (x->done) (void)hipEventDestroy(x->done);
+    for (hipEvent_t ev : x->done_ring) if (ev) (void)hipEventDestroy(ev);
     for (auto* v : {&x->timing, &x->spare})
         for (auto& pr : *v) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     if (x->comm_stream) (void)hipStreamDestroy(x->comm_stream);
@@ -220,6 +226,9 @@ int cognn_rccl_exchange_begin(void* user, const cognn_xfer* xfers, int32_t n) {
     x->timing.push_back(tm);
     // ... and whoever consumes a received buffer (or overwrites a sent one) waits for this event on the compute stream
     X_HIP(hipEventRecord(x->done, x->comm_stream));
+    hipEvent_t& slot = x->done_ring[x->rounds % cognn_rccl_exchange::kRing];
+    if (!slot) X_HIP(hipEventCreateWithFlags(&slot, hipEventDisableTiming));
+    X_HIP(hipEventRecord(slot, x->comm_stream));
     ++x->rounds;
     return 0;
 }
@@ -231,10 +240,22 @@ int cognn_rccl_exchange_wait(void* user) {
     return 0;
 }
 
+// rounds are numbered from 0 at cognn_engine_set_exchange_rccl (cognn_exchange_wait_round_fn); the communication stream
+// completes them in order, so the event of round r covers every earlier one
+int cognn_rccl_exchange_wait_round(void* user, int64_t round) {
+    cognn_rccl_exchange* x = (cognn_rccl_exchange*)user;
+    X_REQUIRE(x && round >= 0, "cognn_rccl_exchange_wait_round: bad arguments");
+    const int64_t r = x->round_base + round;
+    X_REQUIRE(r < x->rounds, "cognn_rccl_exchange_wait_round: round %lld has not been started (%lld so far)", (long long)round, (long long)(x->rounds - x->round_base));
+    X_HIP(hipStreamWaitEvent(x->compute, x->done_ring[r % cognn_rccl_exchange::kRing], 0));
+    return 0;
+}
+
 int cognn_engine_set_exchange_rccl(cognn_engine* e, cognn_rccl_exchange* x) {
     X_REQUIRE(e && x, "cognn_engine_set_exchange_rccl: null argument");
-    if (cognn_engine_set_exchange_async(e, cognn_rccl_exchange_begin, cognn_rccl_exchange_wait, x) != 0)
+    if (cognn_engine_set_exchange_async2(e, cognn_rccl_exchange_begin, cognn_rccl_exchange_wait, cognn_rccl_exchange_wait_round, x) != 0)
         return xerr("cognn_engine_set_exchange_rccl: %s", cognn_engine_last_error());
+    x->round_base = x->rounds;
     return 0;
 }
 

@@ -48,9 +48,10 @@ __device__ __forceinline__ u64 beaver_mul(const cognn_opkeys& k, int p, u64 e, u
 }
 
 // generic pair launcher: thread t handles flat elements 2t, 2t+1
+// (i0: first element of the chunk window, even; n: one past its last)
 template <class F>
-__global__ __launch_bounds__(kThreads) void ew_kernel(int64_t n, F f) {
-    int64_t i = 2 * ((int64_t)blockIdx.x * kThreads + threadIdx.x);
+__global__ __launch_bounds__(kThreads) void ew_kernel(int64_t i0, int64_t n, F f) {
+    int64_t i = i0 + 2 * ((int64_t)blockIdx.x * kThreads + threadIdx.x);
     if (i + 1 < n) f(i, 2);
     else if (i < n) f(i, 1);
 }
@@ -60,7 +61,7 @@ constexpr int kBatchMax = 16;
 template <class F>
 struct EwBatch {
     F f[kBatchMax];
-    int64_t n[kBatchMax];
+    int64_t i0[kBatchMax], n[kBatchMax];       // element range of each tensor (the whole tensor unless a chunk window is set)
     unsigned blk_end[kBatchMax];               // exclusive prefix of workgroup counts
     int count;
 };
@@ -71,7 +72,7 @@ __global__ __launch_bounds__(kThreads) void ew_batch_kernel(EwBatch<F> b) {
     while (seg < b.count - 1 && blk >= b.blk_end[seg]) ++seg;
     const unsigned blk0 = seg ? b.blk_end[seg - 1] : 0u;
     const int64_t n = b.n[seg];
-    const int64_t i = 2 * ((int64_t)(blk - blk0) * kThreads + threadIdx.x);
+    const int64_t i = b.i0[seg] + 2 * ((int64_t)(blk - blk0) * kThreads + threadIdx.x);
     if (i + 1 < n) b.f[seg](i, 2);
     else if (i < n) b.f[seg](i, 1);
 }
@@ -82,16 +83,18 @@ int flush_ew(cognn_ctx* ctx) {
     ctx->pending.flush = nullptr;
     if (b->count <= 0) return 0;
     const unsigned blocks = b->blk_end[b->count - 1];
-    if (b->count == 1) hipLaunchKernelGGL(ew_kernel<F>, dim3(blocks), dim3(kThreads), 0, ctx->stream, b->n[0], b->f[0]);
+    if (b->count == 1) hipLaunchKernelGGL(ew_kernel<F>, dim3(blocks), dim3(kThreads), 0, ctx->stream, b->i0[0], b->n[0], b->f[0]);
     else hipLaunchKernelGGL(ew_batch_kernel<F>, dim3(blocks), dim3(kThreads), 0, ctx->stream, *b);
     b->count = 0;
     CG_LAUNCH_CHECK();
     return 0;
 }
 template <class F>
-int launch_ew(cognn_ctx* ctx, int64_t n, F f) {
-    if (n <= 0) return 0;
-    const int64_t pairs = (n + 1) / 2;
+int launch_ew(cognn_ctx* ctx, int64_t n_all, F f) {
+    int64_t i0, n;
+    cognn_chunk_range(n_all, ctx->chunk_c, ctx->chunk_C, &i0, &n);
+    if (n <= i0) return 0;
+    const int64_t pairs = (n - i0 + 1) / 2;
     const unsigned blocks = (unsigned)((pairs + kThreads - 1) / kThreads);
     if (ctx->batch_depth > 0) {
         int rc;
@@ -99,14 +102,14 @@ int launch_ew(cognn_ctx* ctx, int64_t n, F f) {
         EwBatch<F>* b = reinterpret_cast<EwBatch<F>*>(ctx->pending.storage);
         if (!ctx->pending.flush) { b->count = 0; ctx->pending.flush = &flush_ew<F>; }
         const unsigned base = b->count ? b->blk_end[b->count - 1] : 0u;
-        if ((uint64_t)base + blocks > 0x7fffffffull) { if ((rc = flush_ew<F>(ctx))) return rc; return launch_ew(ctx, n, f); }
-        b->f[b->count] = f; b->n[b->count] = n; b->blk_end[b->count] = base + blocks;
+        if ((uint64_t)base + blocks > 0x7fffffffull) { if ((rc = flush_ew<F>(ctx))) return rc; return launch_ew(ctx, n_all, f); }
+        b->f[b->count] = f; b->i0[b->count] = i0; b->n[b->count] = n; b->blk_end[b->count] = base + blocks;
         if (++b->count == kBatchMax) return flush_ew<F>(ctx);
         return 0;
     }
     int rc;
-    if ((rc = cg_flush(ctx))) return rc;
-    hipLaunchKernelGGL(ew_kernel<F>, dim3(blocks), dim3(kThreads), 0, ctx->stream, n, f);
+    if ((rc = cg_flush_pending(ctx))) return rc;
+    hipLaunchKernelGGL(ew_kernel<F>, dim3(blocks), dim3(kThreads), 0, ctx->stream, i0, n, f);
     CG_LAUNCH_CHECK();
     return 0;
 }

@@ -16,7 +16,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-from .engine_api import EXCHANGE_FN, EXCHANGE_WAIT_FN, RCCL_ID_BYTES
+from .engine_api import EXCHANGE_FN, EXCHANGE_WAIT_FN, EXCHANGE_WAIT_ROUND_FN, RCCL_ID_BYTES
 
 
 class RcclExchange:
@@ -141,12 +141,15 @@ def make_exchange(device, group=None, host_staged=False):
     return EXCHANGE_FN(_exchange)
 
 
-def make_exchange_async(device, group=None, host_staged=False):
+def make_exchange_async(device, group=None, host_staged=False, per_round=False):
     """(begin, wait) callbacks for cognn_engine_set_exchange_async(): begin enqueues a round and returns, wait completes every
     enqueued round - the engine runs the kernels of the sides whose peer is local in between.  With RCCL the p2p group runs on
-    the communicator's stream (ordered after the kernels already launched), wait makes the engine's stream wait for it."""
+    the communicator's stream (ordered after the kernels already launched), wait makes the engine's stream wait for it.
+    per_round: also return the third callback (cognn_exchange_wait_round_fn: completes the rounds up to a given one and leaves
+    the later ones in flight - the chunked pipelines of COGNN_OPT_EXCHANGE_CHUNKS), for cognn_engine_set_exchange_async2()."""
     cache = {}
     inflight = []                                       # (works, [(device tensor, host tensor)] to copy back)
+    counts = [0, 0]                                     # rounds begun / completed
 
     def _build(xfers, n):
         ops, pre, post = [], [], []
@@ -173,22 +176,32 @@ def make_exchange_async(device, group=None, host_staged=False):
             for t, h in pre:
                 h.copy_(t)                                  # device -> host of what is already enqueued on the engine's stream
             inflight.append((dist.batch_isend_irecv(ops), post))
+            counts[0] += 1
             return 0
         except Exception as ex:  # noqa: BLE001 - the C caller only understands a status code
             print("cognn exchange (begin) failed: %r" % (ex,), flush=True)
             return 1
 
-    def _wait(user):
+    def _complete(upto):
         try:
-            while inflight:
+            while inflight and counts[1] < upto:
                 works, post = inflight.pop(0)
                 for w in works:
                     w.wait()
                 for t, h in post:
                     t.copy_(h)
+                counts[1] += 1
             return 0
         except Exception as ex:  # noqa: BLE001
             print("cognn exchange (wait) failed: %r" % (ex,), flush=True)
             return 1
 
+    def _wait(user):
+        return _complete(counts[0])
+
+    def _wait_round(user, rnd):
+        return _complete(rnd + 1)
+
+    if per_round:
+        return EXCHANGE_FN(_begin), EXCHANGE_WAIT_FN(_wait), EXCHANGE_WAIT_ROUND_FN(_wait_round)
     return EXCHANGE_FN(_begin), EXCHANGE_WAIT_FN(_wait)

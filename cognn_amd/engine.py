@@ -103,9 +103,11 @@ class Engine:
         _check(self.lib.cognn_engine_set_weights(self.h, a.ctypes.data, b.ctypes.data))
 
     def set_exchange(self, fn):
-        """fn: the callback of cognn_amd.dist.make_exchange, or the (begin, wait) pair of make_exchange_async."""
+        """fn: the callback of cognn_amd.dist.make_exchange, or the (begin, wait[, wait_round]) tuple of make_exchange_async."""
         self._xfn = fn                                     # keep the ctypes callbacks alive
-        if isinstance(fn, tuple):
+        if isinstance(fn, tuple) and len(fn) == 3:
+            _check(self.lib.cognn_engine_set_exchange_async2(self.h, fn[0], fn[1], fn[2], None))
+        elif isinstance(fn, tuple):
             _check(self.lib.cognn_engine_set_exchange_async(self.h, fn[0], fn[1], None))
         else:
             _check(self.lib.cognn_engine_set_exchange(self.h, fn, None))
@@ -150,6 +152,11 @@ class Engine:
     def graph_epochs(self, on=True):
         """Whole epochs per run() call are recorded once (hipGraph) and replayed (cognn_engine.h: COGNN_OPT_GRAPH_EPOCHS)."""
         _check(self.lib.cognn_engine_set_option(self.h, 6, int(on)))
+
+    def exchange_chunks(self, chunks):
+        """The element-wise open -> exchange -> close steps of share-holders whose peer is on another rank run in `chunks` row
+        chunks, each chunk's messages in flight behind the next chunk's kernels (cognn_engine.h: COGNN_OPT_EXCHANGE_CHUNKS)."""
+        _check(self.lib.cognn_engine_set_option(self.h, 7, int(chunks)))
 
     def public_openings(self, on=True):
         """Share-holders outside pair chains derive the opening that follows a truncation themselves (default) instead of

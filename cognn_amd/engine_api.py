@@ -21,6 +21,7 @@ class Xfer(ctypes.Structure):
 
 EXCHANGE_FN = ctypes.CFUNCTYPE(ctypes.c_int, _P, ctypes.POINTER(Xfer), _I)
 EXCHANGE_WAIT_FN = ctypes.CFUNCTYPE(ctypes.c_int, _P)
+EXCHANGE_WAIT_ROUND_FN = ctypes.CFUNCTYPE(ctypes.c_int, _P, _L)
 
 _SIGNATURES = {
     "cognn_engine_last_error": (ctypes.c_char_p, []),
@@ -28,6 +29,7 @@ _SIGNATURES = {
     "cognn_engine_destroy": (ctypes.c_int, [_P]),
     "cognn_engine_set_exchange": (ctypes.c_int, [_P, EXCHANGE_FN, _P]),
     "cognn_engine_set_exchange_async": (ctypes.c_int, [_P, EXCHANGE_FN, EXCHANGE_WAIT_FN, _P]),
+    "cognn_engine_set_exchange_async2": (ctypes.c_int, [_P, EXCHANGE_FN, EXCHANGE_WAIT_FN, EXCHANGE_WAIT_ROUND_FN, _P]),
     "cognn_engine_party_rows": (ctypes.c_int, [_P, _I, ctypes.POINTER(_L)]),
     "cognn_engine_party_vids": (ctypes.c_int, [_P, _I, _P]),
     "cognn_engine_party_degrees": (ctypes.c_int, [_P, _I, _P, _P, _P]),
@@ -60,6 +62,7 @@ _EXCHANGE_SIGNATURES = {
     "cognn_rccl_exchange_destroy": (ctypes.c_int, [_P]),
     "cognn_rccl_exchange_begin": (ctypes.c_int, [_P, ctypes.POINTER(Xfer), _I]),
     "cognn_rccl_exchange_wait": (ctypes.c_int, [_P]),
+    "cognn_rccl_exchange_wait_round": (ctypes.c_int, [_P, _L]),
     "cognn_engine_set_exchange_rccl": (ctypes.c_int, [_P, _P]),
     "cognn_rccl_exchange_stats": (ctypes.c_int, [_P, ctypes.POINTER(_L), ctypes.POINTER(_L), ctypes.POINTER(_L)]),
     "cognn_rccl_exchange_time": (ctypes.c_int, [_P, ctypes.POINTER(_D)]),

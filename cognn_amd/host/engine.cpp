@@ -113,6 +113,9 @@ struct cognn_engine {
     cognn_exchange_wait_fn xwait = nullptr;   // set: xfn only enqueues the round, xwait completes it (asynchronous exchange)
     void* xuser = nullptr;
     bool xpending = false;                     // an enqueued round has not been waited for yet
+    cognn_exchange_wait_round_fn xwait_round = nullptr;   // optional: completes the rounds up to a given one (chunked pipelines)
+    int64_t xbegun = 0, xdone = 0;             // rounds enqueued on this transport / of them completed (a prefix: transports complete in order)
+    int chunks = 1;                            // COGNN_OPT_EXCHANGE_CHUNKS
     bool started = false, timing = false;
     int64_t gemm_x_opened_for = -1;    // iteration whose PreScatter GEMM input was already opened by the previous ReLU close
     // share table of the current message-passing round
@@ -251,7 +254,16 @@ struct XList {
 void exchange_wait(cognn_engine* E) {
     if (!E->xpending) return;
     E->xpending = false;
+    E->xdone = E->xbegun;
     if (E->xwait(E->xuser) != 0) throw EngineError("engine: exchange wait function failed");
+}
+// completes the rounds up to and including `round` (numbered by xbegun at their start); later rounds stay in flight when the
+// transport can tell them apart (cognn_exchange_wait_round_fn) - otherwise everything enqueued is completed
+void exchange_wait_round(cognn_engine* E, int64_t round) {
+    if (!E->xpending || round < E->xdone) return;
+    if (!E->xwait_round || round + 1 >= E->xbegun) { exchange_wait(E); return; }
+    E->xdone = round + 1;
+    if (E->xwait_round(E->xuser, round) != 0) throw EngineError("engine: exchange wait function failed");
 }
 // starts a round.  With a wait function registered the call only enqueues the messages; whoever consumes received data - or
 // overwrites a buffer that is being sent - calls exchange_wait first (for_sides does, before it touches a side whose peer is remote).
@@ -263,7 +275,9 @@ void run_exchange(cognn_engine* E, XList& xl, bool keep_inflight = false) {
     if (!E->xfn) throw EngineError("engine: world > 1 needs an exchange function (cognn_engine_set_exchange)");
     if (E->xfn(E->xuser, xl.v.data(), (int32_t)xl.v.size()) != 0) throw EngineError("engine: exchange function failed");
     ++E->rounds;
+    ++E->xbegun;
     if (E->xwait) E->xpending = true;
+    else E->xdone = E->xbegun;
 }
 void run_exchange_sync(cognn_engine* E, XList& xl) {
     run_exchange(E, xl);
@@ -362,6 +376,68 @@ void for_sides(cognn_engine* E, bool batched, Fn fn, bool skip_paired = false, i
         else body();
     }
 }
+// The open -> exchange -> close [-> exchange -> close ...] steps of an element-wise stage.  steps[j].fn(side, i) is the call
+// for_sides would issue for step j (it consumes what round j - 1 delivered); steps[j].msg(xl, side, i, c, C), if set, appends the
+// messages that step j's output needs exchanged - chunk c of C of side i (C = 1: whole tensors; element ranges by
+// cognn_chunk_range, msg_range).  Sides whose peer is hosted here run step j as one launch, beside the remote sides' messages.
+// Sides whose peer is remote, with COGNN_OPT_EXCHANGE_CHUNKS = C > 1: step j runs chunk by chunk under the chunk window; chunk
+// c's messages are enqueued as their own round right away and travel while chunk c + 1 is computed, and step j + 1 waits, chunk
+// by chunk, for that chunk's round only (cognn_exchange_wait_round_fn) while the later ones are still in flight.
+// whole: the step's calls are not chunk-safe (they write tensors of several sizes): they run once, unwindowed, before chunk 0's
+// messages; the messages still go chunk by chunk.
+struct Step {
+    std::function<void(Side&, size_t)> fn;
+    std::function<void(XList&, Side&, size_t, int, int)> msg;
+    bool whole = false;
+};
+struct ChunkGuard {           // the window never outlives the step that set it (an exception included)
+    cognn_engine* E;
+    ~ChunkGuard() { E->be->cognn_ctx_set_chunk(E->ctx, 0, 1); }
+};
+void msg_range(XList& xl, Side& s, u64* out, u64* in, int64_t elems, int c, int C) {
+    int64_t lo, hi;
+    cognn_chunk_range(elems, c, C, &lo, &hi);
+    xl.send(s.peer_rank, out + lo, (hi - lo) * 8);
+    xl.recv(s.peer_rank, in + lo, (hi - lo) * 8);
+}
+void chunked_rounds(cognn_engine* E, const std::vector<Step>& steps, bool skip_paired = false) {
+    bool remote = false;
+    for (auto& s : E->sides) remote = remote || !s.peer;
+    const int C = remote ? E->chunks : 1;
+    auto each = [&](bool local, const std::function<void(Side&, size_t)>& fn) {
+        if (!fn) return;
+        Batch batch(E);
+        for (size_t i = 0; i < E->sides.size(); ++i) {
+            Side& s = E->sides[i];
+            if ((s.peer != nullptr) != local || (skip_paired && paired(E, s))) continue;
+            fn(s, i);
+        }
+    };
+    std::vector<int64_t> ticket((size_t)C, -1), next((size_t)C, -1);
+    for (size_t j = 0; j < steps.size(); ++j) {
+        const Step& st = steps[j];
+        each(true, st.fn);
+        if (j == 0) exchange_wait(E);                      // (the remote sides' inputs may still be arriving)
+        ChunkGuard guard{E};
+        for (int c = 0; c < C; ++c) {
+            if (ticket[(size_t)c] >= 0) exchange_wait_round(E, ticket[(size_t)c]);
+            if (st.whole) { if (c == 0) each(false, st.fn); }
+            else {
+                if (C > 1) BE(cognn_ctx_set_chunk(E->ctx, c, C));
+                each(false, st.fn);
+                if (C > 1) BE(cognn_ctx_set_chunk(E->ctx, 0, 1));
+            }
+            next[(size_t)c] = -1;
+            if (!st.msg) continue;
+            XList xl;
+            for (size_t i = 0; i < E->sides.size(); ++i)
+                if (!E->sides[i].peer && !(skip_paired && paired(E, E->sides[i]))) st.msg(xl, E->sides[i], i, c, C);
+            if (!xl.v.empty()) { run_exchange(E, xl, true); next[(size_t)c] = E->xbegun - 1; }
+        }
+        ticket = next;
+    }
+    exchange_wait(E);                                      // (nothing is left in flight unless the last step had messages)
+}
 // the pair chains of one phase: filled per owner (from its p = 0 side), launched together
 struct PairChains {
     std::vector<cognn_pair_chain> v;
@@ -418,15 +494,17 @@ struct FollowScale {
 template <class DstFn>
 void trunc_stage(cognn_engine* E, int64_t it, int op, u64 mul, const std::vector<u64*>& x, const std::vector<int64_t>& elems,
                  DstFn dst, int mode, u64 owner_override = ~0ull, bool skip_paired = false) {
-    for_sides(E, true, [&](Side& s, size_t i) {
+    std::vector<Step> steps(2);
+    steps[0].fn = [&](Side& s, size_t i) {
         cognn_keys k = keys(E, owner_override == ~0ull ? (u64)s.owner : owner_override, it, op);
         BE(cognn_trunc_open_u64(E->ctx, s.ob[2], x[i], mul, &k, s.p, elems[i]));
-    }, skip_paired);
-    exchange_ob(E, 2, elems);
-    for_sides(E, true, [&](Side& s, size_t i) {
+    };
+    steps[0].msg = [&](XList& xl, Side& s, size_t i, int c, int C) { msg_range(xl, s, s.ob[2], s.ib[2], elems[i], c, C); };
+    steps[1].fn = [&](Side& s, size_t i) {
         cognn_keys k = keys(E, owner_override == ~0ull ? (u64)s.owner : owner_override, it, op);
         BE(cognn_trunc_close_u64(E->ctx, dst(s), s.p == 0 ? s.ob[2] : nullptr, s.p == 0 ? s.ib[2] : nullptr, &k, s.p, mode, elems[i]));
-    }, skip_paired);
+    };
+    chunked_rounds(E, steps, skip_paired);
 }
 
 // dealer streams of a Beaver product: its own (owner, iteration, op) streams, except that a reused operand keeps the A streams
@@ -461,20 +539,28 @@ struct OpenNext {
 // Applies to the sides that are not part of a pair chain.
 bool pub_open(const cognn_engine* E, const Side& s) { return E->public_openings && !paired(E, s); }
 template <class DstFn>
-void trunc_close_all(cognn_engine* E, int64_t it, int top, DstFn dst, const std::vector<int64_t>& elems, const OpenNext& open_next,
-                     bool skip_paired = false) {
-    for_sides(E, true, [&](Side& s, size_t i) {
-        cognn_keys tk = keys(E, s.owner, it, top);
-        const u64* c0 = s.p == 0 ? s.ob[2] : nullptr;
-        const u64* c1 = s.p == 0 ? s.ib[2] : nullptr;
-        if (open_next.reveal && pub_open(E, s) && s.p == 0)
-            BE(cognn_trunc_close_pub_u64(E->ctx, dst(s), s.ob[0], s.ob[2], s.ib[2], &tk, 0, 0, 0, 1, elems[i]));
-        else if (open_next && pub_open(E, s))
-            BE(cognn_trunc_close_pub_u64(E->ctx, dst(s), s.ob[open_next.ob], s.p == 0 ? s.ob[2] : s.ib[2], s.p == 0 ? s.ib[2] : s.ob[2], &tk, s.p,
-                                         open_next.keyp(s, 0), open_next.keyp(s, 1), 0, elems[i]));
-        else if (open_next) BE(cognn_trunc_close_open_u64(E->ctx, dst(s), s.ob[open_next.ob], c0, c1, &tk, s.p, open_next.key(s), elems[i]));
-        else BE(cognn_trunc_close_u64(E->ctx, dst(s), c0, c1, &tk, s.p, 0, elems[i]));
-    }, skip_paired);
+void trunc_close_one(cognn_engine* E, int64_t it, int top, DstFn& dst, const std::vector<int64_t>& elems, const OpenNext& open_next, Side& s, size_t i) {
+    cognn_keys tk = keys(E, s.owner, it, top);
+    const u64* c0 = s.p == 0 ? s.ob[2] : nullptr;
+    const u64* c1 = s.p == 0 ? s.ib[2] : nullptr;
+    if (open_next.reveal && pub_open(E, s) && s.p == 0)
+        BE(cognn_trunc_close_pub_u64(E->ctx, dst(s), s.ob[0], s.ob[2], s.ib[2], &tk, 0, 0, 0, 1, elems[i]));
+    else if (open_next && pub_open(E, s))
+        BE(cognn_trunc_close_pub_u64(E->ctx, dst(s), s.ob[open_next.ob], s.p == 0 ? s.ob[2] : s.ib[2], s.p == 0 ? s.ib[2] : s.ob[2], &tk, s.p,
+                                     open_next.keyp(s, 0), open_next.keyp(s, 1), 0, elems[i]));
+    else if (open_next) BE(cognn_trunc_close_open_u64(E->ctx, dst(s), s.ob[open_next.ob], c0, c1, &tk, s.p, open_next.key(s), elems[i]));
+    else BE(cognn_trunc_close_u64(E->ctx, dst(s), c0, c1, &tk, s.p, 0, elems[i]));
+}
+// the exchange of the truncation openings in ob[2] and the closes that consume them (open: what still has to produce ob[2] for
+// the sides whose peer is remote - empty when that already happened)
+template <class DstFn>
+void trunc_exchange_close(cognn_engine* E, int64_t it, int top, DstFn dst, const std::vector<int64_t>& elems, const OpenNext& open_next,
+                          bool skip_paired, std::function<void(Side&, size_t)> open = nullptr) {
+    std::vector<Step> steps(2);
+    steps[0].fn = open;
+    steps[0].msg = [&](XList& xl, Side& s, size_t i, int c, int C) { msg_range(xl, s, s.ob[2], s.ib[2], elems[i], c, C); };
+    steps[1].fn = [&](Side& s, size_t i) { trunc_close_one(E, it, top, dst, elems, open_next, s, i); };
+    chunked_rounds(E, steps, skip_paired);
 }
 
 // Beaver GEMM for every side: X(side), Wm(side) -> truncated product written to dst(side)
@@ -520,6 +606,8 @@ bool gemm_stage(cognn_engine* E, int64_t it, XFn X, WFn Wm, SpecFn spec, DstFn d
         exchange_ob2(E, 0, e0, 1, e1);
     }
     std::vector<u64*> z(ns);                                // (F = F0 + F1 is summed inside the product kernels)
+    std::vector<const u64*> c1_of(ns, nullptr);            // side 1's dealt product share (the map entry may be released before its last use)
+    const bool chunk_trunc = E->chunks > 1;                 // the truncation opening of a side whose peer is remote runs in row chunks
     GemmSpec g0 = spec(E->sides[0]);
     bool all_raw = true;
     for (auto& s : E->sides) { GemmSpec g = spec(s); all_raw = all_raw && E->be->cognn_beaver_gemm_fusable(g.M, g.N, g.K, g.transA); }
@@ -596,10 +684,11 @@ bool gemm_stage(cognn_engine* E, int64_t it, XFn X, WFn Wm, SpecFn spec, DstFn d
             Batch batch(E);                                    // the truncation openings of the sides outside pair chains: one launch
             for (size_t i : idx) {
                 Side& s = E->sides[i];
-                if (paired(E, s)) continue;
+                if (s.p == 1) c1_of[i] = s.c1.at({it, spec(s).op}).ptr;
+                if (paired(E, s) || (chunk_trunc && !s.peer)) continue;   // (chunked: opened chunk by chunk below)
                 GemmSpec g = spec(s);
                 cognn_keys k = gkeys(s, g), tk = keys(E, s.owner, it, g.top);
-                BE(cognn_trunc_open_add_u64(E->ctx, s.ob[2], s.zbuf, s.p == 1 ? s.c1.at({it, g.op}).ptr : nullptr, &k, &tk, s.p, eo[i]));
+                BE(cognn_trunc_open_add_u64(E->ctx, s.ob[2], s.zbuf, c1_of[i], &k, &tk, s.p, eo[i]));
             }
         }
         for (auto& s : E->sides)
@@ -630,7 +719,8 @@ bool gemm_stage(cognn_engine* E, int64_t it, XFn X, WFn Wm, SpecFn spec, DstFn d
         BE(cognn_beaver_gemm_close2_u64(E->ctx, s.zbuf, e_own, e_peer, f_own, f_sum ? nullptr : s.ib[1], c1, &k, s.p, g.M, g.N,
                                         g.K, g.transA, s.scratch, all_raw ? 1 : 0));
         if (E->timing) E->algo[T_GEMM] += 2.0 * 36 * 2 * (double)g.M * g.K * g.N;
-        if (all_raw && !paired(E, s)) {
+        c1_of[i] = c1;
+        if (all_raw && !paired(E, s) && !(chunk_trunc && !s.peer)) {
             cognn_keys tk = keys(E, s.owner, it, g.top);
             BE(cognn_trunc_open_add_u64(E->ctx, s.ob[2], s.zbuf, c1, &k, &tk, s.p, eo[i]));
         }
@@ -671,14 +761,16 @@ bool gemm_stage(cognn_engine* E, int64_t it, XFn X, WFn Wm, SpecFn spec, DstFn d
             if (paired(E, s) && s.p == 1) c1_release(E, s, {it, spec(s).op});
     }
     // all GEMMs of one stage share the truncation op id
-    if (!all_raw) {
-        for_sides(E, true, [&](Side& s, size_t i) {
-            cognn_keys tk = keys(E, s.owner, it, g0.top);
-            BE(cognn_trunc_open_u64(E->ctx, s.ob[2], z[i], 1, &tk, s.p, eo[i]));
-        }, true);
-    }
-    exchange_ob(E, 2, eo);
-    trunc_close_all(E, it, g0.top, dst, eo, open_next, true);
+    // (chunked: the sides whose peer is remote open their truncation here, chunk by chunk, each chunk's messages leaving at once)
+    trunc_exchange_close(E, it, g0.top, dst, eo, open_next, true, [&](Side& s, size_t i) {
+        cognn_keys tk = keys(E, s.owner, it, g0.top);
+        if (!all_raw) BE(cognn_trunc_open_u64(E->ctx, s.ob[2], z[i], 1, &tk, s.p, eo[i]));
+        else if (chunk_trunc && !s.peer) {
+            GemmSpec g = spec(s);
+            cognn_keys k = gkeys(s, g);
+            BE(cognn_trunc_open_add_u64(E->ctx, s.ob[2], s.zbuf, c1_of[i], &k, &tk, s.p, eo[i]));
+        }
+    });
     return all_raw;
 }
 
@@ -738,35 +830,29 @@ void rowscale_stage(cognn_engine* E, int64_t it, int op, int top, int F, XFn X, 
         }
         pc.launch(E);
     }
-    for_sides(E, true, [&](Side& s, size_t i) {
+    for (size_t i = 0; i < ns; ++i) { eF[i] = (int64_t)E->sides[i].n * F; e1[i] = E->sides[i].n; }
+    std::vector<Step> steps(2);
+    // the openings: G_p = s_p - b_p (one value per row) and, unless it exists already, E_p = X_p - a_p.  Two tensors of different
+    // sizes: not a chunk-window call; the messages leave in chunks all the same (G whole with chunk 0)
+    steps[0].whole = true;
+    steps[0].fn = [&](Side& s, size_t) {
         cognn_keys k = keys(E, s.owner, it, op);
         BE(cognn_rowscale_open_u64(E->ctx, e_mode == E_FROM_X ? s.ob[0] : nullptr, s.ob[1], X(s), s.svec, &k, s.p, s.n, F));
-        eF[i] = (int64_t)s.n * F; e1[i] = s.n;
-    }, true);
-    if (e_opened) {
-        XList xl;
-        for (size_t i = 0; i < ns; ++i) {
-            Side& s = E->sides[i];
-            if (s.peer) continue;
-            xl.send(s.peer_rank, X(s), eF[i] * 8);
-            xl.recv(s.peer_rank, s.ib[0], eF[i] * 8);
-            xl.send(s.peer_rank, s.ob[1], e1[i] * 8);
-            xl.recv(s.peer_rank, s.ib[1], e1[i] * 8);
-        }
-        run_exchange(E, xl);
-    } else if (e_public) {
-        exchange_ob(E, 1, e1);                              // only the n scale openings travel
-    } else {
-        exchange_ob2(E, 0, eF, 1, e1);
-    }
-    for_sides(E, true, [&](Side& s, size_t) {               // the opened sums E0+E1, G0+G1 are formed inside the kernel
+    };
+    steps[0].msg = [&](XList& xl, Side& s, size_t i, int c, int C) {
+        if (!e_public) msg_range(xl, s, e_opened ? X(s) : s.ob[0], s.ib[0], eF[i], c, C);   // (public: ob[0] holds E itself, only the scale openings travel)
+        if (c == 0) msg_range(xl, s, s.ob[1], s.ib[1], e1[i], 0, 1);
+    };
+    steps[1].fn = [&](Side& s, size_t) {                    // the opened sums E0+E1, G0+G1 are formed inside the kernel
         cognn_keys k = keys(E, s.owner, it, op), tk = keys(E, s.owner, it, top);
         const u64* e_own = e_opened ? X(s) : s.ob[0];
         const u64* e_peer = e_public ? nullptr : e_opened ? (s.peer ? X(*s.peer) : s.ib[0]) : s.ib[0];
         BE(cognn_rowscale_close_u64(E->ctx, s.ob[2], e_own, e_peer, s.ob[1], s.ib[1], &k, &tk, s.p, s.n, F));
-    }, true);
-    exchange_ob(E, 2, eF);
-    trunc_close_all(E, it, top, dst, eF, open_next, true);
+    };
+    steps[1].msg = [&](XList& xl, Side& s, size_t i, int c, int C) { msg_range(xl, s, s.ob[2], s.ib[2], eF[i], c, C); };
+    steps.emplace_back();
+    steps.back().fn = [&](Side& s, size_t i) { trunc_close_one(E, it, top, dst, eF, open_next, s, i); };
+    chunked_rounds(E, steps, true);
 }
 
 void relu_stage(cognn_engine* E, int64_t it, bool e_opened, bool pairs_done) {
@@ -793,27 +879,34 @@ void relu_stage(cognn_engine* E, int64_t it, bool e_opened, bool pairs_done) {
         pc.launch(E);
     }
     for (auto& s : E->sides) if (paired(E, s)) s.cur = s.h1;
-    for_sides(E, true, [&](Side& s, size_t i) {
-        cognn_keys k = keys(E, s.owner, it, COGNN_OP_AP_RELU);
-        // only E = z - a is opened online: g = t - b is input-independent and published by the dealer offline
-        if (!e_opened) BE(cognn_relu_open_u64(E->ctx, s.ob[0], nullptr, s.cur, &k, s.p, (int64_t)s.n * F));
-        eF[i] = (int64_t)s.n * F;
-    }, true);
+    for (size_t i = 0; i < E->sides.size(); ++i) eF[i] = (int64_t)E->sides[i].n * F;
     const bool e_public = e_opened && E->public_openings;   // ob[0] holds E itself: no exchange
-    if (!e_public) exchange_ob(E, 0, eF);
-    for_sides(E, true, [&](Side& s, size_t i) {
+    std::vector<Step> steps;
+    if (!e_public) {
+        steps.emplace_back();
+        steps.back().fn = [&](Side& s, size_t i) {
+            cognn_keys k = keys(E, s.owner, it, COGNN_OP_AP_RELU);
+            // only E = z - a is opened online: g = t - b is input-independent and published by the dealer offline
+            if (!e_opened) BE(cognn_relu_open_u64(E->ctx, s.ob[0], nullptr, s.cur, &k, s.p, eF[i]));
+        };
+        steps.back().msg = [&](XList& xl, Side& s, size_t i, int c, int C) { msg_range(xl, s, s.ob[0], s.ib[0], eF[i], c, C); };
+    }
+    steps.emplace_back();
+    steps.back().fn = [&](Side& s, size_t i) {
         cognn_keys k = keys(E, s.owner, it, COGNN_OP_AP_RELU);
         BE(cognn_relu_mul_u64(E->ctx, s.ob[2], s.ob[0], e_public ? nullptr : s.ib[0], nullptr, nullptr, &k, s.p, eF[i]));
-    }, true);
-    exchange_ob(E, 2, eF);
+    };
+    steps.back().msg = [&](XList& xl, Side& s, size_t i, int c, int C) { msg_range(xl, s, s.ob[2], s.ib[2], eF[i], c, C); };
     // H is the next iteration's PreScatter GEMM input (layer 1): write it straight into its h_t slot and emit the
     // Beaver opening E_p = H_p - A_p of that product in the same pass (gcn.h:230-239 of iteration it+1)
-    for_sides(E, true, [&](Side& s, size_t i) {
+    steps.emplace_back();
+    steps.back().fn = [&](Side& s, size_t i) {
         cognn_keys nk = keys(E, s.owner, it + 1, COGNN_OP_PS_GEMM);
         BE(cognn_relu_close_open_u64(E->ctx, s.h1, s.h1E, s.relu_mask, s.cur, s.ob[2], s.ib[2],
                                      nk.k[s.p == 0 ? COGNN_SL_A0 : COGNN_SL_A1], eF[i]));
-        s.cur = s.h1;
-    }, true);
+    };
+    chunked_rounds(E, steps, true);
+    for (auto& s : E->sides) if (!paired(E, s)) s.cur = s.h1;
     E->gemm_x_opened_for = it + 1;
 }
 
@@ -1781,13 +1874,24 @@ int cognn_engine_destroy(cognn_engine* E) {
 }
 
 int cognn_engine_set_exchange(cognn_engine* E, cognn_exchange_fn fn, void* user) {
-    return guard([&] { if (!E) throw EngineError("null engine"); E->xfn = fn; E->xwait = nullptr; E->xuser = user; });
+    return guard([&] {
+        if (!E) throw EngineError("null engine");
+        E->xfn = fn; E->xwait = nullptr; E->xwait_round = nullptr; E->xuser = user; E->xbegun = E->xdone = 0;
+    });
+}
+int cognn_engine_set_exchange_async2(cognn_engine* E, cognn_exchange_fn begin_fn, cognn_exchange_wait_fn wait_fn,
+                                     cognn_exchange_wait_round_fn wait_round_fn, void* user) {
+    return guard([&] {
+        if (!E) throw EngineError("null engine");
+        if (!begin_fn || !wait_fn) throw EngineError("cognn_engine_set_exchange_async2: the begin and wait functions are required");
+        E->xfn = begin_fn; E->xwait = wait_fn; E->xwait_round = wait_round_fn; E->xuser = user; E->xbegun = E->xdone = 0;
+    });
 }
 int cognn_engine_set_exchange_async(cognn_engine* E, cognn_exchange_fn begin_fn, cognn_exchange_wait_fn wait_fn, void* user) {
     return guard([&] {
         if (!E) throw EngineError("null engine");
         if (!begin_fn || !wait_fn) throw EngineError("cognn_engine_set_exchange_async: both functions are required");
-        E->xfn = begin_fn; E->xwait = wait_fn; E->xuser = user;
+        E->xfn = begin_fn; E->xwait = wait_fn; E->xwait_round = nullptr; E->xuser = user; E->xbegun = E->xdone = 0;
     });
 }
 
@@ -1951,6 +2055,10 @@ int cognn_engine_set_option(cognn_engine* E, int32_t option, int64_t value) {
             if (value != 0 && !E->graph_epochs) BE(cognn_ctx_use_private_stream(E->ctx));   // (the caller's stream may be the default stream, which cannot record)
             if (E->graph_exec) { E->be->cognn_graph_destroy(E->ctx, E->graph_exec); E->graph_exec = nullptr; }
             E->graph_epochs = value != 0; E->graph_warm = false;
+        }
+        else if (option == COGNN_OPT_EXCHANGE_CHUNKS) {
+            if (value < 1 || value > 8) throw EngineError("cognn_engine_set_option: COGNN_OPT_EXCHANGE_CHUNKS takes 1..8");
+            E->chunks = (int)value;
         }
         else throw EngineError("cognn_engine_set_option: unknown option");
     });

@@ -55,6 +55,12 @@ typedef int (*cognn_exchange_fn)(void* user, const cognn_xfer* xfers, int32_t n)
  * wait (message passing: the co-share replication and the partial-sum exchange travel while the local part of the aggregate
  * runs); the wait covers every enqueued round. */
 typedef int (*cognn_exchange_wait_fn)(void* user);
+/* Optional third callback: makes later work of the engine's stream wait for the rounds enqueued so far UP TO AND INCLUDING
+ * round `round` (rounds are numbered from 0 in the order cognn_exchange_fn was called since the callbacks were registered;
+ * a transport completes them in that order), while later rounds stay in flight.  The chunked open -> exchange -> close
+ * pipeline (COGNN_OPT_EXCHANGE_CHUNKS) uses it to close chunk c while the messages of chunks c+1.. still travel; without it
+ * the engine falls back to cognn_exchange_wait_fn, which waits for everything enqueued. */
+typedef int (*cognn_exchange_wait_round_fn)(void* user, int64_t round);
 
 const char* cognn_engine_last_error(void);
 int cognn_engine_create(const cognn_engine_config* cfg, int64_t num_vertices, int64_t num_edges,
@@ -62,6 +68,8 @@ int cognn_engine_create(const cognn_engine_config* cfg, int64_t num_vertices, in
 int cognn_engine_destroy(cognn_engine* e);
 int cognn_engine_set_exchange(cognn_engine* e, cognn_exchange_fn fn, void* user);
 int cognn_engine_set_exchange_async(cognn_engine* e, cognn_exchange_fn begin_fn, cognn_exchange_wait_fn wait_fn, void* user);
+int cognn_engine_set_exchange_async2(cognn_engine* e, cognn_exchange_fn begin_fn, cognn_exchange_wait_fn wait_fn,
+                                     cognn_exchange_wait_round_fn wait_round_fn, void* user);
 /* rows (local vertices) of a party and their vids in row order (localVertexPos, ss_...h:474) */
 int cognn_engine_party_rows(cognn_engine* e, int32_t party, int64_t* rows);
 int cognn_engine_party_vids(cognn_engine* e, int32_t party, int64_t* vids);
@@ -102,9 +110,14 @@ int cognn_engine_offline(cognn_engine* e, int64_t iter_begin, int64_t iter_end);
  * it is recorded, every later one as a replay under its own epoch salt (cognn_set_epoch_salt) - dataset-sized graphs spend
  * their epoch in launch overhead.  The engine moves to a private stream, deals product shares inside the recording (the
  * offline call becomes a no-op unless COGNN_OPT_RETAIN_OFFLINE keeps one epoch's products for replays of that epoch) and
- * renews the feature opening every epoch.  Shares, weights and metrics are bit-identical to the eager run. */
+ * renews the feature opening every epoch.  Shares, weights and metrics are bit-identical to the eager run.
+ * COGNN_OPT_EXCHANGE_CHUNKS (default 1; 1..8; matters only for share-holders whose peer is on another rank): the element-wise
+ * open -> exchange -> close steps of those sides (product truncation, row scale, ReLU) run in that many row chunks
+ * (cognn_ctx_set_chunk): chunk c's messages are enqueued as their own round as soon as chunk c is opened and travel while
+ * chunk c+1 is opened and chunk c-1 closed, so those kernels hide behind the link instead of waiting for it.  More, smaller
+ * rounds (C times as many for the chunked steps); shares bit-identical for every value. */
 enum { COGNN_OPT_RETAIN_OFFLINE = 1, COGNN_OPT_PAIR_FUSION = 2, COGNN_OPT_FORWARD_ONLY = 3, COGNN_OPT_PUBLIC_OPENINGS = 4,
-       COGNN_OPT_DEALER_STREAMS = 5, COGNN_OPT_GRAPH_EPOCHS = 6 };
+       COGNN_OPT_DEALER_STREAMS = 5, COGNN_OPT_GRAPH_EPOCHS = 6, COGNN_OPT_EXCHANGE_CHUNKS = 7 };
 int cognn_engine_set_option(cognn_engine* e, int32_t option, int64_t value);
 /* Offline-phase cache on disk, the counterpart of the reference's preprocess/<setting>/ directory reused with `-n 1`
  * (include/harness.h:140-146, README.md:215-216): save writes every dealt product share currently held on this rank to

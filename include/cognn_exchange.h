@@ -38,7 +38,11 @@ int cognn_rccl_exchange_destroy(cognn_rccl_exchange* x);
 /* the pair of callbacks for cognn_engine_set_exchange_async (user = the cognn_rccl_exchange*) */
 int cognn_rccl_exchange_begin(void* user, const cognn_xfer* xfers, int32_t n);
 int cognn_rccl_exchange_wait(void* user);
-/* shorthand for cognn_engine_set_exchange_async(e, cognn_rccl_exchange_begin, cognn_rccl_exchange_wait, x) */
+/* cognn_exchange_wait_round_fn: the compute stream waits for the event of round `round` (numbered from 0 at
+ * cognn_engine_set_exchange_rccl; one event per round, 64 in a ring) - later rounds stay in flight */
+int cognn_rccl_exchange_wait_round(void* user, int64_t round);
+/* shorthand for cognn_engine_set_exchange_async2(e, cognn_rccl_exchange_begin, cognn_rccl_exchange_wait,
+ * cognn_rccl_exchange_wait_round, x) */
 int cognn_engine_set_exchange_rccl(cognn_engine* e, cognn_rccl_exchange* x);
 /* rounds started, bytes sent and received by this rank so far (achieved xGMI GB/s = bytes / measured time) */
 int cognn_rccl_exchange_stats(cognn_rccl_exchange* x, int64_t* rounds, int64_t* bytes_sent, int64_t* bytes_received);

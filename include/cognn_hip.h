@@ -54,6 +54,15 @@ int cognn_batch_end(cognn_ctx*);
 int cognn_lane_begin(cognn_ctx*, int32_t lanes);
 int cognn_lane_select(cognn_ctx*, int32_t lane);
 int cognn_lane_end(cognn_ctx*);
+/* Chunk window.  While one is set (C >= 2), the element-wise entry points - codec, mask_open, add / sub / sum / fanout, trunc_*,
+ * rowscale_*, relu_*, mask_select - process only elements [lo, hi) = cognn_chunk_range(n, c, C) of their flat element range n
+ * (pointers stay those of the whole tensors, dealer streams are addressed by the absolute element index: the C windows together
+ * do exactly what the unwindowed call does) and every other entry point fails.  The engine uses it to run the open -> exchange ->
+ * close steps of share-holders on different GPUs in row chunks, chunk c's messages in flight behind chunk c+1's kernels.
+ * c = 0, C <= 1 clears the window.  cognn_rowscale_open_u64 applies the window to E (rows x F) and to G (rows) separately. */
+/* lo = floor(n c / C) rounded down to even (the kernels move 16-byte element pairs), hi = the next chunk's lo, n for the last */
+void cognn_chunk_range(int64_t n, int32_t c, int32_t C, int64_t* lo, int64_t* hi);
+int cognn_ctx_set_chunk(cognn_ctx*, int32_t c, int32_t C);
 int cognn_malloc(cognn_ctx* ctx, void** ptr, size_t bytes);
 int cognn_free(cognn_ctx* ctx, void* ptr);
 int cognn_memcpy_h2d(cognn_ctx* ctx, void* dst, const void* src, size_t bytes);

@@ -33,6 +33,9 @@ struct cognn_ctx {
 };
 
 static thread_local char g_err[512] = "";
+// chunk window of the element-wise entry points (cognn_ctx_set_chunk); one engine per thread in the tests
+static thread_local int g_chunk_c = 0, g_chunk_C = 1;
+#define CHUNK(n) int64_t lo_, hi_; cognn_chunk_range((n), g_chunk_c, g_chunk_C, &lo_, &hi_);
 static int fail(const char* fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
@@ -108,6 +111,16 @@ int cognn_share_split_u64(cognn_ctx*, const uint64_t* fx, uint64_t key, uint64_t
     }
     return 0;
 }
+void cognn_chunk_range(int64_t n, int32_t c, int32_t C, int64_t* lo, int64_t* hi) {
+    if (C <= 1) { *lo = 0; *hi = n; return; }
+    *lo = (n * c / C) & ~(int64_t)1;
+    *hi = (c + 1 == C) ? n : ((n * (c + 1) / C) & ~(int64_t)1);
+}
+int cognn_ctx_set_chunk(cognn_ctx*, int32_t c, int32_t C) {
+    REQ((C <= 1 && c == 0) || (C >= 2 && C <= 64 && c >= 0 && c < C), "ctx_set_chunk: bad window");
+    g_chunk_c = C <= 1 ? 0 : c; g_chunk_C = C <= 1 ? 1 : C;
+    return 0;
+}
 int cognn_batch_begin(cognn_ctx*) { return 0; }              // the reference backend runs every call immediately
 int cognn_batch_end(cognn_ctx*) { return 0; }
 int cognn_lane_begin(cognn_ctx*, int32_t) { return 0; }      // ... and in program order
@@ -169,8 +182,9 @@ int cognn_mask_open_u64(cognn_ctx*, uint64_t* E, const uint64_t* X, uint64_t key
     return 0;
 }
 int cognn_add_u64(cognn_ctx*, uint64_t* o, const uint64_t* a, const uint64_t* b, int64_t n) {
+    CHUNK(n)
     CG_PAR
-    for (int64_t i = 0; i < n; ++i) o[i] = a[i] + b[i];
+    for (int64_t i = lo_; i < hi_; ++i) o[i] = a[i] + b[i];
     return 0;
 }
 int cognn_sum_u64(cognn_ctx*, uint64_t* out, const uint64_t* const* in, int32_t count, int64_t n) {
@@ -184,8 +198,9 @@ int cognn_fanout_u64(cognn_ctx*, uint64_t* const* out, int32_t count, const uint
     return 0;
 }
 int cognn_sub_u64(cognn_ctx*, uint64_t* o, const uint64_t* a, const uint64_t* b, int64_t n) {
+    CHUNK(n)
     CG_PAR
-    for (int64_t i = 0; i < n; ++i) o[i] = a[i] - b[i];
+    for (int64_t i = lo_; i < hi_; ++i) o[i] = a[i] - b[i];
     return 0;
 }
 int cognn_dealer_gemm_c1_u64(cognn_ctx* c, uint64_t* C1, const cognn_keys* keys, int64_t M, int64_t N, int64_t K, int transA,
@@ -265,23 +280,26 @@ int cognn_beaver_gemm_close_group_u64(cognn_ctx* c, const cognn_gemm_job* jobs, 
 }
 int cognn_trunc_open_add_u64(cognn_ctx*, uint64_t* c, const uint64_t* x, const uint64_t* c1, const cognn_keys* gkeys,
                              const cognn_keys* tkeys, int p, int64_t n) {
+    CHUNK(n)
     const cognn_opkeys tk = K(tkeys);
-    for (int64_t i = 0; i < n; ++i)
+    for (int64_t i = lo_; i < hi_; ++i)
         c[i] = x[i] + (p == 0 ? cognn_prng(gkeys->k[COGNN_SL_C0], (u64)i) : c1[i]) + trunc_r(tk, p, (u64)i) + (p == 0 ? COGNN_TRUNC_OFFSET : 0);
     return 0;
 }
 int cognn_trunc_open_u64(cognn_ctx*, uint64_t* c, const uint64_t* x, uint64_t mul, const cognn_keys* keys, int p, int64_t n) {
+    CHUNK(n)
     const cognn_opkeys k = K(keys);
     CG_PAR
-    for (int64_t i = 0; i < n; ++i) c[i] = x[i] * mul + trunc_r(k, p, (u64)i) + (p == 0 ? COGNN_TRUNC_OFFSET : 0);
+    for (int64_t i = lo_; i < hi_; ++i) c[i] = x[i] * mul + trunc_r(k, p, (u64)i) + (p == 0 ? COGNN_TRUNC_OFFSET : 0);
     return 0;
 }
 int cognn_trunc_close_u64(cognn_ctx*, uint64_t* out, const uint64_t* c0, const uint64_t* c1, const cognn_keys* keys, int p,
                           int mode, int64_t n) {
+    CHUNK(n)
     REQ(p == 1 || (c0 && c1), "trunc_close: p=0 needs both opened values");
     const cognn_opkeys k = K(keys);
     CG_PAR
-    for (int64_t i = 0; i < n; ++i) {
+    for (int64_t i = lo_; i < hi_; ++i) {
         u64 y = p == 0 ? ((c0[i] + c1[i]) >> COGNN_FX_BITS) - (COGNN_TRUNC_OFFSET >> COGNN_FX_BITS) - trunc_rp(k, 0, (u64)i)
                        : 0ull - trunc_rp(k, 1, (u64)i);
         out[i] = mode == 1 ? out[i] - y : y;
@@ -290,20 +308,22 @@ int cognn_trunc_close_u64(cognn_ctx*, uint64_t* out, const uint64_t* c0, const u
 }
 int cognn_trunc_close_open_u64(cognn_ctx* c, uint64_t* out, uint64_t* E, const uint64_t* c0, const uint64_t* c1, const cognn_keys* keys,
                                int p, uint64_t key_open, int64_t n) {
+    CHUNK(n)
     const int rc = cognn_trunc_close_u64(c, out, c0, c1, keys, p, 0, n);
     if (rc) return rc;
     CG_PAR
-    for (int64_t i = 0; i < n; ++i) E[i] = out[i] - cognn_prng(key_open, (u64)i);
+    for (int64_t i = lo_; i < hi_; ++i) E[i] = out[i] - cognn_prng(key_open, (u64)i);
     return 0;
 }
 // both parties' closes side by side, then the opening from their sum - what the two-round form would have exchanged
 int cognn_trunc_close_pub_u64(cognn_ctx* c, uint64_t* out, uint64_t* E, const uint64_t* c0, const uint64_t* c1, const cognn_keys* keys,
                               int p, uint64_t key_open0, uint64_t key_open1, int reveal, int64_t n) {
+    CHUNK(n)
     REQ(E && c0 && c1, "trunc_close_pub: both opened values are needed");
     std::vector<u64> y0((size_t)n), y1((size_t)n);
     if (int rc = cognn_trunc_close_u64(c, y0.data(), c0, c1, keys, 0, 0, n)) return rc;
     if (int rc = cognn_trunc_close_u64(c, y1.data(), nullptr, nullptr, keys, 1, 0, n)) return rc;
-    for (int64_t i = 0; i < n; ++i) {
+    for (int64_t i = lo_; i < hi_; ++i) {
         const u64 e0 = reveal ? y0[(size_t)i] : y0[(size_t)i] - cognn_prng(key_open0, (u64)i);
         const u64 e1 = reveal ? y1[(size_t)i] : y1[(size_t)i] - cognn_prng(key_open1, (u64)i);
         E[i] = e0 + e1;
@@ -320,9 +340,10 @@ int cognn_rowscale_open_u64(cognn_ctx*, uint64_t* E, uint64_t* G, const uint64_t
 }
 int cognn_rowscale_close_u64(cognn_ctx*, uint64_t* c, const uint64_t* E, const uint64_t* E1, const uint64_t* G, const uint64_t* G1,
                              const cognn_keys* keys, const cognn_keys* tkeys, int p, int64_t rows, int64_t F) {
+    CHUNK(rows * F)
     const cognn_opkeys k = K(keys), tk = K(tkeys);
     CG_PAR
-    for (int64_t i = 0; i < rows * F; ++i) {
+    for (int64_t i = lo_; i < hi_; ++i) {
         const u64 row = (u64)(i / F);
         const u64 e = E[i] + (E1 ? E1[i] : 0), g = G[row] + (G1 ? G1[row] : 0);
         c[i] = beaver_mul(k, p, e, g, (u64)i, row) + trunc_r(tk, p, (u64)i) + (p == 0 ? COGNN_TRUNC_OFFSET : 0);
@@ -330,8 +351,9 @@ int cognn_rowscale_close_u64(cognn_ctx*, uint64_t* c, const uint64_t* E, const u
     return 0;
 }
 int cognn_relu_open_u64(cognn_ctx*, uint64_t* E, uint64_t* G, const uint64_t* z, const cognn_keys* keys, int p, int64_t n) {
+    CHUNK(n)
     CG_PAR
-    for (int64_t i = 0; i < n; ++i) {
+    for (int64_t i = lo_; i < hi_; ++i) {
         const u64 t0 = cognn_prng(keys->k[COGNN_SL_T0], (u64)i);
         const u64 tp = p == 0 ? t0 : ((cognn_prng(keys->k[COGNN_SL_T], (u64)i) & 0xFFFFFull) | 1ull) - t0;
         E[i] = z[i] - cognn_prng(keys->k[p == 0 ? COGNN_SL_A0 : COGNN_SL_A1], (u64)i);
@@ -341,9 +363,10 @@ int cognn_relu_open_u64(cognn_ctx*, uint64_t* E, uint64_t* G, const uint64_t* z,
 }
 int cognn_relu_mul_u64(cognn_ctx*, uint64_t* w, const uint64_t* E, const uint64_t* E1, const uint64_t* G, const uint64_t* G1,
                        const cognn_keys* keys, int p, int64_t n) {
+    CHUNK(n)
     const cognn_opkeys k = K(keys);
     CG_PAR
-    for (int64_t i = 0; i < n; ++i) {
+    for (int64_t i = lo_; i < hi_; ++i) {
         // G == NULL: dealer-published g = t - (b0 + b1)
         const u64 g = G ? G[i] + (G1 ? G1[i] : 0)
                         : ((cognn_prng(keys->k[COGNN_SL_T], (u64)i) & 0xFFFFFull) | 1ull) - cognn_prng(keys->k[COGNN_SL_B0], (u64)i) -
@@ -353,8 +376,9 @@ int cognn_relu_mul_u64(cognn_ctx*, uint64_t* w, const uint64_t* E, const uint64_
     return 0;
 }
 int cognn_relu_close_u64(cognn_ctx*, uint64_t* h, uint8_t* mask, const uint64_t* z, const uint64_t* w0, const uint64_t* w1, int64_t n) {
+    CHUNK(n)
     CG_PAR
-    for (int64_t i = 0; i < n; ++i) {
+    for (int64_t i = lo_; i < hi_; ++i) {
         const bool pos = (long long)(w0[i] + w1[i]) > 0;
         h[i] = pos ? z[i] : 0;
         if (mask) mask[i] = pos;
@@ -363,14 +387,16 @@ int cognn_relu_close_u64(cognn_ctx*, uint64_t* h, uint8_t* mask, const uint64_t*
 }
 int cognn_relu_close_open_u64(cognn_ctx* c, uint64_t* h, uint64_t* E, uint8_t* mask, const uint64_t* z, const uint64_t* w0, const uint64_t* w1,
                               uint64_t key_open, int64_t n) {
+    CHUNK(n)
     cognn_relu_close_u64(c, h, mask, z, w0, w1, n);
     CG_PAR
-    for (int64_t i = 0; i < n; ++i) E[i] = h[i] - cognn_prng(key_open, (u64)i);
+    for (int64_t i = lo_; i < hi_; ++i) E[i] = h[i] - cognn_prng(key_open, (u64)i);
     return 0;
 }
 int cognn_mask_select_u64(cognn_ctx*, uint64_t* out, const uint64_t* in, const uint8_t* mask, int64_t n) {
+    CHUNK(n)
     CG_PAR
-    for (int64_t i = 0; i < n; ++i) out[i] = mask[i] ? in[i] : 0;
+    for (int64_t i = lo_; i < hi_; ++i) out[i] = mask[i] ? in[i] : 0;
     return 0;
 }
 int cognn_softmax_u64(cognn_ctx*, uint64_t* p_out, uint64_t* d_out, uint64_t* pfx_out, const uint64_t* z0, const uint64_t* z1,

@@ -37,10 +37,15 @@ def main():
     if cfg.get("hostile"):                                 # late, poisoned, shuffled delivery (tests/hostile_transport.py; CPU backend only)
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import hostile_transport
-        fns, hostile_stats = hostile_transport.make_hostile_exchange(cfg["hostile"], skip_waits=cfg.get("hostile_skip_waits", 0))
+        fns, hostile_stats = hostile_transport.make_hostile_exchange(cfg["hostile"], skip_waits=cfg.get("hostile_skip_waits", 0),
+                                                                     per_round=bool(cfg.get("per_round", cfg.get("chunks", 1) > 1)))
         eng.set_exchange(fns)
+    elif cfg.get("chunks", 1) > 1 and not cfg.get("blocking_exchange") and cfg.get("per_round", True):
+        eng.set_exchange(mk(torch.device("cuda", 0), host_staged=True, per_round=True) if hip else mk(torch.device("cpu"), per_round=True))
     else:
         eng.set_exchange(mk(torch.device("cuda", 0), host_staged=True) if hip else mk(torch.device("cpu")))
+    if cfg.get("chunks", 1) > 1:                           # open -> exchange -> close of the cross-rank sides in row chunks
+        eng.exchange_chunks(cfg["chunks"])
     eng.set_global_data(feats, labels)
     eng.start()
     if cfg.get("exchanged_openings"):                      # every opening travels as two shares (COGNN_OPT_PUBLIC_OPENINGS off)
@@ -63,7 +68,7 @@ def main():
                 for l in range(2):
                     out["it%d_o%d_s1_w%d" % (it, o, l)] = eng.weight(o, 1, l)
     if hostile_stats is not None:
-        out["hostile_rounds"] = np.array([hostile_stats["rounds"], hostile_stats["max_inflight"]])
+        out["hostile_rounds"] = np.array([hostile_stats["rounds"], hostile_stats["max_inflight"], hostile_stats.get("left_inflight", 0)])
     np.savez(cfg["out"] + ".rank%d.npz" % rank, **out)
     eng.close()
     dist.destroy_process_group()

@@ -125,8 +125,41 @@ def test_hostile_transport(tmp_path, seed, k, world, variant, iters, extra):
     _check(dict(BASE, k=k, variant=variant, iters=iters, hostile=seed, **extra), world, tmp_path)
 
 
+@pytest.mark.parametrize("chunks,k,world,variant,iters,extra", [
+    (2, 4, 2, "optimize-gcn", 6, {}), (3, 4, 4, "optimize-gcn", 6, {}), (4, 4, 4, "optimize-gcn-inference", 2, {}),
+    (3, 4, 2, "optimize-gcn", 6, {"exchanged_openings": True}), (2, 4, 2, "optimize-gcn", 6, {"pair_fusion": 0}),
+    (8, 3, 3, "optimize-gcn", 6, {}), (2, 4, 2, "optimize-gcn", 6, {"per_round": False}), (3, 4, 2, "optimize-gcn", 6, {"blocking_exchange": True})])
+def test_chunked_exchange_pipeline(tmp_path, chunks, k, world, variant, iters, extra):
+    """COGNN_OPT_EXCHANGE_CHUNKS: the open -> exchange -> close steps of the cross-rank sides in row chunks (chunk c's round in
+    flight behind chunk c+1's kernels, closes waiting round by round) give the oracle's shares bit for bit - over gloo with the
+    per-round wait, with the wait-everything fallback (per_round False), with the blocking callback, with more chunks than some
+    tensors have element pairs (V = 48: 12-16 rows per party)."""
+    _check(dict(BASE, k=k, variant=variant, iters=iters, chunks=chunks, **extra), world, tmp_path)
+
+
+@pytest.mark.parametrize("seed,chunks,k,world,variant,iters", [(1, 2, 4, 2, "optimize-gcn", 6), (2, 3, 4, 4, "optimize-gcn", 6),
+                                                              (3, 4, 4, 2, "optimize-gcn-inference", 2), (4, 3, 6, 2, "optimize-gcn", 12)])
+def test_chunked_exchange_pipeline_hostile_transport(tmp_path, seed, chunks, k, world, variant, iters):
+    """The chunked pipeline over the hostile transport with per-round completion: a close that runs before ITS round has been
+    waited for reads poison, a chunk that is re-opened before its round completed ships the wrong bytes, and the rounds of the
+    later chunks really are still undelivered while an earlier chunk closes (left_inflight > 0)."""
+    got_cfg = dict(BASE, k=k, variant=variant, iters=iters, chunks=chunks, hostile=seed)
+    _check(got_cfg, world, tmp_path)
+    left = 0
+    for r in range(world):
+        with np.load(str(tmp_path / "shares") + ".rank%d.npz" % r) as z:
+            left = max(left, int(z["hostile_rounds"][2]))
+    assert left > 0
+
+
 def test_hostile_transport_detects_a_missing_wait(tmp_path):
     """The transport's own sensitivity: when the first wait() completes nothing (= the engine consumed a round it never waited
     for), the poisoned inboxes reach the arithmetic and the shares no longer match the oracle."""
     with pytest.raises(AssertionError):
         _check(dict(BASE, k=4, variant="optimize-gcn-inference", iters=2, hostile=1, hostile_skip_waits=1), 2, tmp_path)
+
+
+def test_hostile_transport_detects_a_missing_round_wait(tmp_path):
+    """... and with the chunked pipeline: a per-round wait that completes nothing leaves that chunk's inbox poisoned."""
+    with pytest.raises(AssertionError):
+        _check(dict(BASE, k=4, variant="optimize-gcn-inference", iters=2, hostile=1, hostile_skip_waits=2, chunks=3), 2, tmp_path)

@@ -45,6 +45,15 @@ def test_four_parties_four_ranks_training_hip(tmp_path):
     _check(cfg, 4, tmp_path)
 
 
+@pytest.mark.parametrize("chunks,world", [(2, 2), (3, 4), (4, 2)])
+def test_chunked_exchange_pipeline_hip(tmp_path, chunks, world):
+    # COGNN_OPT_EXCHANGE_CHUNKS on the HIP kernels: the chunk window of the element-wise launches (batched and single), the
+    # truncation opening of a product deferred into the chunk loop, per-round waits; one training epoch at kernel-relevant widths
+    cfg = dict(BASE, k=4, V=1500, Eu=6000, hid=16, lab=7, variant="optimize-gcn", iters=6, backend="hip", chunks=chunks)
+    cfg["in"] = 64
+    _check(cfg, world, tmp_path)
+
+
 @pytest.mark.parametrize("seed", range(3 * int(os.environ.get("COGNN_FUZZ_SCALE", "1"))))
 def test_multirank_random_configuration_hip(tmp_path, seed):
     rng = np.random.default_rng(9000 + seed)
@@ -53,6 +62,7 @@ def test_multirank_random_configuration_hip(tmp_path, seed):
     V = int(rng.integers(k, 400)) if seed % 4 else int(rng.integers(300 * k, 700 * k))   # every 4th: rows enough for the MFMA kernels
     cfg = dict(BASE, k=k, V=V, Eu=int(min(V * (V - 1) // 2, rng.integers(1, 4 * V + 1))), gseed=int(rng.integers(1, 1000)),
                seed=int(rng.integers(1, 1 << 30)), hid=int(rng.choice([3, 8, 16, 33])), lab=int(rng.choice([2, 5, 16])),
-               variant="optimize-gcn" if seed % 2 else "optimize-gcn-inference", iters=6 if seed % 2 else 2, backend="hip")
+               variant="optimize-gcn" if seed % 2 else "optimize-gcn-inference", iters=6 if seed % 2 else 2, backend="hip",
+               chunks=int(rng.choice([1, 1, 2, 3, 5])))
     cfg["in"] = int(rng.choice([5, 16, 40]))
     _check(cfg, world, tmp_path)

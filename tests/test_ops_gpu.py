@@ -587,3 +587,51 @@ def test_sum_and_fanout(ctx, count, n):
         ctx.call("cognn_sum_u64", ptr(out), ins, 17, n)
     with pytest.raises(capi.CognnError, match="1..16"):
         ctx.call("cognn_fanout_u64", op, 0, ptr(dx[0]), n)
+
+
+@pytest.mark.parametrize("n,C", [(100003, 3), (7, 5), (2, 2), (1 << 20, 8), (65, 64)])
+def test_chunk_window_of_the_element_wise_entry_points(ctx, n, C):
+    """cognn_ctx_set_chunk: the C windows of an element-wise call together do exactly what the unwindowed call does (dealer
+    streams addressed by the absolute element index), single and batched launches; elements outside the window stay untouched;
+    cognn_chunk_range is the partition both the kernels and the engine's messages use; every other entry point refuses to run
+    under a window."""
+    from cognn_amd import capi
+    rng = np.random.default_rng(n + C)
+    x = rand_u64(rng, n)
+    ks, kf = keys_of(3, 1, 4, co.OP_GA_SCALE_TRUNC)
+    whole = dev_empty(n)
+    ctx.call("cognn_trunc_open_u64", ptr(whole), ptr(dev(x)), ctypes.c_uint64(5), ctypes.byref(ks), 1, n)
+    ctx.sync()
+    want = host(whole).copy()
+    marker = np.full(n, 0xDEADBEEF, dtype=U64)
+    out = dev(marker.copy()); out2 = dev(marker.copy())
+    xd = dev(x)
+    covered = 0
+    lo = ctypes.c_int64(); hi = ctypes.c_int64()
+    for c in range(C):
+        ctx.lib.cognn_chunk_range(n, c, C, ctypes.byref(lo), ctypes.byref(hi))
+        assert lo.value == covered and lo.value % 2 == 0 and hi.value >= lo.value
+        covered = hi.value
+        ctx.call("cognn_ctx_set_chunk", c, C)
+        ctx.call("cognn_batch_begin")
+        ctx.call("cognn_trunc_open_u64", ptr(out), ptr(xd), ctypes.c_uint64(5), ctypes.byref(ks), 1, n)
+        ctx.call("cognn_trunc_open_u64", ptr(out2), ptr(xd), ctypes.c_uint64(5), ctypes.byref(ks), 1, n)
+        ctx.call("cognn_batch_end")
+        if c == 0:
+            with pytest.raises(capi.CognnError, match="chunk window"):
+                ctx.call("cognn_transpose_u64", ptr(out), ptr(xd), 1, n)
+        ctx.call("cognn_ctx_set_chunk", 0, 1)
+        ctx.sync()
+        got = host(out)
+        assert np.array_equal(got[:hi.value], want[:hi.value]) and np.all(got[hi.value:] == 0xDEADBEEF)
+    assert covered == n
+    assert np.array_equal(host(out), want) and np.array_equal(host(out2), want)
+    single = dev(marker.copy())
+    for c in reversed(range(C)):                             # unbatched launches, any order
+        ctx.call("cognn_ctx_set_chunk", c, C)
+        ctx.call("cognn_trunc_open_u64", ptr(single), ptr(xd), ctypes.c_uint64(5), ctypes.byref(ks), 1, n)
+    ctx.call("cognn_ctx_set_chunk", 0, 1)
+    ctx.sync()
+    assert np.array_equal(host(single), want)
+    with pytest.raises(capi.CognnError):
+        ctx.call("cognn_ctx_set_chunk", C, C)

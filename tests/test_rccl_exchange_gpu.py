@@ -56,6 +56,48 @@ def test_world1_loopback_rounds_are_stream_ordered():
     x.close()
 
 
+def test_world1_loopback_per_round_waits():
+    """cognn_rccl_exchange_wait_round: three chunk rounds in flight, each consumer waits for its own round's event only (the
+    pattern of COGNN_OPT_EXCHANGE_CHUNKS); more rounds than the event ring has slots; a round that was never started is refused."""
+    import torch
+    from cognn_amd import capi, dist as cdist
+    from cognn_amd.engine_api import Xfer
+    lib = _lib()
+    stream = torch.cuda.current_stream(0).cuda_stream
+    x = cdist.create_rccl_exchange(0, 1, 0, stream)
+    ctx = capi.Context(0)
+    n = 3 << 18
+    a = gu.dev_empty(n); b = gu.dev_empty(n); d = gu.dev_empty(n)
+    rounds = 0
+    for rep in range(30):                                    # 90 rounds > 64 ring slots
+        lo = ctypes.c_int64(); hi = ctypes.c_int64()
+        for c in range(3):                                   # open chunk c (a kernel under the chunk window), send it at once
+            ctx.call("cognn_ctx_set_chunk", c, 3)
+            ctx.call("cognn_prng_fill_u64", gu.ptr(a), 77 + rep, n)
+            ctx.call("cognn_ctx_set_chunk", 0, 1)
+            lib.cognn_chunk_range(n, c, 3, ctypes.byref(lo), ctypes.byref(hi))
+            xf = (Xfer * 2)(Xfer(0, 1, a.data_ptr() + 8 * lo.value, 8 * (hi.value - lo.value)),
+                            Xfer(0, 0, b.data_ptr() + 8 * lo.value, 8 * (hi.value - lo.value)))
+            assert lib.cognn_rccl_exchange_begin(x.h, xf, 2) == 0, lib.cognn_exchange_last_error()
+            rounds += 1
+        for c in range(3):                                   # close chunk c after ITS round
+            assert lib.cognn_rccl_exchange_wait_round(x.h, rounds - 3 + c) == 0, lib.cognn_exchange_last_error()
+            ctx.call("cognn_ctx_set_chunk", c, 3)
+            ctx.call("cognn_add_u64", gu.ptr(d), gu.ptr(b), gu.ptr(b), n)
+            ctx.call("cognn_ctx_set_chunk", 0, 1)
+        if rep % 10 == 9:
+            ctx.sync()
+            want = gu.host(a).copy()
+            assert np.array_equal(gu.host(b), want)
+            with np.errstate(over="ignore"):
+                assert np.array_equal(gu.host(d), want + want)
+    assert lib.cognn_rccl_exchange_wait_round(x.h, rounds) != 0 and b"not been started" in lib.cognn_exchange_last_error()
+    assert lib.cognn_rccl_exchange_wait(x.h) == 0
+    ctx.sync()
+    ctx.close()
+    x.close()
+
+
 def test_tcp_rendezvous_rank0_and_engine_attach():
     """The harness bootstrap path: rendezvous (world 1: no listener needed), communicator, engine attach; a world-1 engine
     never starts a round, and its results equal the plain single-rank run."""
