@@ -229,6 +229,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true", help="skip the cross-path verification after the timed region")
     ap.add_argument("--no-dealer-streams", action="store_true", help="skip the extra timing of the dealt (memory-streamed dealer) form")
+    ap.add_argument("--chunks", type=int, default=1, help="N > 1: row chunks of the cross-rank open -> exchange -> close steps (COGNN_OPT_EXCHANGE_CHUNKS)")
     ap.add_argument("--graph", action="store_true", help="training workloads: replay the recorded epoch (hipGraph, COGNN_OPT_GRAPH_EPOCHS) instead of launching every kernel")
     args = ap.parse_args()
 
@@ -275,7 +276,9 @@ def main():
         if backend == "nccl":                 # the native transport: ncclSend/ncclRecv groups issued from C++ (include/cognn_exchange.h)
             xch = cdist.attach_rccl(eng, local_rank)
         else:                                 # rehearsal transport (gloo, host-staged)
-            eng.set_exchange(cdist.make_exchange_async(torch.device("cuda", local_rank), host_staged=True))
+            eng.set_exchange(cdist.make_exchange_async(torch.device("cuda", local_rank), host_staged=True, per_round=args.chunks > 1))
+        if args.chunks > 1:
+            eng.exchange_chunks(args.chunks)
     for P in eng.hosted:                      # Bernoulli(0.01) bag-of-words features, uniform labels
         vids = eng.party_vids(P)
         rng = np.random.default_rng(0xC06A12 + P)
@@ -355,7 +358,8 @@ def main():
         "config": {"workload": "%d-party %s pass (GAS iterations 0-%d) on a synthetic %d-vertex/%d-edge global graph, "
                                "partition vid %% %d, input_dim=%d hidden_dim=%d num_labels=%d, %d part%s per GPU"
                                % (k, variant, iters - 1, V, 2 * Eu, k, in_dim, hid, lab, k // world, "y" if k // world == 1 else "ies"),
-                   "name": args.workload, "parties": k, "exchange": "in-device" if world == 1 else ("rccl-p2p" if backend == "nccl" else backend + "-host-staged")},
+                   "name": args.workload, "parties": k, "exchange": "in-device" if world == 1 else ("rccl-p2p" if backend == "nccl" else backend + "-host-staged"),
+                   "exchange_chunks": args.chunks if world > 1 else None},
         "epoch_time_s": dt / args.steps,
         "edges_feat_per_s_per_party": value / k,
         "offline_ms": offline_ms, "setup_s": setup_s,
