@@ -125,6 +125,8 @@ _SIGNATURES = {
     "cognn_trunc_close_u64": (_I, [_P, _P, _P, _P, _KP, _I, _I, _L]),
     "cognn_trunc_close_open_u64": (_I, [_P, _P, _P, _P, _P, _KP, _I, _U, _L]),
     "cognn_trunc_close_pub_u64": (_I, [_P, _P, _P, _P, _P, _KP, _I, _U, _U, _I, _L]),
+    "cognn_trunc_close_pub_dealt_u64": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _L]),
+    "cognn_dealer_trunc_pub_u64": (_I, [_P, _P, _P, _P, _KP, _U, _U, _I, _L]),
     "cognn_rowscale_open_u64": (_I, [_P, _P, _P, _P, _P, _KP, _I, _L, _L]),
     "cognn_rowscale_close_u64": (_I, [_P, _P, _P, _P, _P, _P, _KP, _KP, _I, _L, _L]),
     "cognn_relu_open_u64": (_I, [_P, _P, _P, _P, _KP, _I, _L]),

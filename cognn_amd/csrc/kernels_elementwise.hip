@@ -155,6 +155,38 @@ struct MaskOpen {       // E = X - prng(key, logical idx)
         st2(E, i, w, e);
     }
 };
+// the public-opening close fed by a dealer's tensors instead of stream keys: t = r' + a_0 + a_1 (or r' for a reveal) and the
+// party's own r'_p arrive from memory (cognn_trunc_close_pub_dealt_u64); DealPub is what that dealer computes
+struct TruncClosePubDealt {
+    u64* out; u64* E; const u64* c0; const u64* c1; const u64* t; const u64* rp; int p;
+    __device__ void operator()(int64_t i, int w) const {
+        u64 a[2], b[2], tt[2], r[2] = {0, 0}, y[2], e[2];
+        ld2(c0, i, w, a); ld2(c1, i, w, b); ld2(t, i, w, tt);
+        if (out) ld2(rp, i, w, r);
+        for (int j = 0; j < 2; ++j) {
+            const u64 hi = ((a[j] + b[j]) >> COGNN_FX_BITS) - (COGNN_TRUNC_OFFSET >> COGNN_FX_BITS);
+            e[j] = hi - tt[j];
+            y[j] = (p == 0 ? hi : 0ull) - r[j];
+        }
+        if (out) st2(out, i, w, y);
+        st2(E, i, w, e);
+    }
+};
+struct DealPub {
+    u64* t; u64* rp0; u64* rp1; cognn_opkeys k; u64 key_open0, key_open1; int reveal;
+    __device__ void operator()(int64_t i, int w) const {
+        u64 tt[2], r0[2], r1[2];
+        for (int j = 0; j < 2; ++j) {
+            const u64 idx = (u64)(i + j);
+            const u64 rp = (cognn_prng(k.k[COGNN_SL_R], idx) & COGNN_TRUNC_MASK) >> COGNN_FX_BITS;
+            r0[j] = trunc_rp(k, 0, idx); r1[j] = rp - r0[j];
+            tt[j] = reveal ? rp : rp + cognn_prng(key_open0, idx) + cognn_prng(key_open1, idx);
+        }
+        st2(t, i, w, tt);
+        if (rp0) st2(rp0, i, w, r0);
+        if (rp1) st2(rp1, i, w, r1);
+    }
+};
 struct AddSub {
     u64* out; const u64* a; const u64* b; int sub;
     __device__ void operator()(int64_t i, int w) const {
@@ -790,6 +822,17 @@ int cognn_trunc_close_pub_u64(cognn_ctx* ctx, uint64_t* out, uint64_t* E, const 
                               int p, uint64_t key_open0, uint64_t key_open1, int reveal, int64_t n) {
     CG_REQUIRE(ctx && E && c0 && c1 && keys && (p == 0 || p == 1) && al(out) && al(E) && al(c0) && al(c1), "cognn_trunc_close_pub_u64: bad arguments (both opened values are needed)");
     return launch_ew(ctx, n, TruncClose{(u64*)out, (const u64*)c0, (const u64*)c1, K(keys), p, 0, (u64*)E, key_open0, key_open1, reveal ? 2 : 1});
+}
+int cognn_trunc_close_pub_dealt_u64(cognn_ctx* ctx, uint64_t* out, uint64_t* E, const uint64_t* c0, const uint64_t* c1, const uint64_t* t,
+                                    const uint64_t* rp_own, int p, int64_t n) {
+    CG_REQUIRE(ctx && E && c0 && c1 && t && (p == 0 || p == 1) && (!out || rp_own) && al(out) && al(E) && al(c0) && al(c1) && al(t) && al(rp_own),
+               "cognn_trunc_close_pub_dealt_u64: bad arguments (both opened values, the published t and - with out - the party's r' share are needed)");
+    return launch_ew(ctx, n, TruncClosePubDealt{(u64*)out, (u64*)E, (const u64*)c0, (const u64*)c1, (const u64*)t, (const u64*)rp_own, p});
+}
+int cognn_dealer_trunc_pub_u64(cognn_ctx* ctx, uint64_t* t, uint64_t* rp0, uint64_t* rp1, const cognn_keys* keys, uint64_t key_open0,
+                               uint64_t key_open1, int reveal, int64_t n) {
+    CG_REQUIRE(ctx && t && keys && al(t) && al(rp0) && al(rp1), "cognn_dealer_trunc_pub_u64: bad arguments");
+    return launch_ew(ctx, n, DealPub{(u64*)t, (u64*)rp0, (u64*)rp1, K(keys), key_open0, key_open1, reveal});
 }
 int cognn_rowscale_open_u64(cognn_ctx* ctx, uint64_t* E, uint64_t* G, const uint64_t* V, const uint64_t* s,
                             const cognn_keys* keys, int p, int64_t rows, int64_t F) {

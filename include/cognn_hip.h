@@ -208,6 +208,15 @@ int cognn_trunc_close_open_u64(cognn_ctx*, uint64_t* out, uint64_t* E, const uin
  * result itself (the co-party's reveal of z to the owner before the softmax, gcn.h:603-604). */
 int cognn_trunc_close_pub_u64(cognn_ctx*, uint64_t* out, uint64_t* E, const uint64_t* c0, const uint64_t* c1, const cognn_keys* keys,
                               int p, uint64_t key_open0, uint64_t key_open1, int reveal, int64_t n);
+/* The same close as a party fed by a real dealer would run it - no stream key on the party's side: t[i] = (r>>16) + a_0 + a_1
+ * (reveal: (r>>16)) is the value the dealer PUBLISHES to both parties and rp_own the party's share r'_p, both as device tensors
+ * (+8 B per element each): E = ((c0+c1)>>16) - 2^45 - t, out (may be NULL) = (p == 0 ? ((c0+c1)>>16) - 2^45 : 0) - rp_own.
+ * cognn_dealer_trunc_pub_u64 is that dealer: it fills t (and, when given, rp0 / rp1) from the streams the key form derives in
+ * registers, so the two forms are bit-identical (tests/test_ops_gpu.py).  The engine uses the key form (no HBM bytes). */
+int cognn_trunc_close_pub_dealt_u64(cognn_ctx*, uint64_t* out, uint64_t* E, const uint64_t* c0, const uint64_t* c1, const uint64_t* t,
+                                    const uint64_t* rp_own, int p, int64_t n);
+int cognn_dealer_trunc_pub_u64(cognn_ctx*, uint64_t* t, uint64_t* rp0, uint64_t* rp1, const cognn_keys* keys, uint64_t key_open0,
+                               uint64_t key_open1, int reveal, int64_t n);
 
 /* ---- sci::twoPartyGCNVectorScale (gcn.h:247,476): row scale by an additively shared vector - */
 /* E_p = V_p - a_p [rows x F] (skipped when E == NULL: already opened by cognn_gather_csr_open_u64), G_p = s_p - b_p [rows] */

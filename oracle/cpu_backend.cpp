@@ -331,6 +331,28 @@ int cognn_trunc_close_pub_u64(cognn_ctx* c, uint64_t* out, uint64_t* E, const ui
     }
     return 0;
 }
+int cognn_trunc_close_pub_dealt_u64(cognn_ctx*, uint64_t* out, uint64_t* E, const uint64_t* c0, const uint64_t* c1, const uint64_t* t,
+                                    const uint64_t* rp_own, int p, int64_t n) {
+    CHUNK(n)
+    REQ(E && c0 && c1 && t && (!out || rp_own), "trunc_close_pub_dealt: missing tensor");
+    for (int64_t i = lo_; i < hi_; ++i) {
+        const u64 hi = ((c0[i] + c1[i]) >> COGNN_FX_BITS) - (COGNN_TRUNC_OFFSET >> COGNN_FX_BITS);
+        E[i] = hi - t[i];
+        if (out) out[i] = (p == 0 ? hi : 0ull) - rp_own[i];
+    }
+    return 0;
+}
+int cognn_dealer_trunc_pub_u64(cognn_ctx*, uint64_t* t, uint64_t* rp0, uint64_t* rp1, const cognn_keys* keys, uint64_t key_open0,
+                               uint64_t key_open1, int reveal, int64_t n) {
+    const cognn_opkeys k = K(keys);
+    for (int64_t i = 0; i < n; ++i) {
+        const u64 rp = (cognn_prng(k.k[COGNN_SL_R], (u64)i) & COGNN_TRUNC_MASK) >> COGNN_FX_BITS;
+        t[i] = reveal ? rp : rp + cognn_prng(key_open0, (u64)i) + cognn_prng(key_open1, (u64)i);
+        if (rp0) rp0[i] = trunc_rp(k, 0, (u64)i);
+        if (rp1) rp1[i] = rp - trunc_rp(k, 0, (u64)i);
+    }
+    return 0;
+}
 int cognn_rowscale_open_u64(cognn_ctx*, uint64_t* E, uint64_t* G, const uint64_t* V, const uint64_t* s, const cognn_keys* keys,
                             int p, int64_t rows, int64_t F) {
     if (E) for (int64_t i = 0; i < rows * F; ++i) E[i] = V[i] - cognn_prng(keys->k[p == 0 ? COGNN_SL_A0 : COGNN_SL_A1], (u64)i);

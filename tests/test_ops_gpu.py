@@ -234,6 +234,18 @@ def test_trunc_pair(ctx):
         e = dev_empty(n)
         ctx.call("cognn_trunc_close_pub_u64", None, ptr(e), ptr(c0), ptr(c1), ctypes.byref(k), 0, ctypes.c_uint64(0), ctypes.c_uint64(0), 1, n)
         assert np.array_equal(host(e), w0 + w1)
+        # the same close as a party fed by a real dealer runs it: the published t and the party's r' share arrive as tensors
+        # (cognn_dealer_trunc_pub_u64 fills them), no stream key on the party's side
+        for reveal, want_e in ((0, e_pub), (1, w0 + w1)):
+            t = dev_empty(n); rp = [dev_empty(n), dev_empty(n)]
+            ctx.call("cognn_dealer_trunc_pub_u64", ptr(t), ptr(rp[0]), ptr(rp[1]), ctypes.byref(k), ctypes.c_uint64(ko), ctypes.c_uint64(ko1), reveal, n)
+            for p, w in ((0, w0), (1, w1)):
+                o = dev_empty(n); e = dev_empty(n)
+                ctx.call("cognn_trunc_close_pub_dealt_u64", ptr(o), ptr(e), ptr(c0), ptr(c1), ptr(t), ptr(rp[p]), p, n)
+                assert np.array_equal(host(o), w) and np.array_equal(host(e), want_e)
+            e = dev_empty(n)
+            ctx.call("cognn_trunc_close_pub_dealt_u64", None, ptr(e), ptr(c0), ptr(c1), ptr(t), None, 0, n)
+            assert np.array_equal(host(e), want_e)
     from cognn_amd import capi
     with pytest.raises(capi.CognnError, match="both opened values"):
         ctx.call("cognn_trunc_close_pub_u64", None, ptr(e), ptr(c0), None, ctypes.byref(k), 1, ctypes.c_uint64(ko), ctypes.c_uint64(ko1), 0, n)
