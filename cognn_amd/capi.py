@@ -40,6 +40,13 @@ class PairWUpdate(ctypes.Structure):
                 ("trunc_keys", Keys * 4), ("mul", ctypes.c_uint64 * 3), ("n", ctypes.c_int64), ("flags", ctypes.c_int32)]
 
 
+class ScatterPair(ctypes.Structure):
+    """cognn_scatter_pair (include/cognn_hip.h)."""
+    _fields_ = [("srcA", ctypes.c_void_p), ("srcB", ctypes.c_void_p), ("n0", ctypes.c_void_p), ("n1", ctypes.c_void_p),
+                ("scale0", Keys), ("trunc0", Keys), ("scale1", Keys), ("trunc1", Keys), ("n1_from_server", ctypes.c_int32),
+                ("crossed", ctypes.c_int32)]
+
+
 class GatherPair(ctypes.Structure):
     """cognn_gather_pair (include/cognn_hip.h)."""
     _fields_ = [("a_row0", ctypes.c_int64), ("b_row0", ctypes.c_int64), ("chain", PairChain)]
@@ -140,6 +147,7 @@ _SIGNATURES = {
     "cognn_pair_chain_dealt_slots": (_L, [ctypes.c_int32, ctypes.c_int32]),
     "cognn_pair_chain_deal_u64": (_I, [_P, ctypes.POINTER(PairChain), _P]),
     "cognn_softmax_jobs_u64": (_I, [_P, ctypes.POINTER(SoftmaxJob), ctypes.c_int32, _L]),
+    "cognn_scatter_gather_original_u64": (_I, [_P, _P, _P, _P, _P, _P, _P, _KP, _KP, _L, _L, _P, _P, _P, _P, ctypes.POINTER(ScatterPair), ctypes.c_int32]),
     "cognn_gather_pair_chain_u64": (_I, [_P, _P, _P, _P, _L, ctypes.POINTER(GatherPair), ctypes.c_int32]),
     "cognn_graph_build_colocated": (_I, [_P, _L, _L, ctypes.c_int32] + [_P] * 6 + [_L] + [_P] * 8),
     "cognn_transpose_u64": (_I, [_P, _P, _P, _L, _L]),

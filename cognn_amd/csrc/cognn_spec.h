@@ -23,7 +23,11 @@ enum {
     COGNN_OP_PS_GEMM = 10, COGNN_OP_PS_GEMM_TRUNC, COGNN_OP_PS_SCALE, COGNN_OP_PS_SCALE_TRUNC,
     COGNN_OP_GA_SCALE, COGNN_OP_GA_SCALE_TRUNC, COGNN_OP_AP_RELU, COGNN_OP_AP_SOFTMAX,
     COGNN_OP_AP_GEMM, COGNN_OP_AP_GEMM_TRUNC, COGNN_OP_AP_GSCALE_TRUNC, COGNN_OP_AP_LR_TRUNC,
-    COGNN_OP_WAVG_TRUNC
+    COGNN_OP_WAVG_TRUNC,
+    // original-gcn only (oracle/original_gcn.py): the two per-edge row scales of ScatterComp, the weight-gradient product and the
+    // forward product of the fused Apply
+    COGNN_OP_SC_SCALE0 = 30, COGNN_OP_SC_SCALE0_TRUNC, COGNN_OP_SC_SCALE1, COGNN_OP_SC_SCALE1_TRUNC,
+    COGNN_OP_AP_DGEMM, COGNN_OP_AP_DGEMM_TRUNC, COGNN_OP_AP_FWD_GEMM, COGNN_OP_AP_FWD_GEMM_TRUNC
 };
 /* dealer slots inside one op */
 enum {

@@ -17,6 +17,7 @@
 // loads (unrolled so several row fetches are in flight per lane).
 #include "common.h"
 #include <algorithm>
+#include <cstring>
 #include "../../include/cognn_hip.h"
 #include "pair_chain.h"
 
@@ -297,6 +298,58 @@ int launch_scatter(cognn_ctx* ctx, u64* v, const u64* partial, const uint32_t* r
     return 0;
 }
 
+
+// ---- original-gcn: per-edge two-normaliser Scatter + segmented sum + masked add (cognn_scatter_gather_original_u64) ----------
+struct ScatterPairDev {
+    const u64* srcA; const u64* srcB; const u64* n0; const u64* n1;
+    u64 k0[8], k1[8];            // per scale: A0, A1, B0, B1, C0 of the Beaver product, R, R0, RP0 of its truncation
+    int n1_from_server, crossed;
+};
+constexpr int kScatterPairsMax = 16;
+struct ScatterBatch {
+    ScatterPairDev p[kScatterPairsMax];
+    u64 ks[8];                   // the self row's scale (forward iterations)
+    const u64* self_s0; const u64* self_s1;
+};
+// one share x shared-row-scale product + truncation for both share-holders: RowscaleOpen / RowscaleClose / TruncClose of the per-side
+// kernels with the opened values handed over in registers (the formulas of pair_scale, pair_chain.h)
+__device__ __forceinline__ void scale_trunc_pair(const u64* K, u64 s0, u64 s1, u64 row, u64 idx, u64& v0, u64& v1) {
+    const u64 b0 = cognn_prng(K[2], row), b1 = cognn_prng(K[3], row);
+    const u64 g = (s0 - b0) + (s1 - b1);
+    const u64 a0 = cognn_prng(K[0], idx), a1 = cognn_prng(K[1], idx), c0m = cognn_prng(K[4], idx);
+    const u64 c1m = (a0 + a1) * (b0 + b1) - c0m;
+    const u64 e = (v0 - a0) + (v1 - a1);
+    u64 z0 = e * b0 + a0 * g + c0m;
+    u64 z1 = e * g + e * b1 + a1 * g + c1m;
+    PairChainDev none;
+    none.slab = nullptr; none.n = 0;
+    pair_trunc<false>(none, 0, K[5], K[6], K[7], idx, z0, z1);
+    v0 = z0; v1 = z1;
+}
+__global__ __launch_bounds__(256) void scatter_gather_original_kernel(u64* outA, u64* outB, const u64* selfA, const u64* selfB, int rows, int F,
+                                                                       const uint32_t* rowptr, const uint32_t* ent_src, const uint32_t* ent_pair,
+                                                                       const uint32_t* ent_q, ScatterBatch b) {
+    const int r = blockIdx.x;
+    const int j = blockIdx.y * 256 + threadIdx.x;
+    if (r >= rows || j >= F) return;
+    const u64 own = (u64)r * (u64)F + (u64)j;
+    u64 a = selfA[own], c = selfB[own];
+    if (b.self_s0) scale_trunc_pair(b.ks, b.self_s0[r], b.self_s1[r], (u64)r, own, a, c);
+    for (uint32_t e = rowptr[r]; e < rowptr[r + 1]; ++e) {
+        const ScatterPairDev& P = b.p[ent_pair[e]];
+        const u64 q = ent_q[e], src = (u64)ent_src[e] * (u64)F + (u64)j, idx = q * (u64)F + (u64)j;
+        u64 u0 = P.srcA[src], u1 = P.srcB[src];
+        scale_trunc_pair(P.k0, P.n0[q], 0ull, q, idx, u0, u1);
+        const u64 n1 = P.n1[q];
+        scale_trunc_pair(P.k1, P.n1_from_server ? 0ull : n1, P.n1_from_server ? n1 : 0ull, q, idx, u0, u1);
+        if (P.crossed) { a += u1; c += u0; } else { a += u0; c += u1; }
+    }
+    outA[own] = a; outB[own] = c;
+}
+static void fill_scale_keys(u64* K, const cognn_keys& sk, const cognn_keys& tk) {
+    K[0] = sk.k[COGNN_SL_A0]; K[1] = sk.k[COGNN_SL_A1]; K[2] = sk.k[COGNN_SL_B0]; K[3] = sk.k[COGNN_SL_B1]; K[4] = sk.k[COGNN_SL_C0];
+    K[5] = tk.k[COGNN_SL_R]; K[6] = tk.k[COGNN_SL_R0]; K[7] = tk.k[COGNN_SL_RP0];
+}
 }  // namespace
 
 extern "C" {
@@ -394,6 +447,35 @@ int cognn_scatter_add_rows_u64(cognn_ctx* ctx, uint64_t* v, const uint64_t* part
     const bool vec = (F % 2 == 0) && cg_aligned16(v) && cg_aligned16(partial);
     if (vec) return launch_scatter<2>(ctx, (u64*)v, (const u64*)partial, row_index, (int)n_partial, (int)F);
     return launch_scatter<1>(ctx, (u64*)v, (const u64*)partial, row_index, (int)n_partial, (int)F);
+}
+
+int cognn_scatter_gather_original_u64(cognn_ctx* ctx, uint64_t* outA, uint64_t* outB, const uint64_t* selfA, const uint64_t* selfB,
+                                      const uint64_t* self_scale0, const uint64_t* self_scale1, const cognn_keys* self_scale_keys,
+                                      const cognn_keys* self_trunc_keys, int64_t rows, int64_t F, const uint32_t* rowptr,
+                                      const uint32_t* ent_src, const uint32_t* ent_pair, const uint32_t* ent_q,
+                                      const cognn_scatter_pair* pairs, int32_t npairs) {
+    { const int rc_flush_ = cg_flush(ctx); if (rc_flush_) return rc_flush_; }
+    CG_REQUIRE(ctx && outA && outB && selfA && selfB && rowptr && npairs >= 0 && npairs <= kScatterPairsMax && (npairs == 0 || pairs),
+               "cognn_scatter_gather_original_u64: bad arguments (at most %d Scatter instances per destination party)", kScatterPairsMax);
+    CG_REQUIRE(rows >= 0 && rows < (1ll << 31) && F > 0 && F < (1 << 24), "cognn_scatter_gather_original_u64: bad shape");
+    CG_REQUIRE(!self_scale0 || (self_scale1 && self_scale_keys && self_trunc_keys), "cognn_scatter_gather_original_u64: the self scale needs both shares and its keys");
+    CG_REQUIRE(outA != selfA && outB != selfB, "cognn_scatter_gather_original_u64: in-place aggregation is not possible (rows are sources too)");
+    if (rows == 0) return 0;
+    ScatterBatch b;
+    memset(&b, 0, sizeof(b));
+    for (int32_t i = 0; i < npairs; ++i) {
+        const cognn_scatter_pair& s = pairs[i];
+        CG_REQUIRE(s.srcA && s.srcB && s.n0 && s.n1, "cognn_scatter_gather_original_u64: instance %d has a null tensor", i);
+        ScatterPairDev& d = b.p[i];
+        d.srcA = (const u64*)s.srcA; d.srcB = (const u64*)s.srcB; d.n0 = (const u64*)s.n0; d.n1 = (const u64*)s.n1;
+        fill_scale_keys(d.k0, s.scale0, s.trunc0); fill_scale_keys(d.k1, s.scale1, s.trunc1);
+        d.n1_from_server = s.n1_from_server; d.crossed = s.crossed;
+    }
+    if (self_scale0) { fill_scale_keys(b.ks, *self_scale_keys, *self_trunc_keys); b.self_s0 = (const u64*)self_scale0; b.self_s1 = (const u64*)self_scale1; }
+    hipLaunchKernelGGL(scatter_gather_original_kernel, dim3((unsigned)rows, (unsigned)((F + 255) / 256)), dim3(256), 0, ctx->stream, (u64*)outA, (u64*)outB,
+                       (const u64*)selfA, (const u64*)selfB, (int)rows, (int)F, rowptr, ent_src, ent_pair, ent_q, b);
+    CG_LAUNCH_CHECK();
+    return 0;
 }
 
 }  // extern "C"

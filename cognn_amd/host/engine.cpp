@@ -56,6 +56,7 @@ struct Side {
     u64* W[2] = {nullptr, nullptr};
     u64* h1 = nullptr;             // h_t of layer 1 [n x hid]   (vertexInterData["h_t"], gcn.h:230-231)
     u64* g = nullptr;              // vertexInterData["g"] [n x hid]
+    u64* ah[2] = {nullptr, nullptr};   // original-gcn: vertexInterData["ah_t"] of both layers, stored untransposed [n x in], [n x hid] (gcn.h:452)
     uint8_t* relu_mask = nullptr;  // public sign of z[0] (revealed by the masked-sign ReLU)
     u64* cur = nullptr;            // current vertex tensor share [n x curF]
     int curF = 0;
@@ -116,6 +117,12 @@ struct cognn_engine {
     cognn_exchange_wait_round_fn xwait_round = nullptr;   // optional: completes the rounds up to a given one (chunked pipelines)
     int64_t xbegun = 0, xdone = 0;             // rounds enqueued on this transport / of them completed (a prefix: transports complete in order)
     int chunks = 1;                            // COGNN_OPT_EXCHANGE_CHUNKS
+    // original-gcn: per destination party the in-edge entries of its rows (source row, Scatter instance, position in the instance's
+    // edge list) and per Scatter instance (client P, destination g) the two per-edge normalisers (build_original_index)
+    struct OrigDst { uint32_t* rowptr = nullptr; uint32_t* src = nullptr; uint32_t* pair = nullptr; uint32_t* q = nullptr; int64_t entries = 0; };
+    struct OrigPair { u64* n0 = nullptr; u64* n1 = nullptr; int64_t edges = 0; };
+    std::vector<OrigDst> orig_dst;             // [g]
+    std::vector<OrigPair> orig_pair;           // [P * k + g]
     bool started = false, timing = false;
     int64_t gemm_x_opened_for = -1;    // iteration whose PreScatter GEMM input was already opened by the previous ReLU close
     // share table of the current message-passing round
@@ -207,7 +214,8 @@ T* upload(cognn_engine* E, const std::vector<T>& v) {
 // A dealer stream of GAS iteration `it` is addressed by (seed, owner, it % epoch, op, slot) through the key derivation and by the
 // epoch number through the salt that the device adds to every key (cognn_spec.h): the arguments of an epoch's kernels do not
 // depend on the epoch, so a recorded epoch can be replayed.
-int epoch_len(const cognn_engine* E) { return 3 * E->cfg.num_layers; }
+bool original(const cognn_engine* E) { return E->cfg.variant == COGNN_VARIANT_ORIGINAL_GCN; }
+int epoch_len(const cognn_engine* E) { return (original(E) ? 2 : 3) * E->cfg.num_layers; }   // getEpochLayerNum: original-gcn/gcn.h:842-845, optimize-gcn/gcn.h:942-945
 cognn_keys keys(cognn_engine* E, u64 owner, int64_t it, int op) {
     cognn_keys k;
     cognn_opkeys o = cognn_make_opkeys(E->cfg.seed, owner, (u64)(it % epoch_len(E)), (u64)op);
@@ -1130,7 +1138,7 @@ void weight_average(cognn_engine* E, int64_t it, int layer) {
         if (E->rank == holder[h])
             for (int r = 0; r < E->world; ++r)
                 if (r != E->rank) BE(cognn_add_u64(E->ctx, part[h], part[h], E->wa_recv[h] + (size_t)r * E->wa_stride, elems));
-    if (E->cfg.variant == COGNN_VARIANT_OPTIMIZE_GCN) {    // twoPartyGCNMatrixScale between parties 0 and 1
+    if (E->cfg.variant != COGNN_VARIANT_OPTIMIZE_GCN_INFERENCE) {   // twoPartyGCNMatrixScale between parties 0 and 1
         cognn_keys tk = keys(E, COGNN_OWNER_WAVG, it, COGNN_OP_WAVG_TRUNC);
         const u64 ws = fx_trunc(1.0 / k);
         u64* c0 = E->wa[2];
@@ -1209,7 +1217,9 @@ GemmSpec wgrad_spec(cognn_engine* E, Side& s, int layer, int64_t it) {
 // pairs_fused: the co-located pairs' products are still in zbuf (gemm_stage, pairs_raw): product truncation, both scales and the
 // update run as one pass per pair (cognn_pair_weight_update_u64) - and, when every party's pair is hosted here, the weight
 // average too (returns true: weight_average has been done)
-bool weight_update_chain(cognn_engine* E, int64_t it, int layer, bool pairs_fused, bool raw) {
+bool weight_update_chain(cognn_engine* E, int64_t it, int layer, bool pairs_fused, bool raw,
+                         const std::function<GemmSpec(Side&)>& specfn = nullptr) {
+    auto wspec = [&](Side& s) { return specfn ? specfn(s) : wgrad_spec(E, s, layer, it); };   // the product whose result is being consumed
     // d (in side.small[0]) -> *1/trainSetSize -> W -= lr*d   (gcn.h:673-678, 720-730)
     const int64_t elems = layer == 0 ? (int64_t)E->in() * E->hid() : (int64_t)E->hid() * E->lab();
     const u64 lr = fx_trunc(E->cfg.learning_rate);
@@ -1228,7 +1238,7 @@ bool weight_update_chain(cognn_engine* E, int64_t it, int layer, bool pairs_fuse
             Side& t = *s.peer;
             cognn_pair_wupdate J;
             memset(&J, 0, sizeof(J));
-            GemmSpec g = wgrad_spec(E, s, layer, it);
+            GemmSpec g = wspec(s);
             J.z[0] = s.zbuf; J.z[1] = t.zbuf; J.W[0] = s.W[layer]; J.W[1] = t.W[layer];
             if (raw) J.c1 = t.c1.at({it, g.op}).ptr;
             J.gemm_keys = gemm_keys(E, s, it, g);
@@ -1243,10 +1253,10 @@ bool weight_update_chain(cognn_engine* E, int64_t it, int layer, bool pairs_fuse
         }
         averaged = all && E->world == 1 && jobs.size() <= 16 && elems > 0;
         cognn_keys ak = keys(E, COGNN_OWNER_WAVG, it, COGNN_OP_WAVG_TRUNC);
-        const u64 amul = E->cfg.variant == COGNN_VARIANT_OPTIMIZE_GCN ? fx_trunc(1.0 / E->k) : 0;   // twoPartyGCNMatrixScale between parties 0 and 1 (gcn.h:763-764)
+        const u64 amul = E->cfg.variant != COGNN_VARIANT_OPTIMIZE_GCN_INFERENCE ? fx_trunc(1.0 / E->k) : 0;   // twoPartyGCNMatrixScale between parties 0 and 1 (gcn.h:763-764)
         BE(cognn_pair_weight_update_u64(E->ctx, jobs.data(), (int32_t)jobs.size(), &ak, averaged ? amul : 0, averaged ? 1 : 0));
         for (auto& s : E->sides)
-            if (paired(E, s) && s.p == 1) c1_release(E, s, {it, wgrad_spec(E, s, layer, it).op});
+            if (paired(E, s) && s.p == 1) c1_release(E, s, {it, wspec(s).op});
         if (all) return averaged;
     }
     std::vector<u64*> d, d2;
@@ -1270,7 +1280,9 @@ bool weight_update_chain(cognn_engine* E, int64_t it, int layer, bool pairs_fuse
     return false;
 }
 
+void run_iteration_original(cognn_engine* E, int64_t it);
 void run_iteration(cognn_engine* E, int64_t it) {
+    if (original(E)) { run_iteration_original(E, it); return; }
     const IterInfo I = iter_info(E, it);
     if (E->forward_only && !I.fwd) throw EngineError("engine: COGNN_OPT_FORWARD_ONLY is set but a backward iteration was requested");
     bool relu_opened = false, wgrad_w_opened = false, relu_pairs_done = false, gather_chain_fused = false, z_revealed = false;
@@ -1392,6 +1404,151 @@ void run_iteration(cognn_engine* E, int64_t it) {
     exchange_wait(E);
 }
 
+// ---------------------------------------------------------------------------------------------
+// original-gcn (algo_kernels/vertex_centric/original-gcn/gcn.h; BASELINE config 1) - single process
+// ---------------------------------------------------------------------------------------------
+// Index of the per-edge Scatter: the instance (client P, destination party g) lists P's edges into g ordered by destination vid,
+// then source vid (updateSrcVertexPos[g] / updateDstVertexPos[g], ss_...h:467-504) - for g == P with one dummy self entry for every
+// vertex without a local in-edge (ss_...h:411-418), which occupies a position of the list (its dealer streams are never drawn) and
+// contributes nothing (isGatherDstVertexDummy).  Normalisers per edge: n0 = (outDeg_src + 1)^-1/2 from the client; n1 =
+// (inDeg_dst + 1)^-1/2 from the client for its local edges, from the server (the destination party) otherwise (gcn.h:228-229,
+// ss_...h:800,1041-1043); degrees after the dummy inflation, 0 -> 0 (gcn.h:219-221).
+void build_original_index(cognn_engine* E) {
+    const int k = E->k;
+    auto& G = E->G;
+    auto norm = [](uint32_t deg) { return deg == 0 ? (u64)0 : fx_llround(std::pow((double)deg + 1.0, -0.5)); };
+    E->orig_dst.assign((size_t)k, cognn_engine::OrigDst());
+    E->orig_pair.assign((size_t)k * k, cognn_engine::OrigPair());
+    std::vector<std::vector<std::vector<uint32_t>>> rows_src((size_t)k), rows_pair((size_t)k), rows_q((size_t)k);
+    for (int g = 0; g < k; ++g) {
+        const size_t n = G.party[g].localVertexPos.size();
+        rows_src[g].resize(n); rows_pair[g].resize(n); rows_q[g].resize(n);
+    }
+    for (int P = 0; P < k; ++P)
+        for (int g = 0; g < k; ++g) {
+            const cognn::EdgeBlock& blk = G.party[P].out[g];
+            std::vector<u64> n0, n1;
+            for (size_t r = 0; r + 1 < blk.rowptr.size(); ++r) {
+                const uint32_t dr = G.row_of_vid[blk.rows_vid[r]];
+                if (g == P && blk.rowptr[r + 1] == blk.rowptr[r]) { n0.push_back(0); n1.push_back(0); continue; }   // the dummy self entry's slot
+                for (uint32_t e = blk.rowptr[r]; e < blk.rowptr[r + 1]; ++e) {
+                    rows_src[g][dr].push_back(blk.col[e]);
+                    rows_pair[g][dr].push_back((uint32_t)P);
+                    rows_q[g][dr].push_back((uint32_t)n0.size());
+                    n0.push_back(norm(G.party[P].outDeg[blk.col[e]]));
+                    n1.push_back(norm(G.party[g].inDeg[dr]));
+                }
+            }
+            auto& op = E->orig_pair[(size_t)P * k + g];
+            op.edges = (int64_t)n0.size();
+            op.n0 = upload(E, n0); op.n1 = upload(E, n1);
+        }
+    for (int g = 0; g < k; ++g) {
+        std::vector<uint32_t> rp{0}, src, pr, q;
+        for (size_t r = 0; r < rows_src[g].size(); ++r) {
+            src.insert(src.end(), rows_src[g][r].begin(), rows_src[g][r].end());
+            pr.insert(pr.end(), rows_pair[g][r].begin(), rows_pair[g][r].end());
+            q.insert(q.end(), rows_q[g][r].begin(), rows_q[g][r].end());
+            rp.push_back((uint32_t)src.size());
+        }
+        auto& od = E->orig_dst[g];
+        od.entries = (int64_t)src.size();
+        od.rowptr = upload(E, rp); od.src = upload(E, src); od.pair = upload(E, pr); od.q = upload(E, q);
+    }
+}
+u64 scatter_tag(int P, int g) { return 0x10000ull + (u64)P * 256 + (u64)g; }   // dealer "owner" of the Scatter instance (several run per owner and iteration)
+
+// ScatterComp + UpdatePreMergeComp + GatherComp of one GAS iteration: every side's tensor src(side) [n x F] -> dst(side)
+template <class SrcFn, class DstFn>
+void original_message_passing(cognn_engine* E, int64_t it, int F, bool fwd, SrcFn src, DstFn dst) {
+    const int k = E->k;
+    for (int g = 0; g < k; ++g) {
+        Side* a = E->side(g, 0); Side* b = E->side(g, 1);
+        std::vector<cognn_scatter_pair> pairs((size_t)k);
+        for (int P = 0; P < k; ++P) {
+            cognn_scatter_pair& sp = pairs[(size_t)P];
+            memset(&sp, 0, sizeof(sp));
+            const auto& op = E->orig_pair[(size_t)P * k + g];
+            sp.srcA = src(*E->side(P, 0)); sp.srcB = src(*E->side(P, 1));
+            sp.n0 = op.n0; sp.n1 = op.n1;
+            const u64 tag = scatter_tag(P, g);
+            sp.scale0 = keys(E, tag, it, COGNN_OP_SC_SCALE0); sp.trunc0 = keys(E, tag, it, COGNN_OP_SC_SCALE0_TRUNC);
+            sp.scale1 = keys(E, tag, it, COGNN_OP_SC_SCALE1); sp.trunc1 = keys(E, tag, it, COGNN_OP_SC_SCALE1_TRUNC);
+            sp.n1_from_server = P == g ? 0 : 1;
+            sp.crossed = P == g ? 0 : 1;
+        }
+        cognn_keys sk = keys(E, (u64)g, it, COGNN_OP_GA_SCALE), tk = keys(E, (u64)g, it, COGNN_OP_GA_SCALE_TRUNC);
+        const auto& od = E->orig_dst[(size_t)g];
+        if (E->timing) BE(cognn_timer_begin(E->ctx, T_AGG));
+        BE(cognn_scatter_gather_original_u64(E->ctx, dst(*a), dst(*b), src(*a), src(*b), fwd ? a->svec : nullptr, fwd ? b->svec : nullptr, &sk, &tk,
+                                             (int64_t)a->n, F, od.rowptr, od.src, od.pair, od.q, pairs.data(), k));
+        if (E->timing) {
+            BE(cognn_timer_end(E->ctx, T_AGG));
+            E->algo[T_AGG] += 16.0 * F * ((double)od.entries + 2.0 * a->n);       // both shares of every source row read, of every vertex row read and written
+        }
+    }
+}
+
+void run_iteration_original(cognn_engine* E, int64_t it) {
+    const int f = E->cfg.num_layers, ep = 2 * f;
+    const int e = (int)(it % ep);
+    const bool fwd = e < f;
+    const int layer = fwd ? e : f - 1 - (e - f);           // :337-340, 431-434
+    const bool apply_only = (e != 0 && e % f == 0);        // ss_...h:709, 941
+    const int in = E->in(), hid = E->hid(), lab = E->lab();
+    set_salt(E, it);
+    if (e == 0)                                            // ss_...h:695, 938: back to the input features
+        for (auto& s : E->sides) { s.cur = s.feat; s.curF = in; s.cur_mask = nullptr; }
+    if (!apply_only) {                                     // PreScatterComp is a copy (:198-209)
+        const int F = e == 0 ? in : hid;                   // getPlainNumPerOperand :807-830 ({in, hid, lab, hid}; e = 2 is apply-only)
+        Phase ph_mp(E, T_PH_MP);
+        // forward: the aggregate IS ah_t of the layer (:452); backward: into the scratch buffer that is not the input
+        auto out = [&](Side& s) { return fwd ? s.ah[layer] : (s.cur == s.buf[1] ? s.buf[0] : s.buf[1]); };
+        original_message_passing(E, it, F, fwd, [&](Side& s) { return s.cur; }, out);
+        for (auto& s : E->sides) { s.cur = out(s); s.curF = F; }
+    }
+    Phase ph_ap(E, T_PH_APPLY);
+    if (fwd) {                                             // twoPartyGCNForwardNN / ForwardNNPrediction (:459, 493): z = in . W, then ReLU / softmax
+        const int K = layer == 0 ? in : hid, N = layer == 0 ? hid : lab;
+        gemm_stage(E, it, [&](Side& s) { return s.cur; }, [&](Side& s) { return s.W[layer]; },
+                   [&](Side& s) { return GemmSpec{s.n, N, K, 0, COGNN_OP_AP_FWD_GEMM, COGNN_OP_AP_FWD_GEMM_TRUNC}; },
+                   [&](Side& s) { return s.buf[0]; });
+        for (auto& s : E->sides) { s.cur = s.buf[0]; s.curF = N; }
+        if (layer != f - 1) relu_stage(E, it, false, false);
+        else softmax_stage(E, it, false);
+        return;
+    }
+    // backward: BackwardNNInit (:586, last layer) / BackwardNN (:622): gz = in (.) 1[z > 0] (not for the last layer), d = ah_t^T . gz,
+    // g = gz . W^T with the weights before the update (not for the first layer), then the update and the weight average (:659-711)
+    if (layer != f - 1) {
+        Batch batch(E);
+        for (auto& s : E->sides) {
+            const uint8_t* mask = (paired(E, s) && s.p == 1) ? s.peer->relu_mask : s.relu_mask;   // a pair chain writes one (public) mask
+            u64* dstb = (s.cur == s.buf[1]) ? s.buf[0] : s.buf[1];
+            BE(cognn_mask_select_u64(E->ctx, dstb, s.cur, mask, (int64_t)s.n * hid));
+            s.cur = dstb;
+        }
+    }
+    const int M = layer == 0 ? in : hid, N = layer == 0 ? hid : lab;
+    if (layer != 0)                                        // first: it reads the weights the update below changes
+        gemm_stage(E, it, [&](Side& s) { return s.cur; }, [&](Side& s) { return s.W[layer]; },
+                   [&](Side& s) { GemmSpec g{s.n, M, N, 0, COGNN_OP_AP_GEMM, COGNN_OP_AP_GEMM_TRUNC}; g.transB = 1; return g; },
+                   [&](Side& s) { return s.g; });
+    auto dspec = [&](Side& s) { return GemmSpec{M, N, s.n, 1, COGNN_OP_AP_DGEMM, COGNN_OP_AP_DGEMM_TRUNC}; };
+    const bool pairs_fused = E->pair_fusion && E->wupdate_fusion && !streams_on(E);
+    const bool raw = gemm_stage(E, it, [&](Side& s) { return s.ah[layer]; }, [&](Side& s) { return s.cur; }, dspec,
+                                [&](Side& s) { return s.small[0]; }, false, OpenNext(), false, FollowScale(), pairs_fused);
+    const bool averaged = weight_update_chain(E, it, layer, pairs_fused, raw, dspec);
+    for (auto& s : E->sides) {
+        if (layer != 0) { s.cur = s.g; s.curF = hid; }
+        else s.curF = 0;                                   // :620-621: no g for the first layer
+    }
+    ph_ap.end();
+    Phase ph_wa(E, T_PH_WAVG);
+    if (!averaged) weight_average(E, it, layer);
+    exchange_wait(E);
+}
+
 // the Beaver product a side runs in GAS iteration `it` (at most one: PreScatter in forward iterations, Apply in backward ones)
 bool gemm_of_iteration(cognn_engine* E, Side& s, int64_t it, GemmSpec& g) {
     const IterInfo I = iter_info(E, it);
@@ -1408,6 +1565,7 @@ bool gemm_of_iteration(cognn_engine* E, Side& s, int64_t it, GemmSpec& g) {
 void run_offline(cognn_engine* E, int64_t it0, int64_t it1) {
     // recorded epochs deal their product shares inside the recording (on demand), unless the caller replays ONE epoch and keeps them
     if (E->graph_epochs && !E->retain_offline) return;
+    if (original(E)) return;                               // original-gcn: every product share is dealt when its product runs
     for (int64_t it = it0; it < it1; ++it) {
         set_salt(E, it);
         for (auto& s : E->sides) {
@@ -1692,6 +1850,7 @@ void alloc_sides(cognn_engine* E) {
         s.h1 = dalloc<u64>(E, n * hid);
         s.h1E = dalloc<u64>(E, n * hid);
         s.g = dalloc<u64>(E, n * hid);
+        if (original(E)) { s.ah[0] = dalloc<u64>(E, n * in); s.ah[1] = dalloc<u64>(E, n * hid); }
         s.relu_mask = dalloc<uint8_t>(E, n * hid);
         for (int j = 0; j < 2; ++j) s.buf[j] = dalloc<u64>(E, n * fm);
         for (int j = 0; j < 3; ++j) s.ob[j] = dalloc<u64>(E, big);
@@ -1801,7 +1960,7 @@ void start(cognn_engine* E) {
         }
         s.cur = s.feat; s.curF = in;
     }
-    open_features(E);
+    if (!original(E)) open_features(E);                     // (original-gcn has no product on the constant feature tensor)
     BE(cognn_ctx_sync(E->ctx));
     E->started = true;
 }
@@ -1840,7 +1999,9 @@ int cognn_engine_create(const cognn_engine_config* cfg, int64_t V, int64_t Ecoun
         }
         try {
             // COGNN_HOST_GRAPH_BUILD forces the host builder (tests compare the two)
-            const bool device_build = E->world == 1 && !getenv("COGNN_HOST_GRAPH_BUILD");
+            if (original(E) && E->world != 1) throw EngineError("cognn_engine_create: original-gcn runs as a single process (world = 1)");
+            if (original(E) && E->k > 16) throw EngineError("cognn_engine_create: original-gcn takes at most 16 parties");
+            const bool device_build = E->world == 1 && !getenv("COGNN_HOST_GRAPH_BUILD") && !original(E);   // (original-gcn indexes single edges: host builder)
             if (device_build) {
                 E->G = cognn::build_vertex_layout(E->k, V, part);
                 build_layout(E);
@@ -1850,6 +2011,7 @@ int cognn_engine_create(const cognn_engine_config* cfg, int64_t V, int64_t Ecoun
                 build_layout(E);
                 build_csrs(E);
             }
+            if (original(E)) build_original_index(E);
             alloc_sides(E);
             E->hostFeat.resize(E->hosted.size());
             E->hostLabels.resize(E->hosted.size());

@@ -354,6 +354,35 @@ typedef struct {
 int cognn_gather_pair_chain_u64(cognn_ctx*, const uint64_t* table, const uint32_t* rowptr, const uint32_t* col, int64_t F,
                                 const cognn_gather_pair* pairs, int32_t count);
 
+/* ---- original-gcn message passing (algo_kernels/vertex_centric/original-gcn/gcn.h:211-405) for ONE destination party of a
+ *      single-process run: ScatterComp + UpdatePreMergeComp + GatherComp of every in-edge of its vertices in one launch -----
+ * The unoptimised kernel scales every message on its edge: for edge q of the Scatter instance (client P = source party, server =
+ * the destination party, or P's co-party for P's local edges) the pair computes
+ *     m = trunc(trunc(u * n0[q]) * n1[q]),   u = the source row, both shares (srcA: client's, srcB: server's)
+ * with two Beaver row scales (a per element, b per edge; streams of `scale0` / `trunc0` / `scale1` / `trunc1`, addressed by the
+ * edge's position q in the instance's edge list: element q * F + j) - n0 = (outDeg_src + 1)^-1/2 is the client's value (share
+ * (n0, 0)), n1 = (inDeg_dst + 1)^-1/2 the client's for local edges, the server's for the others (share (0, n1);
+ * ss_...h:800,1041-1043).  Then, per destination vertex r (both share-holders' rows by the same thread):
+ *     out_A[r] = self_A[r] + sum over local edges m_A + sum over the other edges m_B,   out_B[r] likewise with A / B swapped
+ * (which share feeds which side is the crossing of ss_...h:1063-1100), where, in a forward iteration (self_scale != NULL), the self
+ * row first goes through the same scale + truncation with the vertex's own normaliser (gcn.h:365-381; streams of self_scale_keys /
+ * self_trunc_keys at element r * F + j).  Entries of a destination row: ent_src (row inside the source party), ent_pair (index
+ * into pairs[]), ent_q.  Bit-identical to the per-edge sequence of the oracle (oracle/original_gcn.py). npairs <= 16. */
+typedef struct {
+    const uint64_t* srcA;        /* the source party's tensor, owner-side share [n_src x F] */
+    const uint64_t* srcB;        /* ... co-party-side share */
+    const uint64_t* n0;          /* [edges of the instance] */
+    const uint64_t* n1;
+    cognn_keys scale0, trunc0, scale1, trunc1;
+    int32_t n1_from_server;      /* 0: n1 is the client's share, 1: the server's */
+    int32_t crossed;             /* 0: m_A -> out_A (the source party's local edges); 1: m_A -> out_B, m_B -> out_A */
+} cognn_scatter_pair;
+int cognn_scatter_gather_original_u64(cognn_ctx*, uint64_t* outA, uint64_t* outB, const uint64_t* selfA, const uint64_t* selfB,
+                                      const uint64_t* self_scale0, const uint64_t* self_scale1, const cognn_keys* self_scale_keys,
+                                      const cognn_keys* self_trunc_keys, int64_t rows, int64_t F, const uint32_t* rowptr,
+                                      const uint32_t* ent_src, const uint32_t* ent_pair, const uint32_t* ent_q,
+                                      const cognn_scatter_pair* pairs, int32_t npairs);
+
 /* ---- onPreprocessClient index construction (ss_...h:295-534) + degree accounting (graph.h:607-633, graph_io_util.h:167-177)
  *      on the device, for a run whose parties are all hosted by ONE process ------------------------------------------------
  * All pointers are DEVICE pointers.  In: the directed edge list in file order (both directions are generated when

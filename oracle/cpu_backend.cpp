@@ -608,6 +608,44 @@ int cognn_pair_weight_update_u64(cognn_ctx* ctx, const cognn_pair_wupdate* jobs,
     }
     return 0;
 }
+// original-gcn message passing for one destination party: the per-edge sequence (two row scales with truncation per edge, then
+// the sums), both share-holders side by side
+static void cpu_scale_trunc_pair(const cognn_keys& sk, const cognn_keys& tk, u64 s0, u64 s1, u64 row, u64 idx, u64& v0, u64& v1) {
+    const cognn_opkeys k = K(&sk), t = K(&tk);
+    const u64 b0 = cognn_prng(k.k[COGNN_SL_B0], row), b1 = cognn_prng(k.k[COGNN_SL_B1], row);
+    const u64 g = (s0 - b0) + (s1 - b1);
+    const u64 a0 = cognn_prng(k.k[COGNN_SL_A0], idx), a1 = cognn_prng(k.k[COGNN_SL_A1], idx), c0m = cognn_prng(k.k[COGNN_SL_C0], idx);
+    const u64 c1m = (a0 + a1) * (b0 + b1) - c0m;
+    const u64 e = (v0 - a0) + (v1 - a1);
+    const u64 z0 = e * b0 + a0 * g + c0m, z1 = e * g + e * b1 + a1 * g + c1m;
+    const u64 c0 = z0 + trunc_r(t, 0, idx) + COGNN_TRUNC_OFFSET, c1 = z1 + trunc_r(t, 1, idx);
+    v0 = ((c0 + c1) >> COGNN_FX_BITS) - (COGNN_TRUNC_OFFSET >> COGNN_FX_BITS) - trunc_rp(t, 0, idx);
+    v1 = 0ull - trunc_rp(t, 1, idx);
+}
+int cognn_scatter_gather_original_u64(cognn_ctx*, uint64_t* outA, uint64_t* outB, const uint64_t* selfA, const uint64_t* selfB,
+                                      const uint64_t* self_scale0, const uint64_t* self_scale1, const cognn_keys* self_scale_keys,
+                                      const cognn_keys* self_trunc_keys, int64_t rows, int64_t F, const uint32_t* rowptr,
+                                      const uint32_t* ent_src, const uint32_t* ent_pair, const uint32_t* ent_q,
+                                      const cognn_scatter_pair* pairs, int32_t npairs) {
+    REQ(outA && outB && selfA && selfB && rowptr && npairs >= 0 && npairs <= 16, "scatter_gather_original: bad arguments");
+    CG_PAR
+    for (int64_t r = 0; r < rows; ++r)
+        for (int64_t j = 0; j < F; ++j) {
+            const u64 own = (u64)(r * F + j);
+            u64 a = selfA[own], c = selfB[own];
+            if (self_scale0) cpu_scale_trunc_pair(*self_scale_keys, *self_trunc_keys, self_scale0[r], self_scale1[r], (u64)r, own, a, c);
+            for (uint32_t e = rowptr[r]; e < rowptr[r + 1]; ++e) {
+                const cognn_scatter_pair& P = pairs[ent_pair[e]];
+                const u64 q = ent_q[e], src = (u64)ent_src[e] * (u64)F + (u64)j, idx = q * (u64)F + (u64)j;
+                u64 u0 = P.srcA[src], u1 = P.srcB[src];
+                cpu_scale_trunc_pair(P.scale0, P.trunc0, P.n0[q], 0, q, idx, u0, u1);
+                cpu_scale_trunc_pair(P.scale1, P.trunc1, P.n1_from_server ? 0 : P.n1[q], P.n1_from_server ? P.n1[q] : 0, q, idx, u0, u1);
+                if (P.crossed) { a += u1; c += u0; } else { a += u0; c += u1; }
+            }
+            outA[own] = a; outB[own] = c;
+        }
+    return 0;
+}
 int cognn_gather_pair_chain_u64(cognn_ctx* ctx, const uint64_t* table, const uint32_t* rowptr, const uint32_t* col, int64_t F,
                                 const cognn_gather_pair* pairs, int32_t count) {
     for (int32_t c = 0; c < count; ++c) {

@@ -53,7 +53,11 @@ def _check(cfg, world, tmp_path):
     part = [v % k for v in range(V)]
     feats, labels = co.synth_features(V, cfg["in"], cfg["lab"], cfg["gseed"] + 1, density=0.2)
     p = co.GnnParam(num_labels=cfg["lab"], input_dim=cfg["in"], hidden_dim=cfg["hid"], num_samples=V, learning_rate=0.5)
-    o = co.OracleEngine(k, src, dst, part, feats, labels, p, seed=cfg["seed"], variant=cfg["variant"])
+    if cfg["variant"] == "original-gcn":
+        import original_gcn
+        o = original_gcn.OriginalOracleEngine(k, src, dst, part, feats, labels, p, seed=cfg["seed"])
+    else:
+        o = co.OracleEngine(k, src, dst, part, feats, labels, p, seed=cfg["seed"], variant=cfg["variant"])
     got = _run(cfg, world, tmp_path)
     for it in range(cfg["iters"]):
         o.iteration(it)
@@ -113,6 +117,15 @@ def test_whole_epochs_per_call(tmp_path):
 def test_single_rank_host_logic_three_parties(tmp_path):
     """world == 1 through the same worker: the engine's co-located path (in-device hand-off) on the CPU backend."""
     _check(dict(BASE, k=3, iters=12), 1, tmp_path)
+
+
+@pytest.mark.parametrize("k,extra", [(2, {}), (3, {}), (4, {}), (2, {"pair_fusion": 0}), (3, {"V": 9, "Eu": 5}), (5, {"V": 61, "Eu": 300, "hid": 5, "lab": 3})])
+def test_original_gcn_single_process(tmp_path, k, extra):
+    """BASELINE config 1's kernel (original-gcn: per-edge two-normaliser Scatter, aggregate-then-transform, 4 GAS iterations per
+    epoch, weight average after both backward iterations) on the engine - world 1, plain-C++ backend - against
+    oracle/original_gcn.py after every GAS iteration of two epochs: vertex shares (incl. the empty tensor after the first layer's
+    backward Apply) and both weight shares of every party; sparse graphs with dummy self entries, multi-edges, k up to 5."""
+    _check(dict(BASE, k=k, variant="original-gcn", iters=8, **extra), 1, tmp_path)
 
 
 @pytest.mark.parametrize("seed", [1, 2])

@@ -45,6 +45,16 @@ def test_four_parties_four_ranks_training_hip(tmp_path):
     _check(cfg, 4, tmp_path)
 
 
+@pytest.mark.parametrize("k,extra", [(2, {}), (3, {"pair_fusion": 0}), (4, {"V": 700, "Eu": 2500, "in": 33, "hid": 16, "lab": 7}),
+                                     (2, {"V": 2708, "Eu": 5278, "in": 300, "hid": 16, "lab": 7}), (3, {"V": 9, "Eu": 5})])
+def test_original_gcn_single_process_hip(tmp_path, k, extra):
+    # BASELINE config 1's kernel on the HIP engine (world 1): the fused per-edge Scatter + Gather launch, forward products after the
+    # aggregation (grouped / split-K kernels, two opened-share streams), weight-gradient products with freshly masked ah_t^T, the
+    # one-pass weight update + average - two epochs, every GAS iteration against oracle/original_gcn.py; the 2708-vertex case has
+    # Cora's vertex and edge counts (narrower features so that the oracle stays in test time)
+    _check(dict(BASE, k=k, variant="original-gcn", iters=8, backend="hip", **extra), 1, tmp_path)
+
+
 @pytest.mark.parametrize("chunks,world", [(2, 2), (3, 4), (4, 2)])
 def test_chunked_exchange_pipeline_hip(tmp_path, chunks, world):
     # COGNN_OPT_EXCHANGE_CHUNKS on the HIP kernels: the chunk window of the element-wise launches (batched and single), the
