@@ -18,11 +18,12 @@ OBJS := $(KERNEL_SRCS:.hip=.o) $(HOST_SRCS:.cpp=.o)
 
 all: $(OUT) $(HARNESS)
 
-# the reference's command-line entry point (harness.cpp) over the engine; gcn-inference-optimize is the same binary
+# the reference's command-line entry point (harness.cpp) over the engine; gcn-inference-optimize and gcn-original are the same binary
 $(HARNESS): $(HOST)/harness_main.cpp $(OUT) $(HOST)/graph.h include/cognn_engine.h include/cognn_exchange.h
 	mkdir -p bin
 	$(HOSTCXX) $(HOSTFLAGS) -o $@ $(HOST)/harness_main.cpp -Lcognn_amd -lcognn_hip -Wl,-rpath,'$$ORIGIN/../cognn_amd' -Wl,-rpath,/opt/rocm/lib
 	ln -sf gcn-optimize bin/gcn-inference-optimize
+	ln -sf gcn-optimize bin/gcn-original
 
 $(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/common.h $(CSRC)/pair_chain.h $(CSRC)/cognn_spec.h include/cognn_hip.h include/cognn_engine.h include/cognn_exchange.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@

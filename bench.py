@@ -54,11 +54,16 @@ WORKLOADS = {
     "cora-2p": (2, None, None, 1433, 16, 7, "optimize-gcn", 6),
     "citeseer-2p": (2, None, None, 3703, 16, 6, "optimize-gcn", 6),
     "pubmed-4p": (4, None, None, 500, 16, 3, "optimize-gcn", 6),
+    # BASELINE.json configs[0]: the unoptimised kernel (original-gcn, 4 GAS iterations per epoch) on the Cora shape, 2 parties
+    "cora-2p-original": (2, None, None, 1433, 16, 7, "original-gcn", 4),
 }
-DATASET_VE = {"cora-2p": (2708, 10556), "citeseer-2p": (3312, 10016), "pubmed-4p": (19717, 128146)}
+DATASET_VE = {"cora-2p": (2708, 10556), "citeseer-2p": (3312, 10016), "pubmed-4p": (19717, 128146), "cora-2p-original": (2708, 10556)}
 
 
-def message_widths(variant, iters, hid, lab):
+def message_widths(variant, iters, hid, lab, in_dim=0):
+    if variant == "original-gcn":           # original-gcn/gcn.h:807-830: {in, hid, (lab: apply-only), hid}
+        w = [in_dim, hid, 0, hid]
+        return sum(w[i % 4] for i in range(iters))
     w = [hid, lab, 0, lab, 0, hid]          # getPlainNumPerOperand per GAS iteration (gcn.h:898-927); 0 = apply-only
     return sum(w[i % 6] for i in range(iters))
 
@@ -86,7 +91,7 @@ def cpu_baseline(args, wl):
     the engine's host code on the plain-C++ reference backend (oracle/libcognn_engine_cpu.so, OpenMP), all cores on a
     1/4-scale graph plus one single-thread pass on a 1/16-scale graph; fallback (library not built): the numpy oracle."""
     k, lv, le, in_dim, hid, lab, variant, iters = wl
-    widths = message_widths(variant, iters, hid, lab)
+    widths = message_widths(variant, iters, hid, lab, in_dim)
     try:
         cores = len(os.sched_getaffinity(0))
         try:                                                # cgroup v2 CPU quota, when one is set
@@ -290,7 +295,7 @@ def main():
         eng.forward_only(True)                # -m 2: the hidden activation and the ReLU sign mask have no reader
     # measured (MI355X, ROCm 7.2): replaying a recorded epoch is NOT faster than launching its kernels - Cora 0.43 vs 0.45 ms, CiteSeer 0.64 vs
     # 0.54, PubMed 0.80 vs 0.69, config5-train 15.1 vs 13.0 - a serial chain of dependent dispatches costs the same either way; opt-in only
-    recorded = world == 1 and "inference" not in variant and iters % 6 == 0 and args.graph
+    recorded = world == 1 and variant == "optimize-gcn" and iters % 6 == 0 and args.graph
     if recorded:
         eng.graph_epochs(True)                # a training epoch per step: recorded once (hipGraph), replayed (COGNN_OPT_GRAPH_EPOCHS)
     eng.offline(0, iters)
@@ -335,6 +340,8 @@ def main():
     traffic, traffic_src = None, None
     # (single process, every pair co-located, even width, k <= 8: the Gather with the pair chain as its epilogue - engine.cpp can_fuse_gather_chain)
     used = sorted({"gather_pair_chain_kernel" if (world == 1 and k <= 8 and F % 2 == 0) else "gather_csr_kernel" for F in (hid, lab)})
+    if variant == "original-gcn":
+        used = ["scatter_gather_original_kernel"]         # the fused per-edge Scatter + Gather launch of the unoptimised kernel
     cands = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc.json") and f[:1] == "r" and f[1:3].isdigit() and f[3] == "_") \
         if os.path.isdir(os.path.join(ROOT, "profiles")) else []
     if world == 1 and cands:
@@ -347,7 +354,7 @@ def main():
             traffic_src = ("from profiles/%s - the builder's PMC pass on build %s (git %s), not measured in this run: rocprofv3 --pmc FETCH_SIZE / "
                            "WRITE_SIZE in separate passes, FETCH x2 gfx950 correction, kernels %s" % (cands[-1], b.get("tag", "?"), b.get("git_head", "?"), " + ".join(used)))
     ms_per_step = dt / args.steps * 1e3
-    ef_per_step = float(len(src)) * message_widths(variant, iters, hid, lab)
+    ef_per_step = float(len(src)) * message_widths(variant, iters, hid, lab, in_dim)
     value = ef_per_step / (dt / args.steps)
     wlinfo = eng.workload()
     out = {
@@ -363,8 +370,11 @@ def main():
         "epoch_time_s": dt / args.steps,
         "edges_feat_per_s_per_party": value / k,
         "offline_ms": offline_ms, "setup_s": setup_s,
-        "roofline": {"bound": "hbm", "kernel": "aggregate launch of the message passing (gather_pair_chain_kernel when every pair is co-located, "
-                                                "gather_csr_kernel otherwise)",
+        "roofline": {"bound": "hbm", "kernel": ("scatter_gather_original_kernel: per-edge two-normaliser Scatter + Gather of one destination party "
+                                                "(bytes: both shares of every source row and vertex row; the launch is bound by its per-edge dealer arithmetic, not by HBM)")
+                                               if variant == "original-gcn" else
+                                               "aggregate launch of the message passing (gather_pair_chain_kernel when every pair is co-located, "
+                                               "gather_csr_kernel otherwise)",
                      "achieved": (bytes_agg / 1e9) / (ms_agg / 1e3) if ms_agg > 0 else None, "peak": 8000.0, "unit": "GB/s",
                      "frac": ((bytes_agg / 1e9) / (ms_agg / 1e3) / 8000.0) if ms_agg > 0 else None, "traffic": traffic,
                      "traffic_unit": "bytes per launch", "traffic_source": traffic_src,

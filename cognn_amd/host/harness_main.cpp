@@ -1,4 +1,4 @@
-// gcn-optimize / gcn-inference-optimize — command-line entry point with the reference's interface
+// gcn-optimize / gcn-inference-optimize / gcn-original — command-line entry point with the reference's interface
 // (algo_kernels/common_harness/harness.cpp:50-212, include/harness.h:91-220):
 //
 //   gcn-optimize -t <parties> -g <tiles> -i <party index> -m <iterations> -p <parts> -s <setting>
@@ -67,7 +67,7 @@ void printHelp(const char* prog) {
               << "\t-t <threadCount>      Number of parties (tiles handled by this run).\n"
               << "\t-g <graphTileCount>   Total number of graph tiles.\n"
               << "\t-i <tileIndex>        Party whose log lines are printed.\n"
-              << "\t-m [maxIter]          Maximum GAS iterations (6 per training epoch, 2 = one inference pass).\n"
+              << "\t-m [maxIter]          Maximum GAS iterations (6 per training epoch, 2 = one inference pass; gcn-original: 4 per epoch).\n"
               << "\t-p [numParts]         Number of partitions per thread (unused).\n"
               << "\t-s <setting>          Setting string (keys the dealer / offline phase).\n"
               << "\t-n <0|1>              1: skip the offline phase up front (products are dealt on demand).\n"
@@ -157,6 +157,8 @@ int main(int argc, char* argv[]) {
     }
     if (tileIndex >= threadCount) { std::cerr << "Tile index out of range." << std::endl; return -1; }
     const bool inference = prog.find("inference") != std::string::npos || getenv("COGNN_INFERENCE_VARIANT");
+    // bin/gcn-original = the unoptimised kernel (algo_kernels/vertex_centric/original-gcn, tools/tmp_run_cluster.py:285-286); single process
+    const bool original = !inference && (prog.find("gcn-original") != std::string::npos || getenv("COGNN_ORIGINAL_VARIANT"));
 
     GnnParam gp;
     gp.readConfig(configFile);
@@ -193,7 +195,7 @@ int main(int argc, char* argv[]) {
         for (auto& t : part) { t /= (int32_t)(graphTileCount / threadCount); }      // tileMergeFactor (graph_io_util.h:76)
         cognn_engine_config cfg{};
         cfg.num_parties = k; cfg.rank = rank; cfg.world = world;
-        cfg.variant = inference ? COGNN_VARIANT_OPTIMIZE_GCN_INFERENCE : COGNN_VARIANT_OPTIMIZE_GCN;
+        cfg.variant = inference ? COGNN_VARIANT_OPTIMIZE_GCN_INFERENCE : original ? COGNN_VARIANT_ORIGINAL_GCN : COGNN_VARIANT_OPTIMIZE_GCN;
         cfg.num_layers = gp.num_layers; cfg.num_labels = gp.num_labels; cfg.input_dim = gp.input_dim; cfg.hidden_dim = gp.hidden_dim;
         cfg.learning_rate = gp.learning_rate; cfg.train_ratio = gp.train_ratio; cfg.val_ratio = gp.val_ratio; cfg.test_ratio = gp.test_ratio;
         cfg.seed = fnv1a(setting); cfg.device = device; cfg.stream = nullptr; cfg.undirected = undirected; cfg.verbose = 1;
@@ -269,7 +271,7 @@ int main(int argc, char* argv[]) {
             cacheDirOk = make_dirs(cacheDir);
             if (!cacheDirOk) std::cerr << "warning: cannot create " << cacheDir << ": offline cache not written" << std::endl;
         }
-        const int epoch = 3 * gp.num_layers;
+        const int epoch = (original ? 2 : 3) * gp.num_layers;     // getEpochLayerNum
         int64_t reused = 0;
         auto deal_epoch = [&](uint64_t it0) -> bool {
             const int64_t it1 = (int64_t)std::min<uint64_t>(it0 + (uint64_t)epoch, maxIters);

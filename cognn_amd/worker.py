@@ -6,7 +6,7 @@ Shares travel over the library's native RCCL transport (backend "nccl"); backend
 transport of cognn_amd/dist.py.
 
     RANK=r WORLD_SIZE=n MASTER_ADDR=127.0.0.1 MASTER_PORT=p python -m cognn_amd.worker -t <parties> -m <iters> -s <setting> \
-        [--variant optimize-gcn|optimize-gcn-inference] <edge file> <vertex file> <partition file> <output file> <config file>
+        [--variant optimize-gcn|optimize-gcn-inference|original-gcn] <edge file> <vertex file> <partition file> <output file> <config file>
 """
 import argparse
 import os
@@ -77,7 +77,7 @@ def main(argv=None):
     ap.add_argument("-c", type=int, default=0)
     ap.add_argument("-r", type=int, default=1)
     ap.add_argument("-u", action="store_true")
-    ap.add_argument("--variant", default="optimize-gcn", choices=["optimize-gcn", "optimize-gcn-inference"])
+    ap.add_argument("--variant", default="optimize-gcn", choices=["optimize-gcn", "optimize-gcn-inference", "original-gcn"])
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
     ap.add_argument("--log-dir", default=None)
     ap.add_argument("--log-prefix", default="gcn_test_", help="log file name = <prefix><party>.log")
@@ -128,7 +128,7 @@ def main(argv=None):
         print("%d Initialize graph algo kernel" % p, file=logs[p])
         print("::preprocess took %f seconds" % (time.perf_counter() - t_pre), file=logs[p])
     # offline phase one epoch ahead with the on-disk cache keyed by -s, like bin/gcn-optimize (harness_main.cpp)
-    epoch = 3 * gp.num_layers
+    epoch = (2 if a.variant == "original-gcn" else 3) * gp.num_layers     # getEpochLayerNum
     cache_dir = os.path.join("preprocess", a.s.replace(" ", "_"))
     use_cache = not os.environ.get("COGNN_NO_PREPROCESS_CACHE")
     if not a.n and use_cache:

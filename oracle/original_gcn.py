@@ -4,8 +4,9 @@ BASELINE.json configs[0]: "2-party original-gcn on Cora, CPU reference path with
 no GPU)".  This module restates the unoptimised CoGNN kernel — aggregate-then-transform, 4 GAS iterations per epoch,
 message width {input_dim, hidden_dim, num_labels, hidden_dim} — on top of the shared engine restatement in
 cognn_oracle.py (preprocessing, OEP/OGA stand-ins, client/server schedule of ss_vertex_centric_algo_kernel.h).
-Only tests/ import it; the HIP engine does not run this variant (it exists in the reference as the CPU baseline
-of the paper's "unoptimised" experiments, tools/tmp_run_cluster.py:285-286).
+Only tests/ import it.  The engine runs this variant as COGNN_VARIANT_ORIGINAL_GCN (bin/gcn-original, single process) and is
+checked against this module after every GAS iteration (it exists in the reference as the CPU baseline of the paper's
+"unoptimised" experiments, tools/tmp_run_cluster.py:285-286).
 
 PARITY UNPINNED, as for the rest of the oracle: the fused external ops this variant calls
 (sci::twoPartyGCNForwardNN / ForwardNNPrediction / BackwardNNInit / BackwardNN, the two-normaliser
@@ -265,6 +266,7 @@ class OriginalPlainEngine(co.PlainEngine):
                     y = np.zeros_like(p); y[np.arange(n), o.states[P].labels] = 1.0
                     d = p - y; d[train:] = 0
                     I["p"] = p; self.X[P] = d
+                    self.metrics.append(o._metrics(P, it, p, train, int(n * g.val_ratio)))   # what the client prints (gcn.h:511-523)
             else:
                 gz = x if layer == f - 1 else x * (I["z"] > 0)
                 d = I["ah"].T @ gz

@@ -95,3 +95,55 @@ def test_dataset_shaped_90_epochs_track_plaintext(shape, recorded):
             assert np.array_equal(w[0][l], w[P][l])
         assert np.abs(co.fx_decode(w[P][0]) - plain.W[P][0]).max() < 0.05
     eng.close()
+
+
+def test_config1_original_gcn_cora_shaped_epochs_track_plaintext():
+    """BASELINE.json configs[0]: 2-party original-gcn on Cora (the reference's CPU smallest test) - here on the HIP engine's
+    original-gcn variant, Cora's shape and config file (2708 / 10556 / 1433 / 7, learning_rate 0.5) on the learnable planted
+    graph, 60 epochs of 4 GAS iterations: loss and accuracies of both parties after every epoch against the float64 plaintext
+    of the same schedule (oracle/original_gcn.py OriginalPlainEngine)."""
+    import original_gcn
+    from cognn_amd.engine import Engine, GnnParam
+    k, V, E, in_dim, lab, lr, ratios, planted, min_acc = SHAPES["cora-2p"]
+    src, dst, feats, labels = co.synth_planted(V, E // 2, in_dim, lab, 3, **planted)
+    part = np.array([v % k for v in range(V)], dtype=np.int32)
+    kw = dict(num_labels=lab, input_dim=in_dim, hidden_dim=16, num_samples=V, learning_rate=lr, train_ratio=ratios[0], val_ratio=ratios[1],
+              test_ratio=ratios[2])
+    oracle = original_gcn.OriginalOracleEngine(k, src, dst, part, feats, labels, co.GnnParam(**kw), seed=0xC06A11)   # preprocessing / init only
+    plain = original_gcn.OriginalPlainEngine(oracle)
+    eng = Engine(k, src, dst, part, GnnParam(**kw), seed=0xC06A11, variant="original-gcn")
+    eng.set_global_data(feats, labels)
+    eng.start()
+    TOL_LOSS, TOL_ACC = 0.01, 0.02
+    worst = {"loss": 0.0, "acc": 0.0}
+    traj = []
+    mem = None
+    for ep in range(60):
+        for it in range(4 * ep, 4 * ep + 4):
+            plain.iteration(it)
+            eng.run(it, it + 1)
+            if it % 4 == 1:
+                row = []
+                for P in range(k):
+                    m = eng.metrics(P)
+                    pm = [x for x in plain.metrics if x["party"] == P and x["iter"] == it][0]
+                    worst["loss"] = max(worst["loss"], abs(m["loss"] - pm["loss"]))
+                    for key in ("full", "train", "test", "border_test"):
+                        worst["acc"] = max(worst["acc"], abs(m[key] - pm[key]))
+                        assert abs(m[key] - pm[key]) < TOL_ACC, (ep, P, key, m[key], pm[key])
+                    assert abs(m["loss"] - pm["loss"]) < TOL_LOSS, (ep, P, m["loss"], pm["loss"])
+                    row.append((m["loss"], m["full"], m["train"], m["test"]))
+                traj.append(row)
+        if ep == 1:
+            mem = eng.memory()
+    assert eng.memory() == mem, "device allocations grew over the epochs"
+    first, last = np.array(traj[0]), np.array(traj[-1])
+    print("config 1 (original-gcn, Cora-shaped 2-party): max |loss - plaintext| %.5f, max |accuracy - plaintext| %.5f over 60 epochs" % (worst["loss"], worst["acc"]))
+    print("epoch 1 loss %s full %s; epoch 60 loss %s full %s train %s test %s" % (np.round(first[:, 0], 4), np.round(first[:, 1], 4), np.round(last[:, 0], 4),
+                                                                                np.round(last[:, 1], 4), np.round(last[:, 2], 4), np.round(last[:, 3], 4)))
+    assert (last[:, 0] < first[:, 0]).all() and (last[:, 1] > first[:, 1]).all(), "the run did not learn"
+    with np.errstate(over="ignore"):
+        w = [[eng.weight(P, 0, l) + eng.weight(P, 1, l) for l in range(2)] for P in range(k)]
+    for l in range(2):
+        assert np.array_equal(w[0][l], w[1][l])                # the parties agree after the last averaging round
+    eng.close()

@@ -105,8 +105,33 @@ def test_reference_experiment_option_builds_the_reference_layout(tmp_path):
 
 
 def test_unsupported_experiments_are_refused(tmp_path):
-    res = subprocess.run(LAUNCH + ["--cognn-unopt-efficiency"], capture_output=True, text=True, timeout=60)
-    assert res.returncode == 2 and "gcn-original" in res.stderr
+    res = subprocess.run(LAUNCH + ["--graphsc-efficiency"], capture_output=True, text=True, timeout=60)
+    assert res.returncode == 2 and "GraphSC" in res.stderr
+
+
+def test_gcn_original_through_the_launcher(tmp_path):
+    """The unoptimised kernel (bin/gcn-original in the reference's scripts, --cognn-unopt-*): one process hosts both parties; two
+    epochs of 4 GAS iterations; the per-party logs carry one accuracy block per epoch and the oracle's numbers."""
+    import original_gcn
+    from cognn_amd import worker
+    data, logs = tmp_path / "data", tmp_path / "log"
+    cmd = LAUNCH + ["--executable", "gcn-original", "--dataset", "cora_small", "--parties", "2", "--gpus", "1", "--iterations", "8",
+                    "--data-dir", str(data), "--log-dir", str(logs), "--synthetic", "--backend", "gloo", "--worker", CPU_WORKER]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=tmp_path)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    src, dst = worker.read_edge_list(str(data / "cora_small.edge.preprocessed"))
+    part = worker.read_partition(str(data / "cora_small.part.preprocessed"))
+    p = co.GnnParam.read_config(str(data / "cora_small_config.txt"))
+    rows = worker.read_vertex_rows(str(data / "cora_small.vertex.preprocessed"), set(range(len(part))), p.input_dim)
+    feats = np.stack([rows[v][0] for v in range(len(part))]); labels = [rows[v][1] for v in range(len(part))]
+    o = original_gcn.OriginalOracleEngine(2, src, dst, part, feats, labels, p, seed=worker.fnv1a("gcn-original/cora_small/2s"))
+    o.run(8)
+    for party in range(2):
+        text = (logs / ("gcn_test_cora_small_%d.log" % party)).read_text()
+        assert len(extract_cognn_durations(text, "iteration")) == 8
+        loss = [float(x) for x in re.findall(r"cross-entropy-loss = ([0-9.]+)", text)]
+        want = [m["loss"] for m in o.metrics if m["party"] == party]
+        assert len(loss) == 2 and len(want) == 2 and np.allclose(loss, want, atol=1e-5), (loss, want)
 
 
 def test_rank_killed_by_signal_fails_the_launch(tmp_path):
@@ -184,3 +209,34 @@ def test_launcher_runs_the_cpp_binary_on_the_gpu(tmp_path):
                        [str(tmp_path / "out"), str(data / "cora_small_config.txt")], capture_output=True, text=True, timeout=120, cwd=tmp_path, env=env)
     assert r.returncode == 0, r.stderr
     assert "full set accuracy" in r.stdout
+
+
+@pytest.mark.gpu
+def test_launcher_runs_gcn_original_on_the_gpu(tmp_path):
+    """bin/gcn-original (the reference's --cognn-unopt-* executable): the engine's original-gcn variant, 4 GAS iterations per epoch,
+    both parties' logs with the oracle's loss after each of two epochs; -c 1 (one rank per GPU) is refused for this kernel."""
+    import original_gcn
+    from cognn_amd import worker
+    data, logs = tmp_path / "data", tmp_path / "log"
+    cmd = LAUNCH + ["--executable", "gcn-original", "--dataset", "cora_small", "--parties", "2", "--iterations", "8", "--data-dir", str(data),
+                    "--log-dir", str(logs), "--synthetic"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=tmp_path)
+    assert res.returncode == 0, res.stderr + res.stdout
+    src, dst = worker.read_edge_list(str(data / "cora_small.edge.preprocessed"))
+    part = worker.read_partition(str(data / "cora_small.part.preprocessed"))
+    p = co.GnnParam.read_config(str(data / "cora_small_config.txt"))
+    rows = worker.read_vertex_rows(str(data / "cora_small.vertex.preprocessed"), set(range(len(part))), p.input_dim)
+    feats = np.stack([rows[v][0] for v in range(len(part))]); labels = [rows[v][1] for v in range(len(part))]
+    o = original_gcn.OriginalOracleEngine(2, src, dst, part, feats, labels, p, seed=worker.fnv1a("gcn-original/cora_small/2s"))
+    o.run(8)
+    for party in range(2):
+        text = (logs / ("gcn_test_cora_small_%d.log" % party)).read_text()
+        assert len(extract_cognn_durations(text, "iteration")) == 8 and len(extract_cognn_durations(text, "premerging")) == 6
+        loss = [float(x) for x in re.findall(r"cross-entropy-loss = ([0-9.]+)", text)]
+        want = [m["loss"] for m in o.metrics if m["party"] == party]
+        assert len(loss) == 2 and np.allclose(loss, want, atol=1e-5), (loss, want)
+    files = [str(data / ("cora_small" + e)) for e in (".edge.preprocessed", ".vertex.preprocessed", ".part.preprocessed")]
+    r = subprocess.run([os.path.join(ROOT, "bin", "gcn-original"), "-t", "2", "-g", "2", "-i", "0", "-m", "4", "-s", "c1", "-r", "1", "-c", "1"] + files +
+                       [str(tmp_path / "out"), str(data / "cora_small_config.txt")], capture_output=True, text=True, timeout=120, cwd=tmp_path,
+                      env=dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"))
+    assert r.returncode != 0 and "single process" in r.stderr

@@ -12,8 +12,9 @@ names, settings, directory layout and log naming, so tools/plot/*.py keep workin
 (tmp_run_cluster.py:116-118, :146).  Where the reference starts one process per party inside a network namespace
 (:224-241), this launcher either hosts all parties on one GPU (`--gpus 1`, default: bin/<executable> once per party log)
 or starts one bin/<executable> -c 1 process per GPU (`--gpus N`, parties in contiguous blocks, shares over RCCL).
-The --cognn-unopt-* experiments run gcn-original, which exists here only as the CPU oracle (oracle/original_gcn.py): they
-are refused with a message.  A single custom run keeps the explicit form:
+The --cognn-unopt-* experiments run bin/gcn-original (the unoptimised kernel; a single process hosts all its parties, so --gpus
+is ignored for them); the FL / plaintext / GraphSC baselines are other programs of the reference and are refused with a message.
+A single custom run keeps the explicit form:
 
     python tools/run_cluster.py --executable gcn-optimize --dataset pubmed --parties 4 --gpus 4 --iterations 12 \\
         --data-dir ./data/Pubmed/transformed/4s --log-dir ./log/gcn-optimize/pubmed/4s
@@ -169,7 +170,7 @@ def run_one(executable, dataset, parties, iterations, setting, data_dir, log_dir
             env["COGNN_LOG_PREFIX"] = os.path.join(log_dir, "gcn_test_%s_" % dataset)
             procs.append(spawn(cmd, env=env, stdout=lf))
         else:                                                 # Python rank (cognn_amd.worker or a test wrapper of it): one log per hosted party
-            variant = "optimize-gcn-inference" if "inference" in executable else "optimize-gcn"
+            variant = "optimize-gcn-inference" if "inference" in executable else "original-gcn" if "original" in executable else "optimize-gcn"
             head = [sys.executable] + (["-m", worker] if not worker.endswith(".py") else [worker])
             cmd = head + common + ["--variant", variant, "--backend", backend, "--log-dir", log_dir, "--log-prefix", "gcn_test_%s_" % dataset] + files
             procs.append(spawn(cmd, env=env))
@@ -187,9 +188,13 @@ EXPERIMENTS = {
     "cognn_opt_inference": ("gcn-inference-optimize", ["cora", "citeseer", "pubmed"], [2], "p", 2, [True, False], "inference"),     # :396-415
     "cognn_opt_accuracy": ("gcn-optimize", ["cora", "citeseer", "pubmed"], [2, 3, 4, 5], "p", 540, [True], "mp-accuracy"),          # :159-168
     "cognn_opt_accuracy_no_preprocess": ("gcn-optimize", ["cora", "citeseer", "pubmed"], [2], "p", 540, [False], "mp-accuracy"),    # :170-180
+    # the unoptimised kernel: 4 GAS iterations = one epoch, 2 = one inference
+    "cognn_unopt_accuracy": ("gcn-original", ["cora", "citeseer", "pubmed"], [2], "p", 4, [True], "mp-accuracy"),                   # :287-296
+    "cognn_unopt_accuracy_no_preprocess": ("gcn-original", ["cora", "citeseer", "pubmed"], [2], "p", 4, [False], "mp-accuracy"),    # :298-307
+    "cognn_unopt_efficiency": ("gcn-original", ["cora", "citeseer", "pubmed"], [2, 3, 4, 5], "s", 4, [True, False], "cognn-scale"),  # :380-395
+    "cognn_unopt_inference": ("gcn-original", ["cora", "citeseer", "pubmed"], [2], "p", 2, [True, False], "inference"),              # :419-435
 }
-UNSUPPORTED = ["cognn_unopt_accuracy", "cognn_unopt_accuracy_no_preprocess", "cognn_unopt_efficiency", "cognn_unopt_inference",
-               "fedgnn_accuracy", "plaintextgnn_accuracy", "graphsc_efficiency"]
+UNSUPPORTED = ["fedgnn_accuracy", "plaintextgnn_accuracy", "graphsc_efficiency"]
 
 
 def run_experiment(name, a):
@@ -206,6 +211,8 @@ def run_experiment(name, a):
                 log_dir = os.path.join(root, "log", executable, dataset, sub) + ("" if pre else "/noPreprocess")
                 setting = "%s/%s/%s" % (executable, dataset, sub)                        # tmp_run_cluster.py:124, :220
                 gpus = max(d for d in range(1, a.gpus + 1) if n % d == 0)      # ranks must host equally many parties
+                if executable == "gcn-original":
+                    gpus = 1                                               # the unoptimised kernel runs as one process
                 rc = rc or run_one(executable, dataset, n, iterations, setting, data_dir, log_dir, gpus=gpus, no_preprocess=not pre,
                                    worker=a.worker, backend=a.backend, timeout=a.timeout)
     return rc
@@ -217,7 +224,7 @@ def main():
         ap.add_argument("--" + name.replace("_", "-"), action="store_true")
     ap.add_argument("--all", action="store_true", help="every supported experiment")
     ap.add_argument("--root", default=".", help="where <application>/{data,log} are created (the reference uses the cwd)")
-    ap.add_argument("--executable", default="gcn-optimize", choices=["gcn-optimize", "gcn-inference-optimize"])
+    ap.add_argument("--executable", default="gcn-optimize", choices=["gcn-optimize", "gcn-inference-optimize", "gcn-original"])
     ap.add_argument("--dataset", default="cora")
     ap.add_argument("--parties", type=int, default=2)
     ap.add_argument("--gpus", type=int, default=1)
@@ -233,8 +240,8 @@ def main():
     a = ap.parse_args()
     for name in UNSUPPORTED:
         if getattr(a, name):
-            print("--%s: gcn-original / the FL, plaintext and GraphSC baselines are not part of this engine "
-                  "(gcn-original exists as the CPU oracle only, oracle/original_gcn.py)" % name.replace("_", "-"), file=sys.stderr)
+            print("--%s: the FL, plaintext and GraphSC baselines are other programs of the reference, not part of this engine"
+                  % name.replace("_", "-"), file=sys.stderr)
             return 2
     chosen = [n for n in EXPERIMENTS if getattr(a, n) or a.all]
     if chosen:
