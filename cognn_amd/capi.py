@@ -31,7 +31,7 @@ class PairChain(ctypes.Structure):
                 ("rows", ctypes.c_int64), ("F", ctypes.c_int64), ("flags", ctypes.c_int32), ("mask_in", ctypes.c_void_p), ("dealt", ctypes.c_void_p)]
 
 
-PC_TRUNC_IN, PC_SCALE, PC_RELU, PC_INPUT_OPENED, PC_NO_C, PC_OPEN_SUM, WU_SWAP = 1, 2, 4, 8, 16, 32, 64
+PC_TRUNC_IN, PC_SCALE, PC_RELU, PC_INPUT_OPENED, PC_NO_C, PC_OPEN_SUM, WU_SWAP, PC_CLEAR_INPUT, WU_CLEAR_Z = 1, 2, 4, 8, 16, 32, 64, 128, 128
 
 
 class PairWUpdate(ctypes.Structure):
@@ -63,7 +63,7 @@ class GemmJob(ctypes.Structure):
     """cognn_gemm_job (include/cognn_hip.h)."""
     _fields_ = [("Z", ctypes.c_void_p), ("E0", ctypes.c_void_p), ("E1", ctypes.c_void_p), ("F0", ctypes.c_void_p), ("F1", ctypes.c_void_p),
                 ("c1", ctypes.c_void_p), ("keys", Keys), ("p", ctypes.c_int32), ("M", ctypes.c_int64), ("scratch", ctypes.c_void_p),
-                ("E_presplit", ctypes.c_void_p), ("A_dealt", ctypes.c_void_p), ("K", ctypes.c_int64)]
+                ("E_presplit", ctypes.c_void_p), ("A_dealt", ctypes.c_void_p), ("K", ctypes.c_int64), ("Z_zeroed", ctypes.c_int32)]
 
 
 class CognnError(RuntimeError):

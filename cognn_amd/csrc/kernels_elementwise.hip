@@ -512,8 +512,10 @@ __global__ void softmax_jobs_zero_kernel(SoftmaxBatch b) {
 // A group of G lanes (G = power of two >= L) owns G consecutive rows: row i of the group is evaluated across the G lanes
 // (lane j = column j, reductions by shuffles, coalesced 8*L-byte row accesses), and lane i keeps row i's bookkeeping, so that
 // the double-precision log of the loss runs once per lane instead of once per row on 1 lane in G.
+// rpg = rows per lane group: G for large inputs (every lane ends up with one row's bookkeeping), 1 for small ones (a group walks one row
+// instead of G in sequence: G times the parallelism when the whole input is a few workgroups)
 template <int G>
-__global__ __launch_bounds__(kThreads) void softmax_jobs_kernel(SoftmaxBatch b, int L) {
+__global__ __launch_bounds__(kThreads) void softmax_jobs_kernel(SoftmaxBatch b, int L, int rpg) {
     __shared__ unsigned long long s_cnt[5];
     __shared__ double s_loss;
     const unsigned blk = blockIdx.x;
@@ -522,9 +524,9 @@ __global__ __launch_bounds__(kThreads) void softmax_jobs_kernel(SoftmaxBatch b, 
     const SoftmaxJobDev& d = b.j[seg];
     const unsigned blk0 = seg ? b.blk_end[seg - 1] : 0u;
     const int j = threadIdx.x % G;
-    const int64_t rb = (((int64_t)(blk - blk0) * kThreads + threadIdx.x) / G) * G;     // first row of this lane group
+    const int64_t rb = (((int64_t)(blk - blk0) * kThreads + threadIdx.x) / G) * rpg;   // first row of this lane group
     if (d.p == 1) {                                          // (uniform per workgroup) the co-party's share is its mask
-        for (int i = 0; i < G; ++i) {
+        for (int i = 0; i < rpg; ++i) {
             const int64_t r = rb + i, idx = r * L + j;
             if (r < d.rows && j < L) d.d_out[idx] = r < d.train_rows ? cognn_prng(d.keyRho, (u64)idx) : 0ull;
         }
@@ -536,7 +538,7 @@ __global__ __launch_bounds__(kThreads) void softmax_jobs_kernel(SoftmaxBatch b, 
     const long long NEG = -(1ll << 62);
     double my_pl = 1.0;                                      // log(1) = 0 for lanes without a row
     bool ok = false, tr = false, te = false, bd = false;
-    for (int i = 0; i < G; ++i) {                            // (uniform inside every shuffle group)
+    for (int i = 0; i < rpg; ++i) {                          // (uniform inside every shuffle group)
         const int64_t r = rb + i;
         const bool valid = r < d.rows && j < L;
         const int64_t idx = r * L + j;
@@ -614,6 +616,10 @@ __global__ __launch_bounds__(kThreads) void pair_chain_kernel(PairBatch b) {
     const PcSlotBase SB = pc_slot_base(flags, d.open0 != nullptr || d.open1 != nullptr);
     u64 v0[2], v1[2];
     ld2(d.x0, i, w, v0); ld2(d.x1, i, w, v1);
+    if (flags & COGNN_PC_CLEAR_INPUT) {                      // the product buffers go back clean (cognn_gemm_job::Z_zeroed)
+        const u64 zero[2] = {0, 0};
+        st2(const_cast<u64*>(d.x0), i, w, zero); st2(const_cast<u64*>(d.x1), i, w, zero);
+    }
     if (d.mask_in) {                                         // MaskSelect on both sides' inputs
         if (!d.mask_in[i]) { v0[0] = 0; v1[0] = 0; }
         if (w == 2 && !d.mask_in[i + 1]) { v0[1] = 0; v1[1] = 0; }
@@ -670,7 +676,7 @@ struct PairWUpdateDev {
     u64 keyC0;
     u64 kR[4], kR0[4], kRP0[4];      // the three truncation streams of: product, gradient scale, learning rate, post scale
     u64 mul[3];
-    int64_t n; int addc; int swap;
+    int64_t n; int addc; int swap; int clear;
 };
 constexpr int kWUpdateMax = 16;
 struct PairWUpdateBatch {
@@ -688,6 +694,10 @@ __device__ __forceinline__ void trunc2(u64 kR, u64 kR0, u64 kRP0, u64 idx, u64& 
 __device__ __forceinline__ void wupdate_pair(const PairWUpdateDev& d, int64_t i, int w, u64* w0, u64* w1) {
     u64 v0[2], v1[2], cc[2] = {0, 0};
     ld2(d.z0, i, w, v0); ld2(d.z1, i, w, v1);
+    if (d.clear) {
+        const u64 zero[2] = {0, 0};
+        st2(const_cast<u64*>(d.z0), i, w, zero); st2(const_cast<u64*>(d.z1), i, w, zero);
+    }
     ld2(d.W0, i, w, w0); ld2(d.W1, i, w, w1);
     if (d.addc) ld2(d.c1, i, w, cc);
     for (int j = 0; j < w; ++j) {
@@ -915,6 +925,9 @@ int cognn_softmax_jobs_u64(cognn_ctx* ctx, const cognn_softmax_job* jobs, int32_
     CG_REQUIRE(L > 0 && L <= 64, "cognn_softmax_jobs_u64: unsupported label count %lld (max 64)", (long long)L);
     int G = 1;
     while (G < L) G <<= 1;
+    int64_t rows_all = 0;
+    for (int32_t c = 0; c < count; ++c) rows_all += std::max<int64_t>(jobs[c].rows, 0);
+    const int rpg = (rows_all * G <= 2048ll * kThreads) ? 1 : G;     // small inputs: one row per lane group
     for (int32_t c0 = 0; c0 < count; c0 += kSoftmaxJobsMax) {
         SoftmaxBatch b;
         b.count = 0;
@@ -926,7 +939,7 @@ int cognn_softmax_jobs_u64(cognn_ctx* ctx, const cognn_softmax_job* jobs, int32_
             d.d_out = (u64*)s.d_out; d.z0 = (const u64*)s.z0; d.z1 = (const u64*)s.z1; d.labels = s.labels; d.border = s.border;
             d.keyRho = s.keys.k[COGNN_SL_RHO]; d.p = s.p; d.rows = s.rows; d.train_rows = s.train_rows; d.val_rows = s.val_rows;
             d.counts = (unsigned long long*)s.counts6; d.loss = s.loss;
-            const unsigned blocks = (unsigned)cg_div_up(s.rows, kThreads);      // a lane group of G lanes owns G rows
+            const unsigned blocks = (unsigned)cg_div_up(cg_div_up(s.rows, rpg) * (int64_t)G, kThreads);   // a lane group of G lanes owns rpg rows
             b.blk_end[b.count] = (b.count ? b.blk_end[b.count - 1] : 0u) + blocks;
             ++b.count;
         }
@@ -934,7 +947,7 @@ int cognn_softmax_jobs_u64(cognn_ctx* ctx, const cognn_softmax_job* jobs, int32_
         CG_LAUNCH_CHECK();
         const unsigned blocks = b.blk_end[b.count - 1];
         if (blocks == 0) continue;
-#define CG_SJ_CASE(g) case g: hipLaunchKernelGGL(softmax_jobs_kernel<g>, dim3(blocks), dim3(kThreads), 0, ctx->stream, b, (int)L); break;
+#define CG_SJ_CASE(g) case g: hipLaunchKernelGGL(softmax_jobs_kernel<g>, dim3(blocks), dim3(kThreads), 0, ctx->stream, b, (int)L, rpg); break;
         switch (G) { CG_SJ_CASE(1) CG_SJ_CASE(2) CG_SJ_CASE(4) CG_SJ_CASE(8) CG_SJ_CASE(16) CG_SJ_CASE(32) CG_SJ_CASE(64) }
 #undef CG_SJ_CASE
         CG_LAUNCH_CHECK();
@@ -977,6 +990,8 @@ int cognn_pair_chain_u64(cognn_ctx* ctx, const cognn_pair_chain* chains, int32_t
         d.out0 = (u64*)s.out[0]; d.out1 = (u64*)s.out[1]; d.open0 = (u64*)s.open[0]; d.open1 = (u64*)s.open[1]; d.mask = s.mask;
         d.mask_in = s.mask_in;
         CG_REQUIRE(!s.mask_in || !(fl & COGNN_PC_INPUT_OPENED), "cognn_pair_chain_u64: chain %d: mask_in needs plain input shares", c);
+        CG_REQUIRE(!(fl & COGNN_PC_CLEAR_INPUT) || ((fl & COGNN_PC_TRUNC_IN) && s.x[0] != s.out[0] && s.x[1] != s.out[1] && s.x[0] != s.out[1] && s.x[1] != s.out[0]),
+                   "cognn_pair_chain_u64: chain %d: COGNN_PC_CLEAR_INPUT is for product buffers that are not also an output", c);
         pair_chain_fill_keys(d, s);
         d.n = n; d.F = (uint32_t)std::max<int64_t>(s.F, 1); d.flags = (uint32_t)fl;
         d.slab = (const u64*)s.dealt;
@@ -1021,7 +1036,7 @@ int cognn_pair_weight_update_u64(cognn_ctx* ctx, const cognn_pair_wupdate* jobs,
             d.kR[t] = s.trunc_keys[t].k[COGNN_SL_R]; d.kR0[t] = s.trunc_keys[t].k[COGNN_SL_R0]; d.kRP0[t] = s.trunc_keys[t].k[COGNN_SL_RP0];
         }
         for (int t = 0; t < 3; ++t) d.mul[t] = s.mul[t];
-        d.n = s.n; d.addc = addc ? 1 : 0; d.swap = (s.flags & COGNN_WU_SWAP) ? 1 : 0;
+        d.n = s.n; d.addc = addc ? 1 : 0; d.swap = (s.flags & COGNN_WU_SWAP) ? 1 : 0; d.clear = (s.flags & COGNN_WU_CLEAR_Z) ? 1 : 0;
         const unsigned blocks = (unsigned)(((s.n + 1) / 2 + kThreads - 1) / kThreads);
         b.blk_end[b.count] = (b.count ? b.blk_end[b.count - 1] : 0u) + blocks;
         ++b.count;

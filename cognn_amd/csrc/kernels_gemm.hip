@@ -1959,7 +1959,7 @@ extern "C" int cognn_beaver_gemm_close_group_u64(cognn_ctx* ctx, const cognn_gem
         } else {
             d.ngroups = (tiles + waves - 1) / waves;           // one row tile per wave and K range
             wg_end += d.ngroups * splits;
-            z.p[z.count] = (u64*)J.Z; z.n[z.count] = (unsigned)(J.M * N); zmax = std::max(zmax, z.n[z.count]); ++z.count;
+            if (!J.Z_zeroed) { z.p[z.count] = (u64*)J.Z; z.n[z.count] = (unsigned)(J.M * N); zmax = std::max(zmax, z.n[z.count]); ++z.count; }
             CG_REQUIRE(J.M * N < (1ll << 32), "cognn_beaver_gemm_close_group_u64: job %d: output too large for the split-K form", j);
         }
         d.wg_end = wg_end;
@@ -2021,7 +2021,7 @@ extern "C" int cognn_beaver_gemm_close_group_tn_u64(cognn_ctx* ctx, const cognn_
     unsigned zmax = 0;
     for (int32_t j = 0; j < count; ++j) {
         const cognn_gemm_job& J = jobs[j];
-        z.p[z.count] = (u64*)J.Z; z.n[z.count] = (unsigned)(M * N); zmax = std::max(zmax, z.n[z.count]); ++z.count;
+        if (!J.Z_zeroed) { z.p[z.count] = (u64*)J.Z; z.n[z.count] = (unsigned)(M * N); zmax = std::max(zmax, z.n[z.count]); ++z.count; }
         if (J.K <= 0) continue;
         GemmTnJob& d = g.j[g.count++];
         d.Z = (u64*)J.Z; d.E0 = (const u64*)J.E0; d.E1 = (const u64*)J.E1; d.F = (const u64*)J.F0; d.F1 = (const u64*)J.F1;

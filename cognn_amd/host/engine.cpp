@@ -66,6 +66,9 @@ struct Side {
     u64* ib[3] = {nullptr, nullptr, nullptr};      // peer's outboxes (aliases when the peer is on this rank)
     u64* scratch = nullptr;
     u64* zbuf = nullptr;           // untruncated GEMM output
+    // zbuf[z_dirty, z_zero) is known to be zero: a product dirties [0, M x N); the pair kernels that consume a SMALL product clear
+    // it behind their read (COGNN_PC_CLEAR_INPUT / COGNN_WU_CLEAR_Z), so the next split-K product skips its zeroing launch
+    int64_t z_dirty = 0, z_zero = 0;
     u64* small[3] = {nullptr, nullptr, nullptr};   // [in x hid]-sized temporaries for the weight chain
     u64* svec = nullptr;           // normaliser share [n]
     int32_t* labels = nullptr;
@@ -345,6 +348,12 @@ enum { X_OPEN_HERE = 0, X_H1E_FRESH = 1, X_H1E_REUSE = 2 };
 // (cognn_pair_chain_u64: both sides' local arithmetic in one kernel, opened values handed over in registers) instead of
 // open -> HBM -> close passes; the per-side stages below then skip those sides.
 bool paired(const cognn_engine* E, const Side& s) { return E->pair_fusion && s.peer != nullptr; }
+// product-buffer bookkeeping (Side::z_dirty / z_zero): small products are handed back clean by their consumer
+const int64_t kClearMaxElems = 1 << 19;                    // 4 MiB per side: above that the extra writes cost more than a zeroing launch
+bool z_is_zero(const Side& s, int64_t n) { return s.z_dirty == 0 && s.z_zero >= n; }
+void z_written(Side& s, int64_t n) { s.z_dirty = std::max(s.z_dirty, n); }
+bool z_clear_wanted(const Side& s, int64_t n) { return n <= kClearMaxElems && n >= s.z_dirty; }   // the clear leaves the whole buffer clean
+void z_cleared(Side& s, int64_t n) { if (n >= s.z_dirty) s.z_dirty = 0; }
 // A pair chain writes the opening of the step that follows it ONCE, as the sum of both parties' shares of it, into the owner
 // side's buffer (COGNN_PC_OPEN_SUM): both sides of the pair read it from there as a pre-summed operand.
 template <class Sel>
@@ -680,6 +689,8 @@ bool gemm_stage(cognn_engine* E, int64_t it, XFn X, WFn Wm, SpecFn spec, DstFn d
                 J.F0 = (w_opened && paired(E, s)) ? pair_opening(s, [](Side& x) { return x.ob[1]; }) : s.ob[1];
                 J.F1 = f_sum ? nullptr : s.ib[1];
                 J.Z = s.zbuf; J.keys = k; J.p = s.p; J.M = g.M; J.K = g.K; J.scratch = s.scratch;
+                J.Z_zeroed = z_is_zero(s, eo[i]) ? 1 : 0;
+                z_written(s, eo[i]);
                 if (g.feature == 1) J.E_presplit = s.featPl;
                 if (!tn_group) J.A_dealt = dealt_mask(E, s.owner, it, s.p == 0 ? DEAL_GEMM_A0 : DEAL_GEMM_A1, k.k[s.p == 0 ? COGNN_SL_A0 : COGNN_SL_A1], g.M * g.K);
                 jobs.push_back(J); idx.push_back(i);
@@ -728,6 +739,7 @@ bool gemm_stage(cognn_engine* E, int64_t it, XFn X, WFn Wm, SpecFn spec, DstFn d
                                         g.K, g.transA, s.scratch, all_raw ? 1 : 0));
         if (E->timing) E->algo[T_GEMM] += 2.0 * 36 * 2 * (double)g.M * g.K * g.N;
         c1_of[i] = c1;
+        z_written(s, eo[i]);
         if (all_raw && !paired(E, s) && !(chunk_trunc && !s.peer)) {
             cognn_keys tk = keys(E, s.owner, it, g.top);
             BE(cognn_trunc_open_add_u64(E->ctx, s.ob[2], s.zbuf, c1, &k, &tk, s.p, eo[i]));
@@ -745,6 +757,7 @@ bool gemm_stage(cognn_engine* E, int64_t it, XFn X, WFn Wm, SpecFn spec, DstFn d
             GemmSpec g = spec(s);
             cognn_pair_chain& c = pc.add(s, s.zbuf, t.zbuf, g.M, g.N);
             c.flags = COGNN_PC_TRUNC_IN | (all_raw ? 0 : COGNN_PC_NO_C);
+            if (z_clear_wanted(s, g.M * g.N) && z_clear_wanted(t, g.M * g.N)) { c.flags |= COGNN_PC_CLEAR_INPUT; z_cleared(s, g.M * g.N); z_cleared(t, g.M * g.N); }
             c.gemm_keys = gkeys(s, g);
             c.trunc_in_keys = keys(E, s.owner, it, g.top);
             if (all_raw) c.c1 = t.c1.at({it, g.op}).ptr;
@@ -1249,6 +1262,7 @@ bool weight_update_chain(cognn_engine* E, int64_t it, int layer, bool pairs_fuse
             J.mul[0] = gscale(s); J.mul[1] = lr; J.mul[2] = inference ? fx_trunc(1.0 / E->k) : 0;   // optimize-gcn-inference/gcn.h:680-681,732-733
             J.n = elems;
             J.flags = (raw ? 0 : COGNN_PC_NO_C) | (s.owner == 0 ? 0 : COGNN_WU_SWAP);   // owner 0 keeps (s0, s1); owners >= 1 keep (s1, s0)
+            if (z_clear_wanted(s, elems) && z_clear_wanted(t, elems)) { J.flags |= COGNN_WU_CLEAR_Z; z_cleared(s, elems); z_cleared(t, elems); }
             jobs.push_back(J);
         }
         averaged = all && E->world == 1 && jobs.size() <= 16 && elems > 0;
@@ -1856,7 +1870,12 @@ void alloc_sides(cognn_engine* E) {
         for (int j = 0; j < 3; ++j) s.ob[j] = dalloc<u64>(E, big);
         for (int j = 0; j < 3; ++j) s.small[j] = dalloc<u64>(E, (size_t)in * hid + (size_t)hid * lab);
         s.scratch = dalloc<u64>(E, big + std::max<size_t>({(size_t)in * hid, n * (size_t)fm, (size_t)hid * lab}));
-        s.zbuf = dalloc<u64>(E, std::max<size_t>({(size_t)in * hid, n * (size_t)fm, (size_t)hid * lab}));
+        {
+            const size_t zcap = std::max<size_t>({(size_t)in * hid, n * (size_t)fm, (size_t)hid * lab});
+            s.zbuf = dalloc<u64>(E, zcap);
+            BE(cognn_memset0(E->ctx, s.zbuf, zcap * 8));
+            s.z_dirty = 0; s.z_zero = (int64_t)zcap;
+        }
         s.svec = dalloc<u64>(E, n);
         if (s.p == 0) {
             s.labels = dalloc<int32_t>(E, n);

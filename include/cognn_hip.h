@@ -171,6 +171,9 @@ typedef struct {
     const uint64_t* A_dealt;                     /* optional (COGNN_OPT_DEALER_STREAMS): this party's mask A_p [M x K] as dealt (cognn_prng_fill_u64
                                                   * with its A key): read instead of regenerated (grouped kernel only) */
     int64_t K;                                   /* cognn_beaver_gemm_close_group_tn_u64 only: the job's inner dimension (rows of its party) */
+    int32_t Z_zeroed;                            /* the caller guarantees that Z[0 .. M x N) is zero on entry (its last reader cleared it:
+                                                  * COGNN_PC_CLEAR_INPUT / COGNN_WU_CLEAR_Z): the split-K forms, which add partial tiles
+                                                  * into Z, then skip their own zeroing launch; ignored by the whole-K form */
 } cognn_gemm_job;
 int cognn_beaver_gemm_close_group_u64(cognn_ctx*, const cognn_gemm_job* jobs, int32_t count, int64_t N, int64_t K, int raw);
 /* The weight-gradient products of one phase, d = h_t^T . in of every hosted side (gcn.h:671,710), as one launch: logical A [M x K]
@@ -286,7 +289,11 @@ int cognn_softmax_jobs_u64(cognn_ctx*, const cognn_softmax_job* jobs, int32_t co
 enum { COGNN_PC_TRUNC_IN = 1, COGNN_PC_SCALE = 2, COGNN_PC_RELU = 4, COGNN_PC_INPUT_OPENED = 8, COGNN_PC_NO_C = 16,
        /* open[0] receives (out_0 - a_0) + (out_1 - a_1), the opening as both parties hold it after the exchange; open[1] must be
         * NULL: one tensor written instead of two, and the consuming product streams one operand instead of summing two */
-       COGNN_PC_OPEN_SUM = 32 };
+       COGNN_PC_OPEN_SUM = 32,
+       /* COGNN_PC_TRUNC_IN chains only: x[0], x[1] are zeroed behind the read - the product buffer is handed back clean to the next
+        * split-K product (cognn_gemm_job::Z_zeroed), which saves that product's zeroing launch; worth it for small tensors only
+        * (+16 B of writes per element pair) */
+       COGNN_PC_CLEAR_INPUT = 128 };
 typedef struct {
     const uint64_t* x[2];        /* the two sides' input shares [rows x F] */
     const uint64_t* c1;          /* side 1's dealt product share (COGNN_PC_TRUNC_IN without COGNN_PC_NO_C) */
@@ -326,7 +333,7 @@ int cognn_pair_chain_u64(cognn_ctx*, const cognn_pair_chain* chains, int32_t cou
  * the same pass - sum_0 = sum over jobs of W[swap ? 1 : 0], sum_1 = of the other share (owner 0 keeps (s0, s1), owners >= 1
  * (s1, s0): COGNN_WU_SWAP); avg_mul != 0: (sum_0, sum_1) = trunc(sum * avg_mul; avg_keys) between parties 0 and 1; every job's
  * W[swap ? 1 : 0] = sum_0 and its other share = sum_1.  Bit-identical to cognn_sum_u64 x 2, the truncation and cognn_fanout_u64 x 2. */
-enum { COGNN_WU_SWAP = 64 };
+enum { COGNN_WU_SWAP = 64, COGNN_WU_CLEAR_Z = 128 /* z[0], z[1] are zeroed behind the read (see COGNN_PC_CLEAR_INPUT) */ };
 typedef struct {
     const uint64_t* z[2];        /* the two sides' product shares [n] */
     const uint64_t* c1;          /* side 1's dealt product share (flags without COGNN_PC_NO_C) */
@@ -335,7 +342,7 @@ typedef struct {
     cognn_keys trunc_keys[4];
     uint64_t mul[3];             /* gradient scale 1/|train|, learning rate, post scale (0: none) - Q16 */
     int64_t n;
-    int32_t flags;               /* COGNN_PC_NO_C, COGNN_WU_SWAP */
+    int32_t flags;               /* COGNN_PC_NO_C, COGNN_WU_SWAP, COGNN_WU_CLEAR_Z */
 } cognn_pair_wupdate;
 int cognn_pair_weight_update_u64(cognn_ctx*, const cognn_pair_wupdate* jobs, int32_t count, const cognn_keys* avg_keys, uint64_t avg_mul,
                                  int32_t average);

@@ -492,6 +492,8 @@ int cognn_pair_chain_u64(cognn_ctx* ctx, const cognn_pair_chain* chains, int32_t
         REQ(s.x[0] && s.x[1], "pair_chain: null input");
         std::vector<u64> cur[2], o0[2], o1[2];
         for (int p = 0; p < 2; ++p) { cur[p].assign(s.x[p], s.x[p] + n); o0[p].resize((size_t)n); o1[p].resize((size_t)n); }
+        if (s.flags & COGNN_PC_CLEAR_INPUT)                 // the product buffers go back clean
+            for (int p = 0; p < 2; ++p) memset(const_cast<uint64_t*>(s.x[p]), 0, (size_t)n * 8);
         if (s.mask_in)                                      // cognn_mask_select_u64 on both sides' inputs
             for (int p = 0; p < 2; ++p) {
                 std::vector<u64> sel((size_t)n);
@@ -585,6 +587,8 @@ int cognn_pair_weight_update_u64(cognn_ctx* ctx, const cognn_pair_wupdate* jobs,
             cognn_trunc_close_u64(ctx, s.W[0], c0.data(), c1.data(), &s.trunc_keys[3], 0, 0, n);
             cognn_trunc_close_u64(ctx, s.W[1], nullptr, nullptr, &s.trunc_keys[3], 1, 0, n);
         }
+        if (s.flags & COGNN_WU_CLEAR_Z)
+            for (int p = 0; p < 2; ++p) memset(const_cast<uint64_t*>(s.z[p]), 0, (size_t)n * 8);
     }
     if (average) {                                         // cognn_sum_u64 x 2, the 1/k truncation, cognn_fanout_u64 x 2
         const int64_t n = jobs[0].n;

@@ -507,6 +507,23 @@ def test_beaver_gemm_group(ctx, N, K, Ms, two, presplit):
         with np.errstate(over="ignore"):
             assert np.array_equal(host(want[2 * q][0]) + co.prng_shape(kf(co.SL_C0), (M, N)), want[2 * q][1])
             assert np.array_equal(host(want[2 * q + 1][0]) + host(c1s[q]), want[2 * q + 1][1])
+    # Z_zeroed: the caller vouches for a clean output (its last reader cleared it: COGNN_PC_CLEAR_INPUT / COGNN_WU_CLEAR_Z).  The split-K
+    # form then adds into Z without zeroing it first - shown by planting a marker: it survives in the result exactly when the launch
+    # took K ranges (few row tiles / long K), and a clean Z gives the plain raw product either way
+    raw = [host(Z).copy() for Z, _ in want]
+    for j in range(len(jobs)):
+        jobs[j].Z_zeroed = 1
+        want[j][0].zero_()
+    ctx.call("cognn_beaver_gemm_close_group_u64", jobs, len(jobs), N, K, 1)
+    for j, (Z, _) in enumerate(want):
+        assert np.array_equal(host(Z), raw[j])
+    for Z, _ in want:
+        Z.fill_(5)
+    ctx.call("cognn_beaver_gemm_close_group_u64", jobs, len(jobs), N, K, 1)
+    with np.errstate(over="ignore"):
+        kept = [np.array_equal(host(Z), raw[j] + U64(5)) for j, (Z, _) in enumerate(want)]
+        plain = [np.array_equal(host(Z), raw[j]) for j, (Z, _) in enumerate(want)]
+    assert all(kept) or all(plain), (kept, plain)            # (split K: added onto the marker; whole K or per-job path: plain stores)
 
 
 def test_gather_csr_open_epilogue(ctx):

@@ -304,3 +304,51 @@ def test_mask_open_reads_a_transposed_weight_matrix(ctx, rows, cols):
     ctx.sync()
     with np.errstate(over="ignore"):
         assert np.array_equal(host(E), X.T - co.prng_shape(key, (rows, cols)))
+
+
+def test_consumers_hand_the_product_buffers_back_clean(ctx):
+    """COGNN_PC_CLEAR_INPUT / COGNN_WU_CLEAR_Z: the kernel that reads a raw product zeroes it behind the read (the next split-K
+    product then skips its zeroing launch, cognn_gemm_job::Z_zeroed); results are those of the plain form."""
+    from cognn_amd import capi
+    rng = np.random.default_rng(12)
+    rows, F = 301, 16
+    n = rows * F
+    x0 = rand_u64(rng, (rows, F)) >> U64(20); x1 = rand_u64(rng, (rows, F)); c1 = rand_u64(rng, (rows, F)) >> U64(30)
+    ks = {nm: _keys(5, 3, 9, op) for nm, op in (("gemm", co.OP_PS_GEMM), ("tin", co.OP_PS_GEMM_TRUNC))}
+    outs = []
+    for clear in (0, capi.PC_CLEAR_INPUT):
+        X0, X1 = dev(x0), dev(x1)
+        out0, out1 = dev_empty((rows, F)), dev_empty((rows, F))
+        c = capi.PairChain()
+        c.x[0] = X0.data_ptr(); c.x[1] = X1.data_ptr(); c.c1 = dev(c1).data_ptr()
+        c.out[0] = out0.data_ptr(); c.out[1] = out1.data_ptr()
+        c.gemm_keys = ks["gemm"][0]; c.trunc_in_keys = ks["tin"][0]
+        c.rows = rows; c.F = F; c.flags = TRUNC_IN | clear
+        ctx.call("cognn_pair_chain_u64", ctypes.byref(c), 1)
+        ctx.sync()
+        outs.append((host(out0).copy(), host(out1).copy()))
+        if clear:
+            assert not host(X0).any() and not host(X1).any()
+        else:
+            assert np.array_equal(host(X0), x0) and np.array_equal(host(X1), x1)
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    # an output that aliases the product buffer cannot be combined with the clear
+    c.out[0] = c.x[0]
+    with pytest.raises(capi.CognnError, match="CLEAR_INPUT"):
+        ctx.call("cognn_pair_chain_u64", ctypes.byref(c), 1)
+    # weight update
+    res = []
+    for clear in (0, capi.WU_CLEAR_Z):
+        jobs = (capi.PairWUpdate * 1)()
+        J = jobs[0]
+        Z0, Z1, W0, W1 = dev(x0.reshape(-1)), dev(x1.reshape(-1)), dev(x1.reshape(-1) >> U64(3)), dev(x0.reshape(-1))
+        J.z[0] = Z0.data_ptr(); J.z[1] = Z1.data_ptr(); J.c1 = dev(c1.reshape(-1)).data_ptr(); J.W[0] = W0.data_ptr(); J.W[1] = W1.data_ptr()
+        J.gemm_keys = ks["gemm"][0]
+        for t in range(4):
+            J.trunc_keys[t] = _keys(5, 3, 9, co.OP_AP_GSCALE_TRUNC + t)[0]
+        J.mul[0] = 700; J.mul[1] = 32768; J.mul[2] = 0; J.n = n; J.flags = clear
+        ctx.call("cognn_pair_weight_update_u64", jobs, 1, None, 0, 0)
+        ctx.sync()
+        res.append((host(W0).copy(), host(W1).copy()))
+        assert (not host(Z0).any() and not host(Z1).any()) if clear else np.array_equal(host(Z0), x0.reshape(-1))
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
