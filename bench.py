@@ -206,6 +206,7 @@ def dealer_streams_leg(eng, torch, args, iters, k, digest_before):
     dt = time.perf_counter() - t0
     n_agg, ms_agg, bytes_agg = eng.timing(0)
     n_gemm, ms_gemm, ops_gemm = eng.timing(2)
+    n_gepi, ms_gepi, ops_gepi = eng.timing(3)
     eng.enable_timing(False)
     res = {"what": "dealer values of the pair chains (truncations, row scales, ReLUs, openings: what each party receives) and the A masks of the "
                    "grouped products read from HBM instead of regenerated from the counter PRNG; same shares",
@@ -331,6 +332,7 @@ def main():
     n_agg, ms_agg, bytes_agg = eng.timing(0)
     n_part, ms_part, bytes_part = eng.timing(1)
     n_gemm, ms_gemm, ops_gemm = eng.timing(2)
+    n_gepi, ms_gepi, ops_gepi = eng.timing(3)
     eng.enable_timing(False)
 
     # HBM traffic of the dominant kernel: NOT measured by this run - it is read from the newest committed PMC summary
@@ -384,7 +386,14 @@ def main():
                     # one timed phase = the products of all hosted sides in one GAS iteration (they overlap on two launch lanes)
                     "beaver_gemm_close": {"phases": n_gemm, "avg_ms_per_phase": ms_gemm / max(n_gemm, 1),
                                           "i8_TOPs": (ops_gemm / 1e12) / (ms_gemm / 1e3) if ms_gemm > 0 else None,
-                                          "frac_of_5000_TOPs": ((ops_gemm / 1e12) / (ms_gemm / 1e3) / 5000.0) if ms_gemm > 0 else None}},
+                                          "frac_of_5000_TOPs": ((ops_gemm / 1e12) / (ms_gemm / 1e3) / 5000.0) if ms_gemm > 0 else None,
+                                          "what": "the launches that are Beaver products and nothing else"},
+                    # products of the co-located pairs' p = 1 sides with the pair's truncation chain as their epilogue (cognn_gemm_job::epilogue,
+                    # N > 16): the launch also does the chain's work (reads the p = 0 product and C_1, writes both outputs) - its operation
+                    # count is the product's alone, so this rate is NOT comparable with the pure products' above
+                    "beaver_gemm_close_with_chain_epilogue": {"launches": n_gepi, "avg_ms": ms_gepi / max(n_gepi, 1),
+                                                              "i8_TOPs": (ops_gepi / 1e12) / (ms_gepi / 1e3) if ms_gepi > 0 else None,
+                                                              "frac_of_5000_TOPs": ((ops_gepi / 1e12) / (ms_gepi / 1e3) / 5000.0) if ms_gepi > 0 else None}},
         "graph": wlinfo,
         "launch": "recorded epoch replayed (hipGraph)" if recorded else "one launch per kernel",
     }

@@ -161,7 +161,7 @@ int cognn_memset0(cognn_ctx* ctx, void* dst, size_t bytes) {
 }
 int cognn_timer_begin(cognn_ctx* ctx, int kind) {
     { const int rc_flush_ = cg_flush(ctx); if (rc_flush_) return rc_flush_; }
-    CG_REQUIRE(ctx && kind >= 0 && kind < 8, "cognn_timer_begin: bad arguments");
+    CG_REQUIRE(ctx && kind >= 0 && kind < 10, "cognn_timer_begin: bad arguments");
     hipEvent_t ev;
     CG_HIP(hipEventCreate(&ev));
     CG_HIP(hipEventRecord(ev, ctx->stream));
@@ -170,7 +170,7 @@ int cognn_timer_begin(cognn_ctx* ctx, int kind) {
 }
 int cognn_timer_end(cognn_ctx* ctx, int kind) {
     { const int rc_flush_ = cg_flush(ctx); if (rc_flush_) return rc_flush_; }
-    CG_REQUIRE(ctx && kind >= 0 && kind < 8 && !ctx->open_begin[kind].empty(), "cognn_timer_end: no open timer");
+    CG_REQUIRE(ctx && kind >= 0 && kind < 10 && !ctx->open_begin[kind].empty(), "cognn_timer_end: no open timer");
     hipEvent_t ev;
     CG_HIP(hipEventCreate(&ev));
     CG_HIP(hipEventRecord(ev, ctx->stream));
@@ -180,7 +180,7 @@ int cognn_timer_end(cognn_ctx* ctx, int kind) {
     return 0;
 }
 int cognn_timer_read(cognn_ctx* ctx, int kind, int64_t* launches, double* total_ms) {
-    CG_REQUIRE(ctx && kind >= 0 && kind < 8 && launches && total_ms, "cognn_timer_read: bad arguments");
+    CG_REQUIRE(ctx && kind >= 0 && kind < 10 && launches && total_ms, "cognn_timer_read: bad arguments");
     CG_HIP(hipStreamSynchronize(ctx->stream));
     double tot = 0;
     for (auto& pr : ctx->timers[kind]) {

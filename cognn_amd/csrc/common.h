@@ -19,8 +19,8 @@ struct cognn_ctx {
     int device;
     hipStream_t stream;
     bool own_stream;
-    std::vector<cognn_timer_pair> timers[8];   // per kind
-    std::vector<hipEvent_t> open_begin[8];
+    std::vector<cognn_timer_pair> timers[10];  // per kind
+    std::vector<hipEvent_t> open_begin[10];
     int batch_depth = 0;
     cognn_pending_batch pending;
     // launch lanes (cognn_lane_begin): auxiliary streams, created on first use

@@ -17,6 +17,7 @@
 #include <cstdlib>
 #include <cstring>
 #include "../../include/cognn_hip.h"
+#include "pair_chain.h"
 
 namespace {
 
@@ -797,6 +798,13 @@ struct GemmGroup {
     int count, N, K, nst;
     int ksteps;                                              // SPLITK: K steps per workgroup (its B fragments fit LDS); Z holds zeros on entry
 };
+// EPI: the jobs of the launch are the p = 1 sides of co-located pairs whose p = 0 products an earlier launch has written: the
+// truncation (+ row scale) chain of the pair (pair_chain.h) runs on the accumulator tile and the peer's raw product, and the chain's
+// outputs are stored instead of the product (cognn_gemm_job::epilogue).  One descriptor per job, at most kEpiMax jobs.
+constexpr int kEpiMax = 8;
+struct GemmEpi {
+    PairChainDev d[kEpiMax];
+};
 // The E halves of the A fragments ([tile][k step][16-byte piece j][lane]: piece j of a lane = plane words (pe0[2j], pe1[2j],
 // pe0[2j+1], pe1[2j+1]) of beaver_gemm_group_kernel) of an opened operand that is used many times - the constant feature opening
 // of the layer-0 product: the same bytes as the operand itself (8 per element, rows padded to 16, K to 32), limb-split and
@@ -831,9 +839,9 @@ __global__ __launch_bounds__(256) void presplit_e_kernel(u64x2* out, const u64* 
 // SPLITK (few row tiles, long K: the dataset-sized graphs - Cora's 1354 x 1433): a workgroup serves (job, group of row tiles,
 // K range of g.ksteps steps), builds the B fragments of its K range only and adds its partial tiles into the zeroed Z with
 // uint64 atomics (exact: integer adds commute).
-template <int NT, int WAVES, bool FULL, bool KEVEN, bool PRE = false, bool SPLITK = false>
+template <int NT, int WAVES, bool FULL, bool KEVEN, bool PRE = false, bool SPLITK = false, bool EPI = false>
 __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(2, NT == 1 ? 4 : 2)))
-void beaver_gemm_group_kernel(GemmGroup g) {
+void beaver_gemm_group_kernel(GemmGroup g, GemmEpi epi) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int kThreadsG = WAVES * 64;
     int job = 0;
@@ -980,7 +988,34 @@ void beaver_gemm_group_kernel(GemmGroup g) {
 #pragma unroll
                 for (int jj = 0; jj + i < 8; ++jj) acc[t][i + jj] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[i], bf[jj], acc[t][i + jj], 0, 0, 0);
         }
-        if (ls == nst - 1) {
+        if (EPI && ls == nst - 1) {
+            // the pair's chain on this tile: own accumulators = side 1's raw product, side 0's comes from the earlier launch
+            const PairChainDev& d = epi.d[job];
+            const bool addc = !(d.flags & COGNN_PC_NO_C), scale = (d.flags & COGNN_PC_SCALE) != 0;
+            PairRow rw[4];
+            if (scale)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) rw[q] = pair_row(d, (u64)min(tile * 16 + 4 * b + q, M - 1));
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int col = t * 16 + (lane & 15);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int row = tile * 16 + 4 * b + q;
+                    const uint32_t hi = (uint32_t)acc[t][4][q] + ((uint32_t)acc[t][5][q] << 8) + ((uint32_t)acc[t][6][q] << 16) + ((uint32_t)acc[t][7][q] << 24);
+                    const long long lo = (long long)acc[t][0][q] + (long long)acc[t][1][q] * 256 + (long long)acc[t][2][q] * 65536 +
+                                         (long long)acc[t][3][q] * 16777216;
+                    if ((FULL || row < M) && col < N) {
+                        const u64 idx = (u64)row * (u64)N + (u64)col;
+                        u64 v1 = (u64)lo + ((u64)hi << 32), v0 = d.x0[idx];
+                        if (addc) { v0 += cognn_prng(d.keyC0, idx); v1 += d.c1[idx]; }
+                        pair_trunc<false>(d, 0, d.tiR, d.tiR0, d.tiRP0, idx, v0, v1);
+                        if (scale) pair_scale<false>(d, 0, idx, rw[q], false, v0, v1);
+                        d.out0[idx] = v0; d.out1[idx] = v1;
+                    }
+                }
+            }
+        } else if (ls == nst - 1) {
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 const int col = t * 16 + (lane & 15);        // C/D map of the 16x16 MFMA family: col = lane & 15, row = 4 * (lane >> 4) + reg
@@ -1865,13 +1900,21 @@ int beaver_close_impl(cognn_ctx* ctx, uint64_t* Z, const uint64_t* E, const uint
 // ---- grouped launch of one phase's products ------------------------------------------------------------------------------
 namespace {
 template <int NT, int WAVES>
-int launch_group(cognn_ctx* ctx, const GemmGroup& g, int wgs, size_t lds, bool full, bool keven, bool pre, bool splitk) {
+int launch_group(cognn_ctx* ctx, const GemmGroup& g, int wgs, size_t lds, bool full, bool keven, bool pre, bool splitk, const GemmEpi* epi) {
+    static const GemmEpi no_epi = GemmEpi();
+    const GemmEpi& ep = epi ? *epi : no_epi;
 #define CG_GROUP_LAUNCH(...)                                                                                                     \
     do {                                                                                                                          \
         CG_HIP(hipFuncSetAttribute((const void*)beaver_gemm_group_kernel<NT, WAVES, __VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        hipLaunchKernelGGL((beaver_gemm_group_kernel<NT, WAVES, __VA_ARGS__>), dim3((unsigned)wgs), dim3(WAVES * 64), lds, ctx->stream, g);             \
+        hipLaunchKernelGGL((beaver_gemm_group_kernel<NT, WAVES, __VA_ARGS__>), dim3((unsigned)wgs), dim3(WAVES * 64), lds, ctx->stream, g, ep);         \
     } while (0)
-    if (splitk) {
+    if (epi) {                                               // (whole-K form only)
+        if (pre) { if (full) CG_GROUP_LAUNCH(true, true, true, false, true); else CG_GROUP_LAUNCH(false, true, true, false, true); }
+        else if (full) CG_GROUP_LAUNCH(true, true, false, false, true);
+        else if (keven) CG_GROUP_LAUNCH(false, true, false, false, true);
+        else CG_GROUP_LAUNCH(false, false, false, false, true);
+    }
+    else if (splitk) {
         if (pre) CG_GROUP_LAUNCH(false, true, true, true);
         else if (keven) CG_GROUP_LAUNCH(false, true, false, true);
         else CG_GROUP_LAUNCH(false, false, false, true);
@@ -1886,6 +1929,18 @@ int launch_group(cognn_ctx* ctx, const GemmGroup& g, int wgs, size_t lds, bool f
 }
 }  // namespace
 
+static bool group_whole_k(int64_t N, int64_t K, int64_t tiles_all) {
+    const int nst = (int)((K + 31) / 32), NT = (int)((N + 15) / 16);
+    return (size_t)nst * NT * kD16Stage <= 128 * 1024 && tiles_all >= 2048;
+}
+extern "C" int cognn_beaver_gemm_group_takes_epilogue(int64_t N, int64_t K, int64_t row_tiles) {
+    static const bool no_group = getenv("COGNN_GEMM_NO_GROUP") != nullptr;
+    // N <= 16 (one column tile): the product kernel is bound by its producers' VALU work and the chain is cheaper as its own (HBM-bound)
+    // launch - measured on config5-h16: 2.53 ms per pass with the epilogue, 2.40 without; N = 64: 5.40 vs 5.47 (the epilogue costs the
+    // launch about what the chain launch took - at two waves per SIMD its loads and dealer arithmetic are not hidden; touching the
+    // operands' cache lines one K step ahead changed nothing - what is saved is the p = 1 product's write and re-read)
+    return (!no_group && N > 16 && N <= kFusedBN && K >= 4 && group_whole_k(N, K, row_tiles)) ? 1 : 0;
+}
 extern "C" int cognn_beaver_gemm_close_group_u64(cognn_ctx* ctx, const cognn_gemm_job* jobs, int32_t count, int64_t N, int64_t K, int raw) {
     { const int rc_flush_ = cg_flush(ctx); if (rc_flush_) return rc_flush_; }
     CG_REQUIRE(ctx && (count == 0 || jobs) && count >= 0 && count <= kGroupMax, "cognn_beaver_gemm_close_group_u64: bad arguments");
@@ -1911,6 +1966,30 @@ extern "C" int cognn_beaver_gemm_close_group_u64(cognn_ctx* ctx, const cognn_gem
     // into the zeroed outputs (split K).
     const bool whole_k = lds_all <= 128 * 1024 && tiles_all >= 2048;
     const bool grouped = !no_group && count > 0 && N <= kFusedBN && K >= 4 && aligned && tiles_all > 0;
+    int nepi = 0;
+    for (int32_t j = 0; j < count; ++j) if (jobs[j].epilogue) ++nepi;
+    GemmEpi epi;
+    if (nepi) {
+        CG_REQUIRE(nepi == count && count <= kEpiMax && raw && grouped && whole_k,
+                   "cognn_beaver_gemm_close_group_u64: an epilogue chain needs raw products of the whole-K grouped form (cognn_beaver_gemm_group_takes_epilogue), "
+                   "on every job of the call, at most %d jobs", kEpiMax);
+        memset(&epi, 0, sizeof(epi));
+        int slot = 0;
+        for (int32_t j = 0; j < count; ++j) {
+            const cognn_gemm_job& J = jobs[j];
+            const cognn_pair_chain& c = *J.epilogue;
+            if ((J.M + 15) / 16 == 0) continue;              // (jobs without rows take no descriptor slot, as below)
+            CG_REQUIRE(J.p == 1 && c.rows == J.M && c.F == N && (c.flags & COGNN_PC_TRUNC_IN) && !(c.flags & ~(COGNN_PC_TRUNC_IN | COGNN_PC_SCALE | COGNN_PC_NO_C)) &&
+                       c.x[0] && c.out[0] && c.out[1] && !c.open[0] && !c.open[1] && !c.mask && !c.mask_in && !c.dealt && ((c.flags & COGNN_PC_NO_C) || c.c1) &&
+                       (!(c.flags & COGNN_PC_SCALE) || (c.scale[0] && c.scale[1])),
+                       "cognn_beaver_gemm_close_group_u64: job %d: the epilogue chain is malformed (p = 1 job, TRUNC_IN [| SCALE], both outputs, the peer's product in x[0])", j);
+            PairChainDev& d = epi.d[slot++];
+            d.x0 = (const u64*)c.x[0]; d.x1 = nullptr; d.c1 = (const u64*)c.c1; d.sc0 = (const u64*)c.scale[0]; d.sc1 = (const u64*)c.scale[1];
+            d.out0 = (u64*)c.out[0]; d.out1 = (u64*)c.out[1];
+            pair_chain_fill_keys(d, c);
+            d.n = J.M * N; d.F = (uint32_t)N; d.flags = (uint32_t)c.flags;
+        }
+    }
     if (!grouped) {
         for (int32_t j = 0; j < count; ++j) {
             const cognn_gemm_job& J = jobs[j];
@@ -1971,10 +2050,11 @@ extern "C" int cognn_beaver_gemm_close_group_u64(cognn_ctx* ctx, const cognn_gem
     }
     const bool keven = (K % 2 == 0);
     int rc;
-    if (NT == 1) rc = launch_group<1, 4>(ctx, g, wg_end, lds, full, keven, pre, !whole_k);
-    else if (NT == 2) rc = launch_group<2, 8>(ctx, g, wg_end, lds, full, keven, pre, !whole_k);
-    else if (NT == 3) rc = launch_group<3, 8>(ctx, g, wg_end, lds, full, keven, pre, !whole_k);
-    else rc = launch_group<4, 8>(ctx, g, wg_end, lds, full, keven, pre, !whole_k);
+    const GemmEpi* ep = nepi ? &epi : nullptr;
+    if (NT == 1) rc = launch_group<1, 4>(ctx, g, wg_end, lds, full, keven, pre, !whole_k, ep);
+    else if (NT == 2) rc = launch_group<2, 8>(ctx, g, wg_end, lds, full, keven, pre, !whole_k, ep);
+    else if (NT == 3) rc = launch_group<3, 8>(ctx, g, wg_end, lds, full, keven, pre, !whole_k, ep);
+    else rc = launch_group<4, 8>(ctx, g, wg_end, lds, full, keven, pre, !whole_k, ep);
     if (rc || raw) return rc;
     for (int32_t j = 0; j < count; ++j) {                      // C_p joins here when the caller did not ask for the raw product
         const cognn_gemm_job& J = jobs[j];

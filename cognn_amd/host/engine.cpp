@@ -38,7 +38,7 @@ struct EngineError : std::runtime_error {
     using std::runtime_error::runtime_error;
 };
 
-enum { T_AGG = 0, T_PART = 1, T_GEMM = 2, T_PH_PRESCATTER = 3, T_PH_MP = 4, T_PH_GATHER = 5, T_PH_APPLY = 6, T_PH_WAVG = 7 };
+enum { T_AGG = 0, T_PART = 1, T_GEMM = 2, T_PH_PRESCATTER = 3, T_PH_MP = 4, T_PH_GATHER = 5, T_PH_APPLY = 6, T_PH_WAVG = 7, T_GEMM_EPI = 8 };
 
 struct Side {
     int owner = 0, p = 0, n = 0;
@@ -97,6 +97,9 @@ struct cognn_engine {
     bool retain_offline = false;                    // COGNN_OPT_RETAIN_OFFLINE
     int gemm_lanes = getenv("COGNN_GEMM_LANES") ? atoi(getenv("COGNN_GEMM_LANES")) : 2;   // launch lanes of the per-side products (A/B switch: 1 = one stream)
     bool gemm_group = !getenv("COGNN_GEMM_PER_SIDE");       // one grouped launch per phase (A/B switch: the per-side launch sequences)
+    // co-located pairs: the product's chain as the epilogue of the p = 1 side's launch (cognn_gemm_job::epilogue).  Opt-in: measured
+    // 1.6 % faster on config5 (5.40 vs 5.47 ms, 5.50 vs 5.59 on another box), inside the box-to-box spread; COGNN_GEMM_EPILOGUE=1
+    bool gemm_epilogue = getenv("COGNN_GEMM_EPILOGUE") != nullptr;
     bool wupdate_fusion = !getenv("COGNN_NO_WUPDATE_FUSION"); // co-located pairs: weight update (+ average) as one pass (A/B switch)
     bool gemm_presplit = !getenv("COGNN_GEMM_NO_PRESPLIT"); // the constant feature opening kept in MFMA fragment order (A/B switch)
     bool public_openings = true;                    // COGNN_OPT_PUBLIC_OPENINGS (see pub_open)
@@ -145,7 +148,7 @@ struct cognn_engine {
     std::vector<std::vector<double>> hostFeat;
     std::vector<std::vector<int32_t>> hostLabels;
     std::vector<double> w0, w1;
-    double algo[3] = {0, 0, 0};
+    double algo[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     u64* wa[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // weight-averaging temporaries
     u64* wa_recv[2] = {nullptr, nullptr};                                    // [world x wa_stride] each
     size_t wa_stride = 0;                                                     // even element count: every rank's slot is 16-byte aligned
@@ -658,6 +661,7 @@ bool gemm_stage(cognn_engine* E, int64_t it, XFn X, WFn Wm, SpecFn spec, DstFn d
     const int lanes = (dealt && large && E->gemm_lanes > 1 && ns > 1 && !E->graph_epochs) ? E->gemm_lanes : 0;   // (no auxiliary streams inside a recording)
     // timed as one phase on the engine's stream (the lanes overlap each other): all sides' products of this stage, with their
     // operand preparation (and, for sides whose peer is remote, the truncation opening and the wait for the peer's opening)
+    bool tg_open = E->timing;
     if (E->timing) BE(cognn_timer_begin(E->ctx, T_GEMM));
     // The sides' products of this phase as ONE grouped launch (cognn_beaver_gemm_close_group_u64: every workgroup builds its job's
     // weight planes in its prologue): possible when all of them are raw fusable products of one (N, K) - the PreScatter products
@@ -665,10 +669,47 @@ bool gemm_stage(cognn_engine* E, int64_t it, XFn X, WFn Wm, SpecFn spec, DstFn d
     bool same_nk = true;
     for (auto& s : E->sides) { GemmSpec g = spec(s); same_nk = same_nk && g.N == g0.N && g.K == g0.K && g.transA == 0; }
     const bool grouped = tn_group || (all_raw && same_nk && ns <= 16 && E->gemm_group);
+    // the chain that consumes a co-located pair's product: truncation (+ the row scale that follows, + the next opening)
+    auto chain_of = [&](Side& s) {                           // s: the pair's p = 0 side
+        Side& t = *s.peer;
+        GemmSpec g = spec(s);
+        cognn_pair_chain c;
+        memset(&c, 0, sizeof(c));
+        c.x[0] = s.zbuf; c.x[1] = t.zbuf; c.rows = g.M; c.F = g.N;
+        c.flags = COGNN_PC_TRUNC_IN | (all_raw ? 0 : COGNN_PC_NO_C);
+        c.gemm_keys = gkeys(s, g);
+        c.trunc_in_keys = keys(E, s.owner, it, g.top);
+        if (all_raw) c.c1 = t.c1.at({it, g.op}).ptr;
+        if (follow) {
+            c.flags |= COGNN_PC_SCALE;
+            c.scale[0] = s.svec; c.scale[1] = t.svec;
+            c.scale_keys = keys(E, s.owner, it, follow.op);
+            c.scale_trunc_keys = keys(E, s.owner, it, follow.top);
+            c.out[0] = follow.dst(s); c.out[1] = follow.dst(t);
+        } else {
+            c.out[0] = dst(s); c.out[1] = dst(t);
+            if (open_next) {
+                c.open[0] = s.ob[open_next.ob]; c.flags |= COGNN_PC_OPEN_SUM;
+                c.open_key[0] = open_next.key(s); c.open_key[1] = open_next.key(t);
+            }
+        }
+        return c;
+    };
+    // ... as the EPILOGUE of the p = 1 side's product when the grouped launch takes one (whole-K form, no opening to write): the
+    // p = 0 sides' products go first, then one launch computes the p = 1 products and runs the chains on their tiles in registers
+    // - the p = 1 product is never written or re-read, and the chain launch disappears
+    bool epi = false;
+    if (grouped && !tn_group && all_raw && E->gemm_epilogue && !pairs_raw && !streams_on(E) && (!open_next || follow)) {
+        int64_t tilesB = 0; int nB = 0;
+        for (auto& s : E->sides) if (paired(E, s) && s.p == 1) { tilesB += (spec(s).M + 15) / 16; ++nB; }
+        epi = nB >= 1 && nB <= 8 && E->be->cognn_beaver_gemm_group_takes_epilogue(g0.N, g0.K, tilesB) != 0;
+    }
     if (grouped) {
         for (int pass = 0; pass < 2; ++pass) {
             if (pass == 1) exchange_wait(E);
-            std::vector<cognn_gemm_job> jobs;
+            std::vector<cognn_gemm_job> jobs, jobs_epi;
+            std::vector<cognn_pair_chain> chains;
+            chains.reserve(ns);                                // (the jobs point into it)
             std::vector<size_t> idx;
             for (size_t i = 0; i < ns; ++i) {
                 Side& s = E->sides[i];
@@ -693,13 +734,26 @@ bool gemm_stage(cognn_engine* E, int64_t it, XFn X, WFn Wm, SpecFn spec, DstFn d
                 z_written(s, eo[i]);
                 if (g.feature == 1) J.E_presplit = s.featPl;
                 if (!tn_group) J.A_dealt = dealt_mask(E, s.owner, it, s.p == 0 ? DEAL_GEMM_A0 : DEAL_GEMM_A1, k.k[s.p == 0 ? COGNN_SL_A0 : COGNN_SL_A1], g.M * g.K);
-                jobs.push_back(J); idx.push_back(i);
-                if (E->timing) E->algo[T_GEMM] += 2.0 * 36 * 2 * (double)g.M * g.K * g.N;
+                if (epi && paired(E, s) && s.p == 1) {
+                    chains.push_back(chain_of(*s.peer));
+                    J.epilogue = &chains.back();
+                    jobs_epi.push_back(J);
+                } else jobs.push_back(J);
+                idx.push_back(i);
+                if (E->timing) E->algo[J.epilogue ? T_GEMM_EPI : T_GEMM] += 2.0 * 36 * 2 * (double)g.M * g.K * g.N;
                 z[i] = s.zbuf;
             }
-            if (jobs.empty()) continue;
+            if (jobs.empty() && jobs_epi.empty()) continue;
             if (tn_group) BE(cognn_beaver_gemm_close_group_tn_u64(E->ctx, jobs.data(), (int32_t)jobs.size(), g0.M, g0.N, g0.transA == 2 ? 1 : 0));
-            else BE(cognn_beaver_gemm_close_group_u64(E->ctx, jobs.data(), (int32_t)jobs.size(), g0.N, g0.K, 1));
+            else {
+                if (!jobs.empty()) BE(cognn_beaver_gemm_close_group_u64(E->ctx, jobs.data(), (int32_t)jobs.size(), g0.N, g0.K, 1));
+                if (!jobs_epi.empty()) {                       // (timed apart from the pure products: this launch also does the chains' work)
+                    if (tg_open) { BE(cognn_timer_end(E->ctx, T_GEMM)); tg_open = false; }   // (nothing but this launch follows for these sides)
+                    if (E->timing) BE(cognn_timer_begin(E->ctx, T_GEMM_EPI));
+                    BE(cognn_beaver_gemm_close_group_u64(E->ctx, jobs_epi.data(), (int32_t)jobs_epi.size(), g0.N, g0.K, 1));
+                    if (E->timing) BE(cognn_timer_end(E->ctx, T_GEMM_EPI));
+                }
+            }
             Batch batch(E);                                    // the truncation openings of the sides outside pair chains: one launch
             for (size_t i : idx) {
                 Side& s = E->sides[i];
@@ -747,33 +801,17 @@ bool gemm_stage(cognn_engine* E, int64_t it, XFn X, WFn Wm, SpecFn spec, DstFn d
         if (s.p == 1 && !paired(E, s)) c1_release(E, s, {it, g.op});   // consumed: the buffer serves a later deal
         z[i] = s.zbuf;
     }, false, lanes);
-    if (E->timing) BE(cognn_timer_end(E->ctx, T_GEMM));
+    if (tg_open) BE(cognn_timer_end(E->ctx, T_GEMM));
     // co-located pairs: truncation of the product (+ the row scale that follows) as one chain per owner
     if (!pairs_raw) {
         PairChains pc;
         for (auto& s : E->sides) {
-            if (!paired(E, s) || s.p != 0) continue;
+            if (!paired(E, s) || s.p != 0 || epi) continue;  // (epi: the chains ran inside the p = 1 sides' product launch)
             Side& t = *s.peer;
             GemmSpec g = spec(s);
-            cognn_pair_chain& c = pc.add(s, s.zbuf, t.zbuf, g.M, g.N);
-            c.flags = COGNN_PC_TRUNC_IN | (all_raw ? 0 : COGNN_PC_NO_C);
+            pc.v.push_back(chain_of(s));
+            cognn_pair_chain& c = pc.v.back();
             if (z_clear_wanted(s, g.M * g.N) && z_clear_wanted(t, g.M * g.N)) { c.flags |= COGNN_PC_CLEAR_INPUT; z_cleared(s, g.M * g.N); z_cleared(t, g.M * g.N); }
-            c.gemm_keys = gkeys(s, g);
-            c.trunc_in_keys = keys(E, s.owner, it, g.top);
-            if (all_raw) c.c1 = t.c1.at({it, g.op}).ptr;
-            if (follow) {
-                c.flags |= COGNN_PC_SCALE;
-                c.scale[0] = s.svec; c.scale[1] = t.svec;
-                c.scale_keys = keys(E, s.owner, it, follow.op);
-                c.scale_trunc_keys = keys(E, s.owner, it, follow.top);
-                c.out[0] = follow.dst(s); c.out[1] = follow.dst(t);
-            } else {
-                c.out[0] = dst(s); c.out[1] = dst(t);
-                if (open_next) {
-                    c.open[0] = s.ob[open_next.ob]; c.flags |= COGNN_PC_OPEN_SUM;
-                    c.open_key[0] = open_next.key(s); c.open_key[1] = open_next.key(t);
-                }
-            }
             attach_dealt(E, c, s.owner, it, DEAL_GEMM_CHAIN);
         }
         if (streams_on(E)) { bool all = true; for (auto& c : pc.v) all = all && c.dealt; if (!all) for (auto& c : pc.v) c.dealt = nullptr; }
@@ -2299,14 +2337,15 @@ int cognn_engine_enable_timing(cognn_engine* E, int32_t on) {
         if (!E) throw EngineError("null engine");
         E->timing = on != 0;
         BE(cognn_timer_reset(E->ctx));
-        E->algo[0] = E->algo[1] = E->algo[2] = 0;
+        E->algo[0] = E->algo[1] = E->algo[2] = E->algo[T_GEMM_EPI] = 0;
     });
 }
 int cognn_engine_get_timing(cognn_engine* E, int32_t kind, int64_t* launches, double* total_ms, double* algo) {
     return guard([&] {
-        if (!E || kind < 0 || kind > 2) throw EngineError("cognn_engine_get_timing: bad arguments");
-        BE(cognn_timer_read(E->ctx, kind, launches, total_ms));
-        if (algo) *algo = E->algo[kind];
+        if (!E || kind < 0 || kind > 3) throw EngineError("cognn_engine_get_timing: bad arguments");
+        const int t = kind == 3 ? T_GEMM_EPI : kind;
+        BE(cognn_timer_read(E->ctx, t, launches, total_ms));
+        if (algo) *algo = E->algo[t];
     });
 }
 int cognn_engine_get_workload(cognn_engine* E, int64_t* out6) {

@@ -152,7 +152,8 @@ int cognn_engine_get_weight(cognn_engine* e, int32_t owner, int32_t side, int32_
 int cognn_engine_get_metrics(cognn_engine* e, int32_t party, double* out8);
 /* kernel timing (HIP events on the engine's stream). kind: 0 gather-aggregate launches, 1 gather-partials launches, 2 the
  * Beaver product phase of a GAS iteration (all hosted sides' products; they overlap each other on two launch lanes, so the unit
- * timed is the phase, `launches` = number of phases) */
+ * timed is the phase, `launches` = number of phases; the launches that are products and nothing else), 3 the product launches that
+ * carry the co-located pairs' truncation chain as their epilogue (cognn_gemm_job::epilogue; algo = the product's operations) */
 int cognn_engine_enable_timing(cognn_engine* e, int32_t on);
 int cognn_engine_get_timing(cognn_engine* e, int32_t kind, int64_t* launches, double* total_ms, double* algo_bytes_or_ops);
 /* static workload numbers: per message-passing round at width F=1 (multiply by F):

@@ -171,6 +171,13 @@ typedef struct {
     const uint64_t* A_dealt;                     /* optional (COGNN_OPT_DEALER_STREAMS): this party's mask A_p [M x K] as dealt (cognn_prng_fill_u64
                                                   * with its A key): read instead of regenerated (grouped kernel only) */
     int64_t K;                                   /* cognn_beaver_gemm_close_group_tn_u64 only: the job's inner dimension (rows of its party) */
+    const struct cognn_pair_chain_s* epilogue;   /* optional (co-located pairs; every job of the call or none; p == 1; raw; count <= 8; shapes for which
+                                                  * cognn_beaver_gemm_group_takes_epilogue says yes): the truncation (+ row scale) chain of the pair
+                                                  * runs on this product's tiles while they are still in registers - epilogue->x[0] = the raw product
+                                                  * of the pair's p = 0 side (written by an earlier call), x[1] unused, flags within COGNN_PC_TRUNC_IN |
+                                                  * COGNN_PC_SCALE | COGNN_PC_NO_C, out[0], out[1] set, no opening / mask / dealt values - and its
+                                                  * outputs are stored INSTEAD of Z: bit-identical to the product followed by cognn_pair_chain_u64,
+                                                  * without writing and re-reading this side's product */
     int32_t Z_zeroed;                            /* the caller guarantees that Z[0 .. M x N) is zero on entry (its last reader cleared it:
                                                   * COGNN_PC_CLEAR_INPUT / COGNN_WU_CLEAR_Z): the split-K forms, which add partial tiles
                                                   * into Z, then skip their own zeroing launch; ignored by the whole-K form */
@@ -186,6 +193,9 @@ int cognn_beaver_gemm_close_group_tn_u64(cognn_ctx*, const cognn_gemm_job* jobs,
 /* An opened left operand that many products reuse - the constant input-feature opening of the layer-0 product (gcn.h:233 in
  * every epoch) - limb-split and byte-transposed ONCE into the order the grouped kernel's A fragments have: the same 8 bytes per
  * element (rows padded to 16, K to 32), so a pass reads as many bytes as before and skips the split.  image: _bytes(M, K) bytes. */
+/* whether the grouped launch of products [. x K] . [K x N] with `row_tiles` 16-row tiles in all takes cognn_gemm_job::epilogue (the
+ * whole-K form: the weight planes of every K step fit the LDS image and there are row tiles enough to fill the chip) */
+int cognn_beaver_gemm_group_takes_epilogue(int64_t N, int64_t K, int64_t row_tiles);
 int64_t cognn_gemm_presplit_bytes(int64_t M, int64_t K);
 int cognn_gemm_presplit_u64(cognn_ctx*, void* image, const uint64_t* E0, const uint64_t* E1, int64_t M, int64_t K);
 
@@ -294,7 +304,7 @@ enum { COGNN_PC_TRUNC_IN = 1, COGNN_PC_SCALE = 2, COGNN_PC_RELU = 4, COGNN_PC_IN
         * split-K product (cognn_gemm_job::Z_zeroed), which saves that product's zeroing launch; worth it for small tensors only
         * (+16 B of writes per element pair) */
        COGNN_PC_CLEAR_INPUT = 128 };
-typedef struct {
+typedef struct cognn_pair_chain_s {
     const uint64_t* x[2];        /* the two sides' input shares [rows x F] */
     const uint64_t* c1;          /* side 1's dealt product share (COGNN_PC_TRUNC_IN without COGNN_PC_NO_C) */
     const uint64_t* scale[2];    /* the two sides' shares of the row scale [rows] (COGNN_PC_SCALE) */

@@ -82,6 +82,31 @@ def test_config5_hidden_layer_at_full_size():
         assert (ha > 0).mean() > 0.05                        # (not all zero)
 
 
+def test_config5_product_with_chain_epilogue_is_bit_identical(monkeypatch):
+    """COGNN_GEMM_EPILOGUE=1: the layer-0 products of the p = 1 sides carry their pair's truncation chain as the launch's epilogue
+    (cognn_gemm_job::epilogue, N = 64; 8 x 8192 row tiles) - same shares as the default product + chain sequence, every party, after the
+    hidden layer and after the prediction layer."""
+    graph, feats = _inputs()
+    for iters in (1, 2):
+        monkeypatch.delenv("COGNN_GEMM_EPILOGUE", raising=False)
+        a, _ = _run(11, graph, feats, iters=iters)
+        monkeypatch.setenv("COGNN_GEMM_EPILOGUE", "1")
+        b, _ = _run(11, graph, feats, iters=iters)
+        for P in range(K):
+            assert np.array_equal(a[P][0], b[P][0]) and np.array_equal(a[P][1], b[P][1]), (iters, P)
+    # ... and the epilogue form really ran: the engine times those launches as their own kind
+    from cognn_amd.engine import Engine, GnnParam
+    src, dst = graph
+    V = 1 << LV
+    eng = Engine(K, src, dst, (np.arange(V) % K).astype(np.int32), GnnParam(num_labels=LAB, input_dim=IN, hidden_dim=HID, num_samples=V, num_edges=len(src)),
+                 seed=11, variant="optimize-gcn-inference")
+    for P in eng.hosted:
+        eng.set_party_data(P, *feats[P])
+    eng.start(); eng.enable_timing(True); eng.run(0, 2); eng.sync()
+    assert eng.timing(3)[0] == 1 and eng.timing(2)[0] == 2      # one launch with the chain (layer 0, N = 64), two pure product phases
+    eng.close()
+
+
 def test_config5_full_size_properties():
     V = 1 << LV
     graph, feats = _inputs()

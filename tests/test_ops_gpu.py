@@ -664,3 +664,58 @@ def test_chunk_window_of_the_element_wise_entry_points(ctx, n, C):
     assert np.array_equal(host(single), want)
     with pytest.raises(capi.CognnError):
         ctx.call("cognn_ctx_set_chunk", C, C)
+
+
+@pytest.mark.parametrize("N,K,Ms,scale,presplit", [(64, 128, (16400, 16384), False, True), (32, 64, (32768, 8200), True, False), (48, 96, (20000, 20001), True, False)])
+def test_beaver_gemm_group_with_the_pair_chain_as_epilogue(ctx, N, K, Ms, scale, presplit):
+    """cognn_gemm_job::epilogue: the p = 1 side's grouped product runs the pair's truncation (+ row scale) chain on its accumulator
+    tiles, reading the p = 0 side's raw product written by an earlier call - against the plain sequence (both raw products, then
+    cognn_pair_chain_u64), bit for bit; shapes outside the whole-K form are refused."""
+    from cognn_amd import capi
+    lib = capi.load()
+    assert lib.cognn_beaver_gemm_group_takes_epilogue(N, K, sum((M + 15) // 16 for M in Ms)) == 1
+    rng = np.random.default_rng(N + K)
+    P = len(Ms)
+    jobs0 = (capi.GemmJob * P)(); jobs1 = (capi.GemmJob * P)(); chains = (capi.PairChain * P)(); chains_ref = (capi.PairChain * P)()
+    keep, outs, refs = [], [], []
+    for q, M in enumerate(Ms):
+        E = dev(rand_u64(rng, (M, K))); F = dev(rand_u64(rng, (K, N))); c1 = dev(rand_u64(rng, (M, N)) >> U64(8))
+        s0 = dev(co.normalizer(rng.integers(0, 9, size=M))); s1 = dev(np.zeros(M, dtype=U64))
+        k = capi.make_keys(11, q, 4, co.OP_PS_GEMM); tk = capi.make_keys(11, q, 4, co.OP_PS_GEMM_TRUNC)
+        sk = capi.make_keys(11, q, 4, co.OP_PS_SCALE); stk = capi.make_keys(11, q, 4, co.OP_PS_SCALE_TRUNC)
+        img = None
+        if presplit:
+            img = dev_empty(lib.cognn_gemm_presplit_bytes(M, K) // 8)
+            ctx.call("cognn_gemm_presplit_u64", ptr(img), ptr(E), None, M, K)
+        Z = [dev_empty((M, N)), dev_empty((M, N))]; scr = dev_empty(M * K + K * N)
+        for p, J in ((0, jobs0[q]), (1, jobs1[q])):
+            J.Z = Z[p].data_ptr(); J.E0 = E.data_ptr(); J.F0 = F.data_ptr(); J.keys = k; J.p = p; J.M = M; J.scratch = scr.data_ptr()
+            J.E_presplit = img.data_ptr() if img is not None else None
+        o = [dev_empty((M, N)) for _ in range(4)]
+        for c, (o0, o1) in ((chains[q], o[:2]), (chains_ref[q], o[2:])):
+            c.x[0] = Z[0].data_ptr(); c.x[1] = Z[1].data_ptr(); c.c1 = c1.data_ptr(); c.out[0] = o0.data_ptr(); c.out[1] = o1.data_ptr()
+            c.scale[0] = s0.data_ptr(); c.scale[1] = s1.data_ptr()
+            c.gemm_keys = k; c.trunc_in_keys = tk; c.scale_keys = sk; c.scale_trunc_keys = stk
+            c.rows = M; c.F = N; c.flags = 1 | (2 if scale else 0)
+        keep += [E, F, c1, s0, s1, img, Z, scr, o]
+        outs.append(o[:2]); refs.append(o[2:])
+    # reference: both raw products, then the chain launch
+    ctx.call("cognn_beaver_gemm_close_group_u64", jobs0, P, N, K, 1)
+    ctx.call("cognn_beaver_gemm_close_group_u64", jobs1, P, N, K, 1)
+    ctx.call("cognn_pair_chain_u64", chains_ref, P)
+    ctx.sync()
+    z1_ref = [host(dev_z).copy() for dev_z in (keep[9 * q + 6][1] for q in range(P))]
+    # epilogue form: the p = 1 products are never stored
+    for q in range(P):
+        keep[9 * q + 6][1].fill_(7)
+        jobs1[q].epilogue = ctypes.addressof(chains[q])
+    ctx.call("cognn_beaver_gemm_close_group_u64", jobs1, P, N, K, 1)
+    ctx.sync()
+    for q in range(P):
+        assert np.array_equal(host(outs[q][0]), host(refs[q][0])) and np.array_equal(host(outs[q][1]), host(refs[q][1])), q
+        assert np.all(host(keep[9 * q + 6][1]) == 7) and z1_ref[q].any()            # (Z of the p = 1 job was not written)
+    jobs1[0].epilogue = None
+    with pytest.raises(capi.CognnError, match="epilogue"):                          # on some jobs only
+        ctx.call("cognn_beaver_gemm_close_group_u64", jobs1, P, N, K, 1)
+    assert lib.cognn_beaver_gemm_group_takes_epilogue(32, 1433, 170) == 0           # the split-K shapes take none
+    assert lib.cognn_beaver_gemm_group_takes_epilogue(16, 64, 65536) == 0           # ... nor one-column-tile products (VALU-bound: the chain is cheaper alone)
