@@ -954,9 +954,11 @@ void beaver_gemm_group_kernel(GemmGroup g, GemmEpi epi) {
                 const size_t xc = FULL ? (size_t)x : (size_t)min((u64)x, (u64)M * (u64)K - 2);
                 if (KEVEN) { const u64x2 t = *reinterpret_cast<const u64x2*>(Amask + xc); w[2 * jj] = t.x; w[2 * jj + 1] = t.y; }
                 else { w[2 * jj] = Amask[xc]; w[2 * jj + 1] = Amask[xc + 1]; }
-            } else {
+            } else if (FULL || st * 32 + 8 * jj < K) {      // (uniform: a ragged K - the hidden_dim = 16 layer-1 product - skips the k values past it)
                 w[2 * jj] = cognn_prng(keyA, x);
                 w[2 * jj + 1] = cognn_prng(keyA, x + 1);
+            } else {
+                w[2 * jj] = 0; w[2 * jj + 1] = 0;
             }
         }
         if (!FULL) {
