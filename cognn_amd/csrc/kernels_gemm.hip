@@ -1962,7 +1962,11 @@ extern "C" int cognn_beaver_gemm_close_group_u64(cognn_ctx* ctx, const cognn_gem
     const int nst = (int)((K + 31) / 32), NT = (int)((N + 15) / 16);
     const size_t lds_all = (size_t)nst * NT * kD16Stage;
     static const bool no_group = getenv("COGNN_GEMM_NO_GROUP") != nullptr;   // A/B switch: job by job through the per-side kernels
-    const bool pre = npre == count && count > 0 && (K % 2 == 0);   // every job brings its fragment-ordered image (else none is used)
+    bool any_dealt = false;
+    for (int32_t j = 0; j < count; ++j) any_dealt = any_dealt || jobs[j].A_dealt != nullptr;
+    // every job brings its fragment-ordered image (else none is used); the image form reads no operand element by element, so an odd K
+    // (Cora's 1433, CiteSeer's 3703 features) is fine - unless a dealt mask is streamed too, whose vector loads assume an even K
+    const bool pre = npre == count && count > 0 && (K % 2 == 0 || !any_dealt);
     // Either every workgroup keeps the B fragments of ALL K steps in LDS and walks whole rows (enough row tiles to fill the chip),
     // or - few row tiles, or a K too long for LDS: the dataset-sized graphs - workgroups take K ranges and add partial tiles
     // into the zeroed outputs (split K).
