@@ -1931,9 +1931,14 @@ int launch_group(cognn_ctx* ctx, const GemmGroup& g, int wgs, size_t lds, bool f
 }
 }  // namespace
 
+// Whole K per workgroup (B fragments of every K step in LDS, workgroups walk row tiles) needs the image to fit and row tiles enough to
+// fill the chip - and, for one column tile (4-wave workgroups, several per CU), an image small enough that several workgroups still
+// share a CU, unless there is work for every wave many times over: PubMed's 4929 x 500 . 16 per side (128 KiB image, 2472 tiles)
+// ran at one workgroup per CU and took 148 us; as K ranges it takes a third of that.
 static bool group_whole_k(int64_t N, int64_t K, int64_t tiles_all) {
     const int nst = (int)((K + 31) / 32), NT = (int)((N + 15) / 16);
-    return (size_t)nst * NT * kD16Stage <= 128 * 1024 && tiles_all >= 2048;
+    const size_t lds_all = (size_t)nst * NT * kD16Stage;
+    return lds_all <= 128 * 1024 && tiles_all >= 2048 && (NT >= 2 || lds_all <= 48 * 1024 || tiles_all >= 65536);
 }
 extern "C" int cognn_beaver_gemm_group_takes_epilogue(int64_t N, int64_t K, int64_t row_tiles) {
     static const bool no_group = getenv("COGNN_GEMM_NO_GROUP") != nullptr;
@@ -1960,7 +1965,6 @@ extern "C" int cognn_beaver_gemm_close_group_u64(cognn_ctx* ctx, const cognn_gem
         aligned = aligned && cg_aligned16(J.E0) && (!J.E1 || cg_aligned16(J.E1)) && cg_aligned16(J.Z);
     }
     const int nst = (int)((K + 31) / 32), NT = (int)((N + 15) / 16);
-    const size_t lds_all = (size_t)nst * NT * kD16Stage;
     static const bool no_group = getenv("COGNN_GEMM_NO_GROUP") != nullptr;   // A/B switch: job by job through the per-side kernels
     bool any_dealt = false;
     for (int32_t j = 0; j < count; ++j) any_dealt = any_dealt || jobs[j].A_dealt != nullptr;
@@ -1970,8 +1974,8 @@ extern "C" int cognn_beaver_gemm_close_group_u64(cognn_ctx* ctx, const cognn_gem
     // Either every workgroup keeps the B fragments of ALL K steps in LDS and walks whole rows (enough row tiles to fill the chip),
     // or - few row tiles, or a K too long for LDS: the dataset-sized graphs - workgroups take K ranges and add partial tiles
     // into the zeroed outputs (split K).
-    const bool whole_k = lds_all <= 128 * 1024 && tiles_all >= 2048;
-    const bool grouped = !no_group && count > 0 && N <= kFusedBN && K >= 4 && aligned && tiles_all > 0;
+    const bool whole_k = group_whole_k(N, K, tiles_all);
+    const bool grouped = !no_group && count > 0 && N <= kFusedBN && K >= 1 && aligned && tiles_all > 0;
     int nepi = 0;
     for (int32_t j = 0; j < count; ++j) if (jobs[j].epilogue) ++nepi;
     GemmEpi epi;

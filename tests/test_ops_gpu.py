@@ -459,7 +459,10 @@ def test_beaver_gemm_pair(ctx, M, N, K, transA):
                                                    (16, 1433, (1354, 1354), False, False), (16, 3703, (1656,), True, False), (16, 7, (1354, 1300), False, False),
                                                    (64, 1432, (600, 40), False, True), (3, 5, (100,), True, False), (48, 500, (4930, 4929), False, False),
                                                    # the fragment-ordered operand with an odd K (Cora / CiteSeer feature counts), split K and whole K
-                                                   (16, 1433, (1354, 1354), False, True), (16, 3703, (1656, 1656), False, True), (16, 33, (40000, 33000), False, True)])
+                                                   (16, 1433, (1354, 1354), False, True), (16, 3703, (1656, 1656), False, True), (16, 33, (40000, 33000), False, True),
+                                                   # very short K (g = (p - y) . W1^T with 3 labels), PubMed's layer-0 shape (K ranges although the image would fit)
+                                                   (16, 3, (4929, 4930), False, False), (16, 1, (300,), True, False), (7, 2, (40000,), False, False),
+                                                   (16, 500, (4929, 4930, 4929), False, True)])
 def test_beaver_gemm_group(ctx, N, K, Ms, two, presplit):
     """cognn_beaver_gemm_close_group_u64: the products of a phase as one grouped launch (weight planes built in the kernel's
     prologue; optionally the left operand pre-split in fragment order) against the oracle's Beaver product, job by job - jobs
