@@ -340,8 +340,8 @@ def main():
     # reduced by tools/summarize_profiles.py) and labelled so.  It is only reported when that summary profiled the gather
     # kernel this run launched.
     traffic, traffic_src = None, None
-    # (single process, every pair co-located, even width, k <= 8: the Gather with the pair chain as its epilogue - engine.cpp can_fuse_gather_chain)
-    used = sorted({"gather_pair_chain_kernel" if (world == 1 and k <= 8 and F % 2 == 0) else "gather_csr_kernel" for F in (hid, lab)})
+    # (single process, every pair co-located, k <= 8: the Gather with the pair chain as its epilogue - engine.cpp can_fuse_gather_chain)
+    used = sorted({"gather_pair_chain_kernel" if (world == 1 and k <= 8) else "gather_csr_kernel" for F in (hid, lab)})
     if variant == "original-gcn":
         used = ["scatter_gather_original_kernel"]         # the fused per-edge Scatter + Gather launch of the unoptimised kernel
     cands = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc.json") and f[:1] == "r" and f[1:3].isdigit() and f[3] == "_") \

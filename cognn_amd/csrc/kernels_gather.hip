@@ -35,6 +35,8 @@ template <> struct Chunk<2> {
     __device__ __forceinline__ void add(const Chunk& o) { v.x += o.v.x; v.y += o.v.y; }
     __device__ __forceinline__ void store(u64* p) const { *reinterpret_cast<u64x2*>(p) = v; }
     __device__ __forceinline__ void sub_prng(u64 key, u64 idx) { v.x -= cognn_prng(key, idx); v.y -= cognn_prng(key, idx + 1); }
+    __device__ __forceinline__ void get(u64* a) const { a[0] = v.x; a[1] = v.y; }
+    static __device__ __forceinline__ void put(u64* p, const u64* a) { u64x2 t; t.x = a[0]; t.y = a[1]; *reinterpret_cast<u64x2*>(p) = t; }
 };
 template <> struct Chunk<1> {
     u64 v;
@@ -43,6 +45,8 @@ template <> struct Chunk<1> {
     __device__ __forceinline__ void add(const Chunk& o) { v += o.v; }
     __device__ __forceinline__ void store(u64* p) const { *p = v; }
     __device__ __forceinline__ void sub_prng(u64 key, u64 idx) { v -= cognn_prng(key, idx); }
+    __device__ __forceinline__ void get(u64* a) const { a[0] = v; a[1] = 0; }
+    static __device__ __forceinline__ void put(u64* p, const u64* a) { *p = a[0]; }
 };
 
 struct OpenSegs {                 // row segments whose output is written as a Beaver opening (value - dealer mask)
@@ -149,14 +153,15 @@ struct GatherPairBatch {
     GatherPairSeg s[kGatherPairsMax];
     int count;
 };
-template <int LPR, bool STREAM>
+// W: u64 per lane and step - 2 (16-byte accesses) for an even width, 1 for an odd one (7 or 3 labels)
+template <int LPR, int W, bool STREAM>
 __device__ __forceinline__ void gather_pair_chain_body(const u64* __restrict__ table, const uint32_t* __restrict__ rowptr,
                                                        const uint32_t* __restrict__ col, int F, int ntiles, const GatherPairBatch& b,
                                                        uint32_t (&s_rp)[2][kPairTile + 1], uint32_t (&s_col)[2][kPairColCap]) {
     constexpr int kGroups = kThreads / LPR;
     const int tid = threadIdx.x;
     const int grp = tid / LPR, ln = tid % LPR;
-    const int nchunk = F / 2;
+    const int nchunk = F / W;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         int seg = 0;
         while (seg < b.count - 1 && tile >= b.s[seg].tile_end) ++seg;
@@ -180,17 +185,17 @@ __device__ __forceinline__ void gather_pair_chain_body(const u64* __restrict__ t
         for (int lr = grp; lr < nr; lr += kGroups) {
             const int vr = v0row + lr;                       // vertex row
             for (int c = ln; c < nchunk; c += LPR) {
-                const int off = c * 2;
-                u64x2 sum[2];
+                const int off = c * W;
+                Chunk<W> sum[2];
 #pragma unroll
                 for (int sd = 0; sd < 2; ++sd) {
                     const uint32_t e0 = s_rp[sd][0], bq = s_rp[sd][lr], eq = s_rp[sd][lr + 1];
-                    Chunk<2> acc;
+                    Chunk<W> acc;
                     acc.load(table + (size_t)(rbase[sd] + lr) * F + off);                 // the self row
                     uint32_t q = bq;
                     if (staged[sd]) {
                         for (; q + 4 <= eq; q += 4) {
-                            Chunk<2> t0c, t1c, t2c, t3c;
+                            Chunk<W> t0c, t1c, t2c, t3c;
                             const uint32_t c0 = s_col[sd][q - e0], c1 = s_col[sd][q + 1 - e0], c2 = s_col[sd][q + 2 - e0], c3 = s_col[sd][q + 3 - e0];
                             t0c.load(table + (size_t)c0 * F + off);
                             t1c.load(table + (size_t)c1 * F + off);
@@ -198,36 +203,38 @@ __device__ __forceinline__ void gather_pair_chain_body(const u64* __restrict__ t
                             t3c.load(table + (size_t)c3 * F + off);
                             t0c.add(t1c); t2c.add(t3c); acc.add(t0c); acc.add(t2c);
                         }
-                        for (; q < eq; ++q) { Chunk<2> t; t.load(table + (size_t)s_col[sd][q - e0] * F + off); acc.add(t); }
+                        for (; q < eq; ++q) { Chunk<W> t; t.load(table + (size_t)s_col[sd][q - e0] * F + off); acc.add(t); }
                     } else {
-                        for (; q < eq; ++q) { Chunk<2> t; t.load(table + (size_t)col[q] * F + off); acc.add(t); }
+                        for (; q < eq; ++q) { Chunk<W> t; t.load(table + (size_t)col[q] * F + off); acc.add(t); }
                     }
-                    sum[sd] = acc.v;
+                    sum[sd] = acc;
                 }
                 // the chain on the two sides' sums (pair_chain.h): row scale + truncation [+ ReLU], outputs / openings
                 const u64 idx = (u64)vr * (u64)F + (u64)off;
-                u64 a[2] = {sum[0].x, sum[0].y}, bb[2] = {sum[1].x, sum[1].y};
+                u64 a[2], bb[2];
+                sum[0].get(a); sum[1].get(bb);
                 bool pos[2] = {true, true};
                 PairRow rw = {0, 0, 0};
                 const PcSlotBase SB = pc_slot_base(d.flags, d.open0 != nullptr || d.open1 != nullptr);
                 if (d.flags & COGNN_PC_SCALE) rw = pair_row(d, (u64)vr);
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
+                for (int j = 0; j < W; ++j) {
                     if (d.flags & COGNN_PC_SCALE) pair_scale<STREAM>(d, SB.sc, idx + j, rw, false, a[j], bb[j]);
                     if (d.flags & COGNN_PC_RELU) pos[j] = pair_relu<STREAM>(d, SB.re, idx + j, a[j], bb[j]);
                 }
-                if ((d.flags & COGNN_PC_RELU) && d.mask) { d.mask[idx] = pos[0] ? 1 : 0; d.mask[idx + 1] = pos[1] ? 1 : 0; }
-                if (d.out0) { u64x2 t; t.x = a[0]; t.y = a[1]; *reinterpret_cast<u64x2*>(d.out0 + idx) = t; }
-                if (d.out1) { u64x2 t; t.x = bb[0]; t.y = bb[1]; *reinterpret_cast<u64x2*>(d.out1 + idx) = t; }
+                if ((d.flags & COGNN_PC_RELU) && d.mask) { d.mask[idx] = pos[0] ? 1 : 0; if (W == 2) d.mask[idx + 1] = pos[1] ? 1 : 0; }
+                if (d.out0) Chunk<W>::put(d.out0 + idx, a);
+                if (d.out1) Chunk<W>::put(d.out1 + idx, bb);
                 if (d.open0 || d.open1) {
                     u64 m0[2], m1[2];
+                    m0[1] = m1[1] = 0;
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) pair_open_masks<STREAM>(d, SB.op, idx + j, m0[j], m1[j]);
+                    for (int j = 0; j < W; ++j) pair_open_masks<STREAM>(d, SB.op, idx + j, m0[j], m1[j]);
                     if (d.flags & COGNN_PC_OPEN_SUM) {
-                        if (d.open0) { u64x2 t; t.x = (a[0] - m0[0]) + (bb[0] - m1[0]); t.y = (a[1] - m0[1]) + (bb[1] - m1[1]); *reinterpret_cast<u64x2*>(d.open0 + idx) = t; }
+                        if (d.open0) { const u64 t[2] = {(a[0] - m0[0]) + (bb[0] - m1[0]), (a[1] - m0[1]) + (bb[1] - m1[1])}; Chunk<W>::put(d.open0 + idx, t); }
                     } else {
-                        if (d.open0) { u64x2 t; t.x = a[0] - m0[0]; t.y = a[1] - m0[1]; *reinterpret_cast<u64x2*>(d.open0 + idx) = t; }
-                        if (d.open1) { u64x2 t; t.x = bb[0] - m1[0]; t.y = bb[1] - m1[1]; *reinterpret_cast<u64x2*>(d.open1 + idx) = t; }
+                        if (d.open0) { const u64 t[2] = {a[0] - m0[0], a[1] - m0[1]}; Chunk<W>::put(d.open0 + idx, t); }
+                        if (d.open1) { const u64 t[2] = {bb[0] - m1[0], bb[1] - m1[1]}; Chunk<W>::put(d.open1 + idx, t); }
                     }
                 }
             }
@@ -235,12 +242,12 @@ __device__ __forceinline__ void gather_pair_chain_body(const u64* __restrict__ t
     }
 }
 
-template <int LPR, bool STREAM>   // STREAM: every pair brings the dealt slab of its chain (pair_chain.h)
+template <int LPR, bool STREAM, int W = 2>   // STREAM: every pair brings the dealt slab of its chain (pair_chain.h)
 __global__ __launch_bounds__(kThreads) void gather_pair_chain_kernel(const u64* __restrict__ table, const uint32_t* __restrict__ rowptr,
                                                                       const uint32_t* __restrict__ col, int F, int ntiles, GatherPairBatch b) {
     __shared__ uint32_t s_rp[2][kPairTile + 1];
     __shared__ uint32_t s_col[2][kPairColCap];
-    gather_pair_chain_body<LPR, STREAM>(table, rowptr, col, F, ntiles, b, s_rp, s_col);
+    gather_pair_chain_body<LPR, W, STREAM>(table, rowptr, col, F, ntiles, b, s_rp, s_col);
 }
 // Grid of the gather kernels: one workgroup per tile up to this cap (the kernels keep their grid-stride loop).  Measured on
 // MI355X (config5, fused F = 64 launch): persistent grids lose to the hardware dispatcher - 1792 workgroups (one per slot)
@@ -391,7 +398,8 @@ int cognn_gather_pair_chain_u64(cognn_ctx* ctx, const uint64_t* table, const uin
                                 const cognn_gather_pair* pairs, int32_t count) {
     { const int rc_flush_ = cg_flush(ctx); if (rc_flush_) return rc_flush_; }
     CG_REQUIRE(ctx && table && rowptr && (count == 0 || pairs) && count >= 0 && count <= kGatherPairsMax, "cognn_gather_pair_chain_u64: bad arguments");
-    CG_REQUIRE(F > 0 && F % 2 == 0 && F < (1 << 20) && cg_aligned16(table), "cognn_gather_pair_chain_u64: F must be even and the table 16-byte aligned");
+    CG_REQUIRE(F > 0 && F < (1 << 20) && cg_aligned16(table), "cognn_gather_pair_chain_u64: bad width or misaligned table");
+    const bool odd = (F & 1) != 0;                           // 8-byte lanes: the row stride is not a multiple of 16 bytes
     GatherPairBatch b;
     b.count = 0;
     int ntiles = 0, nstream = 0;
@@ -405,7 +413,7 @@ int cognn_gather_pair_chain_u64(cognn_ctx* ctx, const uint64_t* table, const uin
         CG_REQUIRE((!(fl & COGNN_PC_SCALE) || (s.scale[0] && s.scale[1])) && s.rows * F < (1ll << 32) && p.a_row0 >= 0 && p.b_row0 >= 0, "cognn_gather_pair_chain_u64: pair %d is malformed", c);
         CG_REQUIRE(s.out[0] || s.out[1] || s.open[0] || s.open[1], "cognn_gather_pair_chain_u64: pair %d writes nothing", c);
         CG_REQUIRE(!(fl & COGNN_PC_OPEN_SUM) || !s.open[1], "cognn_gather_pair_chain_u64: pair %d: COGNN_PC_OPEN_SUM writes open[0] only", c);
-        CG_REQUIRE(cg_aligned16(s.out[0]) && cg_aligned16(s.out[1]) && cg_aligned16(s.open[0]) && cg_aligned16(s.open[1]), "cognn_gather_pair_chain_u64: pair %d: misaligned output", c);
+        CG_REQUIRE(odd || (cg_aligned16(s.out[0]) && cg_aligned16(s.out[1]) && cg_aligned16(s.open[0]) && cg_aligned16(s.open[1])), "cognn_gather_pair_chain_u64: pair %d: misaligned output", c);
         GatherPairSeg& g = b.s[b.count];
         PairChainDev& d = g.d;
         d.x0 = d.x1 = d.c1 = nullptr; d.mask_in = nullptr;
@@ -421,12 +429,14 @@ int cognn_gather_pair_chain_u64(cognn_ctx* ctx, const uint64_t* table, const uin
         ++b.count;
     }
     if (ntiles == 0) return 0;
-    const int lpr = pick_lpr((int)(F / 2));
+    const int lpr = pick_lpr(odd ? (int)F : (int)(F / 2));
     dim3 grid((unsigned)gather_grid(ntiles)), block(kThreads);
     CG_REQUIRE(nstream == 0 || nstream == b.count, "cognn_gather_pair_chain_u64: either every pair brings its dealt values or none does");
 #define CG_GP_CASE(L)                                                                                                                              \
     case L:                                                                                                                                        \
-        if (nstream) hipLaunchKernelGGL((gather_pair_chain_kernel<L, true>), grid, block, 0, ctx->stream, (const u64*)table, rowptr, col, (int)F, ntiles, b); \
+        if (odd && nstream) hipLaunchKernelGGL((gather_pair_chain_kernel<L, true, 1>), grid, block, 0, ctx->stream, (const u64*)table, rowptr, col, (int)F, ntiles, b); \
+        else if (odd) hipLaunchKernelGGL((gather_pair_chain_kernel<L, false, 1>), grid, block, 0, ctx->stream, (const u64*)table, rowptr, col, (int)F, ntiles, b);    \
+        else if (nstream) hipLaunchKernelGGL((gather_pair_chain_kernel<L, true>), grid, block, 0, ctx->stream, (const u64*)table, rowptr, col, (int)F, ntiles, b); \
         else hipLaunchKernelGGL((gather_pair_chain_kernel<L, false>), grid, block, 0, ctx->stream, (const u64*)table, rowptr, col, (int)F, ntiles, b);        \
         break;
     switch (lpr) {

@@ -1085,7 +1085,7 @@ void message_passing(cognn_engine* E, int F, int64_t it, bool open_scale) {
 // epilogue (cognn_gather_pair_chain_u64): the lanes that aggregate vertex r's owner-side row also aggregate its co-party-side
 // row and run the pair chain on the two sums in registers, so the aggregate itself is never written or re-read.
 bool can_fuse_gather_chain(const cognn_engine* E, int F) {
-    if (E->world != 1 || !E->pair_fusion || (F & 1) || E->k > 8) return false;
+    if (E->world != 1 || !E->pair_fusion || E->k > 8) return false;
     for (auto& s : E->sides) if (!s.peer) return false;
     return true;
 }

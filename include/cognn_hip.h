@@ -363,7 +363,7 @@ int cognn_pair_weight_update_u64(cognn_ctx*, const cognn_pair_wupdate* jobs, int
  * - and the chain (COGNN_PC_SCALE, optionally | COGNN_PC_RELU; chain.x / rows-of-x are unused, chain.rows = rows of the segment)
  * runs on (V_0, V_1) in registers: the aggregate is never written, only the chain's outputs / openings are.  Bit-identical to
  * cognn_gather_csr_u64 followed by cognn_pair_chain_u64.  flags = 0 (the last backward Gather has no scale, gcn.h:470): the
- * outputs / openings are those of the aggregate itself.  rowptr / col index rows of `table`; F even; count <= 8. */
+ * outputs / openings are those of the aggregate itself.  rowptr / col index rows of `table`; count <= 8.  An odd F (7 or 3 labels) runs with 8-byte lanes. */
 typedef struct {
     int64_t a_row0, b_row0;
     cognn_pair_chain chain;

@@ -172,7 +172,9 @@ def test_pair_chain_batches_and_rejects_bad_chains(ctx):
 
 
 @pytest.mark.parametrize("F,relu,forward_only", [(64, True, False), (16, False, False), (64, True, True), (6, True, False), (2, False, False),
-                                                 (64, None, True), (16, None, False), (64, True, "sum"), (16, None, "sum")])
+                                                 (64, None, True), (16, None, False), (64, True, "sum"), (16, None, "sum"),
+                                                 # odd widths (7 or 3 labels): 8-byte lanes
+                                                 (7, False, False), (3, True, False), (7, None, "sum"), (1, False, False), (33, True, "sum")])
 def test_gather_with_pair_chain_epilogue_equals_gather_then_chain(ctx, F, relu, forward_only):
     """cognn_gather_pair_chain_u64 (the aggregate never written) against cognn_gather_csr_u64 on both sides' row segments followed
     by cognn_pair_chain_u64, and against the oracle's two-party functions; two owners of different sizes (tiles of 32 vertices,
