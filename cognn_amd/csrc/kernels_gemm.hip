@@ -1933,12 +1933,12 @@ int launch_group(cognn_ctx* ctx, const GemmGroup& g, int wgs, size_t lds, bool f
 
 // Whole K per workgroup (B fragments of every K step in LDS, workgroups walk row tiles) needs the image to fit and row tiles enough to
 // fill the chip - and, for one column tile (4-wave workgroups, several per CU), an image small enough that several workgroups still
-// share a CU, unless there is work for every wave many times over: PubMed's 4929 x 500 . 16 per side (128 KiB image, 2472 tiles)
-// ran at one workgroup per CU and took 148 us; as K ranges it takes a third of that.
+// share a CU: PubMed's 4929 x 500 . 16 per side (128 KiB image, 2472 tiles) ran at one workgroup per CU and took 148 us; as K
+// ranges of at most 6 steps (48 KiB) it takes a third of that.
 static bool group_whole_k(int64_t N, int64_t K, int64_t tiles_all) {
     const int nst = (int)((K + 31) / 32), NT = (int)((N + 15) / 16);
     const size_t lds_all = (size_t)nst * NT * kD16Stage;
-    return lds_all <= 128 * 1024 && tiles_all >= 2048 && (NT >= 2 || lds_all <= 48 * 1024 || tiles_all >= 65536);
+    return lds_all <= 128 * 1024 && tiles_all >= 2048 && (NT >= 2 || lds_all <= 48 * 1024);
 }
 extern "C" int cognn_beaver_gemm_group_takes_epilogue(int64_t N, int64_t K, int64_t row_tiles) {
     static const bool no_group = getenv("COGNN_GEMM_NO_GROUP") != nullptr;
@@ -2019,7 +2019,7 @@ extern "C" int cognn_beaver_gemm_close_group_u64(cognn_ctx* ctx, const cognn_gem
     for (int32_t j = 0; j < count; ++j) groups_all += ((jobs[j].M + 15) / 16 + waves - 1) / waves;
     int ksteps = nst;
     if (!whole_k) {
-        const int ksteps_max = std::max(1, (int)((128 * 1024) / ((size_t)NT * kD16Stage)));
+        const int ksteps_max = std::max(1, (int)(((NT == 1 ? 48 : 128) * 1024) / ((size_t)NT * kD16Stage)));   // (one column tile: several workgroups per CU)
         const int want_splits = (int)std::max<int64_t>(1, (2 * budget + groups_all - 1) / groups_all);   // about two waves of workgroups
         ksteps = std::min(ksteps_max, std::max(std::min(2, nst), (nst + want_splits - 1) / want_splits));
     }
