@@ -2022,6 +2022,8 @@ extern "C" int cognn_beaver_gemm_close_group_u64(cognn_ctx* ctx, const cognn_gem
         const int ksteps_max = std::max(1, (int)(((NT == 1 ? 48 : 128) * 1024) / ((size_t)NT * kD16Stage)));   // (one column tile: several workgroups per CU)
         const int want_splits = (int)std::max<int64_t>(1, (2 * budget + groups_all - 1) / groups_all);   // about two waves of workgroups
         ksteps = std::min(ksteps_max, std::max(std::min(2, nst), (nst + want_splits - 1) / want_splits));
+        static const int ksteps_env = getenv("COGNN_GROUP_KSTEPS") ? atoi(getenv("COGNN_GROUP_KSTEPS")) : 0;   // A/B switch: K steps per workgroup of the split-K form
+        if (ksteps_env > 0) ksteps = std::min(ksteps_max, std::min(nst, ksteps_env));
     }
     const int splits = (nst + ksteps - 1) / ksteps;
     g.ksteps = ksteps;
