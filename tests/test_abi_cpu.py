@@ -56,3 +56,18 @@ def test_key_derivation_matches_oracle(lib):
     k = capi.make_keys(0xC06A11, 3, 7, co.OP_GA_SCALE)
     for s in range(capi.NUM_SLOTS):
         assert k.k[s] == co.stream_key(0xC06A11, 3, 7, co.OP_GA_SCALE, s)
+
+
+def test_chunk_range_partitions_every_length(lib):
+    """cognn_chunk_range (host function, no GPU): the C chunks of any length are contiguous, even-aligned, ordered and cover
+    [0, n) exactly - the partition the element-wise kernels' chunk window and the engine's chunked messages share."""
+    import ctypes
+    lo = ctypes.c_int64(); hi = ctypes.c_int64()
+    for n in list(range(0, 40)) + [1433 * 16, (1 << 20) * 64 + 3, 7 * 19717]:
+        for C in (1, 2, 3, 4, 5, 8, 64):
+            end = 0
+            for c in range(C):
+                lib.cognn_chunk_range(n, c, C, ctypes.byref(lo), ctypes.byref(hi))
+                assert lo.value == end and hi.value >= lo.value and (lo.value % 2 == 0 or C == 1), (n, C, c, lo.value, hi.value)
+                end = hi.value
+            assert end == n, (n, C)
