@@ -2271,7 +2271,7 @@ int cognn_engine_set_option(cognn_engine* E, int32_t option, int64_t value) {
         else if (option == COGNN_OPT_PUBLIC_OPENINGS) E->public_openings = value != 0;
         else if (option == COGNN_OPT_DEALER_STREAMS) E->dealer_streams = value != 0;
         else if (option == COGNN_OPT_GRAPH_EPOCHS) {
-            if (value != 0 && original(E)) throw EngineError("cognn_engine_set_option: recorded epochs are not available for original-gcn (its dealer keys are uploaded per iteration)");
+            if (value != 0 && original(E)) throw EngineError("cognn_engine_set_option: recorded epochs are not supported for original-gcn");
             if (value != 0 && !E->graph_epochs) BE(cognn_ctx_use_private_stream(E->ctx));   // (the caller's stream may be the default stream, which cannot record)
             if (E->graph_exec) { E->be->cognn_graph_destroy(E->ctx, E->graph_exec); E->graph_exec = nullptr; }
             E->graph_epochs = value != 0; E->graph_warm = false;
