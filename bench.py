@@ -405,9 +405,15 @@ def main():
                            "GBps_while_communicating": ((x1["bytes_sent"] - x0["bytes_sent"]) / 1e9) / max((x1["comm_ms"] - x0["comm_ms"]) / 1e3, 1e-12),
                            "transport": "native RCCL p2p groups on a communication stream (csrc/exchange_rccl.hip)"}
     if not args.no_check and world == 1:
-        out["check"] = cross_path_check(eng, Engine, k, src, dst, part, param, variant, iters, in_dim, lab, n_warm + args.steps)
+        try:
+            out["check"] = cross_path_check(eng, Engine, k, src, dst, part, param, variant, iters, in_dim, lab, n_warm + args.steps)
+        except Exception as ex:  # noqa: BLE001 - e.g. a second engine of an 8x workload does not fit beside the first: the measurement stands
+            out["check"] = {"skipped": "the verification engine could not run: %s" % (str(ex)[-200:],)}
     if world == 1 and not args.no_dealer_streams and not recorded:
-        out["dealer_streams"] = dealer_streams_leg(eng, torch, args, iters, k, out.get("check", {}).get("digest"))
+        try:
+            out["dealer_streams"] = dealer_streams_leg(eng, torch, args, iters, k, out.get("check", {}).get("digest"))
+        except Exception as ex:  # noqa: BLE001 - the dealt values of a large workload may not fit
+            out["dealer_streams"] = {"skipped": "the dealt form could not run: %s" % (str(ex)[-200:],)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args, wl)
     elif rank == 0:
