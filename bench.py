@@ -372,6 +372,7 @@ def main():
         "epoch_time_s": dt / args.steps,
         "edges_feat_per_s_per_party": value / k,
         "offline_ms": offline_ms, "setup_s": setup_s,
+        "device_GB_allocated_by_the_engine": eng.memory()[1] / 1e9,
         "roofline": {"bound": "hbm", "kernel": ("scatter_gather_original_kernel: per-edge two-normaliser Scatter + Gather of one destination party "
                                                 "(bytes: both shares of every source row and vertex row; the launch is bound by its per-edge dealer arithmetic, not by HBM)")
                                                if variant == "original-gcn" else
