@@ -25,6 +25,8 @@
 //   sci::twoPartyGCNMatrixScale(m, fx, out, tid, party)        gcn.h:676,723,764       public constant * share, truncation
 //   sci::twoPartyGCNApplyGradient(W, d, fxLr, Wout, ..)        gcn.h:678,730           W - trunc(lr * d)
 //   sci::twoPartyGCNBackwardNNWithoutAH(in, z, wT, out, g, first, ..)  gcn.h:705       in (.) 1[z > 0]  (+ g = out . wT)
+//   sci::twoPartyGCNVectorScale(in, n0, n1, out, ..) / ForwardNN / ForwardNNPrediction / BackwardNNInit / BackwardNN
+//                                                              original-gcn/gcn.h:243,459,493,586,622   compositions of the above
 //   sci::plaintext_add_matrix[_in_place](a, b)                 gcn.h:758,762           local add
 //   sci::cross_entropy_loss / accuracy / count_true            gcn.h:620-632           host metrics on the revealed p
 //   prefix_network_aggregate(pos, svv, ADD_AGG, coTid, party, b)   gcn.h:328-335       segmented inclusive prefix sum
@@ -739,6 +741,48 @@ inline ShareVecVec plaintext_add_matrix(const ShareVecVec& a, const ShareVecVec&
     ShareVecVec o(a);
     plaintext_add_matrix_in_place(o, b);
     return o;
+}
+
+// ---- the fused ops of the unoptimised kernel (algo_kernels/vertex_centric/original-gcn/gcn.h), for either container ------------
+// Their definitions live in the absent SCI library; the input / output relation is INFERRED from the call sites and stated here
+// as compositions of the ops above (oracle/original_gcn.py restates the same compositions for the engine's original-gcn variant).
+// The `normalizer` arguments of the Apply ops are accepted and unused: in the reference's call sites the degree normalisation has
+// already happened in ScatterComp / GatherComp.
+// two-normaliser scale of ScatterComp (:243-250): out = trunc(trunc(in * n0) * n1), one normaliser pair per row (= per edge)
+template <class Mat>
+inline void twoPartyGCNVectorScale(const Mat& in, const std::vector<uint64_t>& normalizer0, const std::vector<uint64_t>& normalizer1, Mat& out,
+                                   uint64_t coTid, int party) {
+    Mat mid;
+    twoPartyGCNVectorScale(in, normalizer0, mid, true, coTid, party);
+    twoPartyGCNVectorScale(mid, normalizer1, out, true, coTid, party);
+}
+// GCN_FORWARD_NN (:459): z = in . W, new_h = ReLU(z)
+template <class Mat, class Ten>
+inline void twoPartyGCNForwardNN(const Mat& in, const Ten& weight, const std::vector<uint64_t>& /*normalizer*/, Ten& z, Ten& new_h, uint64_t tid, int party) {
+    twoPartyGCNMatMul(in, weight, z, tid, party);
+    twoPartyGCNRelu(z, new_h, tid, party);
+}
+// prediction layer (:493,508): z = in . W, then softmax, p - y
+template <class Mat, class Ten>
+inline void twoPartyGCNForwardNNPrediction(const Mat& in, const Ten& weight, const ShareVecVec& label, const std::vector<uint64_t>& /*normalizer*/, Ten& z, Ten& p,
+                                           Ten& p_minus_y, uint64_t tid, int party) {
+    twoPartyGCNMatMul(in, weight, z, tid, party);
+    twoPartyGCNForwardNNPredictionWithoutWeight(z, label, p, p_minus_y, tid, party);
+}
+// last layer's backward (:586): d = ah_t . in (ah_t: the transposed aggregate saved by the forward pass), g = in . W^T
+template <class Mat, class Ten>
+inline void twoPartyGCNBackwardNNInit(const Mat& in, const Ten& ah_t, const Ten& weightT, const std::vector<uint64_t>& /*normalizer*/, Ten& d, Ten& g, uint64_t tid,
+                                      int party) {
+    twoPartyGCNMatMul(in, weightT, g, tid, party);
+    twoPartyGCNMatMul(ah_t, in, d, tid, party);
+}
+// hidden layers' backward (:622): gz = in (.) 1[z > 0], d = ah_t . gz, g = gz . W^T unless this is the first layer
+template <class Mat, class Ten>
+inline void twoPartyGCNBackwardNN(const Mat& in, const Ten& ah_t, const Ten& z, const Ten& weightT, const std::vector<uint64_t>& /*normalizer*/, Ten& d, Ten& g,
+                                  bool isFirstLayer, uint64_t tid, int party) {
+    Mat gz;
+    twoPartyGCNBackwardNNWithoutAH(in, z, weightT, gz, g, isFirstLayer, tid, party);
+    twoPartyGCNMatMul(ah_t, gz, d, tid, party);
 }
 
 // metrics on the revealed probabilities (gcn.h:611-632)

@@ -14,9 +14,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BIN = os.path.join(ROOT, "tests", "_build", "gas_epochs")
 
 
-def build():
+def build(name="gas_epochs"):
+    BIN = os.path.join(ROOT, "tests", "_build", name)
     os.makedirs(os.path.dirname(BIN), exist_ok=True)
-    src = os.path.join(ROOT, "tests", "gas_epochs.cpp")
+    src = os.path.join(ROOT, "tests", name + ".cpp")
     deps = [src, os.path.join(ROOT, "include", "cognn_gas_kernel.hpp"), os.path.join(ROOT, "include", "cognn_sci_shim.hpp"),
             os.path.join(ROOT, "include", "cognn_hip.h"), os.path.join(ROOT, "cognn_amd", "libcognn_hip.so")]
     if os.path.exists(BIN) and all(os.path.getmtime(BIN) >= os.path.getmtime(d) for d in deps):

@@ -23,6 +23,10 @@ def test_shim_program_builds_and_refuses_to_run_without_a_gpu(tmp_path):
     shim_util.write_input(tmp_path / "in.bin", o, 2)
     r = subprocess.run([exe, "device", str(tmp_path / "in.bin"), str(tmp_path / "out.bin")], capture_output=True, text=True, timeout=60)
     assert r.returncode != 0 and "no HIP device" in r.stderr
+    # ... and so does the program that drives the op names of the unoptimised kernel (original-gcn) through the shim
+    exe2 = shim_util.build("shim_original_ops")
+    r = subprocess.run([exe2, "fused", "device", str(tmp_path / "o.bin")], capture_output=True, text=True, timeout=60)
+    assert r.returncode != 0 and "no HIP device" in r.stderr
 
 
 def test_shim_host_codecs():

@@ -111,3 +111,38 @@ def test_on_algo_kernel_start_deals_the_oracles_shares(tmp_path):
             with np.errstate(over="ignore"):
                 assert np.array_equal(w0 + w1, w_plain[l])
     assert pos == len(data)
+
+
+def _read_mats(path):
+    import struct
+    raw = open(path, "rb").read()
+    out, off = [], 0
+    while off < len(raw):
+        r, c = struct.unpack_from("<QQ", raw, off); off += 16
+        out.append(np.frombuffer(raw, dtype=np.uint64, count=r * c, offset=off).reshape(r, c)); off += 8 * r * c
+    return out
+
+
+def test_original_gcn_fused_ops_of_the_shim(tmp_path):
+    """The op names of the unoptimised kernel (original-gcn/gcn.h:243,459,493,586,622: two-normaliser VectorScale, ForwardNN,
+    ForwardNNPrediction, BackwardNNInit, BackwardNN) through the shim, client and server threads over a LocalPipe: each equals the
+    sequence of single ops it is defined as (same seed, same inputs), on device-resident tensors and on nested host vectors alike;
+    the two-normaliser scale reconstructs to x . n0 . n1 within the two truncations' slack."""
+    exe = shim_util.build("shim_original_ops")
+    got = {}
+    for form in ("fused", "prim"):
+        for where in ("device", "host"):
+            out = tmp_path / ("%s_%s.bin" % (form, where))
+            r = subprocess.run([exe, form, where, str(out)], capture_output=True, text=True, timeout=300)
+            assert r.returncode == 0, r.stderr[-2000:]
+            got[(form, where)] = _read_mats(out)
+    ref = got[("prim", "device")]
+    assert len(ref) == 18                                       # 9 tensors per role
+    for key, mats in got.items():
+        assert len(mats) == len(ref), key
+        for i, (a, b) in enumerate(zip(mats, ref)):
+            assert a.shape == b.shape and np.array_equal(a, b), (key, i)
+    with np.errstate(over="ignore"):
+        sc = (ref[0] + ref[9]).astype(np.int64)                 # both roles' shares of the scaled tensor
+    assert np.abs(sc).max() < (1 << 22) and np.abs(sc).max() > 0   # Q16 values of magnitude < 2^19 scaled by two factors < 1
+    assert np.abs(sc[0::7]).max() <= 1                          # rows whose second normaliser is 0 reconstruct to 0 (+ 1 ulp of truncation)
