@@ -422,7 +422,7 @@ public:
                    uint64_t dstTid, bool isClient) const override {
         const uint32_t epochLayerNum = getEpochLayerNum(), forwardLayerNum = getForwardLayerNum(), coForwardLayer = coForwardLayerOf(iter);
         const bool isForward = (iter % epochLayerNum) < forwardLayerNum;
-        const size_t vecSize = vertexDataVec.size(), tileNum = gs.tileNum;
+        const size_t vecSize = vertexDataVec.size();
         const int party = isClient ? sci::ALICE : sci::BOB;
         const uint64_t trainSetSize = (uint64_t)(vecSize * gnnParam.train_ratio), valSetSize = (uint64_t)(vecSize * gnnParam.val_ratio);
         TensorVecMap& vertexInterData = isClient ? gs.localVertexInterDataTVs[coForwardLayer] : gs.remoteVertexInterDataTVs[coForwardLayer];
@@ -473,8 +473,13 @@ public:
         sci::twoPartyGCNApplyGradient(weightRef, d, static_cast<uint64_t>(gs.learningRate * (1 << SCALER_BIT_LENGTH)), weightRef, dstTid, party);
         vertexInterData["d"] = {d};
         dstVec.swap(vertexInterData["g"][0]);
-        // weight averaging, gcn.h:747-802: parties >= 2 ship both their weight shares to parties 1 (local share) and 0 (the share they
-        // hold as a co-party); 0 and 1 sum, scale by 1 / tileNum between themselves and hand the average back
+        averageWeights(gs, tileIndex, coForwardLayer, isClient, weightRef, coWeightRef);
+    }
+
+    // weight averaging, gcn.h:747-802 (original-gcn/gcn.h:659-711): parties >= 2 ship both their weight shares to parties 1 (local
+    // share) and 0 (the share they hold as a co-party); 0 and 1 sum, scale by 1 / tileNum between themselves and hand the average back
+    void averageWeights(GS& gs, uint64_t tileIndex, uint32_t coForwardLayer, bool isClient, Svv& weightRef, Svv& coWeightRef) const {
+        const size_t tileNum = gs.tileNum;
         Transport<Svv>* comm = this->comm;
         if (isClient) {
             gs.remoteWeightReadySmp.acquire();                          // this party's server thread updated its share of the layer
@@ -540,7 +545,7 @@ public:
     size_t tileNum = 0;
     void tileNumIs(size_t n) { tileNum = n; }
 
-private:
+protected:
     void reportMetrics(GS& gs, DoubleTensor plainP, uint64_t trainSetSize, uint64_t valSetSize) const {   // gcn.h:606-632
         const size_t vecSize = plainP.size(), L = gnnParam.num_labels;
         DoubleTensor y(vecSize, std::vector<double>(L, 0.0));
@@ -569,6 +574,102 @@ private:
             printf("border test set accuracy = %lf\n", m.borderTest);
             printf("the number of vertices is %lu, the number of border vertices is %lu\n", (unsigned long)m.vertices, (unsigned long)m.border);
         }
+    }
+};
+
+// ---- CoGNN (unoptimised): algo_kernels/vertex_centric/original-gcn/gcn.h -----------------------------------------------------
+// Aggregate-then-transform: PreScatterComp copies, ScatterComp scales every message on its edge by the two degree normalisers,
+// GatherComp scales the vertex's own row once in forward iterations, ApplyComp runs the fused ForwardNN / Prediction / BackwardNNInit /
+// BackwardNN ops (cognn_sci_shim.hpp) and averages the weights after both backward iterations; 4 GAS iterations per epoch.
+template <class Svv>
+class GCNOriginalEdgeCentricAlgoKernel : public GCNEdgeCentricAlgoKernel<Svv> {
+public:
+    typedef GCNEdgeCentricAlgoKernel<Svv> Base;
+    typedef GraphSummary<Svv> GS;
+    typedef typename GS::TensorVecMap TensorVecMap;
+    using Base::gnnParam;
+    explicit GCNOriginalEdgeCentricAlgoKernel(const GNNParam& p) : Base(p) {}
+
+    // original-gcn/gcn.h:802-851
+    uint32_t getBackwardLayerNum() const override { return gnnParam.num_layers; }
+    std::vector<uint32_t> getDimensionVec() const override { return {gnnParam.input_dim, gnnParam.hidden_dim, gnnParam.num_labels, gnnParam.hidden_dim}; }
+    uint32_t getPlainNumPerOperand() const override { return gnnParam.input_dim; }
+    uint32_t getPlainNumPerOperand(uint64_t iter) const override { return getDimensionVec()[iter % this->getEpochLayerNum()]; }
+    uint32_t coForwardLayerOfOriginal(uint64_t iter) const {  // :337-340, 431-434
+        const uint32_t e = (uint32_t)(iter % this->getEpochLayerNum()), f = this->getForwardLayerNum();
+        return e < f ? e : f - 1 - (e - f);
+    }
+
+    // :198-209 - both arguments are the same object at the call sites: nothing to do
+    void PreScatterComp(GS&, const Svv& vertexSvv, std::vector<uint64_t>&, Svv& scaledVertexSvv, uint64_t, uint64_t, int) const override {
+        if (&vertexSvv != &scaledVertexSvv) scaledVertexSvv = cognn_shim::svv_clone(vertexSvv);
+    }
+    // :211-251 - the client passes the real degrees of its edges, the server zeros / the destination's in-degrees (ss_...h:800, 1041-1043)
+    void ScatterComp(Svv& updateSrcSvv, std::vector<uint64_t>& updateSrcOutDeg, std::vector<uint64_t>& updateDstInDeg, Svv& duplicatedUpdateSvv, uint64_t coTid,
+                     int party) const override {
+        std::vector<uint64_t> normalizer0 = Base::normalizerOf(updateSrcOutDeg), normalizer1 = Base::normalizerOf(updateDstInDeg);
+        sci::twoPartyGCNVectorScale(updateSrcSvv, normalizer0, normalizer1, duplicatedUpdateSvv, coTid, party);
+    }
+    // :323-405 - forward: the vertex's own row is scaled once, before the first addition
+    void GatherComp(Svv& vertexSvv, Svv& updateSvv, std::vector<bool>& isGatherDstVertexDummy, std::vector<uint64_t>& localVertexInDeg, uint64_t iter,
+                    uint64_t updateSrcTid, uint64_t coTid, int party) const override {
+        const bool isForward = (iter % this->getEpochLayerNum()) < this->getForwardLayerNum();
+        if (isForward && updateSrcTid == 0) {
+            std::vector<uint64_t> normalizer = Base::normalizerOf(localVertexInDeg);
+            sci::twoPartyGCNVectorScale(vertexSvv, normalizer, vertexSvv, true, coTid, party);
+        }
+        std::vector<bool> cond(isGatherDstVertexDummy.size());
+        for (size_t i = 0; i < cond.size(); ++i) cond[i] = !isGatherDstVertexDummy[i];
+        sci::twoPartyGCNCondVectorAddition(vertexSvv, updateSvv, cond, vertexSvv, coTid, party);
+    }
+    // :426-713
+    void ApplyComp(GS& gs, uint64_t iter, const Svv& vertexDataVec, const std::vector<uint64_t>& /*localVertexInDeg*/, Svv& dstVec, uint64_t tileIndex,
+                   uint64_t dstTid, bool isClient) const override {
+        const uint32_t epochLayerNum = this->getEpochLayerNum(), forwardLayerNum = this->getForwardLayerNum(), coForwardLayer = coForwardLayerOfOriginal(iter);
+        const bool isForward = (iter % epochLayerNum) < forwardLayerNum;
+        const size_t vecSize = vertexDataVec.size();
+        const int party = isClient ? sci::ALICE : sci::BOB;
+        const uint64_t trainSetSize = (uint64_t)(vecSize * gnnParam.train_ratio), valSetSize = (uint64_t)(vecSize * gnnParam.val_ratio);
+        const std::vector<uint64_t> normalizer;               // (declared and left empty at :446)
+        TensorVecMap& vertexInterData = isClient ? gs.localVertexInterDataTVs[coForwardLayer] : gs.remoteVertexInterDataTVs[coForwardLayer];
+        if (isForward) {
+            const Svv& weight = isClient ? gs.localWeight[coForwardLayer] : gs.remoteWeight[coForwardLayer];
+            vertexInterData["ah_t"] = {transpose(vertexDataVec)};       // :452
+            if (iter % epochLayerNum != forwardLayerNum - 1) {         // GCN_FORWARD_NN :455-485
+                Svv z, new_h;
+                sci::twoPartyGCNForwardNN(vertexDataVec, weight, normalizer, z, new_h, dstTid, party);
+                vertexInterData["z"] = {z};
+                dstVec.swap(new_h);
+                return;
+            }
+            ShareVecVec label;                                          // GCN_FORWARD_PREDICTION :486-560
+            for (size_t i = 0; i < vecSize; ++i)
+                label.push_back(isClient ? toShareVec(gs.localVertexLabel[i], (int)gnnParam.num_labels) : ShareVec(gnnParam.num_labels, 0));
+            Svv z, p, p_minus_y;
+            sci::twoPartyGCNForwardNNPrediction(vertexDataVec, weight, label, normalizer, z, p, p_minus_y, dstTid, party);
+            DoubleTensor plainP;
+            sci::getPlainShareVecVec(p, plainP, dstTid, party);
+            if (isClient) this->reportMetrics(gs, plainP, trainSetSize, valSetSize);
+            vertexInterData["z"] = {z};
+            vertexInterData["p"] = {p};
+            cognn_shim::svv_zero_rows_from(p_minus_y, trainSetSize);
+            dstVec.swap(p_minus_y);
+            return;
+        }
+        Svv& weightRef = isClient ? gs.localWeight[coForwardLayer] : gs.remoteWeight[coForwardLayer];
+        Svv& coWeightRef = isClient ? gs.remoteWeight[coForwardLayer] : gs.localWeight[coForwardLayer];
+        Svv weightT = transpose(weightRef);                             // :565-568, taken before the update
+        Svv d, g;
+        if (coForwardLayer == forwardLayerNum - 1)                      // GCN_BACKWARD_NN_INIT :573-612
+            sci::twoPartyGCNBackwardNNInit(vertexDataVec, vertexInterData["ah_t"][0], weightT, normalizer, d, g, dstTid, party);
+        else                                                            // GCN_BACKWARD_NN :613-655
+            sci::twoPartyGCNBackwardNN(vertexDataVec, vertexInterData["ah_t"][0], vertexInterData["z"][0], weightT, normalizer, d, g, coForwardLayer == 0, dstTid, party);
+        const double gradientScaler = (double)1 / trainSetSize;
+        sci::twoPartyGCNMatrixScale(d, static_cast<uint64_t>(gradientScaler * (1 << SCALER_BIT_LENGTH)), d, dstTid, party);
+        sci::twoPartyGCNApplyGradient(weightRef, d, static_cast<uint64_t>(gs.learningRate * (1 << SCALER_BIT_LENGTH)), weightRef, dstTid, party);
+        vertexInterData["d"] = {d};
+        dstVec.swap(g);
+        this->averageWeights(gs, tileIndex, coForwardLayer, isClient, weightRef, coWeightRef);   // :659-711, after BOTH backward iterations
     }
 };
 

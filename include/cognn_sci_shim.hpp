@@ -242,6 +242,7 @@ struct Session {
     cognn_ctx* ctx = nullptr;
     int p = 0;
     uint64_t seed = 0, owner = 0, counter = 0;
+    uint64_t server = 0;                                     // the BOB side of the pair (owner = the ALICE side)
     Channel* ch = nullptr;
     std::map<uint64_t, std::unique_ptr<Plan>> plans;         // by hash of the index structure (both roles hold the same plans)
     std::map<uint64_t, std::unique_ptr<Dev>> vectors;        // host side vectors already on the device (normalisers, labels)
@@ -249,6 +250,13 @@ struct Session {
     cognn_keys keys(int op) const {
         cognn_keys k;
         cognn_make_keys(seed, owner, counter, (uint64_t)op, &k);
+        return k;
+    }
+    // the streams of a Scatter instance (client = owner, server): several sessions of one owner run such calls with equal call
+    // numbers, so they are addressed by the pair, not by the owner (the tag of oracle/original_gcn.py pair_tag)
+    cognn_keys pair_keys(int op) const {
+        cognn_keys k;
+        cognn_make_keys(seed, 0x10000ull + owner * 256 + server, counter, (uint64_t)op, &k);
         return k;
     }
     // one exchange round on device buffers
@@ -293,6 +301,7 @@ inline void open_session(uint64_t selfTid, uint64_t coTid, int party, uint64_t s
     s->p = party - 1;
     s->seed = seed;
     s->owner = party == 1 ? selfTid : coTid;                 // the data owner is the ALICE side of the pair
+    s->server = party == 1 ? coTid : selfTid;
     s->ch = ch;
     Registry& r = Registry::get();
     std::lock_guard<std::mutex> lk(r.m);
@@ -438,10 +447,13 @@ inline DevMat matmul(Session& s, const DevMat& A, const DevMat& B) {
     return O;
 }
 
-inline DevMat vector_scale(Session& s, const DevMat& in, const std::vector<uint64_t>& rowScale) {
+// (k_over / tk_over: streams other than the session's own for this call - the two scales of a Scatter instance; advance: the call
+// number moves on)
+inline DevMat vector_scale(Session& s, const DevMat& in, const std::vector<uint64_t>& rowScale, const cognn_keys* k_over = nullptr,
+                           const cognn_keys* tk_over = nullptr, bool advance = true) {
     const size_t n = in.rows(), F = in.cols();
     if (rowScale.size() != n) throw Error("twoPartyGCNVectorScale: one scale per row expected");
-    cognn_keys k = s.keys(OP_SCALE), tk = s.keys(OP_SCALE_TRUNC);
+    cognn_keys k = k_over ? *k_over : s.keys(OP_SCALE), tk = tk_over ? *tk_over : s.keys(OP_SCALE_TRUNC);
     const Dev& S = s.cached(rowScale.data(), n, 8);
     DevMat E(s.ctx, n, F), Ep(s.ctx, n, F), c(s.ctx, n, F), cp(s.ctx, n, F), O(s.ctx, n, F);
     Dev G(s.ctx, n), Gp(s.ctx, n);
@@ -453,8 +465,18 @@ inline DevMat vector_scale(Session& s, const DevMat& in, const std::vector<uint6
     check(cognn_trunc_close_u64(s.ctx, O.u64(), s.p == 0 ? c.u64() : nullptr, s.p == 0 ? cp.u64() : nullptr, &tk, s.p, 0, (int64_t)(n * F)),
           "cognn_trunc_close_u64");
     check(cognn_ctx_sync(s.ctx), "cognn_ctx_sync");
-    ++s.counter;
+    if (advance) ++s.counter;
     return O;
+}
+// ScatterComp of the unoptimised kernel (original-gcn/gcn.h:243-250): trunc(trunc(in * n0) * n1), one normaliser pair per row
+// (= per edge of the Scatter instance); ONE protocol call with four stream families (ops 30..33) addressed by the pair
+enum { OP_SC_SCALE0 = 30, OP_SC_SCALE0_TRUNC = 31, OP_SC_SCALE1 = 32, OP_SC_SCALE1_TRUNC = 33 };
+inline DevMat vector_scale2(Session& s, const DevMat& in, const std::vector<uint64_t>& n0, const std::vector<uint64_t>& n1) {
+    const cognn_keys k0 = s.pair_keys(OP_SC_SCALE0), t0 = s.pair_keys(OP_SC_SCALE0_TRUNC), k1 = s.pair_keys(OP_SC_SCALE1), t1 = s.pair_keys(OP_SC_SCALE1_TRUNC);
+    DevMat mid = vector_scale(s, in, n0, &k0, &t0, false);
+    DevMat out = vector_scale(s, mid, n1, &k1, &t1, false);
+    ++s.counter;
+    return out;
 }
 
 // masked-sign ReLU: h (optional) and the public sign mask (optional, 1 byte per element)
@@ -748,13 +770,18 @@ inline ShareVecVec plaintext_add_matrix(const ShareVecVec& a, const ShareVecVec&
 // as compositions of the ops above (oracle/original_gcn.py restates the same compositions for the engine's original-gcn variant).
 // The `normalizer` arguments of the Apply ops are accepted and unused: in the reference's call sites the degree normalisation has
 // already happened in ScatterComp / GatherComp.
-// two-normaliser scale of ScatterComp (:243-250): out = trunc(trunc(in * n0) * n1), one normaliser pair per row (= per edge)
-template <class Mat>
-inline void twoPartyGCNVectorScale(const Mat& in, const std::vector<uint64_t>& normalizer0, const std::vector<uint64_t>& normalizer1, Mat& out,
+// two-normaliser scale of ScatterComp (:243-250): out = trunc(trunc(in * n0) * n1), one normaliser pair per row (= per edge); its
+// dealer streams belong to the Scatter instance (cognn_shim::dev::vector_scale2)
+inline void twoPartyGCNVectorScale(const DevMat& in, const std::vector<uint64_t>& normalizer0, const std::vector<uint64_t>& normalizer1, DevMat& out,
                                    uint64_t coTid, int party) {
-    Mat mid;
-    twoPartyGCNVectorScale(in, normalizer0, mid, true, coTid, party);
-    twoPartyGCNVectorScale(mid, normalizer1, out, true, coTid, party);
+    out = cognn_shim::dev::vector_scale2(cognn_shim::session(coTid, party), in, normalizer0, normalizer1);
+}
+inline void twoPartyGCNVectorScale(const ShareVecVec& in, const std::vector<uint64_t>& normalizer0, const std::vector<uint64_t>& normalizer1, ShareVecVec& out,
+                                   uint64_t coTid, int party) {
+    Session& s = cognn_shim::session(coTid, party);
+    DevMat o;
+    twoPartyGCNVectorScale(DevMat::from_host(s.ctx, in), normalizer0, normalizer1, o, coTid, party);
+    o.to_host(out);
 }
 // GCN_FORWARD_NN (:459): z = in . W, new_h = ReLU(z)
 template <class Mat, class Ten>

@@ -44,13 +44,14 @@ void put(FILE* f, const ShareVecVec& m) {
 struct PartyInput {
     std::vector<uint64_t> localVertexPos, localVertexInDeg, labels, border;
     std::vector<std::vector<uint64_t>> updateSrcVertexPos, updateDstVertexPos, remoteMirrorVertexPos, dummy;
+    std::vector<std::vector<uint64_t>> updateSrcOutDeg, updateDstInDeg, remoteUpdateDstInDeg;   // original-gcn only (its ScatterComp reads them)
     ShareVecVec localVertexSvv;
     std::vector<ShareVecVec> remoteVertexSvvs;
     std::vector<ShareVecVec> localWeight, remoteWeight;
 };
 
 template <class Svv>
-int run(uint64_t k, uint64_t seed, uint64_t iters, const cognn_gas::GNNParam& param, const std::vector<PartyInput>& in, const char* out_path) {
+int run(uint64_t k, uint64_t seed, uint64_t iters, const cognn_gas::GNNParam& param, const std::vector<PartyInput>& in, const char* out_path, bool original) {
     using namespace cognn_gas;
     // one channel per ordered pair (owner t, server j): t's client thread for j (ALICE) <-> j's server thread for t (BOB)
     std::vector<std::unique_ptr<cognn_shim::LocalPipe>> pipes(k * k);
@@ -62,7 +63,9 @@ int run(uint64_t k, uint64_t seed, uint64_t iters, const cognn_gas::GNNParam& pa
             cognn_shim::open_session(j, t, sci::BOB, seed, pipes[t * k + j]->bob());
         }
     LocalMesh<Svv> mesh;
-    GCNEdgeCentricAlgoKernel<Svv> kernel(param);
+    // the callbacks of optimize-gcn/gcn.h, or of original-gcn/gcn.h (the unoptimised kernel: 4 GAS iterations per epoch)
+    std::unique_ptr<GCNEdgeCentricAlgoKernel<Svv>> kernel_ptr(original ? new GCNOriginalEdgeCentricAlgoKernel<Svv>(param) : new GCNEdgeCentricAlgoKernel<Svv>(param));
+    GCNEdgeCentricAlgoKernel<Svv>& kernel = *kernel_ptr;
     kernel.comm = &mesh;
     kernel.tileNumIs(k);
     std::vector<std::unique_ptr<GraphSummary<Svv>>> gs(k);
@@ -81,6 +84,7 @@ int run(uint64_t k, uint64_t seed, uint64_t iters, const cognn_gas::GNNParam& pa
             g.updateSrcVertexPos[j] = pi.updateSrcVertexPos[j]; g.updateDstVertexPos[j] = pi.updateDstVertexPos[j];
             g.remoteMirrorVertexPos[j] = pi.remoteMirrorVertexPos[j];
             g.isGatherDstVertexDummy[j].assign(pi.dummy[j].begin(), pi.dummy[j].end());
+            if (original) { g.updateSrcOutDeg[j] = pi.updateSrcOutDeg[j]; g.updateDstInDeg[j] = pi.updateDstInDeg[j]; g.remoteUpdateDstInDeg[j] = pi.remoteUpdateDstInDeg[j]; }
             if (j != t) {
                 cognn_shim::svv_from_host(mine, pi.remoteVertexSvvs[j], g.remoteVertexSvvs[j]);
                 g.remoteVertexSvvsBackup[j] = cognn_shim::svv_clone(g.remoteVertexSvvs[j]);     // ss_...h:226-227
@@ -170,11 +174,13 @@ int run_start(Reader& in, const char* out_path) {
 }  // namespace
 
 int main(int argc, char** argv) {
-    if (argc < 4) { fprintf(stderr, "usage: %s <device|host|start> <input> <output>\n", argv[0]); return 2; }
+    if (argc < 4) { fprintf(stderr, "usage: %s <device|host|odevice|ohost|start> <input> <output>\n", argv[0]); return 2; }
     try {
         Reader in{fopen(argv[2], "rb")};
         if (!in.f) throw std::runtime_error("cannot open input");
         if (std::string(argv[1]) == "start") return run_start(in, argv[3]);
+        const std::string mode = argv[1];
+        const bool original = mode == "odevice" || mode == "ohost";   // the input then carries the per-edge degree vectors too
         const uint64_t k = in.one(), seed = in.one(), iters = in.one();
         cognn_gas::GNNParam param;
         param.input_dim = (uint32_t)in.one(); param.hidden_dim = (uint32_t)in.one(); param.num_labels = (uint32_t)in.one();
@@ -184,8 +190,10 @@ int main(int argc, char** argv) {
             PartyInput& p = parties[t];
             p.localVertexPos = in.vec(); p.localVertexInDeg = in.vec(); p.labels = in.vec(); p.border = in.vec();
             p.updateSrcVertexPos.resize(k); p.updateDstVertexPos.resize(k); p.remoteMirrorVertexPos.resize(k); p.dummy.resize(k);
+            p.updateSrcOutDeg.resize(k); p.updateDstInDeg.resize(k); p.remoteUpdateDstInDeg.resize(k);
             for (uint64_t j = 0; j < k; ++j) {
                 p.updateSrcVertexPos[j] = in.vec(); p.updateDstVertexPos[j] = in.vec(); p.remoteMirrorVertexPos[j] = in.vec(); p.dummy[j] = in.vec();
+                if (original) { p.updateSrcOutDeg[j] = in.vec(); p.updateDstInDeg[j] = in.vec(); p.remoteUpdateDstInDeg[j] = in.vec(); }
             }
             p.localVertexSvv = in.mat();
             p.remoteVertexSvvs.resize(k);
@@ -194,10 +202,9 @@ int main(int argc, char** argv) {
             for (int l = 0; l < 2; ++l) p.remoteWeight.push_back(in.mat());
         }
         fclose(in.f);
-        const std::string mode = argv[1];
-        if (mode == "device") return run<cognn_shim::DevMat>(k, seed, iters, param, parties, argv[3]);
-        if (mode == "host") return run<ShareVecVec>(k, seed, iters, param, parties, argv[3]);
-        throw std::runtime_error("mode must be device or host");
+        if (mode == "device" || mode == "odevice") return run<cognn_shim::DevMat>(k, seed, iters, param, parties, argv[3], original);
+        if (mode == "host" || mode == "ohost") return run<ShareVecVec>(k, seed, iters, param, parties, argv[3], original);
+        throw std::runtime_error("mode must be device, host, odevice or ohost");
     } catch (const std::exception& ex) {
         fprintf(stderr, "gas_epochs: %s\n", ex.what());
         return 1;

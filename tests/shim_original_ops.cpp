@@ -2,7 +2,7 @@
 // sci::twoPartyGCNVectorScale with two normalisers, ForwardNN, ForwardNNPrediction, BackwardNNInit, BackwardNN
 // (algo_kernels/vertex_centric/original-gcn/gcn.h:243,459,493,586,622) - run by a client (ALICE) and a server (BOB) thread over
 // a LocalPipe, on device-resident tensors or on the reference's nested vectors.  Mode `fused` calls them; mode `prim` calls the
-// sequence of single ops each is defined as.  Same seed, same inputs: the outputs must be identical (tests/test_shim_gpu.py).
+// sequence of single ops each of the four Apply ops is defined as.  Same seed, same inputs: the outputs must be identical (tests/test_shim_gpu.py).
 //   usage: shim_original_ops <fused|prim> <device|host> <output file>
 #include <cstdio>
 #include <stdexcept>
@@ -40,8 +40,7 @@ void role(bool fused, int party, uint64_t tid, uint64_t coTid, const Inputs& in,
     const Mat x = from_host<Mat>(s, in.x), w0 = from_host<Mat>(s, in.w0), w1 = from_host<Mat>(s, in.w1);
     const std::vector<uint64_t> none;
     Mat sc, z0, h, z1, p, pmy, d1, g1, d0, g0;
-    if (fused) sci::twoPartyGCNVectorScale(x, in.n0, in.n1, sc, coTid, party);
-    else { Mat mid; sci::twoPartyGCNVectorScale(x, in.n0, mid, true, coTid, party); sci::twoPartyGCNVectorScale(mid, in.n1, sc, true, coTid, party); }
+    sci::twoPartyGCNVectorScale(x, in.n0, in.n1, sc, coTid, party);   // (one protocol call with its own streams: no single-op form)
     if (fused) sci::twoPartyGCNForwardNN(sc, w0, none, z0, h, coTid, party);
     else { sci::twoPartyGCNMatMul(sc, w0, z0, coTid, party); sci::twoPartyGCNRelu(z0, h, coTid, party); }
     if (fused) sci::twoPartyGCNForwardNNPrediction(h, w1, in.label, none, z1, p, pmy, coTid, party);

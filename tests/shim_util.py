@@ -91,6 +91,76 @@ class ShimKeyedOracle(co.OracleEngine):
         return self.key_of(owner, it, co.OP_AP_GEMM)
 
 
+def shim_calls_original(P, k, iters):
+    """The unoptimised kernel (original-gcn/gcn.h, 4 GAS iterations per epoch) through include/cognn_gas_kernel.hpp: call numbers of
+    the sessions of data owner P.  Returns (own, scatter): own[(it, engine op)] = (call number, shim op) in the session of P and its
+    co-party - Gather's self scale (:365), ForwardNN / Prediction (:459,493), BackwardNNInit (:586: g first, then d), BackwardNN (:622:
+    the sign protocol on z, then d), MatrixScale / ApplyGradient (:590,593,634,642), the averaging scale in party 0's pair (:676) -
+    and scatter[(it, destination party i)] = (server tid of the session, call number): ScatterComp is one call of the session
+    (P, i) - for P's local edges and for the edges towards its co-party both in the session (P, co(P)), local edges first."""
+    cop = (P + 1) % k
+    own, scatter = {}, {}
+    cnt = {i: 0 for i in range(k) if i != P}                 # per session (P, server i)
+    for it in range(iters):
+        e = it % 4
+        if e != 2:                                           # not the apply-only iteration
+            scatter[(it, P)] = (cop, cnt[cop]); cnt[cop] += 1
+            for i in range(k):
+                if i != P:
+                    scatter[(it, i)] = (i, cnt[i]); cnt[i] += 1
+        c = cnt[cop]
+        if e < 2:
+            own[(it, co.OP_GA_SCALE)] = (c, S_SCALE); own[(it, co.OP_GA_SCALE_TRUNC)] = (c, S_SCALE_T); c += 1
+            own[(it, OP_AP_FWD_GEMM)] = (c, S_GEMM); own[(it, OP_AP_FWD_GEMM_TRUNC)] = (c, S_GEMM_T); c += 1
+            if e == 0:
+                own[(it, co.OP_AP_RELU)] = (c, S_RELU); c += 1
+            else:
+                own[(it, co.OP_AP_SOFTMAX)] = (c, S_SOFTMAX); c += 1
+        else:
+            if e == 2:                                       # last layer: g = in . W^T, then d = ah_t . in
+                own[(it, co.OP_AP_GEMM)] = (c, S_GEMM); own[(it, co.OP_AP_GEMM_TRUNC)] = (c, S_GEMM_T); c += 1
+            else:                                            # first layer: the sign protocol on z (public result), no g
+                c += 1
+            own[(it, OP_AP_DGEMM)] = (c, S_GEMM); own[(it, OP_AP_DGEMM_TRUNC)] = (c, S_GEMM_T); c += 1
+            own[(it, co.OP_AP_GSCALE_TRUNC)] = (c, S_MSCALE); c += 1
+            own[(it, co.OP_AP_LR_TRUNC)] = (c, S_LR); c += 1
+            if P == 0:
+                own[(it, co.OP_WAVG_TRUNC)] = (c, S_MSCALE); c += 1
+        cnt[cop] = c
+    return own, scatter
+
+
+OP_AP_DGEMM, OP_AP_DGEMM_TRUNC, OP_AP_FWD_GEMM, OP_AP_FWD_GEMM_TRUNC = 34, 35, 36, 37      # oracle/original_gcn.py
+
+
+def keyed_original_oracle(*args, **kw):
+    """oracle/original_gcn.py with the shim's dealer addressing (see shim_calls_original)."""
+    import original_gcn
+
+    class ShimKeyedOriginalOracle(original_gcn.OriginalOracleEngine):
+        MAX_ITERS = 16
+
+        def _maps(self, P):
+            if not hasattr(self, "_calls"):
+                self._calls = {}
+            if P not in self._calls:
+                self._calls[P] = shim_calls_original(P, self.k, self.MAX_ITERS)
+            return self._calls[P]
+
+        def key_of(self, owner, it, op):
+            if owner >= 0x10000 and owner != co.OWNER_WAVG:  # a Scatter instance (client P, destination party i): pair_tag
+                P, i = (owner - 0x10000) // 256, (owner - 0x10000) % 256
+                server, c = self._maps(P)[1][(it, i)]
+                tag = 0x10000 + P * 256 + server
+                return lambda slot: co.stream_key(self.seed, tag, c, op, slot)
+            if owner == co.OWNER_WAVG:
+                owner = 0
+            c, sop = self._maps(owner)[0][(it, op)]
+            return lambda slot: co.stream_key(self.seed, owner, c, sop, slot)
+
+    return ShimKeyedOriginalOracle(*args, **kw)
+
+
 def _vec(f, a):
     a = np.ascontiguousarray(np.asarray(a, dtype=np.uint64))
     f.write(struct.pack("<Q", a.size)); f.write(a.tobytes())
@@ -105,8 +175,9 @@ def _mat(f, m):
     _vec(f, [m.shape[0]]); _vec(f, [m.shape[1]]); _vec(f, m.reshape(-1))
 
 
-def write_input(path, o, iters):
-    """State of a freshly started k-party OracleEngine in the order tests/gas_epochs.cpp reads it."""
+def write_input(path, o, iters, original=False):
+    """State of a freshly started k-party OracleEngine in the order tests/gas_epochs.cpp reads it (original: with the per-edge degree
+    vectors the unoptimised kernel's ScatterComp reads)."""
     k = o.k
     p = o.param
     with open(path, "wb") as f:
@@ -119,6 +190,8 @@ def write_input(path, o, iters):
             for j in range(k):
                 _vec(f, gs.updateSrcVertexPos[j]); _vec(f, gs.updateDstVertexPos[j]); _vec(f, gs.remoteMirrorVertexPos[j])
                 _vec(f, [int(b) for b in gs.isGatherDstVertexDummy[j]])
+                if original:
+                    _vec(f, gs.updateSrcOutDeg[j]); _vec(f, gs.updateDstInDeg[j]); _vec(f, gs.remoteUpdateDstInDeg[j])
             _mat(f, gs.localVertexSvv)
             for j in range(k):
                 if j != t:

@@ -16,14 +16,18 @@ import shim_util
 pytestmark = pytest.mark.gpu
 
 
-def run_case(tmp_path, mode, k, V, Eu, in_dim, hid, lab, iters, graph_seed=3):
+def run_case(tmp_path, mode, k, V, Eu, in_dim, hid, lab, iters, graph_seed=3, original=False):
     exe = shim_util.build()
     src, dst = co.synth_graph(V, Eu, graph_seed)
     part = [v % k for v in range(V)]
     feats, labels = co.synth_features(V, in_dim, lab, 4, density=0.25)
     p = co.GnnParam(num_labels=lab, input_dim=in_dim, hidden_dim=hid, num_samples=V, learning_rate=0.5)
-    o = shim_util.ShimKeyedOracle(k, src, dst, part, feats, labels, p, seed=0xC06A11)
-    shim_util.write_input(tmp_path / "in.bin", o, iters)
+    if original:                                             # the unoptimised kernel's callbacks (GCNOriginalEdgeCentricAlgoKernel)
+        o = shim_util.keyed_original_oracle(k, src, dst, part, feats, labels, p, seed=0xC06A11)
+        mode = "o" + mode
+    else:
+        o = shim_util.ShimKeyedOracle(k, src, dst, part, feats, labels, p, seed=0xC06A11)
+    shim_util.write_input(tmp_path / "in.bin", o, iters, original=original)
     r = subprocess.run([exe, mode, str(tmp_path / "in.bin"), str(tmp_path / "out.bin")], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     per_iter, weights, probs, metrics = shim_util.read_output(tmp_path / "out.bin", k, iters)
@@ -60,6 +64,15 @@ def run_case(tmp_path, mode, k, V, Eu, in_dim, hid, lab, iters, graph_seed=3):
 @pytest.mark.parametrize("k,V,Eu,in_dim,hid,lab", [(2, 40, 90, 12, 8, 4), (3, 60, 140, 12, 8, 4)])
 def test_two_training_epochs_through_the_gas_kernel_match_the_oracle(tmp_path, mode, k, V, Eu, in_dim, hid, lab):
     run_case(tmp_path, mode, k, V, Eu, in_dim, hid, lab, 12)
+
+
+@pytest.mark.parametrize("mode,k,V,Eu", [("device", 2, 40, 90), ("host", 2, 40, 90), ("device", 3, 60, 140), ("device", 4, 50, 60)])
+def test_original_gcn_epochs_through_the_gas_kernel_match_the_oracle(tmp_path, mode, k, V, Eu):
+    """The upper seam with the callbacks of the unoptimised kernel (original-gcn/gcn.h: copy PreScatter, per-edge two-normaliser
+    ScatterComp, forward self scale in GatherComp, fused ForwardNN / Prediction / BackwardNNInit / BackwardNN Apply, weight average
+    after both backward iterations; 4 GAS iterations per epoch): two epochs against oracle/original_gcn.py under the shim's dealer
+    addressing, every share after every iteration and the weights, k = 2, 3, 4 (sparse: dummy self entries, empty Scatter instances)."""
+    run_case(tmp_path, mode, k, V, Eu, 12, 8, 4, 8, original=True)
 
 
 def test_device_mode_at_a_wider_shape_and_four_parties(tmp_path):
