@@ -357,6 +357,8 @@ public:
     GNNParam gnnParam;
     uint64_t sharingSeed = 0;                                // keys CryptoUtil::intoShares in onAlgoKernelStart
     bool printMetrics = false;                               // the client's printf lines of gcn.h:620-632
+    bool inferenceVariant = false;                           // optimize-gcn-inference/gcn.h (bin/gcn-inference-optimize): each party scales its updated
+                                                             // weights by 1 / tileNum itself (:680-681, 732-733) and the averaging step does not (:763-764 absent)
     explicit GCNEdgeCentricAlgoKernel(const GNNParam& p) : gnnParam(p) {}
 
     // gcn.h:893-948
@@ -471,6 +473,10 @@ public:
         const double gradientScaler = (double)1 / trainSetSize;
         sci::twoPartyGCNMatrixScale(d, static_cast<uint64_t>(gradientScaler * (1 << SCALER_BIT_LENGTH)), d, dstTid, party);
         sci::twoPartyGCNApplyGradient(weightRef, d, static_cast<uint64_t>(gs.learningRate * (1 << SCALER_BIT_LENGTH)), weightRef, dstTid, party);
+        if (inferenceVariant) {
+            const double weightScaler = (double)1 / gs.tileNum;
+            sci::twoPartyGCNMatrixScale(weightRef, static_cast<uint64_t>(weightScaler * (1 << SCALER_BIT_LENGTH)), weightRef, dstTid, party);
+        }
         vertexInterData["d"] = {d};
         dstVec.swap(vertexInterData["g"][0]);
         averageWeights(gs, tileIndex, coForwardLayer, isClient, weightRef, coWeightRef);
@@ -491,8 +497,10 @@ public:
                     sci::plaintext_add_matrix_in_place(weightRef, fromOther);
                 }
                 sci::plaintext_add_matrix_in_place(weightRef, coWeightRef);
-                const double weightScaler = (double)1 / tileNum;
-                sci::twoPartyGCNMatrixScale(weightRef, static_cast<uint64_t>(weightScaler * (1 << SCALER_BIT_LENGTH)), weightRef, 1 - tileIndex, (int)tileIndex + 1);
+                if (!inferenceVariant) {
+                    const double weightScaler = (double)1 / tileNum;
+                    sci::twoPartyGCNMatrixScale(weightRef, static_cast<uint64_t>(weightScaler * (1 << SCALER_BIT_LENGTH)), weightRef, 1 - tileIndex, (int)tileIndex + 1);
+                }
                 coWeightRef = weightRef;
                 for (size_t i = 0; i < tileNum; ++i)
                     if (i != tileIndex && i != 1 - tileIndex)

@@ -51,7 +51,8 @@ struct PartyInput {
 };
 
 template <class Svv>
-int run(uint64_t k, uint64_t seed, uint64_t iters, const cognn_gas::GNNParam& param, const std::vector<PartyInput>& in, const char* out_path, bool original) {
+int run(uint64_t k, uint64_t seed, uint64_t iters, const cognn_gas::GNNParam& param, const std::vector<PartyInput>& in, const char* out_path, bool original,
+        bool inference = false) {
     using namespace cognn_gas;
     // one channel per ordered pair (owner t, server j): t's client thread for j (ALICE) <-> j's server thread for t (BOB)
     std::vector<std::unique_ptr<cognn_shim::LocalPipe>> pipes(k * k);
@@ -67,6 +68,7 @@ int run(uint64_t k, uint64_t seed, uint64_t iters, const cognn_gas::GNNParam& pa
     std::unique_ptr<GCNEdgeCentricAlgoKernel<Svv>> kernel_ptr(original ? new GCNOriginalEdgeCentricAlgoKernel<Svv>(param) : new GCNEdgeCentricAlgoKernel<Svv>(param));
     GCNEdgeCentricAlgoKernel<Svv>& kernel = *kernel_ptr;
     kernel.comm = &mesh;
+    kernel.inferenceVariant = inference;                      // optimize-gcn-inference/gcn.h
     kernel.tileNumIs(k);
     std::vector<std::unique_ptr<GraphSummary<Svv>>> gs(k);
     for (uint64_t t = 0; t < k; ++t) {
@@ -174,7 +176,7 @@ int run_start(Reader& in, const char* out_path) {
 }  // namespace
 
 int main(int argc, char** argv) {
-    if (argc < 4) { fprintf(stderr, "usage: %s <device|host|odevice|ohost|start> <input> <output>\n", argv[0]); return 2; }
+    if (argc < 4) { fprintf(stderr, "usage: %s <device|host|idevice|odevice|ohost|start> <input> <output>\n", argv[0]); return 2; }
     try {
         Reader in{fopen(argv[2], "rb")};
         if (!in.f) throw std::runtime_error("cannot open input");
@@ -202,9 +204,10 @@ int main(int argc, char** argv) {
             for (int l = 0; l < 2; ++l) p.remoteWeight.push_back(in.mat());
         }
         fclose(in.f);
+        if (mode == "idevice") return run<cognn_shim::DevMat>(k, seed, iters, param, parties, argv[3], false, true);
         if (mode == "device" || mode == "odevice") return run<cognn_shim::DevMat>(k, seed, iters, param, parties, argv[3], original);
         if (mode == "host" || mode == "ohost") return run<ShareVecVec>(k, seed, iters, param, parties, argv[3], original);
-        throw std::runtime_error("mode must be device, host, odevice or ohost");
+        throw std::runtime_error("mode must be device, host, idevice, odevice or ohost");
     } catch (const std::exception& ex) {
         fprintf(stderr, "gas_epochs: %s\n", ex.what());
         return 1;

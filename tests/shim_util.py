@@ -32,7 +32,7 @@ def build(name="gas_epochs"):
 S_GEMM, S_GEMM_T, S_SCALE, S_SCALE_T, S_RELU, S_SOFTMAX, S_MSCALE, S_LR = 10, 11, 12, 13, 16, 17, 20, 21
 
 
-def shim_calls(owner, iters):
+def shim_calls(owner, iters, inference=False):
     """(GAS iteration, engine op id) -> (call number of the owner's (owner, co) session, shim op id): the order in which the
     callbacks of gcn.h reach the protocol functions - PreScatterComp (:233,247), GatherComp (:476), ApplyComp (:549,578,665,671,
     676,678,705,710,723,730) and, in the session of party 0's pair, the weight-averaging scale (:764)."""
@@ -60,7 +60,7 @@ def shim_calls(owner, iters):
             m[(it, co.OP_AP_GEMM)] = (c, S_GEMM); m[(it, co.OP_AP_GEMM_TRUNC)] = (c, S_GEMM_T); c += 1
             m[(it, co.OP_AP_GSCALE_TRUNC)] = (c, S_MSCALE); c += 1
             m[(it, co.OP_AP_LR_TRUNC)] = (c, S_LR); c += 1
-            if owner == 0:
+            if inference or owner == 0:                     # inference variant: every party scales its own weights (:680-681); else the average, in party 0's pair
                 m[(it, co.OP_WAVG_TRUNC)] = (c, S_MSCALE); c += 1
     return m
 
@@ -75,7 +75,7 @@ class ShimKeyedOracle(co.OracleEngine):
         if not hasattr(self, "_calls"):
             self._calls = {}
         if owner not in self._calls:
-            self._calls[owner] = shim_calls(owner, self.MAX_ITERS)
+            self._calls[owner] = shim_calls(owner, self.MAX_ITERS, inference=self.variant == "optimize-gcn-inference")
         c, sop = self._calls[owner][(it, op)]
         return lambda slot: co.stream_key(self.seed, owner, c, sop, slot)
 

@@ -16,7 +16,7 @@ import shim_util
 pytestmark = pytest.mark.gpu
 
 
-def run_case(tmp_path, mode, k, V, Eu, in_dim, hid, lab, iters, graph_seed=3, original=False):
+def run_case(tmp_path, mode, k, V, Eu, in_dim, hid, lab, iters, graph_seed=3, original=False, inference=False):
     exe = shim_util.build()
     src, dst = co.synth_graph(V, Eu, graph_seed)
     part = [v % k for v in range(V)]
@@ -25,6 +25,9 @@ def run_case(tmp_path, mode, k, V, Eu, in_dim, hid, lab, iters, graph_seed=3, or
     if original:                                             # the unoptimised kernel's callbacks (GCNOriginalEdgeCentricAlgoKernel)
         o = shim_util.keyed_original_oracle(k, src, dst, part, feats, labels, p, seed=0xC06A11)
         mode = "o" + mode
+    elif inference:                                          # optimize-gcn-inference/gcn.h run through whole training epochs
+        o = shim_util.ShimKeyedOracle(k, src, dst, part, feats, labels, p, seed=0xC06A11, variant="optimize-gcn-inference")
+        mode = "i" + mode
     else:
         o = shim_util.ShimKeyedOracle(k, src, dst, part, feats, labels, p, seed=0xC06A11)
     shim_util.write_input(tmp_path / "in.bin", o, iters, original=original)
@@ -73,6 +76,13 @@ def test_original_gcn_epochs_through_the_gas_kernel_match_the_oracle(tmp_path, m
     after both backward iterations; 4 GAS iterations per epoch): two epochs against oracle/original_gcn.py under the shim's dealer
     addressing, every share after every iteration and the weights, k = 2, 3, 4 (sparse: dummy self entries, empty Scatter instances)."""
     run_case(tmp_path, mode, k, V, Eu, 12, 8, 4, 8, original=True)
+
+
+@pytest.mark.parametrize("k,V,Eu", [(2, 40, 90), (3, 60, 140)])
+def test_inference_variant_epochs_through_the_gas_kernel(tmp_path, k, V, Eu):
+    """GCNEdgeCentricAlgoKernel::inferenceVariant (optimize-gcn-inference/gcn.h: every party scales its updated weights by 1 / k itself,
+    the averaging step does not): two whole epochs, bit-exact vs the oracle's inference variant."""
+    run_case(tmp_path, "device", k, V, Eu, 12, 8, 4, 12, inference=True)
 
 
 def test_device_mode_at_a_wider_shape_and_four_parties(tmp_path):
