@@ -509,6 +509,15 @@ __global__ void softmax_jobs_zero_kernel(SoftmaxBatch b) {
         else if ((t & 7) == 6) *b.j[t >> 3].loss = 0.0;
     }
 }
+// floor(num / den) for 0 <= num < 2^52, 0 < den < 2^52 through one double-precision division and an exact integer correction - the same
+// quotient as the 64-bit integer division (which the compiler expands to a long software sequence) at a fraction of its cost
+__device__ __forceinline__ u64 div_floor_small(u64 num, u64 den) {
+    u64 q = (u64)((double)num / (double)den);
+    const long long rem = (long long)num - (long long)(q * den);
+    if (rem < 0) --q;
+    else if ((u64)rem >= den) ++q;
+    return q;
+}
 // A group of G lanes (G = power of two >= L) owns G consecutive rows: row i of the group is evaluated across the G lanes
 // (lane j = column j, reductions by shuffles, coalesced 8*L-byte row accesses), and lane i keeps row i's bookkeeping, so that
 // the double-precision log of the loss runs once per lane instead of once per row on 1 lane in G.
@@ -550,7 +559,8 @@ __global__ __launch_bounds__(kThreads) void softmax_jobs_kernel(SoftmaxBatch b, 
         long long S = e;
 #pragma unroll
         for (int o = G / 2; o > 0; o >>= 1) S += __shfl_xor(S, o, G);
-        const u64 pf = valid ? (u64)(((e << 16) + (S >> 1)) / S) : 0ull;      // the revealed Q16 probability (softmax_kernel)
+        // the revealed Q16 probability (softmax_kernel); e <= 2^30, S <= 64 * 2^30: the dividend stays below 2^47
+        const u64 pf = valid ? div_floor_small((u64)((e << 16) + (S >> 1)), (u64)S) : 0ull;
         const int lab = r < d.rows ? d.labels[r] : 0;
         if (valid) {
             const u64 rho = cognn_prng(d.keyRho, (u64)idx);
