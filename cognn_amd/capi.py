@@ -63,7 +63,7 @@ class GemmJob(ctypes.Structure):
     """cognn_gemm_job (include/cognn_hip.h)."""
     _fields_ = [("Z", ctypes.c_void_p), ("E0", ctypes.c_void_p), ("E1", ctypes.c_void_p), ("F0", ctypes.c_void_p), ("F1", ctypes.c_void_p),
                 ("c1", ctypes.c_void_p), ("keys", Keys), ("p", ctypes.c_int32), ("M", ctypes.c_int64), ("scratch", ctypes.c_void_p),
-                ("E_presplit", ctypes.c_void_p), ("A_dealt", ctypes.c_void_p), ("K", ctypes.c_int64), ("epilogue", ctypes.c_void_p), ("Z_zeroed", ctypes.c_int32)]
+                ("E_presplit", ctypes.c_void_p), ("A_presplit", ctypes.c_void_p), ("A_dealt", ctypes.c_void_p), ("K", ctypes.c_int64), ("epilogue", ctypes.c_void_p), ("Z_zeroed", ctypes.c_int32)]
 
 
 class CognnError(RuntimeError):
@@ -128,6 +128,7 @@ _SIGNATURES = {
     "cognn_beaver_gemm_tn_groupable": (_I, [_L, _L, _L, _I]),
     "cognn_beaver_gemm_close_group_tn_u64": (_I, [_P, ctypes.POINTER(GemmJob), ctypes.c_int32, _L, _L, _I]),
     "cognn_beaver_gemm_group_takes_epilogue": (_I, [_L, _L, _L]),
+    "cognn_beaver_gemm_group_is_whole_k": (_I, [_L, _L, _L]),
     "cognn_gemm_presplit_bytes": (_L, [_L, _L]),
     "cognn_gemm_presplit_u64": (_I, [_P, _P, _P, _P, _L, _L]),
     "cognn_trunc_close_u64": (_I, [_P, _P, _P, _P, _KP, _I, _I, _L]),

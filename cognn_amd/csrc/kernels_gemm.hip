@@ -788,6 +788,7 @@ constexpr int kGroupMax = 16;
 struct GemmGroupJob {
     u64* Z; const u64* E0; const u64* E1; const u64* F0; const u64* F1;
     const u64x2* Epl;                                        // PRE: the opened left operand already in fragment order (presplit_e_kernel)
+    const u64x2* Apl;                                        // PREA: the party's mask A_p of that operand in the same order (a mask that is dealt once)
     const u64* Amask;                                        // the party's mask A_p as dealt [M x K] (COGNN_OPT_DEALER_STREAMS): read, not regenerated
     u64 keyA, keyB;
     int p, M, tiles, wg_end;                                 // wg_end: exclusive prefix of the workgroups assigned to the jobs
@@ -839,7 +840,7 @@ __global__ __launch_bounds__(256) void presplit_e_kernel(u64x2* out, const u64* 
 // SPLITK (few row tiles, long K: the dataset-sized graphs - Cora's 1354 x 1433): a workgroup serves (job, group of row tiles,
 // K range of g.ksteps steps), builds the B fragments of its K range only and adds its partial tiles into the zeroed Z with
 // uint64 atomics (exact: integer adds commute).
-template <int NT, int WAVES, bool FULL, bool KEVEN, bool PRE = false, bool SPLITK = false, bool EPI = false>
+template <int NT, int WAVES, bool FULL, bool KEVEN, bool PRE = false, bool SPLITK = false, bool EPI = false, bool PREA = false>
 __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(2, NT == 1 ? 4 : 2)))
 void beaver_gemm_group_kernel(GemmGroup g, GemmEpi epi) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -893,14 +894,21 @@ void beaver_gemm_group_kernel(GemmGroup g, GemmEpi epi) {
     const int my_tiles = (tiles - wid + nw - 1) / nw;
     const int total = my_tiles * nst;                      // flattened (row tile, K step) space of this wave
     if (total <= 0) return;                                // (after the only barrier)
-    u64 nx0[8], nx1[PRE ? 1 : 8];
+    u64 nx0[8], nx1[PRE ? 1 : 8], nm0[PREA ? 8 : 1];
     const u64x2* __restrict__ Epl = J.Epl;
+    const u64x2* __restrict__ Apl = J.Apl;
     auto load_step = [&](int it) {
         const int tile = wid + (it / nst) * nw, st = st_lo + it % nst;
         if (PRE) {                                           // fragment-ordered image: four coalesced 16-byte pieces
-            const u64x2* src = Epl + (((size_t)tile * g.nst + st) * 4 << 6) + lane;
+            const size_t off = (((size_t)tile * g.nst + st) * 4 << 6) + lane;
+            const u64x2* src = Epl + off;
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) { const u64x2 x = src[jj << 6]; nx0[2 * jj] = x.x; nx0[2 * jj + 1] = x.y; }
+            if (PREA) {                                      // ... and the mask half of the fragment likewise
+                const u64x2* srm = Apl + off;
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) { const u64x2 x = srm[jj << 6]; nm0[2 * jj] = x.x; nm0[2 * jj + 1] = x.y; }
+            }
             return;
         }
         const int mc = FULL ? tile * 16 + r : min(tile * 16 + r, M - 1);
@@ -946,9 +954,14 @@ void beaver_gemm_group_kernel(GemmGroup g, GemmEpi epi) {
         u64 v[8], w[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = (!PRE && two) ? nx0[e] + nx1[PRE ? 0 : e] : nx0[e];
+        if (PREA) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) w[e] = nm0[e];
+        }
         if (it + 1 < total) load_step(it + 1);             // the next step's opened shares are in flight during this step's arithmetic
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
+            if (PREA) break;
             const u64 x = (u64)m * (u64)K + (u64)(st * 32 + 8 * jj + 2 * b);
             if (Amask) {                                     // (uniform) dealt mask: a memory stream instead of the counter PRNG
                 const size_t xc = FULL ? (size_t)x : (size_t)min((u64)x, (u64)M * (u64)K - 2);
@@ -966,7 +979,7 @@ void beaver_gemm_group_kernel(GemmGroup g, GemmEpi epi) {
             for (int e = 0; e < 8; ++e) {
                 const u64 keep = (m < M && d16_k(st, b, e) < K) ? ~0ull : 0ull;
                 if (!PRE) v[e] &= keep;                      // (the image is zero-padded)
-                w[e] &= keep;
+                if (!PREA) w[e] &= keep;
             }
         }
         uint32_t pe0[8], pe1[8], pm0[8], pm1[8];
@@ -976,7 +989,12 @@ void beaver_gemm_group_kernel(GemmGroup g, GemmEpi epi) {
         } else {
             split4(v, pe0); split4(v + 4, pe1);
         }
-        split4(w, pm0); split4(w + 4, pm1);
+        if (PREA) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { pm0[i] = (uint32_t)w[i]; pm1[i] = (uint32_t)(w[i] >> 32); }
+        } else {
+            split4(w, pm0); split4(w + 4, pm1);
+        }
         v4i af[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) af[i] = v4i{(int)pe0[i], (int)pe1[i], (int)pm0[i], (int)pm1[i]};
@@ -1902,7 +1920,7 @@ int beaver_close_impl(cognn_ctx* ctx, uint64_t* Z, const uint64_t* E, const uint
 // ---- grouped launch of one phase's products ------------------------------------------------------------------------------
 namespace {
 template <int NT, int WAVES>
-int launch_group(cognn_ctx* ctx, const GemmGroup& g, int wgs, size_t lds, bool full, bool keven, bool pre, bool splitk, const GemmEpi* epi) {
+int launch_group(cognn_ctx* ctx, const GemmGroup& g, int wgs, size_t lds, bool full, bool keven, bool pre, bool splitk, const GemmEpi* epi, bool prea = false) {
     static const GemmEpi no_epi = GemmEpi();
     const GemmEpi& ep = epi ? *epi : no_epi;
 #define CG_GROUP_LAUNCH(...)                                                                                                     \
@@ -1910,7 +1928,10 @@ int launch_group(cognn_ctx* ctx, const GemmGroup& g, int wgs, size_t lds, bool f
         CG_HIP(hipFuncSetAttribute((const void*)beaver_gemm_group_kernel<NT, WAVES, __VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
         hipLaunchKernelGGL((beaver_gemm_group_kernel<NT, WAVES, __VA_ARGS__>), dim3((unsigned)wgs), dim3(WAVES * 64), lds, ctx->stream, g, ep);         \
     } while (0)
-    if (epi) {                                               // (whole-K form only)
+    if (prea && pre && !splitk && !epi) {                    // both halves of the A fragment come as images: no producer arithmetic at all
+        if (full) CG_GROUP_LAUNCH(true, true, true, false, false, true); else CG_GROUP_LAUNCH(false, true, true, false, false, true);
+    }
+    else if (epi) {                                          // (whole-K form only)
         if (pre) { if (full) CG_GROUP_LAUNCH(true, true, true, false, true); else CG_GROUP_LAUNCH(false, true, true, false, true); }
         else if (full) CG_GROUP_LAUNCH(true, true, false, false, true);
         else if (keven) CG_GROUP_LAUNCH(false, true, false, false, true);
@@ -1940,6 +1961,10 @@ static bool group_whole_k(int64_t N, int64_t K, int64_t tiles_all) {
     const size_t lds_all = (size_t)nst * NT * kD16Stage;
     return lds_all <= 128 * 1024 && tiles_all >= 2048 && (NT >= 2 || lds_all <= 48 * 1024);
 }
+extern "C" int cognn_beaver_gemm_group_is_whole_k(int64_t N, int64_t K, int64_t row_tiles) {
+    static const bool no_group = getenv("COGNN_GEMM_NO_GROUP") != nullptr;
+    return (!no_group && N >= 1 && N <= kFusedBN && K >= 1 && group_whole_k(N, K, row_tiles)) ? 1 : 0;
+}
 extern "C" int cognn_beaver_gemm_group_takes_epilogue(int64_t N, int64_t K, int64_t row_tiles) {
     static const bool no_group = getenv("COGNN_GEMM_NO_GROUP") != nullptr;
     // N <= 16 (one column tile): the product kernel is bound by its producers' VALU work and the chain is cheaper as its own (HBM-bound)
@@ -1966,11 +1991,17 @@ extern "C" int cognn_beaver_gemm_close_group_u64(cognn_ctx* ctx, const cognn_gem
     }
     const int nst = (int)((K + 31) / 32), NT = (int)((N + 15) / 16);
     static const bool no_group = getenv("COGNN_GEMM_NO_GROUP") != nullptr;   // A/B switch: job by job through the per-side kernels
-    bool any_dealt = false;
-    for (int32_t j = 0; j < count; ++j) any_dealt = any_dealt || jobs[j].A_dealt != nullptr;
+    bool any_dealt = false, nepi_any = false;
+    for (int32_t j = 0; j < count; ++j) { any_dealt = any_dealt || jobs[j].A_dealt != nullptr; nepi_any = nepi_any || jobs[j].epilogue != nullptr; }
     // every job brings its fragment-ordered image (else none is used); the image form reads no operand element by element, so an odd K
     // (Cora's 1433, CiteSeer's 3703 features) is fine - unless a dealt mask is streamed too, whose vector loads assume an even K
     const bool pre = npre == count && count > 0 && (K % 2 == 0 || !any_dealt);
+    int nprea = 0;
+    for (int32_t j = 0; j < count; ++j) if (jobs[j].A_presplit) ++nprea;
+    // the masks' image too (every job or none; whole-K form, see launch_group) - for more than one column tile only: at N <= 16 the product
+    // moves few bytes per MFMA and the extra 8 B per operand element cost more than the mask arithmetic they replace (hid = 16 pass:
+    // 2.36 -> 2.65 ms with the image)
+    const bool prea = pre && nprea == count && !any_dealt && !nepi_any && N > 16;
     // Either every workgroup keeps the B fragments of ALL K steps in LDS and walks whole rows (enough row tiles to fill the chip),
     // or - few row tiles, or a K too long for LDS: the dataset-sized graphs - workgroups take K ranges and add partial tiles
     // into the zeroed outputs (split K).
@@ -2039,6 +2070,7 @@ extern "C" int cognn_beaver_gemm_close_group_u64(cognn_ctx* ctx, const cognn_gem
         GemmGroupJob& d = g.j[g.count++];
         d.Z = (u64*)J.Z; d.E0 = (const u64*)J.E0; d.E1 = (const u64*)J.E1; d.F0 = (const u64*)J.F0; d.F1 = (const u64*)J.F1;
         d.Epl = pre ? (const u64x2*)J.E_presplit : nullptr;
+        d.Apl = prea ? (const u64x2*)J.A_presplit : nullptr;
         d.Amask = (const u64*)J.A_dealt;
         d.keyA = J.keys.k[J.p == 0 ? COGNN_SL_A0 : COGNN_SL_A1]; d.keyB = J.keys.k[J.p == 0 ? COGNN_SL_B0 : COGNN_SL_B1];
         d.p = J.p; d.M = (int)J.M; d.tiles = tiles;
@@ -2063,10 +2095,10 @@ extern "C" int cognn_beaver_gemm_close_group_u64(cognn_ctx* ctx, const cognn_gem
     const bool keven = (K % 2 == 0);
     int rc;
     const GemmEpi* ep = nepi ? &epi : nullptr;
-    if (NT == 1) rc = launch_group<1, 4>(ctx, g, wg_end, lds, full, keven, pre, !whole_k, ep);
-    else if (NT == 2) rc = launch_group<2, 8>(ctx, g, wg_end, lds, full, keven, pre, !whole_k, ep);
-    else if (NT == 3) rc = launch_group<3, 8>(ctx, g, wg_end, lds, full, keven, pre, !whole_k, ep);
-    else rc = launch_group<4, 8>(ctx, g, wg_end, lds, full, keven, pre, !whole_k, ep);
+    if (NT == 1) rc = launch_group<1, 4>(ctx, g, wg_end, lds, full, keven, pre, !whole_k, ep, prea);
+    else if (NT == 2) rc = launch_group<2, 8>(ctx, g, wg_end, lds, full, keven, pre, !whole_k, ep, prea);
+    else if (NT == 3) rc = launch_group<3, 8>(ctx, g, wg_end, lds, full, keven, pre, !whole_k, ep, prea);
+    else rc = launch_group<4, 8>(ctx, g, wg_end, lds, full, keven, pre, !whole_k, ep, prea);
     if (rc || raw) return rc;
     for (int32_t j = 0; j < count; ++j) {                      // C_p joins here when the caller did not ask for the raw product
         const cognn_gemm_job& J = jobs[j];

@@ -49,6 +49,7 @@ struct Side {
     u64* featE_peer = nullptr;     // the peer's opening (alias when co-located)
     const u64* featSum = nullptr;  // E = E_0 + E_1 of that product, summed once in start() (one copy per co-located pair)
     const void* featPl = nullptr;  // the same opening limb-split in MFMA fragment order (cognn_gemm_presplit_u64), for the grouped forward product
+    const void* featMaskPl = nullptr;   // ... and this side's mask A_p of the feature operand in that order (COGNN_GEMM_MASK_IMAGE; dealt once like the opening)
     u64* h1E = nullptr;            // E_p = h_p - A_p of the layer-1 forward product (written by the ReLU close); kept for the epoch:
     u64* h1E_peer = nullptr;       // the layer-1 weight gradient h^T.g reuses mask and opening (alias when co-located)
     const uint8_t* cur_mask = nullptr;   // co-located pairs, between the backward ReLU' and the row scale that consumes it: the tensor is
@@ -101,6 +102,10 @@ struct cognn_engine {
     // 1.6 % faster on config5 (5.40 vs 5.47 ms, 5.50 vs 5.59 on another box), inside the box-to-box spread; COGNN_GEMM_EPILOGUE=1
     bool gemm_epilogue = getenv("COGNN_GEMM_EPILOGUE") != nullptr;
     bool wupdate_fusion = !getenv("COGNN_NO_WUPDATE_FUSION"); // co-located pairs: weight update (+ average) as one pass (A/B switch)
+    // the feature operand's mask A_p (dealt once, like its opening) kept in fragment order too: the layer-0 product's K loop then has no
+    // producer arithmetic (+ 8 B read per operand element; config5 5.66 -> 5.6 ms, product phases 0.43 -> 0.45 of the i8 peak; more than one
+    // column tile only: at hidden_dim <= 16 the bytes cost more than the arithmetic).  A/B switch.
+    bool gemm_mask_image = !getenv("COGNN_GEMM_NO_MASK_IMAGE");
     bool gemm_presplit = !getenv("COGNN_GEMM_NO_PRESPLIT"); // the constant feature opening kept in MFMA fragment order (A/B switch)
     bool public_openings = true;                    // COGNN_OPT_PUBLIC_OPENINGS (see pub_open)
     bool h1e_pairs_summed = false;                  // the co-located pairs' h1E holds E_0 + E_1 (written by a pair chain), not E_p
@@ -732,7 +737,7 @@ bool gemm_stage(cognn_engine* E, int64_t it, XFn X, WFn Wm, SpecFn spec, DstFn d
                 J.Z = s.zbuf; J.keys = k; J.p = s.p; J.M = g.M; J.K = g.K; J.scratch = s.scratch;
                 J.Z_zeroed = z_is_zero(s, eo[i]) ? 1 : 0;
                 z_written(s, eo[i]);
-                if (g.feature == 1) J.E_presplit = s.featPl;
+                if (g.feature == 1) { J.E_presplit = s.featPl; J.A_presplit = E->graph_epochs ? nullptr : s.featMaskPl; }   // (recorded epochs: a new mask every epoch)
                 if (!tn_group) J.A_dealt = dealt_mask(E, s.owner, it, s.p == 0 ? DEAL_GEMM_A0 : DEAL_GEMM_A1, k.k[s.p == 0 ? COGNN_SL_A0 : COGNN_SL_A1], g.M * g.K);
                 if (epi && paired(E, s) && s.p == 1) {
                     chains.push_back(chain_of(*s.peer));
@@ -1978,6 +1983,18 @@ void open_features(cognn_engine* E) {
             BE(cognn_gemm_presplit_u64(E->ctx, (void*)s.featPl, s.featSum, nullptr, (int64_t)s.n, in));
         }
         for (auto& s : E->sides) if (s.peer && s.p == 1) s.featPl = s.peer->featPl;
+        int64_t tiles_all = 0;
+        for (auto& s : E->sides) tiles_all += (s.n + 15) / 16;
+        // (the mask is the same in every epoch only outside recorded epochs; only the whole-K form of the grouped launch reads the image)
+        if (E->gemm_mask_image && !E->graph_epochs && E->hid() > 16 && E->be->cognn_beaver_gemm_group_is_whole_k(E->hid(), in, tiles_all))
+            for (auto& s : E->sides) {
+                const int64_t bytes = E->be->cognn_gemm_presplit_bytes((int64_t)s.n, in);
+                if (bytes <= 0 || !s.featPl) continue;
+                cognn_keys fk = feature_gemm_keys(E, s.owner, 0);
+                if (!s.featMaskPl) s.featMaskPl = dalloc<unsigned char>(E, (size_t)bytes);
+                BE(cognn_prng_fill_u64(E->ctx, s.ob[0], fk.k[s.p == 0 ? COGNN_SL_A0 : COGNN_SL_A1], (int64_t)s.n * in));
+                BE(cognn_gemm_presplit_u64(E->ctx, (void*)s.featMaskPl, s.ob[0], nullptr, (int64_t)s.n, in));
+            }
     }
 }
 

@@ -168,6 +168,10 @@ typedef struct {
     uint64_t* scratch;                           /* M x K + K x N u64: used by the per-job fallback only */
     const void* E_presplit;                      /* optional: E0 + E1 already limb-split in MFMA fragment order (cognn_gemm_presplit_u64);
                                                   * used by the grouped kernel when EVERY job of the call brings one */
+    const void* A_presplit;                      /* optional, with E_presplit (every job of the call or none; whole-K form): this party's mask A_p of the
+                                                  * operand in the same fragment order (cognn_gemm_presplit_u64 of cognn_prng_fill_u64 with its A key) -
+                                                  * for an operand whose mask is dealt ONCE (the constant feature tensor): the K loop then has no
+                                                  * producer arithmetic, at the price of 8 more bytes read per operand element */
     const uint64_t* A_dealt;                     /* optional (COGNN_OPT_DEALER_STREAMS): this party's mask A_p [M x K] as dealt (cognn_prng_fill_u64
                                                   * with its A key): read instead of regenerated (grouped kernel only) */
     int64_t K;                                   /* cognn_beaver_gemm_close_group_tn_u64 only: the job's inner dimension (rows of its party) */
@@ -196,6 +200,8 @@ int cognn_beaver_gemm_close_group_tn_u64(cognn_ctx*, const cognn_gemm_job* jobs,
 /* whether the grouped launch of products [. x K] . [K x N] with `row_tiles` 16-row tiles in all takes cognn_gemm_job::epilogue (the
  * whole-K form: the weight planes of every K step fit the LDS image and there are row tiles enough to fill the chip) */
 int cognn_beaver_gemm_group_takes_epilogue(int64_t N, int64_t K, int64_t row_tiles);
+/* whether that grouped launch runs in the whole-K form at all (the form that reads cognn_gemm_job::A_presplit) */
+int cognn_beaver_gemm_group_is_whole_k(int64_t N, int64_t K, int64_t row_tiles);
 int64_t cognn_gemm_presplit_bytes(int64_t M, int64_t K);
 int cognn_gemm_presplit_u64(cognn_ctx*, void* image, const uint64_t* E0, const uint64_t* E1, int64_t M, int64_t K);
 

@@ -267,7 +267,8 @@ int cognn_graph_launch(cognn_ctx*, void*) { return fail("the CPU stand-in record
 int cognn_graph_destroy(cognn_ctx*, void*) { return 0; }
 int64_t cognn_pair_chain_dealt_slots(int32_t, int32_t) { return 0; }     // the CPU stand-in regenerates every dealer value
 int cognn_pair_chain_deal_u64(cognn_ctx*, const cognn_pair_chain*, uint64_t*) { return 0; }
-int cognn_beaver_gemm_group_takes_epilogue(int64_t, int64_t, int64_t) { return 0; }   // the CPU stand-in runs product and chain separately
+int cognn_beaver_gemm_group_takes_epilogue(int64_t, int64_t, int64_t) { return 0; }
+int cognn_beaver_gemm_group_is_whole_k(int64_t, int64_t, int64_t) { return 0; }   // the CPU stand-in runs product and chain separately
 int64_t cognn_gemm_presplit_bytes(int64_t, int64_t) { return 0; }      // the CPU stand-in has no fragment-ordered form
 int cognn_gemm_presplit_u64(cognn_ctx*, void*, const uint64_t*, const uint64_t*, int64_t, int64_t) { return 0; }
 int cognn_beaver_gemm_tn_groupable(int64_t, int64_t, int64_t, int) { return 0; }    // the CPU stand-in runs the weight gradients job by job

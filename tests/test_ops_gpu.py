@@ -462,7 +462,10 @@ def test_beaver_gemm_pair(ctx, M, N, K, transA):
                                                    (16, 1433, (1354, 1354), False, True), (16, 3703, (1656, 1656), False, True), (16, 33, (40000, 33000), False, True),
                                                    # very short K (g = (p - y) . W1^T with 3 labels), PubMed's layer-0 shape (K ranges although the image would fit)
                                                    (16, 3, (4929, 4930), False, False), (16, 1, (300,), True, False), (7, 2, (40000,), False, False),
-                                                   (16, 500, (4929, 4930, 4929), False, True)])
+                                                   (16, 500, (4929, 4930, 4929), False, True),
+                                                   # both halves of the A fragment as images (cognn_gemm_job::A_presplit): N > 16 whole-K uses them, the others ignore them
+                                                   (64, 128, (16384, 16400), False, "masks"), (48, 96, (20000, 20001), False, "masks"), (16, 64, (40000,), False, "masks"),
+                                                   (64, 1432, (600, 40), False, "masks")])
 def test_beaver_gemm_group(ctx, N, K, Ms, two, presplit):
     """cognn_beaver_gemm_close_group_u64: the products of a phase as one grouped launch (weight planes built in the kernel's
     prologue; optionally the left operand pre-split in fragment order) against the oracle's Beaver product, job by job - jobs
@@ -484,9 +487,16 @@ def test_beaver_gemm_group(ctx, N, K, Ms, two, presplit):
         c1 = dev_empty((M, N)); sa = dev_empty(M * K + K * N)
         ctx.call("cognn_dealer_gemm_c1_u64", ptr(c1), ctypes.byref(k), M, N, K, 0, ptr(sa), ctypes.c_void_p(sa.data_ptr() + 8 * M * K))
         img = None
+        mimg = [None, None]
         if presplit:
             img = dev_empty(capi.load().cognn_gemm_presplit_bytes(M, K) // 8)
             ctx.call("cognn_gemm_presplit_u64", ptr(img), ptr(E[0]), ptr(E[1]), M, K)
+        if presplit == "masks":                              # ... and each side's mask A_p in the same order (a mask that is dealt once)
+            for p in range(2):
+                tmp = dev_empty((M, K)); mimg[p] = dev_empty(capi.load().cognn_gemm_presplit_bytes(M, K) // 8)
+                ctx.call("cognn_prng_fill_u64", ptr(tmp), ctypes.c_uint64(kf(co.SL_A0 + p)), M * K)
+                ctx.call("cognn_gemm_presplit_u64", ptr(mimg[p]), ptr(tmp), None, M, K)
+                keep.append(tmp)
         z0, z1 = co.beaver_gemm_pair(X0, X1, W0, W1, kf)
         for p in range(2):
             J = jobs[2 * q + p]
@@ -499,7 +509,8 @@ def test_beaver_gemm_group(ctx, N, K, Ms, two, presplit):
             J.c1 = c1.data_ptr() if p == 1 else None
             J.keys = k; J.p = p; J.M = M; J.scratch = scr.data_ptr()
             J.E_presplit = img.data_ptr() if img is not None else None
-            keep += [Z, scr]; want.append((Z, (z0, z1)[p]))
+            J.A_presplit = mimg[p].data_ptr() if mimg[p] is not None else None
+            keep += [Z, scr, mimg[p]]; want.append((Z, (z0, z1)[p]))
         keep += [E, Fm, Es, Fs, c1, sa, img]
         c1s.append(c1)
     ctx.call("cognn_beaver_gemm_close_group_u64", jobs, len(jobs), N, K, 0)
