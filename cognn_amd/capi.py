@@ -131,6 +131,8 @@ _SIGNATURES = {
     "cognn_beaver_gemm_group_is_whole_k": (_I, [_L, _L, _L]),
     "cognn_gemm_presplit_bytes": (_L, [_L, _L]),
     "cognn_gemm_presplit_u64": (_I, [_P, _P, _P, _P, _L, _L]),
+    "cognn_gemm_presplit_tn_bytes": (_L, [_L, _L]),
+    "cognn_gemm_presplit_tn_u64": (_I, [_P, _P, _P, _P, _U, _I, _L, _L]),
     "cognn_trunc_close_u64": (_I, [_P, _P, _P, _P, _KP, _I, _I, _L]),
     "cognn_trunc_close_open_u64": (_I, [_P, _P, _P, _P, _P, _KP, _I, _U, _L]),
     "cognn_trunc_close_pub_u64": (_I, [_P, _P, _P, _P, _P, _KP, _I, _U, _U, _I, _L]),

@@ -1324,10 +1324,13 @@ void beaver_gemm_tn_ws_kernel(u64* Z, const u64* __restrict__ E0, const u64* __r
 // ------------------------------------------------------------------------------------------
 // NT = ceil(N / 16) column tiles per wave (one B image of NT x 8 KiB per K step), WAVES row tiles per workgroup: <1, 4> for
 // N <= 16, <NT, 8> for 16 < N <= 64 (128 x 64 output block, as many accumulator registers as beaver_gemm_d16n_kernel).
-template <int NT, int WAVES, bool TWO>   // TWO: an operand may arrive as two shares (E1 / F1 given); false saves the second stream's registers
+template <int NT, int WAVES, bool TWO, bool PREA = false>   // TWO: an operand may arrive as two shares (E1 / F1 given); false saves the second stream's registers
 __device__ __forceinline__ void tn_d16_body(u64* Z, const u64* __restrict__ E0, const u64* __restrict__ E1, const u64* __restrict__ F,
                                             const u64* __restrict__ F1, u64 keyA, u64 keyB, int p, int M, int N, int K, int nst, int ksteps, int mtiles,
-                                            int a_storage, int bx, int by, unsigned char* sB) {
+                                            int a_storage, int bx, int by, unsigned char* sB, const u64x2* __restrict__ Epl = nullptr,
+                                            const u64x2* __restrict__ Apl = nullptr) {
+    // PREA (a constant left operand whose mask is dealt once - the feature tensor of the layer-0 weight gradient): both halves of the A
+    // fragment are read from fragment-ordered images (presplit_tn_kernel) - no loads along m, no mask generation, no limb split
     constexpr int kThreadsTn = WAVES * 64;
     constexpr int kImage = NT * kD16Stage;                   // B fragments of one K step: [column tile][plane][lane][16 B]
     constexpr int kTasks = 256 * NT;                         // (column, lane block, entry pair) triples of one K step
@@ -1360,8 +1363,17 @@ __device__ __forceinline__ void tn_d16_body(u64* Z, const u64* __restrict__ E0, 
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int s = 0; s < 8; ++s) acc[t][s] = v4i{0, 0, 0, 0};
-    u64 a0[8], a1[TWO ? 8 : 1], f0[TPT][2], f1[TWO ? TPT : 1][2];
+    u64 a0[8], a1[(TWO || PREA) ? 8 : 1], f0[TPT][2], f1[TWO ? TPT : 1][2];
     auto load_a = [&](int st) {
+        if (PREA) {                                          // a0: the E half, a1: the mask half, four coalesced 16-byte pieces each
+            const size_t off = (((size_t)tile * nst + st) * 4 << 6) + lane;
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const u64x2 x = Epl[off + (jj << 6)], y = Apl[off + (jj << 6)];
+                a0[2 * jj] = x.x; a0[2 * jj + 1] = x.y; a1[2 * jj] = y.x; a1[2 * jj + 1] = y.y;
+            }
+            return;
+        }
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const size_t k = (size_t)min(st * 32 + b * 8 + e, K - 1);
@@ -1413,7 +1425,7 @@ __device__ __forceinline__ void tn_d16_body(u64* Z, const u64* __restrict__ E0, 
         u64 v[8], w[8];
         if (active) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = TWO ? a0[e] + a1[e] : a0[e];
+            for (int e = 0; e < 8; ++e) { v[e] = (TWO && !PREA) ? a0[e] + a1[e] : a0[e]; if (PREA) w[e] = a1[e]; }
             if (st + 1 < st1) load_a(st + 1);               // the next step's opened shares are in flight during this step's arithmetic
         }
         if (st + 1 < st1) {
@@ -1421,18 +1433,23 @@ __device__ __forceinline__ void tn_d16_body(u64* Z, const u64* __restrict__ E0, 
             if (st + 2 < st1) load_b(st + 2);
         }
         if (active) {
-            const int k0 = st * 32 + b * 8;
-            u64 x = a_storage ? (u64)k0 * (u64)M + (u64)m : (u64)m * (u64)K + (u64)k0;
-            const u64 xs = a_storage ? (u64)M : 1ull;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const u64 keep = (mok && k0 + e < K) ? ~0ull : 0ull;
-                v[e] &= keep;
-                w[e] = cognn_prng(keyA, x) & keep;
-                x += xs;
-            }
             uint32_t pe0[8], pe1[8], pm0[8], pm1[8];
-            split4(v, pe0); split4(v + 4, pe1); split4(w, pm0); split4(w + 4, pm1);
+            if (PREA) {                                      // (the images are zero-padded)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { pe0[i] = (uint32_t)v[i]; pe1[i] = (uint32_t)(v[i] >> 32); pm0[i] = (uint32_t)w[i]; pm1[i] = (uint32_t)(w[i] >> 32); }
+            } else {
+                const int k0 = st * 32 + b * 8;
+                u64 x = a_storage ? (u64)k0 * (u64)M + (u64)m : (u64)m * (u64)K + (u64)k0;
+                const u64 xs = a_storage ? (u64)M : 1ull;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const u64 keep = (mok && k0 + e < K) ? ~0ull : 0ull;
+                    v[e] &= keep;
+                    w[e] = cognn_prng(keyA, x) & keep;
+                    x += xs;
+                }
+                split4(v, pe0); split4(v + 4, pe1); split4(w, pm0); split4(w + 4, pm1);
+            }
             v4i af[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) af[i] = v4i{(int)pe0[i], (int)pe1[i], (int)pm0[i], (int)pm1[i]};
@@ -1480,6 +1497,7 @@ void beaver_gemm_tn_d16_kernel(u64* Z, const u64* __restrict__ E0, const u64* __
 // on entry (zero_jobs_kernel): the products are raw, C_p joins in the consumer's truncation opening.
 struct GemmTnJob {
     u64* Z; const u64* E0; const u64* E1; const u64* F; const u64* F1;
+    const u64x2* Epl; const u64x2* Apl;                     // PREA: both halves of the A fragments as images (cognn_gemm_presplit_tn_u64)
     u64 keyA, keyB;
     int p, K, nst, ksteps, splits, a_storage, wg_end;
 };
@@ -1487,7 +1505,7 @@ struct GemmTnGroup {
     GemmTnJob j[kGroupMax];
     int count, M, N, mtiles, gx;
 };
-template <int NT, int WAVES, bool TWO>
+template <int NT, int WAVES, bool TWO, bool PREA = false>
 __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(2, (NT == 1 && !TWO) ? 3 : 2)))
 void beaver_gemm_tn_group_kernel(GemmTnGroup g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char sB[];
@@ -1495,7 +1513,41 @@ void beaver_gemm_tn_group_kernel(GemmTnGroup g) {
     while (job < g.count - 1 && (int)blockIdx.x >= g.j[job].wg_end) ++job;
     const GemmTnJob& J = g.j[job];
     const int w = (int)blockIdx.x - (job ? g.j[job - 1].wg_end : 0);
-    tn_d16_body<NT, WAVES, TWO>(J.Z, J.E0, J.E1, J.F, J.F1, J.keyA, J.keyB, J.p, g.M, g.N, J.K, J.nst, J.ksteps, g.mtiles, J.a_storage, w % g.gx, w / g.gx, sB);
+    tn_d16_body<NT, WAVES, TWO, PREA>(J.Z, J.E0, J.E1, J.F, J.F1, J.keyA, J.keyB, J.p, g.M, g.N, J.K, J.nst, J.ksteps, g.mtiles, J.a_storage, w % g.gx, w / g.gx, sB,
+                                      J.Epl, J.Apl);
+}
+// the images PREA reads: [row tile of M][K step][16-byte piece j][lane] with lane (r = m - 16 tile, b) holding k = 32 st + 8 b + e,
+// e = 0..7 (the k order of tn_d16_body's A fragment); src: the operand stored [K x M] (summed with src1 if given) - or, src == NULL,
+// the mask stream `key` addressed as tn_d16_body addresses it (a_storage)
+__global__ __launch_bounds__(256) void presplit_tn_kernel(u64x2* out, const u64* __restrict__ src, const u64* __restrict__ src1, u64 key, int a_storage, int M,
+                                                          int K, int nst, int mtiles) {
+    const int64_t total = (int64_t)mtiles * nst * 64;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+        const int lane = (int)(t & 63);
+        const int64_t ts = t >> 6;
+        const int st = (int)(ts % nst), tile = (int)(ts / nst);
+        const int r = lane & 15, b = lane >> 4, m = tile * 16 + r;
+        u64 v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = st * 32 + b * 8 + e;
+            u64 x = 0;
+            if (m < M && k < K) {
+                if (src) x = src[(size_t)k * M + m] + (src1 ? src1[(size_t)k * M + m] : 0ull);
+                else x = cognn_prng(key, a_storage ? (u64)k * (u64)M + (u64)m : (u64)m * (u64)K + (u64)k);
+            }
+            v[e] = x;
+        }
+        uint32_t p0[8], p1[8];
+        split4(v, p0); split4(v + 4, p1);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            u64x2 w;
+            w.x = (u64)p0[2 * j] | ((u64)p1[2 * j] << 32);
+            w.y = (u64)p0[2 * j + 1] | ((u64)p1[2 * j + 1] << 32);
+            out[((ts * 4 + j) << 6) + lane] = w;
+        }
+    }
 }
 struct ZeroJobs { u64* p[kGroupMax]; unsigned n[kGroupMax]; int count; };
 __global__ __launch_bounds__(256) void zero_jobs_kernel(ZeroJobs z) {
@@ -2141,6 +2193,10 @@ extern "C" int cognn_beaver_gemm_close_group_tn_u64(cognn_ctx* ctx, const cognn_
     for (int32_t j = 0; j < count; ++j) if (jobs[j].K > 0) ++live;
     // resident workgroups (launch_tn_d16): two (single-stream N <= 16: three) waves per SIMD; shared out evenly over the jobs
     const int budget = NT == 1 ? (two ? 512 : 768) : 256;
+    // both halves of the A fragments as images (cognn_gemm_presplit_tn_u64): every live job or none, single-stream operands, more than
+    // one column tile (see the NN form: at N <= 16 the extra bytes cost more than the arithmetic they replace)
+    bool prea = !two && NT >= 2 && live > 0;
+    for (int32_t j = 0; j < count; ++j) if (jobs[j].K > 0) prea = prea && jobs[j].E_presplit && jobs[j].A_presplit;
     int wg_end = 0;
     unsigned zmax = 0;
     for (int32_t j = 0; j < count; ++j) {
@@ -2150,6 +2206,7 @@ extern "C" int cognn_beaver_gemm_close_group_tn_u64(cognn_ctx* ctx, const cognn_
         GemmTnJob& d = g.j[g.count++];
         d.Z = (u64*)J.Z; d.E0 = (const u64*)J.E0; d.E1 = (const u64*)J.E1; d.F = (const u64*)J.F0; d.F1 = (const u64*)J.F1;
         d.keyA = J.keys.k[J.p == 0 ? COGNN_SL_A0 : COGNN_SL_A1]; d.keyB = J.keys.k[J.p == 0 ? COGNN_SL_B0 : COGNN_SL_B1];
+        d.Epl = (const u64x2*)J.E_presplit; d.Apl = (const u64x2*)J.A_presplit;
         d.p = J.p; d.K = (int)J.K; d.nst = (int)((J.K + 31) / 32); d.a_storage = storage_order_mask ? 1 : 0;
         int splits = std::max(1, std::min(d.nst, (budget / std::max(live, 1) + gx - 1) / gx));
         d.ksteps = (d.nst + splits - 1) / splits;
@@ -2165,7 +2222,10 @@ extern "C" int cognn_beaver_gemm_close_group_tn_u64(cognn_ctx* ctx, const cognn_
     const size_t lds = 2 * (size_t)NT * kD16Stage;
 #define CG_TNG_LAUNCH(NT_, W_)                                                                                                           \
     do {                                                                                                                                  \
-        if (two) {                                                                                                                        \
+        if (prea) {                                                                                                                       \
+            CG_HIP(hipFuncSetAttribute((const void*)beaver_gemm_tn_group_kernel<NT_, W_, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            hipLaunchKernelGGL((beaver_gemm_tn_group_kernel<NT_, W_, false, true>), dim3((unsigned)wg_end), dim3(W_ * 64), lds, ctx->stream, g);       \
+        } else if (two) {                                                                                                                 \
             CG_HIP(hipFuncSetAttribute((const void*)beaver_gemm_tn_group_kernel<NT_, W_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
             hipLaunchKernelGGL((beaver_gemm_tn_group_kernel<NT_, W_, true>), dim3((unsigned)wg_end), dim3(W_ * 64), lds, ctx->stream, g);              \
         } else {                                                                                                                          \
@@ -2178,6 +2238,24 @@ extern "C" int cognn_beaver_gemm_close_group_tn_u64(cognn_ctx* ctx, const cognn_
     else if (NT == 3) CG_TNG_LAUNCH(3, 8);
     else CG_TNG_LAUNCH(4, 8);
 #undef CG_TNG_LAUNCH
+    CG_LAUNCH_CHECK();
+    return 0;
+}
+
+// the images of a constant left operand for cognn_beaver_gemm_close_group_tn_u64: E [K x M as stored] (E1 optional, summed), or -
+// E0 == NULL - the mask stream `key` in the product's addressing (storage_order_mask as in that call)
+extern "C" int64_t cognn_gemm_presplit_tn_bytes(int64_t M, int64_t K) {
+    return ((M + 15) / 16) * ((K + 31) / 32) * 64 * 64;
+}
+extern "C" int cognn_gemm_presplit_tn_u64(cognn_ctx* ctx, void* image, const uint64_t* E0, const uint64_t* E1, uint64_t key, int storage_order_mask, int64_t M,
+                                          int64_t K) {
+    { const int rc_flush_ = cg_flush(ctx); if (rc_flush_) return rc_flush_; }
+    CG_REQUIRE(ctx && image && M >= 0 && K > 0 && M < (1ll << 31) && K < (1ll << 31) && cg_aligned16(image), "cognn_gemm_presplit_tn_u64: bad arguments");
+    if (M == 0) return 0;
+    const int nst = (int)((K + 31) / 32), mtiles = (int)((M + 15) / 16);
+    const int64_t total = (int64_t)mtiles * nst * 64;
+    hipLaunchKernelGGL(presplit_tn_kernel, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 1 << 16)), dim3(256), 0, ctx->stream, (u64x2*)image,
+                       (const u64*)E0, (const u64*)E1, key, storage_order_mask ? 1 : 0, (int)M, (int)K, nst, mtiles);
     CG_LAUNCH_CHECK();
     return 0;
 }

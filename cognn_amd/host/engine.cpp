@@ -50,6 +50,7 @@ struct Side {
     const u64* featSum = nullptr;  // E = E_0 + E_1 of that product, summed once in start() (one copy per co-located pair)
     const void* featPl = nullptr;  // the same opening limb-split in MFMA fragment order (cognn_gemm_presplit_u64), for the grouped forward product
     const void* featMaskPl = nullptr;   // ... and this side's mask A_p of the feature operand in that order (COGNN_GEMM_MASK_IMAGE; dealt once like the opening)
+    const void* featTnPl = nullptr, *featMaskTnPl = nullptr;   // both once more in the order of the weight-gradient kernel's A fragments (training only)
     u64* h1E = nullptr;            // E_p = h_p - A_p of the layer-1 forward product (written by the ReLU close); kept for the epoch:
     u64* h1E_peer = nullptr;       // the layer-1 weight gradient h^T.g reuses mask and opening (alias when co-located)
     const uint8_t* cur_mask = nullptr;   // co-located pairs, between the backward ReLU' and the row scale that consumes it: the tensor is
@@ -738,6 +739,7 @@ bool gemm_stage(cognn_engine* E, int64_t it, XFn X, WFn Wm, SpecFn spec, DstFn d
                 J.Z_zeroed = z_is_zero(s, eo[i]) ? 1 : 0;
                 z_written(s, eo[i]);
                 if (g.feature == 1) { J.E_presplit = s.featPl; J.A_presplit = E->graph_epochs ? nullptr : s.featMaskPl; }   // (recorded epochs: a new mask every epoch)
+                if (g.feature == 2 && tn_group && !E->graph_epochs) { J.E_presplit = s.featTnPl; J.A_presplit = s.featMaskTnPl; }
                 if (!tn_group) J.A_dealt = dealt_mask(E, s.owner, it, s.p == 0 ? DEAL_GEMM_A0 : DEAL_GEMM_A1, k.k[s.p == 0 ? COGNN_SL_A0 : COGNN_SL_A1], g.M * g.K);
                 if (epi && paired(E, s) && s.p == 1) {
                     chains.push_back(chain_of(*s.peer));
@@ -1995,6 +1997,21 @@ void open_features(cognn_engine* E) {
                 BE(cognn_prng_fill_u64(E->ctx, s.ob[0], fk.k[s.p == 0 ? COGNN_SL_A0 : COGNN_SL_A1], (int64_t)s.n * in));
                 BE(cognn_gemm_presplit_u64(E->ctx, (void*)s.featMaskPl, s.ob[0], nullptr, (int64_t)s.n, in));
             }
+        // the layer-0 weight gradient X^T . g reads the same opening and the same mask along the other axis: its kernel's A fragments,
+        // for N = hidden_dim > 16 (cognn_gemm_presplit_tn_u64)
+        if (E->gemm_mask_image && !E->graph_epochs && E->cfg.variant != COGNN_VARIANT_OPTIMIZE_GCN_INFERENCE && E->hid() > 16)
+            for (auto& s : E->sides) {
+                const int64_t bytes = E->be->cognn_gemm_presplit_tn_bytes(in, (int64_t)s.n);
+                if (bytes <= 0) continue;
+                cognn_keys fk = feature_gemm_keys(E, s.owner, 0);
+                if (!(s.peer && s.p == 1)) {
+                    if (!s.featTnPl) s.featTnPl = dalloc<unsigned char>(E, (size_t)bytes);
+                    BE(cognn_gemm_presplit_tn_u64(E->ctx, (void*)s.featTnPl, s.featSum, nullptr, 0, 1, in, (int64_t)s.n));
+                }
+                if (!s.featMaskTnPl) s.featMaskTnPl = dalloc<unsigned char>(E, (size_t)bytes);
+                BE(cognn_gemm_presplit_tn_u64(E->ctx, (void*)s.featMaskTnPl, nullptr, nullptr, fk.k[s.p == 0 ? COGNN_SL_A0 : COGNN_SL_A1], 1, in, (int64_t)s.n));
+            }
+        for (auto& s : E->sides) if (s.peer && s.p == 1) s.featTnPl = s.peer->featTnPl;
     }
 }
 

@@ -194,6 +194,14 @@ int cognn_beaver_gemm_close_group_u64(cognn_ctx*, const cognn_gemm_job* jobs, in
  * Only shapes with cognn_beaver_gemm_tn_groupable(M, N, K, two_share_operands) != 0 (two_share_operands: any job passes E1 or F1). */
 int cognn_beaver_gemm_tn_groupable(int64_t M, int64_t N, int64_t K, int two_share_operands);
 int cognn_beaver_gemm_close_group_tn_u64(cognn_ctx*, const cognn_gemm_job* jobs, int32_t count, int64_t M, int64_t N, int storage_order_mask);
+/* The same idea as cognn_gemm_presplit_u64 for the left operand of the weight-gradient products when it is constant and its mask is
+ * dealt once (the feature tensor of the layer-0 gradient, gcn.h:710): the opening (E0 (+ E1), stored [K x M]) or - E0 == NULL - the
+ * mask stream `key` addressed as that call addresses it (storage_order_mask), in the order of the TN kernel's A fragments.  A call
+ * of cognn_beaver_gemm_close_group_tn_u64 whose every job brings both images (job.E_presplit from the opening, job.A_presplit from
+ * this party's A key) with N > 16 and single-tensor operands reads them instead of the operand and the mask stream; other calls
+ * ignore them.  image: _bytes(M, K) bytes, 16-byte aligned. */
+int64_t cognn_gemm_presplit_tn_bytes(int64_t M, int64_t K);
+int cognn_gemm_presplit_tn_u64(cognn_ctx*, void* image, const uint64_t* E0, const uint64_t* E1, uint64_t key, int storage_order_mask, int64_t M, int64_t K);
 /* An opened left operand that many products reuse - the constant input-feature opening of the layer-0 product (gcn.h:233 in
  * every epoch) - limb-split and byte-transposed ONCE into the order the grouped kernel's A fragments have: the same 8 bytes per
  * element (rows padded to 16, K to 32), so a pass reads as many bytes as before and skips the split.  image: _bytes(M, K) bytes. */

@@ -271,6 +271,8 @@ int cognn_beaver_gemm_group_takes_epilogue(int64_t, int64_t, int64_t) { return 0
 int cognn_beaver_gemm_group_is_whole_k(int64_t, int64_t, int64_t) { return 0; }   // the CPU stand-in runs product and chain separately
 int64_t cognn_gemm_presplit_bytes(int64_t, int64_t) { return 0; }      // the CPU stand-in has no fragment-ordered form
 int cognn_gemm_presplit_u64(cognn_ctx*, void*, const uint64_t*, const uint64_t*, int64_t, int64_t) { return 0; }
+int64_t cognn_gemm_presplit_tn_bytes(int64_t, int64_t) { return 0; }
+int cognn_gemm_presplit_tn_u64(cognn_ctx*, void*, const uint64_t*, const uint64_t*, uint64_t, int, int64_t, int64_t) { return 0; }
 int cognn_beaver_gemm_tn_groupable(int64_t, int64_t, int64_t, int) { return 0; }    // the CPU stand-in runs the weight gradients job by job
 int cognn_beaver_gemm_close_group_tn_u64(cognn_ctx*, const cognn_gemm_job*, int32_t, int64_t, int64_t, int) { return fail("not groupable on the CPU stand-in"); }
 int cognn_beaver_gemm_close_group_u64(cognn_ctx* c, const cognn_gemm_job* jobs, int32_t count, int64_t N, int64_t K, int raw) {

@@ -542,6 +542,73 @@ def test_beaver_gemm_group(ctx, N, K, Ms, two, presplit):
     assert all(kept) or all(plain), (kept, plain)            # (split K: added onto the marker; whole K or per-job path: plain stores)
 
 
+@pytest.mark.parametrize("M,N,Ks,stor_mask,images", [(128, 64, (4100, 4096, 0), 1, True), (130, 48, (1029, 515), 1, True), (100, 33, (700,), 0, True),
+                                                        (128, 16, (5000, 4099), 1, True), (128, 64, (4100, 300), 1, False), (64, 17, (300, 257), 0, False)])
+def test_beaver_gemm_group_tn(ctx, M, N, Ks, stor_mask, images):
+    """cognn_beaver_gemm_close_group_tn_u64: the weight-gradient products d = h_t^T . in of a phase as one launch (per-job K, raw
+    products), job by job against the oracle's Beaver product - and with both halves of the left operand handed over as
+    fragment-ordered images (cognn_gemm_presplit_tn_u64: the constant feature tensor, whose mask is dealt once), which N > 16
+    reads instead of the operand and the mask stream and N <= 16 ignores: bit-identical either way."""
+    from cognn_amd import capi
+    lib = capi.load()
+    rng = np.random.default_rng(M * 5 + N)
+    jobs = (capi.GemmJob * (2 * len(Ks)))()
+    keep, want = [], []
+    for q, K in enumerate(Ks):
+        k, kf = keys_of(13, q, 5, co.OP_AP_GEMM)
+        Kc = max(K, 1)
+        X0 = rand_u64(rng, (M, Kc)); X1 = rand_u64(rng, (M, Kc)); W0 = rand_u64(rng, (Kc, N)); W1 = rand_u64(rng, (Kc, N))
+        E = [dev_empty((Kc, M)) for _ in range(2)]; Fm = [dev_empty((Kc, N)) for _ in range(2)]
+        for p, (xp, wp) in enumerate(((X0, W0), (X1, W1))):     # the operand is stored [K x M]; transA 1: mask addressed (m, k), 2: (k, m)
+            ctx.call("cognn_mask_open_u64", ptr(E[p]), ptr(dev(xp.T.copy())), ctypes.c_uint64(kf(co.SL_A0 + p)), M, Kc, 2 if stor_mask else 1)
+            ctx.call("cognn_mask_open_u64", ptr(Fm[p]), ptr(dev(wp)), ctypes.c_uint64(kf(co.SL_B0 + p)), Kc, N, 0)
+        Es = dev_empty((Kc, M)); Fs = dev_empty((Kc, N))
+        ctx.call("cognn_add_u64", ptr(Es), ptr(E[0]), ptr(E[1]), M * Kc)
+        ctx.call("cognn_add_u64", ptr(Fs), ptr(Fm[0]), ptr(Fm[1]), Kc * N)
+        img = None
+        if images and K > 0:
+            nb = lib.cognn_gemm_presplit_tn_bytes(M, K)
+            assert nb == ((M + 15) // 16) * ((K + 31) // 32) * 4096
+            img = dev_empty(nb // 8)
+            ctx.call("cognn_gemm_presplit_tn_u64", ptr(img), ptr(E[0]), ptr(E[1]), ctypes.c_uint64(0), stor_mask, M, K)
+        if K > 0:
+            z0, z1 = co.beaver_gemm_pair(X0, X1, W0, W1, kf, a_of_transposed=bool(stor_mask))
+            with np.errstate(over="ignore"):
+                raw = (z0 - co.prng_shape(kf(co.SL_C0), (M, N)), None)
+        for p in range(2):
+            J = jobs[2 * q + p]
+            Z = dev_empty((M, N)); Z.fill_(3)                    # (the call zeroes it)
+            J.Z = Z.data_ptr(); J.E0, J.E1, J.F0, J.F1 = Es.data_ptr(), None, Fs.data_ptr(), None
+            J.keys = k; J.p = p; J.K = K
+            mimg = None
+            if img is not None:
+                mimg = dev_empty(nb // 8)
+                ctx.call("cognn_gemm_presplit_tn_u64", ptr(mimg), None, None, ctypes.c_uint64(kf(co.SL_A0 + p)), stor_mask, M, K)
+                J.E_presplit = img.data_ptr(); J.A_presplit = mimg.data_ptr()
+            keep += [Z, mimg]
+            want.append((Z, K, raw[0] if (K > 0 and p == 0) else None, z1 if K > 0 else None, kf))
+        keep += [E, Fm, Es, Fs, img]
+    ctx.call("cognn_beaver_gemm_close_group_tn_u64", jobs, len(jobs), M, N, stor_mask)
+    got = [host(Z) for Z, *_ in want]
+    for j, (Z, K, r0, z1, kf) in enumerate(want):
+        if K == 0:
+            assert not got[j].any()
+        elif j % 2 == 0:
+            assert np.array_equal(got[j], r0)
+        else:                                                # the p = 1 side's raw product + its dealt share C_1 = the oracle's share
+            c1 = dev_empty((M, N)); sa = dev_empty(M * K + K * N)
+            k, _ = keys_of(13, j // 2, 5, co.OP_AP_GEMM)
+            ctx.call("cognn_dealer_gemm_c1_u64", ptr(c1), ctypes.byref(k), M, N, K, 2 if stor_mask else 1, ptr(sa), ctypes.c_void_p(sa.data_ptr() + 8 * M * K))
+            with np.errstate(over="ignore"):
+                assert np.array_equal(got[j] + host(c1), z1)
+    if images:                                               # ... and the same launch without the images
+        for j in range(len(jobs)):
+            jobs[j].E_presplit = None; jobs[j].A_presplit = None
+        ctx.call("cognn_beaver_gemm_close_group_tn_u64", jobs, len(jobs), M, N, stor_mask)
+        for j, (Z, *_r) in enumerate(want):
+            assert np.array_equal(host(Z), got[j])
+
+
 def test_gather_csr_open_epilogue(ctx):
     """Gather whose output rows inside given segments are the Beaver opening V - prng(key, local index)."""
     rng = np.random.default_rng(77)
