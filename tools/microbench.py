@@ -85,8 +85,10 @@ def bench_gather(ctx, iters, rows=1 << 21, table_rows=1 << 21, deg=12, F=64):
     g = torch.Generator(device="cuda"); g.manual_seed(1)
     table = torch.randint(-2**62, 2**62, (table_rows, F), dtype=torch.int64, device="cuda", generator=g)
     out = torch.empty((rows, F), dtype=torch.int64, device="cuda")
+    base = table if table_rows >= rows else torch.zeros((rows, F), dtype=torch.int64, device="cuda")   # (base has `rows` rows)
     rp = torch.from_numpy(rowptr.view(np.int32)).cuda(); cl = torch.from_numpy(col.view(np.int32)).cuda()
-    ms = timeit(lambda: ctx.call("cognn_gather_csr_u64", P(out), P(table), P(table), P(rp), P(cl), rows, F), iters)
+    assert int(col.max()) < table_rows and len(rowptr) == rows + 1 and base.shape[0] >= rows
+    ms = timeit(lambda: ctx.call("cognn_gather_csr_u64", P(out), P(base), P(table), P(rp), P(cl), rows, F), iters)
     E = int(rowptr[-1])
     by = 8.0 * F * (E + 2 * rows) + 4.0 * E + 4.0 * (rows + 1)
     print("gather_csr rows=%d edges=%d F=%d: %.3f ms  %.0f GB/s algorithmic (%.1f%% of 8000)" % (rows, E, F, ms, by / ms / 1e6, by / ms / 1e6 / 80.0))
@@ -146,6 +148,10 @@ if __name__ == "__main__":
     if a.what in ("overlap",):
         bench_overlap(ctx, a.iters)
         bench_overlap(ctx, a.iters, K=128, N=64, n_gemm=8)
+    if a.what in ("gather_sizes",):                          # how fast do indexed row fetches go when the table fits the Infinity Cache / L2?
+        for lt in (21, 20, 19, 18, 17, 16, 14):
+            print("table %d MiB:" % ((1 << lt) * 64 * 8 >> 20), end=" ")
+            bench_gather(ctx, a.iters, table_rows=1 << lt, deg=16, F=64)
     if a.what in ("gather", "all"):
         bench_gather(ctx, a.iters, F=64)
         bench_gather(ctx, a.iters, F=16)
