@@ -342,6 +342,8 @@ def main():
     traffic, traffic_src = None, None
     # (single process, every pair co-located, k <= 8: the Gather with the pair chain as its epilogue - engine.cpp can_fuse_gather_chain)
     used = sorted({"gather_pair_chain_kernel" if (world == 1 and k <= 8) else "gather_csr_kernel" for F in (hid, lab)})
+    if world == 1 and k <= 8 and not os.environ.get("COGNN_NO_SOFTMAX_FUSION"):
+        used.append("gather_pair_softmax_kernel")          # the label-wide Gather of the prediction iteration carries the softmax too
     if variant == "original-gcn":
         used = ["scatter_gather_original_kernel"]         # the fused per-edge Scatter + Gather launch of the unoptimised kernel
     cands = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc.json") and f[:1] == "r" and f[1:3].isdigit() and f[3] == "_") \
@@ -376,8 +378,8 @@ def main():
         "roofline": {"bound": "hbm", "kernel": ("scatter_gather_original_kernel: per-edge two-normaliser Scatter + Gather of one destination party "
                                                 "(bytes: both shares of every source row and vertex row; the launch is bound by its per-edge dealer arithmetic, not by HBM)")
                                                if variant == "original-gcn" else
-                                               "aggregate launch of the message passing (gather_pair_chain_kernel when every pair is co-located, "
-                                               "gather_csr_kernel otherwise)",
+                                               "aggregate launch of the message passing (gather_pair_chain_kernel when every pair is co-located - "
+                                               "gather_pair_softmax_kernel for the label-wide one that also carries the prediction layer -, gather_csr_kernel otherwise)",
                      "achieved": (bytes_agg / 1e9) / (ms_agg / 1e3) if ms_agg > 0 else None, "peak": 8000.0, "unit": "GB/s",
                      "frac": ((bytes_agg / 1e9) / (ms_agg / 1e3) / 8000.0) if ms_agg > 0 else None, "traffic": traffic,
                      "traffic_unit": "bytes per launch", "traffic_source": traffic_src,

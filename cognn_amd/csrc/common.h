@@ -62,3 +62,13 @@ typedef ulonglong2 u64x2;
 
 static inline int cg_div_up(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 static inline bool cg_aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
+
+// floor(num / den) for 0 <= num < 2^52, 0 < den < 2^52 through one double-precision division and an exact integer correction - the same
+// quotient as the 64-bit integer division (which the compiler expands to a long software sequence) at a fraction of its cost
+__device__ __forceinline__ u64 div_floor_small(u64 num, u64 den) {
+    u64 q = (u64)((double)num / (double)den);
+    const long long rem = (long long)num - (long long)(q * den);
+    if (rem < 0) --q;
+    else if ((u64)rem >= den) ++q;
+    return q;
+}

@@ -509,15 +509,6 @@ __global__ void softmax_jobs_zero_kernel(SoftmaxBatch b) {
         else if ((t & 7) == 6) *b.j[t >> 3].loss = 0.0;
     }
 }
-// floor(num / den) for 0 <= num < 2^52, 0 < den < 2^52 through one double-precision division and an exact integer correction - the same
-// quotient as the 64-bit integer division (which the compiler expands to a long software sequence) at a fraction of its cost
-__device__ __forceinline__ u64 div_floor_small(u64 num, u64 den) {
-    u64 q = (u64)((double)num / (double)den);
-    const long long rem = (long long)num - (long long)(q * den);
-    if (rem < 0) --q;
-    else if ((u64)rem >= den) ++q;
-    return q;
-}
 // A group of G lanes (G = power of two >= L) owns G consecutive rows: row i of the group is evaluated across the G lanes
 // (lane j = column j, reductions by shuffles, coalesced 8*L-byte row accesses), and lane i keeps row i's bookkeeping, so that
 // the double-precision log of the loss runs once per lane instead of once per row on 1 lane in G.

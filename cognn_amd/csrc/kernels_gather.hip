@@ -153,11 +153,29 @@ struct GatherPairBatch {
     GatherPairSeg s[kGatherPairsMax];
     int count;
 };
+// the prediction layer of a pair as the launch's second epilogue (cognn_gather_pair::softmax): what softmax_jobs_kernel does for an
+// owner job and its co-party job, on the chain's results in registers
+struct SoftmaxPairDev {
+    u64* d_out0; u64* d_out1; const int32_t* labels; const uint8_t* border;
+    u64 keyRho; int64_t train_rows, val_rows;
+    unsigned long long* counts; double* loss;
+};
+struct GatherSoftmaxBatch { SoftmaxPairDev s[kGatherPairsMax]; };
+__global__ void gather_softmax_zero_kernel(GatherSoftmaxBatch q, int count) {
+    const int t = threadIdx.x;
+    if (t < count * 8) {
+        if ((t & 7) < 6) q.s[t >> 3].counts[t & 7] = 0ull;
+        else if ((t & 7) == 6) *q.s[t >> 3].loss = 0.0;
+    }
+}
 // W: u64 per lane and step - 2 (16-byte accesses) for an even width, 1 for an odd one (7 or 3 labels)
-template <int LPR, int W, bool STREAM>
+// SMX: the prediction layer follows as a second epilogue (LPR lanes hold a row of F <= LPR * W logits: row reductions by shuffles)
+template <int LPR, int W, bool STREAM, bool SMX = false>
 __device__ __forceinline__ void gather_pair_chain_body(const u64* __restrict__ table, const uint32_t* __restrict__ rowptr,
                                                        const uint32_t* __restrict__ col, int F, int ntiles, const GatherPairBatch& b,
-                                                       uint32_t (&s_rp)[2][kPairTile + 1], uint32_t (&s_col)[2][kPairColCap]) {
+                                                       uint32_t (&s_rp)[2][kPairTile + 1], uint32_t (&s_col)[2][kPairColCap],
+                                                       const GatherSoftmaxBatch* sm = nullptr, unsigned long long* s_cnt = nullptr,
+                                                       double* s_loss = nullptr) {
     constexpr int kGroups = kThreads / LPR;
     const int tid = threadIdx.x;
     const int grp = tid / LPR, ln = tid % LPR;
@@ -173,6 +191,7 @@ __device__ __forceinline__ void gather_pair_chain_body(const u64* __restrict__ t
         const int rbase[2] = {S.a_row0 + v0row, S.b_row0 + v0row};
         __syncthreads();                                     // previous tile's LDS reads are done
         for (int i = tid; i < 2 * (nr + 1); i += kThreads) { const int sd = i / (nr + 1), j = i % (nr + 1); s_rp[sd][j] = rowptr[rbase[sd] + j]; }
+        if (SMX) { if (tid < 5) s_cnt[tid] = 0ull; if (tid == 0) *s_loss = 0.0; }
         __syncthreads();
         bool staged[2];
 #pragma unroll
@@ -184,8 +203,12 @@ __device__ __forceinline__ void gather_pair_chain_body(const u64* __restrict__ t
         __syncthreads();
         for (int lr = grp; lr < nr; lr += kGroups) {
             const int vr = v0row + lr;                       // vertex row
-            for (int c = ln; c < nchunk; c += LPR) {
+            for (int c = ln; c < (SMX ? LPR : nchunk); c += LPR) {   // (SMX: every lane of the group runs this once - the shuffles below)
+                const bool have = !SMX || c < nchunk;
                 const int off = c * W;
+                const u64 idx = (u64)vr * (u64)F + (u64)off;
+                u64 a[2] = {0, 0}, bb[2] = {0, 0};
+                if (have) {
                 Chunk<W> sum[2];
 #pragma unroll
                 for (int sd = 0; sd < 2; ++sd) {
@@ -210,8 +233,6 @@ __device__ __forceinline__ void gather_pair_chain_body(const u64* __restrict__ t
                     sum[sd] = acc;
                 }
                 // the chain on the two sides' sums (pair_chain.h): row scale + truncation [+ ReLU], outputs / openings
-                const u64 idx = (u64)vr * (u64)F + (u64)off;
-                u64 a[2], bb[2];
                 sum[0].get(a); sum[1].get(bb);
                 bool pos[2] = {true, true};
                 PairRow rw = {0, 0, 0};
@@ -237,7 +258,68 @@ __device__ __forceinline__ void gather_pair_chain_body(const u64* __restrict__ t
                         if (d.open1) { const u64 t[2] = {bb[0] - m1[0], bb[1] - m1[1]}; Chunk<W>::put(d.open1 + idx, t); }
                     }
                 }
+                }
+                if (SMX) {
+                    // the prediction layer on the row (a + bb = z, the logits): softmax_jobs_kernel's arithmetic with W columns per lane
+                    const SoftmaxPairDev& q = sm->s[seg];
+                    const long long NEG = -(1ll << 62);
+                    long long z[W], e[W];
+#pragma unroll
+                    for (int j = 0; j < W; ++j) z[j] = have ? (long long)(a[j] + bb[j]) : NEG;
+                    long long m = z[0];
+                    if (W == 2 && z[W - 1] > m) m = z[W - 1];
+#pragma unroll
+                    for (int o = LPR / 2; o > 0; o >>= 1) { const long long t = __shfl_xor(m, o, LPR); m = t > m ? t : m; }
+                    long long S = 0;
+#pragma unroll
+                    for (int j = 0; j < W; ++j) { e[j] = have ? cognn_exp_neg_q30(m - z[j]) : 0; S += e[j]; }
+#pragma unroll
+                    for (int o = LPR / 2; o > 0; o >>= 1) S += __shfl_xor(S, o, LPR);
+                    const int lab = q.labels[vr];
+                    const bool trn = vr < q.train_rows;
+                    u64 pf[W], d0[2] = {0, 0}, d1[2] = {0, 0};
+#pragma unroll
+                    for (int j = 0; j < W; ++j) {
+                        pf[j] = have ? div_floor_small((u64)((e[j] << 16) + (S >> 1)), (u64)S) : 0ull;
+                        const u64 rho = cognn_prng(q.keyRho, idx + j);
+                        d0[j] = trn ? ((pf[j] - rho) - (off + j == lab ? COGNN_FX_ONE : 0ull)) : 0ull;
+                        d1[j] = trn ? rho : 0ull;
+                    }
+                    if (have) { Chunk<W>::put(q.d_out0 + idx, d0); Chunk<W>::put(q.d_out1 + idx, d1); }
+                    // metrics on the revealed probabilities: argmax (the first maximum wins ties), p[label]
+                    u64 bv = have ? pf[0] : 0ull;
+                    int bj = have ? off : (1 << 20);
+                    if (W == 2 && have && pf[W - 1] > bv) { bv = pf[W - 1]; bj = off + 1; }
+#pragma unroll
+                    for (int o = LPR / 2; o > 0; o >>= 1) {
+                        const u64 ov = __shfl_xor(bv, o, LPR);
+                        const int oj = __shfl_xor(bj, o, LPR);
+                        if (ov > bv || (ov == bv && oj < bj)) { bv = ov; bj = oj; }
+                    }
+                    const u64 mine = (W == 2 && (lab & 1)) ? pf[W - 1] : pf[0];
+                    const u64 p_lab = __shfl(mine, lab / W, LPR);
+                    if (ln == 0) {                           // one lane keeps the row's books
+                        const bool te = vr >= q.train_rows + q.val_rows, bd = q.border ? q.border[vr] != 0 : false;
+                        if (bj == lab) {
+                            atomicAdd(&s_cnt[0], 1ull);
+                            if (trn) atomicAdd(&s_cnt[1], 1ull);
+                            if (trn && bd) atomicAdd(&s_cnt[2], 1ull);
+                            if (te) atomicAdd(&s_cnt[3], 1ull);
+                            if (te && bd) atomicAdd(&s_cnt[4], 1ull);
+                        }
+                        double my_pl = (double)p_lab / (double)COGNN_FX_ONE;
+                        if (my_pl == 0.0) my_pl = 0.001;     /* gcn.h:613-615 */
+                        const double ls = -log(my_pl);
+                        if (ls != 0.0) atomicAdd(s_loss, ls);
+                    }
+                }
             }
+        }
+        if (SMX) {                                           // this tile's counts and loss (a tile belongs to one pair)
+            __syncthreads();
+            const SoftmaxPairDev& q = sm->s[seg];
+            if (tid < 5 && s_cnt[tid]) atomicAdd(&q.counts[tid], s_cnt[tid]);
+            if (tid == 0 && *s_loss != 0.0) atomicAdd(q.loss, *s_loss);
         }
     }
 }
@@ -248,6 +330,16 @@ __global__ __launch_bounds__(kThreads) void gather_pair_chain_kernel(const u64* 
     __shared__ uint32_t s_rp[2][kPairTile + 1];
     __shared__ uint32_t s_col[2][kPairColCap];
     gather_pair_chain_body<LPR, W, STREAM>(table, rowptr, col, F, ntiles, b, s_rp, s_col);
+}
+template <int LPR, int W>
+__global__ __launch_bounds__(kThreads) void gather_pair_softmax_kernel(const u64* __restrict__ table, const uint32_t* __restrict__ rowptr,
+                                                                        const uint32_t* __restrict__ col, int F, int ntiles, GatherPairBatch b,
+                                                                        GatherSoftmaxBatch sm) {
+    __shared__ uint32_t s_rp[2][kPairTile + 1];
+    __shared__ uint32_t s_col[2][kPairColCap];
+    __shared__ unsigned long long s_cnt[5];
+    __shared__ double s_loss;
+    gather_pair_chain_body<LPR, W, false, true>(table, rowptr, col, F, ntiles, b, s_rp, s_col, &sm, s_cnt, &s_loss);
 }
 // Grid of the gather kernels: one workgroup per tile up to this cap (the kernels keep their grid-stride loop).  Measured on
 // MI355X (config5, fused F = 64 launch): persistent grids lose to the hardware dispatcher - 1792 workgroups (one per slot)
@@ -394,6 +486,9 @@ static int gather_impl(cognn_ctx* ctx, uint64_t* out, const uint64_t* base, cons
     return launch_gather<1>(ctx, (u64*)out, (const u64*)base, (const u64*)table, rowptr, col, (int)n_rows, (int)F, segs);
 }
 
+int cognn_gather_pair_chain_takes_softmax(int64_t F) {      // the widths cognn_gather_pair::softmax is served for
+    return (F >= 1 && ((F & 1) ? F <= 31 : F <= 64)) ? 1 : 0;
+}
 int cognn_gather_pair_chain_u64(cognn_ctx* ctx, const uint64_t* table, const uint32_t* rowptr, const uint32_t* col, int64_t F,
                                 const cognn_gather_pair* pairs, int32_t count) {
     { const int rc_flush_ = cg_flush(ctx); if (rc_flush_) return rc_flush_; }
@@ -401,17 +496,33 @@ int cognn_gather_pair_chain_u64(cognn_ctx* ctx, const uint64_t* table, const uin
     CG_REQUIRE(F > 0 && F < (1 << 20) && cg_aligned16(table), "cognn_gather_pair_chain_u64: bad width or misaligned table");
     const bool odd = (F & 1) != 0;                           // 8-byte lanes: the row stride is not a multiple of 16 bytes
     GatherPairBatch b;
+    GatherSoftmaxBatch sm;
     b.count = 0;
-    int ntiles = 0, nstream = 0;
+    int ntiles = 0, nstream = 0, nsoftmax = 0;
     for (int32_t c = 0; c < count; ++c) {
         const cognn_gather_pair& p = pairs[c];
         const cognn_pair_chain& s = p.chain;
         if (s.rows <= 0) continue;
         const int fl = s.flags;
+        if (p.softmax[0] || p.softmax[1]) {                  // the prediction layer rides along: the logits need not be written
+            const cognn_softmax_job* o = p.softmax[0];
+            const cognn_softmax_job* t = p.softmax[1];
+            CG_REQUIRE(o && t && o->p == 0 && t->p == 1 && o->rows == s.rows && t->rows == s.rows && o->train_rows == t->train_rows,
+                       "cognn_gather_pair_chain_u64: pair %d: softmax wants the owner's (p = 0) and the co-party's (p = 1) job of the chain's rows", c);
+            CG_REQUIRE(o->d_out && t->d_out && o->labels && o->counts6 && o->loss && (odd || (cg_aligned16(o->d_out) && cg_aligned16(t->d_out))),
+                       "cognn_gather_pair_chain_u64: pair %d: softmax job is malformed", c);
+            CG_REQUIRE(cognn_gather_pair_chain_takes_softmax(F) && !(fl & COGNN_PC_RELU) && !s.open[0] && !s.open[1] && !s.dealt,
+                       "cognn_gather_pair_chain_u64: pair %d: softmax follows a plain or scaled aggregate of at most 64 (odd: 31) labels, without opening or dealt values", c);
+            SoftmaxPairDev& q = sm.s[b.count];
+            q.d_out0 = (u64*)o->d_out; q.d_out1 = (u64*)t->d_out; q.labels = o->labels; q.border = o->border;
+            q.keyRho = o->keys.k[COGNN_SL_RHO]; q.train_rows = o->train_rows; q.val_rows = o->val_rows;
+            q.counts = (unsigned long long*)o->counts6; q.loss = o->loss;
+            ++nsoftmax;
+        }
         CG_REQUIRE(!(fl & (COGNN_PC_TRUNC_IN | COGNN_PC_INPUT_OPENED)), "cognn_gather_pair_chain_u64: pair %d: the aggregate is neither a raw product nor an opening", c);
         CG_REQUIRE((fl & COGNN_PC_SCALE) || !(fl & COGNN_PC_RELU), "cognn_gather_pair_chain_u64: pair %d: a ReLU follows the row scale only", c);
         CG_REQUIRE((!(fl & COGNN_PC_SCALE) || (s.scale[0] && s.scale[1])) && s.rows * F < (1ll << 32) && p.a_row0 >= 0 && p.b_row0 >= 0, "cognn_gather_pair_chain_u64: pair %d is malformed", c);
-        CG_REQUIRE(s.out[0] || s.out[1] || s.open[0] || s.open[1], "cognn_gather_pair_chain_u64: pair %d writes nothing", c);
+        CG_REQUIRE(s.out[0] || s.out[1] || s.open[0] || s.open[1] || p.softmax[0], "cognn_gather_pair_chain_u64: pair %d writes nothing", c);
         CG_REQUIRE(!(fl & COGNN_PC_OPEN_SUM) || !s.open[1], "cognn_gather_pair_chain_u64: pair %d: COGNN_PC_OPEN_SUM writes open[0] only", c);
         CG_REQUIRE(odd || (cg_aligned16(s.out[0]) && cg_aligned16(s.out[1]) && cg_aligned16(s.open[0]) && cg_aligned16(s.open[1])), "cognn_gather_pair_chain_u64: pair %d: misaligned output", c);
         GatherPairSeg& g = b.s[b.count];
@@ -432,6 +543,23 @@ int cognn_gather_pair_chain_u64(cognn_ctx* ctx, const uint64_t* table, const uin
     const int lpr = pick_lpr(odd ? (int)F : (int)(F / 2));
     dim3 grid((unsigned)gather_grid(ntiles)), block(kThreads);
     CG_REQUIRE(nstream == 0 || nstream == b.count, "cognn_gather_pair_chain_u64: either every pair brings its dealt values or none does");
+    CG_REQUIRE(nsoftmax == 0 || nsoftmax == b.count, "cognn_gather_pair_chain_u64: either every pair brings its softmax jobs or none does");
+    if (nsoftmax) {
+        hipLaunchKernelGGL(gather_softmax_zero_kernel, dim3(1), dim3(64), 0, ctx->stream, sm, b.count);
+        CG_LAUNCH_CHECK();
+#define CG_GS_CASE(L)                                                                                                                              \
+    case L:                                                                                                                                        \
+        if (odd) hipLaunchKernelGGL((gather_pair_softmax_kernel<L, 1>), grid, block, 0, ctx->stream, (const u64*)table, rowptr, col, (int)F, ntiles, b, sm); \
+        else hipLaunchKernelGGL((gather_pair_softmax_kernel<L, 2>), grid, block, 0, ctx->stream, (const u64*)table, rowptr, col, (int)F, ntiles, b, sm);    \
+        break;
+        switch (lpr) {
+            CG_GS_CASE(1) CG_GS_CASE(2) CG_GS_CASE(4) CG_GS_CASE(8) CG_GS_CASE(16) CG_GS_CASE(32)
+            default: return cognn_set_error("gather_pair_chain: bad lanes-per-row %d for the softmax epilogue", lpr);
+        }
+#undef CG_GS_CASE
+        CG_LAUNCH_CHECK();
+        return 0;
+    }
 #define CG_GP_CASE(L)                                                                                                                              \
     case L:                                                                                                                                        \
         if (odd && nstream) hipLaunchKernelGGL((gather_pair_chain_kernel<L, true, 1>), grid, block, 0, ctx->stream, (const u64*)table, rowptr, col, (int)F, ntiles, b); \

@@ -110,6 +110,7 @@ struct cognn_engine {
     bool gemm_presplit = !getenv("COGNN_GEMM_NO_PRESPLIT"); // the constant feature opening kept in MFMA fragment order (A/B switch)
     bool public_openings = true;                    // COGNN_OPT_PUBLIC_OPENINGS (see pub_open)
     bool h1e_pairs_summed = false;                  // the co-located pairs' h1E holds E_0 + E_1 (written by a pair chain), not E_p
+    bool softmax_fusion = !getenv("COGNN_NO_SOFTMAX_FUSION");   // the prediction layer as the second epilogue of the label-wide Gather (A/B switch)
     bool pair_fusion = true;                        // COGNN_OPT_PAIR_FUSION: co-located share-holders run their two-party steps as pair chains
     bool forward_only = false;                      // COGNN_OPT_FORWARD_ONLY: no backward iteration will follow (inference, -m 2)
     bool graph_epochs = false;                      // COGNN_OPT_GRAPH_EPOCHS: whole epochs are recorded once (hipGraph) and replayed
@@ -1096,10 +1097,14 @@ bool can_fuse_gather_chain(const cognn_engine* E, int F) {
     for (auto& s : E->sides) if (!s.peer) return false;
     return true;
 }
-void message_passing_fused(cognn_engine* E, int F, int64_t it, bool scale, bool relu_follows, const OpenNext& open_next, bool out_read) {
+void message_passing_fused(cognn_engine* E, int F, int64_t it, bool scale, bool relu_follows, const OpenNext& open_next, bool out_read,
+                           bool softmax_follows = false) {
     // scale: GatherComp's post-gather scale follows (every Gather but the last of an epoch, gcn.h:470); out_read: somebody reads
-    // the result itself, not only its opening (the weight-gradient product reads the opening alone)
+    // the result itself, not only its opening (the weight-gradient product reads the opening alone); softmax_follows: ApplyComp is
+    // the prediction layer (softmax_stage) and runs as this launch's second epilogue - the logits are not written
     std::vector<cognn_gather_pair> gp;
+    std::vector<cognn_softmax_job> sj;
+    sj.reserve(E->sides.size());                             // (the pairs point into it)
     double out_bytes = 0;
     for (auto& s : E->sides) {
         if (s.p != 0) continue;
@@ -1125,6 +1130,19 @@ void message_passing_fused(cognn_engine* E, int F, int64_t it, bool scale, bool 
                 E->h1e_pairs_summed = true;
             c.open_key[0] = nk.k[COGNN_SL_A0]; c.open_key[1] = nk.k[COGNN_SL_A1];
             if (E->forward_only) { c.out[0] = c.out[1] = nullptr; c.mask = nullptr; }
+        } else if (softmax_follows) {
+            for (Side* x : {&s, &t}) {
+                cognn_softmax_job j;
+                memset(&j, 0, sizeof(j));
+                j.keys = keys(E, s.owner, it, COGNN_OP_AP_SOFTMAX);
+                j.p = x->p; j.rows = x->n;
+                j.train_rows = (int64_t)((double)x->n * E->cfg.train_ratio);      // gcn.h:560
+                j.val_rows = (int64_t)((double)x->n * E->cfg.val_ratio);
+                j.d_out = x->buf[0];
+                if (x->p == 0) { j.labels = x->labels; j.border = x->border; j.counts6 = x->counts; j.loss = x->loss; x->has_metrics = true; }
+                sj.push_back(j);
+                g.softmax[x->p] = &sj.back();
+            }
         } else {
             if (out_read || !open_next) { c.out[0] = s.buf[1]; c.out[1] = t.buf[1]; }
             if (open_next) {
@@ -1134,7 +1152,8 @@ void message_passing_fused(cognn_engine* E, int F, int64_t it, bool scale, bool 
         }
         const double elems = (double)s.n * F;
         out_bytes += 8.0 * elems * ((c.out[0] ? 2 : 0) + (c.open[0] ? ((c.flags & COGNN_PC_OPEN_SUM) ? 1 : 2) : 0)) + (c.mask ? elems : 0.0);
-        attach_dealt(E, c, s.owner, it, DEAL_GATHER_CHAIN);
+        if (softmax_follows) out_bytes += 8.0 * elems * 2 + 4.0 * (double)s.n;      // both sides' d_out, the labels
+        if (!softmax_follows) attach_dealt(E, c, s.owner, it, DEAL_GATHER_CHAIN);
         if (c.dealt) out_bytes += 8.0 * elems * (double)E->be->cognn_pair_chain_dealt_slots(c.flags, c.open[0] ? 1 : 0);   // the dealt values it reads
         gp.push_back(g);
     }
@@ -1147,7 +1166,7 @@ void message_passing_fused(cognn_engine* E, int F, int64_t it, bool scale, bool 
         E->algo[T_AGG] += 8.0 * F * ((double)E->aggEdges + (double)E->aggRows) + 4.0 * E->aggEdges + 4.0 * (E->aggRows + 1) + out_bytes;
     }
     for (auto& s : E->sides) {
-        s.cur = relu_follows ? s.h1 : s.buf[1];
+        s.cur = relu_follows ? s.h1 : softmax_follows ? s.buf[0] : s.buf[1];
         s.curF = F;
     }
     if (relu_follows) E->gemm_x_opened_for = it + 1;
@@ -1344,7 +1363,7 @@ void run_iteration(cognn_engine* E, int64_t it) {
     if (original(E)) { run_iteration_original(E, it); return; }
     const IterInfo I = iter_info(E, it);
     if (E->forward_only && !I.fwd) throw EngineError("engine: COGNN_OPT_FORWARD_ONLY is set but a backward iteration was requested");
-    bool relu_opened = false, wgrad_w_opened = false, relu_pairs_done = false, gather_chain_fused = false, z_revealed = false;
+    bool relu_opened = false, wgrad_w_opened = false, relu_pairs_done = false, gather_chain_fused = false, z_revealed = false, softmax_done = false;
     set_salt(E, it);                                       // (a launch only when the epoch changes: never inside a recorded epoch)
     if (I.e == 0) {                                        // ss_...h:695, 938: back to the input features
         for (auto& s : E->sides) { s.cur = s.feat; s.curF = E->in(); s.cur_mask = nullptr; }
@@ -1396,8 +1415,10 @@ void run_iteration(cognn_engine* E, int64_t it) {
             relu_opened = gscale && I.fwd && I.e != I.f - 1;
             wgrad_w_opened = !I.fwd;
             OpenNext open_wgrad([&](Side& s, int p) { return gemm_keys(E, s, it, wgrad_spec(E, s, I.layer, it)).k[p == 0 ? COGNN_SL_B0 : COGNN_SL_B1]; }, 1);
+            // ... and in the last forward iteration ApplyComp's prediction layer rides along as well
+            softmax_done = I.fwd && I.e == I.f - 1 && E->softmax_fusion && !streams_on(E) && E->be->cognn_gather_pair_chain_takes_softmax(F) != 0;
             Phase ph_mp(E, T_PH_MP);
-            message_passing_fused(E, F, it, gscale, relu_opened, wgrad_w_opened ? open_wgrad : OpenNext(), !wgrad_w_opened);
+            message_passing_fused(E, F, it, gscale, relu_opened, wgrad_w_opened ? open_wgrad : OpenNext(), !wgrad_w_opened, softmax_done);
             relu_pairs_done = relu_opened;
             gather_chain_fused = true;
         } else {
@@ -1424,7 +1445,7 @@ void run_iteration(cognn_engine* E, int64_t it) {
     Phase ph_ap(E, T_PH_APPLY);
     if (I.fwd) {
         if (I.e != I.f - 1) relu_stage(E, it, relu_opened, relu_pairs_done);
-        else softmax_stage(E, it, z_revealed);
+        else if (!softmax_done) softmax_stage(E, it, z_revealed);
         for (auto& s : E->sides) s.curF = (I.e != I.f - 1) ? E->hid() : E->lab();
         return;
     }

@@ -377,11 +377,19 @@ int cognn_pair_weight_update_u64(cognn_ctx*, const cognn_pair_wupdate* jobs, int
  * - and the chain (COGNN_PC_SCALE, optionally | COGNN_PC_RELU; chain.x / rows-of-x are unused, chain.rows = rows of the segment)
  * runs on (V_0, V_1) in registers: the aggregate is never written, only the chain's outputs / openings are.  Bit-identical to
  * cognn_gather_csr_u64 followed by cognn_pair_chain_u64.  flags = 0 (the last backward Gather has no scale, gcn.h:470): the
- * outputs / openings are those of the aggregate itself.  rowptr / col index rows of `table`; count <= 8.  An odd F (7 or 3 labels) runs with 8-byte lanes. */
+ * outputs / openings are those of the aggregate itself.  rowptr / col index rows of `table`; count <= 8.  An odd F (7 or 3 labels) runs with 8-byte lanes.
+ * softmax[0], softmax[1] (every pair of the call or none; F = the label count with cognn_gather_pair_chain_takes_softmax(F) != 0;
+ * chain.flags without COGNN_PC_RELU, no opening, no dealt values): the prediction layer that consumes this Gather (gcn.h:578-632) runs
+ * as the launch's second epilogue - the owner's (p = 0) and the co-party's (p = 1) job as cognn_softmax_jobs_u64 takes them (rows =
+ * chain.rows; z0 / z1 are ignored: z is the chain's result, still in registers), and chain.out may be NULL: the logits are neither
+ * written nor re-read.  d_out and counts6 bit-identical to cognn_softmax_jobs_u64 on the chain's outputs, loss up to the order of its
+ * floating-point atomic additions. */
 typedef struct {
     int64_t a_row0, b_row0;
     cognn_pair_chain chain;
+    const cognn_softmax_job* softmax[2];
 } cognn_gather_pair;
+int cognn_gather_pair_chain_takes_softmax(int64_t F);
 int cognn_gather_pair_chain_u64(cognn_ctx*, const uint64_t* table, const uint32_t* rowptr, const uint32_t* col, int64_t F,
                                 const cognn_gather_pair* pairs, int32_t count);
 

@@ -669,10 +669,21 @@ int cognn_gather_pair_chain_u64(cognn_ctx* ctx, const uint64_t* table, const uin
         }
         cognn_pair_chain ch = p.chain;
         ch.x[0] = v[0].data(); ch.x[1] = v[1].data(); ch.F = F;
+        std::vector<u64> z[2];
+        if (p.softmax[0]) {                                  // the prediction layer as the plain sequence: the chain's outputs, then the two jobs
+            REQ(p.softmax[1], "gather_pair_chain: softmax wants both jobs");
+            for (int sd = 0; sd < 2; ++sd) if (!ch.out[sd]) { z[sd].resize((size_t)(rows * F)); ch.out[sd] = z[sd].data(); }
+        }
         if (int rc = cognn_pair_chain_u64(ctx, &ch, 1)) return rc;
+        if (p.softmax[0]) {
+            cognn_softmax_job jobs[2] = {*p.softmax[0], *p.softmax[1]};
+            jobs[0].z0 = ch.out[0]; jobs[0].z1 = ch.out[1];
+            if (int rc = cognn_softmax_jobs_u64(ctx, jobs, 2, F)) return rc;
+        }
     }
     return 0;
 }
+int cognn_gather_pair_chain_takes_softmax(int64_t F) { return (F >= 1 && F <= 64) ? 1 : 0; }
 // the device index construction, as plain loops (count, scan, fill in edge order)
 int cognn_graph_build_colocated(cognn_ctx*, int64_t V, int64_t E, int32_t undirected, const int64_t* src, const int64_t* dst, const int32_t* tid,
                                 const uint32_t* row_of_vid, const int64_t* a_off, const int64_t* b_off, int64_t table_rows, uint32_t* rowptr,

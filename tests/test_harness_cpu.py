@@ -198,7 +198,9 @@ def _log_contract(exe, tmp_path):
             assert len(dur[t]) == (0 if apply_only else 1), (it, t)
         if not apply_only:
             phases = dur["PreScatterComp Client"][0] + dur["premerging"][0] + dur["Gather_computation"][0] + dur["Apply_computation"][0]
-            assert dur["premerging"][0] > 0 and dur["Apply_computation"][0] > 0
+            # (iteration 1: the prediction layer rides in the label-wide Gather's launch - cognn_gather_pair::softmax -, so ApplyComp's own
+            # phase is empty there and its time is part of "premerging")
+            assert dur["premerging"][0] > 0 and (dur["Apply_computation"][0] > 0 or it == 1)
             assert dur["iteration"][0] >= 0.9 * phases, (it, dur)   # the wall time of an iteration covers its device phases
     assert "::preprocess took" in r.stdout and "::preprocess_OM took" in r.stdout
 

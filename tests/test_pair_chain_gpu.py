@@ -241,6 +241,84 @@ def test_gather_with_pair_chain_epilogue_equals_gather_then_chain(ctx, F, relu, 
             assert np.array_equal(host(bufs[0]), e0) and np.array_equal(host(bufs[1]), e1)
 
 
+@pytest.mark.parametrize("F,scale,write_logits", [(16, True, False), (16, True, True), (7, True, False), (3, True, False), (6, True, False), (64, True, False),
+                                                   (1, True, False), (2, False, False), (31, True, False), (16, False, True)])
+def test_gather_with_the_prediction_layer_as_second_epilogue(ctx, F, scale, write_logits):
+    """cognn_gather_pair::softmax: the label-wide Gather, its scale and the prediction layer (softmax - label, reveal, metrics;
+    gcn.h:578-632) in one launch - against the oracle's two-party functions on the plain aggregate (the logits are only written when
+    asked for), incl. odd label counts, one label, empty CSR rows, a hub row and a partial tile."""
+    from cognn_amd import capi
+    rng = np.random.default_rng(1200 + F)
+    sizes = [70, 33, 1]
+    offs, off = [], 0
+    for n in sizes:
+        a = off; off = (off + n + 1) & ~1
+        b = off; off = (off + n + 1) & ~1
+        offs.append((a, b))
+    T = off
+    deg = rng.poisson(5, size=T); deg[rng.random(T) < 0.2] = 0
+    deg[offs[0][0] + 3] = 1700
+    rowptr = np.zeros(T + 1, dtype=np.uint32); rowptr[1:] = np.cumsum(deg)
+    col = rng.integers(0, T, size=int(rowptr[-1]), dtype=np.uint32)
+    # small fixed-point values (a few units in Q16) on every table row: the two sides' aggregates are shares of logits a few units apart
+    val = rng.integers(-(1 << 17), 1 << 17, size=(T, F)).astype(np.int64).astype(U64)
+    dtab, drp, dcl = dev(val), dev(rowptr.view(np.int32)), dev(col.view(np.int32))
+    pairs = (capi.GatherPair * len(sizes))()
+    jobs = (capi.SoftmaxJob * (2 * len(sizes)))()
+    keep = []
+    for i, (n, (a, b)) in enumerate(zip(sizes, offs)):
+        ks = {nm: _keys(7, i, 3, op) for nm, op in (("scale", co.OP_GA_SCALE), ("strunc", co.OP_GA_SCALE_TRUNC), ("smx", co.OP_AP_SOFTMAX))}
+        s0 = co.normalizer(rng.integers(0, 9, size=n)); s1 = np.zeros(n, dtype=U64)
+        bufs = [dev_empty((n, F)) for _ in range(4)]
+        labels = rng.integers(0, F, size=n).astype(np.int32); border = (rng.random(n) < 0.3).astype(np.uint8)
+        train, valr = n // 3, n // 4
+        cnt, loss = dev_empty(6), dev_empty(1, "f64")
+        cnt.fill_(77); loss.fill_(3.0)                       # (the call zeroes them)
+        dl, db = dev(labels), dev(border)
+        p = pairs[i]
+        p.a_row0 = a; p.b_row0 = b
+        c = p.chain
+        c.scale[0] = dev(s0).data_ptr(); c.scale[1] = dev(s1).data_ptr()
+        if write_logits:
+            c.out[0] = bufs[0].data_ptr(); c.out[1] = bufs[1].data_ptr()
+        c.scale_keys = ks["scale"][0]; c.scale_trunc_keys = ks["strunc"][0]
+        c.rows = n; c.F = F; c.flags = SCALE if scale else 0
+        for q in (0, 1):
+            j = jobs[2 * i + q]
+            j.d_out = bufs[2 + q].data_ptr(); j.keys = ks["smx"][0]; j.p = q; j.rows = n; j.train_rows = train; j.val_rows = valr
+            if q == 0:
+                j.labels = dl.data_ptr(); j.border = db.data_ptr(); j.counts6 = cnt.data_ptr(); j.loss = loss.data_ptr()
+            p.softmax[q] = ctypes.addressof(j)
+        keep.append((n, a, b, s0, s1, {k: v[1] for k, v in ks.items()}, bufs, labels, border, train, valr, cnt, loss, dl, db))
+    assert capi.load().cognn_gather_pair_chain_takes_softmax(F) == 1
+    ctx.call("cognn_gather_pair_chain_u64", ptr(dtab), ptr(drp), ptr(dcl), F, pairs, len(sizes))
+    agg = val.copy()
+    with np.errstate(over="ignore"):
+        for r in range(T):
+            for q in range(rowptr[r], rowptr[r + 1]):
+                agg[r] += val[col[q]]
+    for n, a, b, s0, s1, kf, bufs, labels, border, train, valr, cnt, loss, dl, db in keep:
+        v0, v1 = agg[a:a + n], agg[b:b + n]
+        if scale:
+            z0, z1 = co.beaver_rowscale_pair(v0, v1, s0, s1, kf["scale"])
+            v0, v1 = co.trunc_pair(z0, z1, kf["strunc"])
+        if write_logits:
+            assert np.array_equal(host(bufs[0]), v0) and np.array_equal(host(bufs[1]), v1)
+        p0, p1, d0, d1, plainP = co.softmax_pair(v0, v1, labels, train, kf["smx"])
+        assert np.array_equal(host(bufs[2]), d0) and np.array_equal(host(bufs[3]), d1)
+        pp = np.where(plainP == 0, 0.001, plainP)
+        ok = pp.argmax(1) == labels
+        idx = np.arange(n); tr = idx < train; te = idx >= train + valr; bd = border.astype(bool)
+        c = host(cnt, np.int64)
+        assert list(c[:5]) == [ok.sum(), (ok & tr).sum(), (ok & tr & bd).sum(), (ok & te).sum(), (ok & te & bd).sum()]
+        want_loss = -np.log(pp[idx, labels]).sum()
+        assert abs(float(host(loss, np.float64)[0]) - want_loss) < 1e-9 * max(1.0, abs(want_loss))   # fp tolerance: atomics order
+    # a ReLU or an opening in the same chain is refused
+    pairs[0].chain.flags = SCALE | RELU
+    with pytest.raises(capi.CognnError, match="softmax follows"):
+        ctx.call("cognn_gather_pair_chain_u64", ptr(dtab), ptr(drp), ptr(dcl), F, pairs, len(sizes))
+
+
 @pytest.mark.parametrize("n", [1, 7, 16 * 7, 1433 * 16 + 1])
 @pytest.mark.parametrize("pairs,average,avg_scale,post,raw", [(1, 0, 0, 0, 1), (3, 0, 0, 1, 0), (2, 1, 1, 0, 1), (5, 1, 0, 1, 1), (16, 1, 1, 0, 0)])
 def test_pair_weight_update_matches_the_two_party_oracle(ctx, n, pairs, average, avg_scale, post, raw):

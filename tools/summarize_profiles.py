@@ -79,7 +79,7 @@ def main():
             out[k] = e
         # what bench.py reports as roofline.traffic: bytes per aggregate gather launch, averaged over the launches of a step
         g = [(v["hbm_bytes_per_launch"], v["launches_profiled"]) for k, v in out.items()
-             if k.startswith(("gather_csr_kernel", "gather_pair_chain_kernel")) and "hbm_bytes_per_launch" in v]
+             if k.startswith(("gather_csr_kernel", "gather_pair_chain_kernel", "gather_pair_softmax_kernel")) and "hbm_bytes_per_launch" in v]
         if g:
             out["aggregate_launch_avg_bytes"] = sum(b * n for b, n in g) / sum(n for _, n in g)
         pmc[wl] = out
