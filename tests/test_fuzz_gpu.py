@@ -172,3 +172,69 @@ def test_fuzz_softmax(libs, seed):
     both(libs, "cognn_softmax_u64", [O((rows, L)), O((rows, L)), O((rows, L))],
          [("out", 0), ("out", 1), ("out", 2), z0, z1, labels, ctypes.byref(k), 0, rows, L, train])
     both(libs, "cognn_softmax_u64", [O((rows, L)), O((rows, L))], [("out", 0), ("out", 1), None, None, None, None, ctypes.byref(k), 1, rows, L, train])
+
+
+@pytest.mark.parametrize("seed", range(10 * SCALE))
+def test_fuzz_gather_with_prediction_layer(libs, seed):
+    """cognn_gather_pair_chain_u64 with cognn_gather_pair::softmax (Gather + scale + prediction layer in one launch) against the
+    reference backend, which runs the plain sequence (per-side gathers, per-side chain steps, cognn_softmax_u64, cognn_metrics_q16)."""
+    from cognn_amd import capi
+    ctx, cpu = libs
+    rng = np.random.default_rng(9000 + seed)
+    F = int(rng.choice([1, 2, 3, 6, 7, 16, 16, 31, 40, 64]))
+    npairs = int(rng.integers(1, 4))
+    sizes = [int(rng.integers(1, 150)) for _ in range(npairs)]
+    offs, off = [], 0
+    for n in sizes:
+        a = off; off = (off + n + 1) & ~1
+        b = off; off = (off + n + 1) & ~1
+        offs.append((a, b))
+    T = off
+    deg = rng.poisson(rng.choice([0.5, 4, 12]), size=T)
+    if seed % 3 == 0:
+        deg[offs[0][0]] = 1800                                    # beyond the staged slice of its tile
+    rowptr = np.zeros(T + 1, dtype=np.uint32); rowptr[1:] = np.cumsum(deg)
+    col = rng.integers(0, T, size=int(rowptr[-1]), dtype=np.uint32)
+    table = rng.integers(-(1 << 16), 1 << 16, size=(T, F)).astype(np.int64).astype(U64)   # aggregates: logits a few units apart
+    scale = bool(seed % 4 != 3)
+    write_logits = bool(seed % 2)
+    gp, cp = (capi.GatherPair * npairs)(), (capi.GatherPair * npairs)()
+    gj, cj = (capi.SoftmaxJob * (2 * npairs))(), (capi.SoftmaxJob * (2 * npairs))()
+    keep, outs = [], []
+    for i, (n, (a, b)) in enumerate(zip(sizes, offs)):
+        s0 = rand_u64(rng, n) >> U64(44); s1 = np.zeros(n, dtype=U64)      # a row scale below 2^20 (Q16), held by the owner
+        labels = rng.integers(0, F, size=n, dtype=np.int32); border = (rng.random(n) < 0.4).astype(np.uint8)
+        train = int(rng.integers(0, n + 1)); val = int(rng.integers(0, n - train + 1))
+        host_bufs = dict(out0=np.zeros((n, F), U64), out1=np.zeros((n, F), U64), d0=np.zeros((n, F), U64), d1=np.zeros((n, F), U64),
+                         cnt=np.full(6, 9, np.int64), loss=np.full(1, 2.5))
+        dev_bufs = dict(out0=dev_empty((n, F)), out1=dev_empty((n, F)), d0=dev_empty((n, F)), d1=dev_empty((n, F)), cnt=dev(host_bufs["cnt"]),
+                        loss=dev(host_bufs["loss"]))
+        dS0, dS1, dL, dB = dev(s0), dev(s1), dev(labels), dev(border)
+        for P, J, addr, ins in ((gp, gj, (lambda t: t.data_ptr()), dict(s0=dS0, s1=dS1, lab=dL, bd=dB, **dev_bufs)),
+                                (cp, cj, (lambda t: t.ctypes.data), dict(s0=s0, s1=s1, lab=labels, bd=border, **host_bufs))):
+            p = P[i]
+            p.a_row0 = a; p.b_row0 = b
+            c = p.chain
+            c.rows = n; c.F = F; c.flags = 2 if scale else 0
+            c.scale[0] = addr(ins["s0"]); c.scale[1] = addr(ins["s1"])
+            c.scale_keys = keys(seed + i, 11); c.scale_trunc_keys = keys(seed + i, 12)
+            if write_logits:
+                c.out[0] = addr(ins["out0"]); c.out[1] = addr(ins["out1"])
+            for q in (0, 1):
+                j = J[2 * i + q]
+                j.d_out = addr(ins["d0" if q == 0 else "d1"]); j.keys = keys(seed + i, 17); j.p = q; j.rows = n; j.train_rows = train; j.val_rows = val
+                if q == 0:
+                    j.labels = addr(ins["lab"]); j.border = addr(ins["bd"]); j.counts6 = addr(ins["cnt"]); j.loss = addr(ins["loss"])
+                p.softmax[q] = ctypes.addressof(j)
+        keep.append((s0, s1, labels, border, dS0, dS1, dL, dB))
+        outs.append((host_bufs, dev_bufs))
+    dt, drp, dcl = dev(table), dev(rowptr.view(np.int32)), dev(col.view(np.int32))
+    ctx.call("cognn_gather_pair_chain_u64", ptr(dt), ptr(drp), ptr(dcl), F, gp, npairs)
+    assert cpu.cognn_gather_pair_chain_u64(None, hp(table), hp(rowptr), hp(col), F, cp, npairs) == 0
+    for hb, db in outs:
+        assert np.array_equal(host(db["d0"]), hb["d0"]) and np.array_equal(host(db["d1"]), hb["d1"])
+        if write_logits:
+            assert np.array_equal(host(db["out0"]), hb["out0"]) and np.array_equal(host(db["out1"]), hb["out1"])
+        assert np.array_equal(host(db["cnt"], np.int64)[:5], hb["cnt"][:5])
+        got, want = float(host(db["loss"], np.float64)[0]), float(hb["loss"][0])
+        assert abs(got - want) <= 1e-9 * max(1.0, abs(want))        # fp tolerance: order of the atomic additions

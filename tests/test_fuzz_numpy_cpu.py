@@ -212,3 +212,67 @@ def test_softmax_family(cpu, seed):
     assert np.array_equal(P, p0) and np.array_equal(D, d0) and np.array_equal(PF.astype(np.float64) / 65536.0, plain)
     call(cpu, "cognn_softmax_u64", hp(P), hp(D), None, None, None, None, ctypes.byref(k), 1, rows, L, train)
     assert np.array_equal(P, p1) and np.array_equal(D, d1)
+
+
+@pytest.mark.parametrize("seed", SEEDS)
+def test_gather_with_prediction_layer_family(cpu, seed):
+    """cognn_gather_pair_chain_u64 with cognn_gather_pair::softmax on the C++ backend (the checker of tests/test_fuzz_gpu.py's family of
+    the same name) against numpy: plain aggregate, the oracle's row scale + truncation, softmax_pair and the metric definitions."""
+    from cognn_amd import capi
+    rng = np.random.default_rng(9000 + seed)
+    F = int(rng.choice([1, 2, 3, 6, 7, 16, 16, 31, 40, 64]))
+    npairs = int(rng.integers(1, 4))
+    sizes = [int(rng.integers(1, 150)) for _ in range(npairs)]
+    offs, off = [], 0
+    for n in sizes:
+        a = off; off = (off + n + 1) & ~1
+        b = off; off = (off + n + 1) & ~1
+        offs.append((a, b))
+    T = off
+    deg = rng.poisson(rng.choice([0.5, 4, 12]), size=T)
+    rowptr = np.zeros(T + 1, dtype=np.uint32); rowptr[1:] = np.cumsum(deg)
+    col = rng.integers(0, T, size=int(rowptr[-1]), dtype=np.uint32)
+    table = rng.integers(-(1 << 16), 1 << 16, size=(T, F)).astype(np.int64).astype(U64)
+    scale = bool(seed % 4 != 3)
+    pairs = (capi.GatherPair * npairs)()
+    jobs = (capi.SoftmaxJob * (2 * npairs))()
+    keep = []
+    for i, (n, (a, b)) in enumerate(zip(sizes, offs)):
+        s0 = rand_u64(rng, n) >> U64(44); s1 = np.zeros(n, dtype=U64)
+        labels = rng.integers(0, F, size=n, dtype=np.int32); border = (rng.random(n) < 0.4).astype(np.uint8)
+        train = int(rng.integers(0, n + 1)); val = int(rng.integers(0, n - train + 1))
+        d0, d1 = np.zeros((n, F), U64), np.zeros((n, F), U64)
+        cnt, loss = np.full(6, 9, np.int64), np.full(1, 2.5)
+        ks, kfs = keys_of(seed + i, co.OP_GA_SCALE); kt, kft = keys_of(seed + i, co.OP_GA_SCALE_TRUNC); km, kfm = keys_of(seed + i, co.OP_AP_SOFTMAX)
+        p = pairs[i]
+        p.a_row0 = a; p.b_row0 = b
+        c = p.chain
+        c.rows = n; c.F = F; c.flags = 2 if scale else 0
+        c.scale[0] = s0.ctypes.data; c.scale[1] = s1.ctypes.data
+        c.scale_keys = ks; c.scale_trunc_keys = kt
+        for q in (0, 1):
+            j = jobs[2 * i + q]
+            j.d_out = (d0 if q == 0 else d1).ctypes.data; j.keys = km; j.p = q; j.rows = n; j.train_rows = train; j.val_rows = val
+            if q == 0:
+                j.labels = labels.ctypes.data; j.border = border.ctypes.data; j.counts6 = cnt.ctypes.data; j.loss = loss.ctypes.data
+            p.softmax[q] = ctypes.addressof(j)
+        keep.append((n, a, b, s0, s1, labels, border, train, val, d0, d1, cnt, loss, kfs, kft, kfm))
+    call(cpu, "cognn_gather_pair_chain_u64", hp(table), hp(rowptr), hp(col), F, pairs, npairs)
+    agg = table.copy()
+    with np.errstate(over="ignore"):
+        for r in range(T):
+            for q in range(rowptr[r], rowptr[r + 1]):
+                agg[r] += table[col[q]]
+    for n, a, b, s0, s1, labels, border, train, val, d0, d1, cnt, loss, kfs, kft, kfm in keep:
+        v0, v1 = agg[a:a + n], agg[b:b + n]
+        if scale:
+            z0, z1 = co.beaver_rowscale_pair(v0, v1, s0, s1, kfs)
+            v0, v1 = co.trunc_pair(z0, z1, kft)
+        _, _, w0, w1, plain = co.softmax_pair(v0, v1, labels, train, kfm)
+        assert np.array_equal(d0, w0) and np.array_equal(d1, w1)
+        pp = np.where(plain == 0, 0.001, plain)
+        ok = pp.argmax(1) == labels
+        idx = np.arange(n); tr = idx < train; te = idx >= train + val; bd = border.astype(bool)
+        assert list(cnt[:5]) == [ok.sum(), (ok & tr).sum(), (ok & tr & bd).sum(), (ok & te).sum(), (ok & te & bd).sum()]
+        want = -np.log(pp[idx, labels]).sum()
+        assert abs(float(loss[0]) - want) <= 1e-9 * max(1.0, abs(want))
