@@ -166,10 +166,11 @@ def cross_path_check(eng, Engine, k, src, dst, part, param, variant, iters, in_d
         ref.set_party_data(P, (rng.random((len(vids), in_dim)) < 0.01).astype(np.float64), rng.integers(0, lab, size=len(vids)))
     ref.start()
     for _ in range(passes if "inference" not in variant else 1):   # a training pass updates the weights: as many passes as the bench ran
-        ref.run(0, iters)
+        for it in range(iters):                             # one call per GAS iteration: none of the paths that span iterations of a call
+            ref.run(it, it + 1)
     d_plain = digest(ref)
     res = {"what": "sha256 over every party's two vertex-tensor shares and weight shares: the bench sequence (forward-only / retained products / "
-                   "replays) vs the plain sequence on a fresh engine",
+                   "replays, whole passes per call) vs the plain sequence on a fresh engine, one call per GAS iteration",
            "cross_path_identical": d_bench == d_plain, "digest": d_bench}
     if "inference" in variant:
         a = ref.shares(0, 0); b = ref.shares(0, 1)

@@ -621,7 +621,8 @@ __global__ __launch_bounds__(kThreads) void pair_chain_kernel(PairBatch b) {
         const u64 zero[2] = {0, 0};
         st2(const_cast<u64*>(d.x0), i, w, zero); st2(const_cast<u64*>(d.x1), i, w, zero);
     }
-    if (d.mask_in) {                                         // MaskSelect on both sides' inputs
+    const bool mask_mid = (flags & COGNN_PC_MASK_AFTER_TRUNC) != 0;
+    if (d.mask_in && !mask_mid) {                            // MaskSelect on both sides' inputs
         if (!d.mask_in[i]) { v0[0] = 0; v1[0] = 0; }
         if (w == 2 && !d.mask_in[i + 1]) { v0[1] = 0; v1[1] = 0; }
     }
@@ -635,6 +636,10 @@ __global__ __launch_bounds__(kThreads) void pair_chain_kernel(PairBatch b) {
             if (addc) { v0[j] += STREAM ? d.slab[(u64)(SB.ti + PCS_TI_C0) * (u64)d.n + idx] : cognn_prng(d.keyC0, idx); v1[j] += cc[j]; }     // TruncOpenAdd: x + C_p
             if (j < w) pair_trunc<STREAM>(d, SB.ti + PCS_TI_R0, d.tiR, d.tiR0, d.tiRP0, idx, v0[j], v1[j]);
         }
+    }
+    if (d.mask_in && mask_mid) {                             // ... or on the truncated product (COGNN_PC_MASK_AFTER_TRUNC)
+        if (!d.mask_in[i]) { v0[0] = 0; v1[0] = 0; }
+        if (w == 2 && !d.mask_in[i + 1]) { v0[1] = 0; v1[1] = 0; }
     }
     if (flags & COGNN_PC_SCALE) {
         // i is even: with an even row width both elements lie in one row, whose values are formed once
@@ -991,6 +996,7 @@ int cognn_pair_chain_u64(cognn_ctx* ctx, const cognn_pair_chain* chains, int32_t
         d.out0 = (u64*)s.out[0]; d.out1 = (u64*)s.out[1]; d.open0 = (u64*)s.open[0]; d.open1 = (u64*)s.open[1]; d.mask = s.mask;
         d.mask_in = s.mask_in;
         CG_REQUIRE(!s.mask_in || !(fl & COGNN_PC_INPUT_OPENED), "cognn_pair_chain_u64: chain %d: mask_in needs plain input shares", c);
+        CG_REQUIRE(!(fl & COGNN_PC_MASK_AFTER_TRUNC) || ((fl & COGNN_PC_TRUNC_IN) && s.mask_in), "cognn_pair_chain_u64: chain %d: COGNN_PC_MASK_AFTER_TRUNC wants COGNN_PC_TRUNC_IN and mask_in", c);
         CG_REQUIRE(!(fl & COGNN_PC_CLEAR_INPUT) || ((fl & COGNN_PC_TRUNC_IN) && s.x[0] != s.out[0] && s.x[1] != s.out[1] && s.x[0] != s.out[1] && s.x[1] != s.out[0]),
                    "cognn_pair_chain_u64: chain %d: COGNN_PC_CLEAR_INPUT is for product buffers that are not also an output", c);
         pair_chain_fill_keys(d, s);

@@ -110,6 +110,13 @@ struct cognn_engine {
     bool gemm_presplit = !getenv("COGNN_GEMM_NO_PRESPLIT"); // the constant feature opening kept in MFMA fragment order (A/B switch)
     bool public_openings = true;                    // COGNN_OPT_PUBLIC_OPENINGS (see pub_open)
     bool h1e_pairs_summed = false;                  // the co-located pairs' h1E holds E_0 + E_1 (written by a pair chain), not E_p
+    // a training epoch inside ONE cognn_engine_run call (nobody can read the state between its iterations): the chain that truncates
+    // g = (p - y) . W1^T already applies the backward ReLU' and the PreScatter scale of three iterations later and writes that
+    // iteration's share table (a second table) - g itself and the later scale pass are never written / run (A/B switch)
+    bool backward_fusion = !getenv("COGNN_NO_BACKWARD_FUSION");
+    int64_t run_end = 0;                            // end of the running cognn_engine_run call (exclusive)
+    int64_t prescaled_it = -1;                      // the iteration whose PreScatter result already sits in table2
+    u64* table2 = nullptr;
     bool softmax_fusion = !getenv("COGNN_NO_SOFTMAX_FUSION");   // the prediction layer as the second epilogue of the label-wide Gather (A/B switch)
     bool pair_fusion = true;                        // COGNN_OPT_PAIR_FUSION: co-located share-holders run their two-party steps as pair chains
     bool forward_only = false;                      // COGNN_OPT_FORWARD_ONLY: no backward iteration will follow (inference, -m 2)
@@ -514,6 +521,8 @@ const u64* dealt_mask(cognn_engine* E, int owner, int64_t it, int place, u64 key
 struct FollowScale {
     int op = 0, top = 0;
     std::function<u64*(Side&)> dst;
+    int64_t it = -1;                                  // the iteration whose scale this is (its dealer streams); -1: the product's own
+    std::function<const uint8_t*(Side&)> mask;        // a public selection between the truncation and the scale (COGNN_PC_MASK_AFTER_TRUNC)
     explicit operator bool() const { return (bool)dst; }
 };
 
@@ -690,9 +699,11 @@ bool gemm_stage(cognn_engine* E, int64_t it, XFn X, WFn Wm, SpecFn spec, DstFn d
         if (follow) {
             c.flags |= COGNN_PC_SCALE;
             c.scale[0] = s.svec; c.scale[1] = t.svec;
-            c.scale_keys = keys(E, s.owner, it, follow.op);
-            c.scale_trunc_keys = keys(E, s.owner, it, follow.top);
+            const int64_t fit = follow.it >= 0 ? follow.it : it;
+            c.scale_keys = keys(E, s.owner, fit, follow.op);
+            c.scale_trunc_keys = keys(E, s.owner, fit, follow.top);
             c.out[0] = follow.dst(s); c.out[1] = follow.dst(t);
+            if (follow.mask) { c.mask_in = follow.mask(s); c.flags |= COGNN_PC_MASK_AFTER_TRUNC; }
         } else {
             c.out[0] = dst(s); c.out[1] = dst(t);
             if (open_next) {
@@ -706,7 +717,7 @@ bool gemm_stage(cognn_engine* E, int64_t it, XFn X, WFn Wm, SpecFn spec, DstFn d
     // p = 0 sides' products go first, then one launch computes the p = 1 products and runs the chains on their tiles in registers
     // - the p = 1 product is never written or re-read, and the chain launch disappears
     bool epi = false;
-    if (grouped && !tn_group && all_raw && E->gemm_epilogue && !pairs_raw && !streams_on(E) && (!open_next || follow)) {
+    if (grouped && !tn_group && all_raw && E->gemm_epilogue && !pairs_raw && !streams_on(E) && (!open_next || follow) && !follow.mask) {
         int64_t tilesB = 0; int nB = 0;
         for (auto& s : E->sides) if (paired(E, s) && s.p == 1) { tilesB += (spec(s).M + 15) / 16; ++nB; }
         epi = nB >= 1 && nB <= 8 && E->be->cognn_beaver_gemm_group_takes_epilogue(g0.N, g0.K, tilesB) != 0;
@@ -1098,7 +1109,8 @@ bool can_fuse_gather_chain(const cognn_engine* E, int F) {
     return true;
 }
 void message_passing_fused(cognn_engine* E, int F, int64_t it, bool scale, bool relu_follows, const OpenNext& open_next, bool out_read,
-                           bool softmax_follows = false) {
+                           bool softmax_follows = false, const u64* table = nullptr) {
+    if (!table) table = E->table;
     // scale: GatherComp's post-gather scale follows (every Gather but the last of an epoch, gcn.h:470); out_read: somebody reads
     // the result itself, not only its opening (the weight-gradient product reads the opening alone); softmax_follows: ApplyComp is
     // the prediction layer (softmax_stage) and runs as this launch's second epilogue - the logits are not written
@@ -1159,7 +1171,7 @@ void message_passing_fused(cognn_engine* E, int F, int64_t it, bool scale, bool 
     }
     if (streams_on(E)) { bool all = true; for (auto& g : gp) all = all && g.chain.dealt; if (!all) for (auto& g : gp) g.chain.dealt = nullptr; }
     if (E->timing) BE(cognn_timer_begin(E->ctx, T_AGG));
-    BE(cognn_gather_pair_chain_u64(E->ctx, E->table, E->agg_rowptr, E->agg_col, F, gp.data(), (int32_t)gp.size()));
+    BE(cognn_gather_pair_chain_u64(E->ctx, table, E->agg_rowptr, E->agg_col, F, gp.data(), (int32_t)gp.size()));
     if (E->timing) {
         BE(cognn_timer_end(E->ctx, T_AGG));
         // source row per entry, base row per output row, u32 col / rowptr + what the epilogue writes
@@ -1363,7 +1375,7 @@ void run_iteration(cognn_engine* E, int64_t it) {
     if (original(E)) { run_iteration_original(E, it); return; }
     const IterInfo I = iter_info(E, it);
     if (E->forward_only && !I.fwd) throw EngineError("engine: COGNN_OPT_FORWARD_ONLY is set but a backward iteration was requested");
-    bool relu_opened = false, wgrad_w_opened = false, relu_pairs_done = false, gather_chain_fused = false, z_revealed = false, softmax_done = false;
+    bool relu_opened = false, wgrad_w_opened = false, relu_pairs_done = false, gather_chain_fused = false, z_revealed = false, softmax_done = false, prescaled = false;
     set_salt(E, it);                                       // (a launch only when the epoch changes: never inside a recorded epoch)
     if (I.e == 0) {                                        // ss_...h:695, 938: back to the input features
         for (auto& s : E->sides) { s.cur = s.feat; s.curF = E->in(); s.cur_mask = nullptr; }
@@ -1400,6 +1412,9 @@ void run_iteration(cognn_engine* E, int64_t it) {
             if (scale_follows)
                 rowscale_stage(E, it, COGNN_OP_PS_SCALE, COGNN_OP_PS_SCALE_TRUNC, F, [&](Side& s) { return s.buf[1]; },
                                [&](Side& s) { return table_seg(E, s, F); }, E_IN_OB0, OpenNext(), true);
+        } else if (E->prescaled_it == it) {                 // done by the chain of iteration it - 3 (see there): the result sits in table2
+            for (auto& s : E->sides) s.cur_mask = nullptr;
+            prescaled = true;
         } else {
             rowscale_stage(E, it, COGNN_OP_PS_SCALE, COGNN_OP_PS_SCALE_TRUNC, F, [&](Side& s) { return s.cur; },
                            [&](Side& s) { return table_seg(E, s, F); });
@@ -1418,7 +1433,9 @@ void run_iteration(cognn_engine* E, int64_t it) {
             // ... and in the last forward iteration ApplyComp's prediction layer rides along as well
             softmax_done = I.fwd && I.e == I.f - 1 && E->softmax_fusion && !streams_on(E) && E->be->cognn_gather_pair_chain_takes_softmax(F) != 0;
             Phase ph_mp(E, T_PH_MP);
-            message_passing_fused(E, F, it, gscale, relu_opened, wgrad_w_opened ? open_wgrad : OpenNext(), !wgrad_w_opened, softmax_done);
+            message_passing_fused(E, F, it, gscale, relu_opened, wgrad_w_opened ? open_wgrad : OpenNext(), !wgrad_w_opened, softmax_done,
+                                  prescaled ? E->table2 : E->table);
+            if (prescaled) E->prescaled_it = -1;
             relu_pairs_done = relu_opened;
             gather_chain_fused = true;
         } else {
@@ -1453,9 +1470,21 @@ void run_iteration(cognn_engine* E, int64_t it) {
     if (first_of_two) {
         if (I.layer == I.f - 1) {                          // g = (p-y) . W1^T, out = in  (gcn.h:664-669)
             // (W1 is read across by the opening of the right operand: no transposed copy)
+            // g's only reader is the PreScatter scale of iteration it + 3 (after the ReLU' of it + 2): when that iteration runs inside this
+            // very cognn_engine_run call, the chain that truncates the product applies both and writes that iteration's share table
+            // (table2: the table itself is used by iteration it + 1) - same dealer streams, same values, g never goes to memory
+            FollowScale follow;
+            if (E->backward_fusion && I.f == 2 && it + 3 < E->run_end && can_fuse_gather_chain(E, E->hid()) && !streams_on(E) && !E->graph_epochs &&
+                !E->cfg.verbose) {
+                if (!E->table2) E->table2 = dalloc<u64>(E, (size_t)E->tableRows * E->hid());
+                follow.op = COGNN_OP_PS_SCALE; follow.top = COGNN_OP_PS_SCALE_TRUNC; follow.it = it + 3;
+                follow.dst = [&](Side& s) { return E->table2 + (s.p == 0 ? E->A_off[s.owner] : E->B_off[s.owner]) * E->hid(); };
+                follow.mask = [&](Side& s) { return (const uint8_t*)s.relu_mask; };
+                E->prescaled_it = it + 3;
+            }
             gemm_stage(E, it, [&](Side& s) { return s.cur; }, [&](Side& s) { return s.W[1]; },
                        [&](Side& s) { GemmSpec g{s.n, E->hid(), E->lab(), 0, COGNN_OP_AP_GEMM, COGNN_OP_AP_GEMM_TRUNC}; g.transB = 1; return g; },
-                       [&](Side& s) { return s.g; });
+                       [&](Side& s) { return s.g; }, false, OpenNext(), false, follow);
         } else {                                           // out = in * 1[z>0]  (gcn.h:702-708; g' skipped for layer 0)
             Batch batch(E);
             for (auto& s : E->sides) {
@@ -2283,6 +2312,8 @@ int cognn_engine_run(cognn_engine* E, int64_t it0, int64_t it1) {
         if (!E || !E->started) throw EngineError("cognn_engine_run: engine not started");
         const int ep = epoch_len(E);
         struct SaltReset { cognn_engine* E; ~SaltReset() { if (E->salt_now) { E->be->cognn_set_epoch_salt(E->ctx, 0); E->salt_now = 0; } } } salt_reset{E};
+        E->run_end = it1;
+        E->prescaled_it = -1;                               // (nothing is carried from one call to the next)
         for (int64_t it = it0; it < it1; ++it) {
             if (E->graph_epochs && E->world == 1 && !E->cfg.verbose && !E->timing && it % ep == 0 && it + ep <= it1) {
                 run_epoch(E, it);

@@ -317,7 +317,11 @@ enum { COGNN_PC_TRUNC_IN = 1, COGNN_PC_SCALE = 2, COGNN_PC_RELU = 4, COGNN_PC_IN
        /* COGNN_PC_TRUNC_IN chains only: x[0], x[1] are zeroed behind the read - the product buffer is handed back clean to the next
         * split-K product (cognn_gemm_job::Z_zeroed), which saves that product's zeroing launch; worth it for small tensors only
         * (+16 B of writes per element pair) */
-       COGNN_PC_CLEAR_INPUT = 128 };
+       COGNN_PC_CLEAR_INPUT = 128,
+       /* with COGNN_PC_TRUNC_IN and mask_in: the selection applies to the truncated product (mask_in[i] ? v_p : 0 on both sides after
+        * the truncation) instead of the raw input - g = (p - y) . W^T truncated, then the backward ReLU' (gcn.h:702-708), then the
+        * steps that follow, in one chain */
+       COGNN_PC_MASK_AFTER_TRUNC = 256 };
 typedef struct cognn_pair_chain_s {
     const uint64_t* x[2];        /* the two sides' input shares [rows x F] */
     const uint64_t* c1;          /* side 1's dealt product share (COGNN_PC_TRUNC_IN without COGNN_PC_NO_C) */

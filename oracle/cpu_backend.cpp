@@ -498,12 +498,17 @@ int cognn_pair_chain_u64(cognn_ctx* ctx, const cognn_pair_chain* chains, int32_t
         for (int p = 0; p < 2; ++p) { cur[p].assign(s.x[p], s.x[p] + n); o0[p].resize((size_t)n); o1[p].resize((size_t)n); }
         if (s.flags & COGNN_PC_CLEAR_INPUT)                 // the product buffers go back clean
             for (int p = 0; p < 2; ++p) memset(const_cast<uint64_t*>(s.x[p]), 0, (size_t)n * 8);
-        if (s.mask_in)                                      // cognn_mask_select_u64 on both sides' inputs
+        auto select = [&]() -> int {                        // cognn_mask_select_u64 on both sides' current values
             for (int p = 0; p < 2; ++p) {
                 std::vector<u64> sel((size_t)n);
                 if (int rc = cognn_mask_select_u64(ctx, sel.data(), cur[p].data(), s.mask_in, n)) return rc;
                 cur[p].swap(sel);
             }
+            return 0;
+        };
+        const bool mask_mid = (s.flags & COGNN_PC_MASK_AFTER_TRUNC) != 0;
+        REQ(!mask_mid || ((s.flags & COGNN_PC_TRUNC_IN) && s.mask_in), "pair_chain: COGNN_PC_MASK_AFTER_TRUNC wants COGNN_PC_TRUNC_IN and mask_in");
+        if (s.mask_in && !mask_mid) if (int rc = select()) return rc;
         bool opened = (s.flags & COGNN_PC_INPUT_OPENED) != 0;
         if (s.flags & COGNN_PC_TRUNC_IN) {
             for (int p = 0; p < 2; ++p) {
@@ -514,6 +519,7 @@ int cognn_pair_chain_u64(cognn_ctx* ctx, const cognn_pair_chain* chains, int32_t
             for (int p = 0; p < 2; ++p)
                 if (int rc = cognn_trunc_close_u64(ctx, cur[p].data(), p == 0 ? o0[0].data() : nullptr, p == 0 ? o0[1].data() : nullptr,
                                                    &s.trunc_in_keys, p, 0, n)) return rc;
+            if (mask_mid) if (int rc = select()) return rc;
         }
         if (s.flags & COGNN_PC_SCALE) {
             REQ(s.scale[0] && s.scale[1], "pair_chain: null scale");

@@ -80,6 +80,29 @@ def main():
         res[str(keep)] = {"same": bool(np.array_equal(a, b)), "grew": m1[0] - m0[0]}
         e5.close()
     out["replay"] = res
+    # 4. whole epochs in one call take the paths that only exist across GAS iterations (the deferred ReLU' selection, the backward
+    #    PreScatter scale run ahead by the chain that truncates g): same shares and weights as one call per iteration, same memory
+    #    from the second epoch on
+    digests, mems = [], []
+    for whole in (True, False):
+        e6 = make(3, 60, 150, 12, 6, 4)
+        for ep in range(3):
+            if whole:
+                e6.run(6 * ep, 6 * ep + 6)
+            else:
+                for it in range(6 * ep, 6 * ep + 6):
+                    e6.run(it, it + 1)
+            if whole:
+                mems.append(e6.memory()[1])
+        d = []
+        for P in range(3):
+            for sd in (0, 1):
+                d.append(e6.shares(P, sd).tolist())
+                d += [e6.weight(P, sd, l).tolist() for l in (0, 1)]
+        digests.append(d)
+        e6.close()
+    out["epoch_calls_identical"] = digests[0] == digests[1]
+    out["epoch_calls_memory"] = mems
     out["ref_rows"] = len(ref_shares)
     print(json.dumps(out))
 

@@ -30,6 +30,8 @@ def check(out):
     assert out["loaded_truncated"] == 14
     assert out["replay"]["True"] == {"same": True, "grew": 0}
     assert out["replay"]["False"]["same"] is True
+    assert out["epoch_calls_identical"] is True
+    assert out["epoch_calls_memory"][1] == out["epoch_calls_memory"][2]
     ph = out["phases"]
     assert ph["rounds"] == 0 and ph["apply"] > 0       # single rank: no exchange rounds; iteration 35 is a backward one
 

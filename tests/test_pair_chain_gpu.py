@@ -142,6 +142,42 @@ def test_pair_chain_with_input_mask(ctx, rows, F):
         ctx.call("cognn_pair_chain_u64", ctypes.byref(c), 1)
 
 
+@pytest.mark.parametrize("rows,F,scale", [(130, 64, True), (33, 3, True), (70, 16, False)])
+def test_pair_chain_with_the_mask_between_truncation_and_scale(ctx, rows, F, scale):
+    """COGNN_PC_MASK_AFTER_TRUNC: g = trunc(product + C), the backward ReLU' selection on g, then (optionally) the PreScatter row scale of
+    the iteration that consumes it - one chain (the engine's whole-epoch path) against the oracle's steps in that order."""
+    from cognn_amd import capi
+    MASK_AFTER_TRUNC = 256
+    rng = np.random.default_rng(7 * rows + F)
+    shape = (rows, F)
+    val = rng.integers(-(1 << 44), 1 << 44, size=shape).astype(np.int64).astype(U64)     # the untruncated product (Q32)
+    ks = {n: _keys(6, 2, 11, op) for n, op in (("gemm", co.OP_AP_GEMM), ("tin", co.OP_AP_GEMM_TRUNC), ("scale", co.OP_PS_SCALE), ("strunc", co.OP_PS_SCALE_TRUNC))}
+    kf = {n: v[1] for n, v in ks.items()}
+    c1 = rand_u64(rng, shape)
+    with np.errstate(over="ignore"):                         # raw product shares: x0 + C_0 + x1 + c1 = val
+        x1 = rand_u64(rng, shape)
+        x0 = val - x1 - c1 - co.prng_shape(kf["gemm"](co.SL_C0), shape)
+    m = rng.random(shape) < 0.5
+    s0 = co.normalizer(rng.integers(0, 9, size=rows)); s1 = np.zeros(rows, dtype=U64)
+    out0, out1 = dev_empty(shape), dev_empty(shape)
+    c = capi.PairChain()
+    c.x[0] = dev(x0).data_ptr(); c.x[1] = dev(x1).data_ptr(); c.c1 = dev(c1).data_ptr()
+    c.scale[0] = dev(s0).data_ptr(); c.scale[1] = dev(s1).data_ptr()
+    c.out[0] = out0.data_ptr(); c.out[1] = out1.data_ptr()
+    c.mask_in = dev(m.astype(np.uint8)).data_ptr()
+    c.gemm_keys = ks["gemm"][0]; c.trunc_in_keys = ks["tin"][0]; c.scale_keys = ks["scale"][0]; c.scale_trunc_keys = ks["strunc"][0]
+    c.rows = rows; c.F = F; c.flags = TRUNC_IN | MASK_AFTER_TRUNC | (SCALE if scale else 0)
+    ctx.call("cognn_pair_chain_u64", ctypes.byref(c), 1)
+    g0, g1, _ = _expect(TRUNC_IN, x0, x1, c1, s0, s1, kf)
+    g0, g1 = np.where(m, g0, U64(0)), np.where(m, g1, U64(0))
+    if scale:
+        g0, g1, _ = _expect(SCALE, g0, g1, None, s0, s1, kf)
+    assert np.array_equal(host(out0), g0) and np.array_equal(host(out1), g1)
+    c.flags = SCALE | MASK_AFTER_TRUNC                       # needs the truncation it follows
+    with pytest.raises(capi.CognnError, match="MASK_AFTER_TRUNC"):
+        ctx.call("cognn_pair_chain_u64", ctypes.byref(c), 1)
+
+
 def test_pair_chain_batches_and_rejects_bad_chains(ctx):
     from cognn_amd import capi
     rng = np.random.default_rng(5)
