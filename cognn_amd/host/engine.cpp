@@ -100,7 +100,7 @@ struct cognn_engine {
     int gemm_lanes = getenv("COGNN_GEMM_LANES") ? atoi(getenv("COGNN_GEMM_LANES")) : 2;   // launch lanes of the per-side products (A/B switch: 1 = one stream)
     bool gemm_group = !getenv("COGNN_GEMM_PER_SIDE");       // one grouped launch per phase (A/B switch: the per-side launch sequences)
     // co-located pairs: the product's chain as the epilogue of the p = 1 side's launch (cognn_gemm_job::epilogue).  Opt-in: measured
-    // 1.6 % faster on config5 (5.40 vs 5.47 ms, 5.50 vs 5.59 on another box), inside the box-to-box spread; COGNN_GEMM_EPILOGUE=1
+    // 1.6 % faster on config5 before the mask image (5.40 vs 5.47 ms), no difference with it (5.36-5.40 both ways); COGNN_GEMM_EPILOGUE=1
     bool gemm_epilogue = getenv("COGNN_GEMM_EPILOGUE") != nullptr;
     bool wupdate_fusion = !getenv("COGNN_NO_WUPDATE_FUSION"); // co-located pairs: weight update (+ average) as one pass (A/B switch)
     // the feature operand's mask A_p (dealt once, like its opening) kept in fragment order too: the layer-0 product's K loop then has no
