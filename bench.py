@@ -237,6 +237,10 @@ def main():
     ap.add_argument("--no-check", action="store_true", help="skip the cross-path verification after the timed region")
     ap.add_argument("--no-dealer-streams", action="store_true", help="skip the extra timing of the dealt (memory-streamed dealer) form")
     ap.add_argument("--chunks", type=int, default=1, help="N > 1: row chunks of the cross-rank open -> exchange -> close steps (COGNN_OPT_EXCHANGE_CHUNKS)")
+    ap.add_argument("--placement", default="vertex-set", choices=["vertex-set", "party"],
+                    help="N > 1: vertex-set = every GPU holds BOTH shares of its parties' vertex sets (the co-located mode of N = 1 extended: two-party "
+                         "steps stay in registers, only Gather replicas / partial sums and the weight average cross xGMI); party = a GPU is a set of "
+                         "parties as in the reference's deployment (every opening of a cross-GPU owner / co-party pair crosses a link)")
     ap.add_argument("--graph", action="store_true", help="training workloads: replay the recorded epoch (hipGraph, COGNN_OPT_GRAPH_EPOCHS) instead of launching every kernel")
     args = ap.parse_args()
 
@@ -276,7 +280,7 @@ def main():
     src, dst = synth_graph(V, Eu, 0xC06A11)
     part = (np.arange(V) % k).astype(np.int32)
     param = GnnParam(num_labels=lab, input_dim=in_dim, hidden_dim=hid, num_samples=V, num_edges=len(src))
-    eng = Engine(k, src, dst, part, param, seed=0xC06A11, variant=variant, rank=rank, world=world, device=local_rank)
+    eng = Engine(k, src, dst, part, param, seed=0xC06A11, variant=variant, rank=rank, world=world, device=local_rank, placement=args.placement)
     xch = None
     if world > 1:
         from cognn_amd import dist as cdist
@@ -371,7 +375,8 @@ def main():
                                "partition vid %% %d, input_dim=%d hidden_dim=%d num_labels=%d, %d part%s per GPU"
                                % (k, variant, iters - 1, V, 2 * Eu, k, in_dim, hid, lab, k // world, "y" if k // world == 1 else "ies"),
                    "name": args.workload, "parties": k, "exchange": "in-device" if world == 1 else ("rccl-p2p" if backend == "nccl" else backend + "-host-staged"),
-                   "exchange_chunks": args.chunks if world > 1 else None},
+                   "exchange_chunks": args.chunks if world > 1 else None,
+                   "placement": (args.placement if world > 1 else "all parties and both share-holders of every vertex set on the one GPU")},
         "epoch_time_s": dt / args.steps,
         "edges_feat_per_s_per_party": value / k,
         "offline_ms": offline_ms, "setup_s": setup_s,

@@ -48,7 +48,9 @@ def _check(rc):
 
 class Engine:
     def __init__(self, num_parties, src, dst, part, param, seed=0xC06A11, variant="optimize-gcn", rank=0, world=1,
-                 device=0, stream=None, undirected=False, verbose=False):
+                 device=0, stream=None, undirected=False, verbose=False, placement="party"):
+        """placement (world > 1): "party" - a rank holds what its parties hold (own shares + the co-shares of the previous party's
+        vertices); "vertex-set" - a rank holds both shares of its parties' vertex sets (cognn_engine_config::placement)."""
         self.lib = capi.load()
         self.k = num_parties; self.rank = rank; self.world = world; self.param = param
         if stream is None:
@@ -56,7 +58,8 @@ class Engine:
             stream = torch.cuda.current_stream(device).cuda_stream if torch.cuda.is_available() else 0
         cfg = EngineConfig(num_parties, rank, world, VARIANTS[variant], param.num_layers, param.num_labels,
                            param.input_dim, param.hidden_dim, param.learning_rate, param.train_ratio, param.val_ratio,
-                           param.test_ratio, seed, device, ctypes.c_void_p(stream), int(undirected), int(verbose))
+                           param.test_ratio, seed, device, ctypes.c_void_p(stream), int(undirected), int(verbose),
+                           {"party": 0, "vertex-set": 1}[placement])
         src = np.ascontiguousarray(src, dtype=np.int64); dst = np.ascontiguousarray(dst, dtype=np.int64)
         part = np.ascontiguousarray(part, dtype=np.int32)
         h = ctypes.c_void_p()

@@ -12,7 +12,7 @@ class EngineConfig(ctypes.Structure):
     _fields_ = [("num_parties", _I), ("rank", _I), ("world", _I), ("variant", _I),
                 ("num_layers", _I), ("num_labels", _I), ("input_dim", _I), ("hidden_dim", _I),
                 ("learning_rate", _D), ("train_ratio", _D), ("val_ratio", _D), ("test_ratio", _D),
-                ("seed", _U), ("device", _I), ("stream", _P), ("undirected", _I), ("verbose", _I)]
+                ("seed", _U), ("device", _I), ("stream", _P), ("undirected", _I), ("verbose", _I), ("placement", _I)]
 
 
 class Xfer(ctypes.Structure):

@@ -172,6 +172,14 @@ struct cognn_engine {
     int lab() const { return cfg.num_labels; }
     int rank_of(int party) const { return party / m; }
     int co(int owner) const { return (owner + 1) % k; }
+    // the rank that holds share p of owner o's vertex set (cognn_engine_config::placement)
+    int holder(int o, int p) const { return cfg.placement == COGNN_PLACE_VERTEX_SET ? rank_of(o) : rank_of(p == 0 ? o : co(o)); }
+    // the owners whose co-share rank r holds, in the order of that rank's table (and of the partial-sum segments sent to it)
+    std::vector<int> cohosted_of(int r) const {
+        std::vector<int> v;
+        for (int p = r * m; p < (r + 1) * m; ++p) v.push_back(cfg.placement == COGNN_PLACE_VERTEX_SET ? p : (p + k - 1) % k);
+        return v;
+    }
     Side* side(int owner, int p) {
         for (auto& s : sides) if (s.owner == owner && s.p == p) return &s;
         return nullptr;
@@ -1032,7 +1040,7 @@ void message_passing(cognn_engine* E, int F, int64_t it, bool open_scale) {
     if (E->world > 1) {
         XList xl;
         for (int o = 0; o < E->k; ++o) {
-            const int rc = E->rank_of(E->co(o));
+            const int rc = E->holder(o, 1);
             const int64_t bytes = (int64_t)E->G.party[o].localVertexPos.size() * F * 8;
             u64* seg = E->table + E->B_off[o] * F;
             if (rc == E->rank) {
@@ -1736,16 +1744,15 @@ void build_layout(cognn_engine* E) {
     auto nrows = [&](int p) { return (int64_t)G.party[p].localVertexPos.size(); };
     E->hosted.clear(); E->cohosted.clear();
     for (int p = 0; p < k; ++p) if (E->rank_of(p) == E->rank) E->hosted.push_back(p);
-    for (int p : E->hosted) E->cohosted.push_back((p + k - 1) % k);
+    E->cohosted = E->cohosted_of(E->rank);
     // sides in canonical (owner, p) order
     E->sides.clear();
     for (int o = 0; o < k; ++o) {
         for (int p = 0; p < 2; ++p) {
-            const int holder = p == 0 ? o : E->co(o);
-            if (E->rank_of(holder) != E->rank) continue;
+            if (E->holder(o, p) != E->rank) continue;
             Side s;
             s.owner = o; s.p = p; s.n = (int)nrows(o);
-            s.peer_rank = E->rank_of(p == 0 ? E->co(o) : o);
+            s.peer_rank = E->holder(o, 1 - p);
             E->sides.push_back(s);
         }
     }
@@ -1790,8 +1797,7 @@ void build_layout(cognn_engine* E) {
     // outbox: one segment per owner co-hosted elsewhere, grouped by destination rank in the receiver's order (its cohosted list)
     for (int dr = 0; dr < E->world; ++dr) {
         if (dr == E->rank) continue;
-        for (int P = dr * E->m; P < (dr + 1) * E->m; ++P) {
-            const int g = (P + k - 1) % k;                 // owner whose co-party P lives on rank dr
+        for (int g : E->cohosted_of(dr)) {                  // owners whose co-share lives on rank dr
             cognn_engine::Seg sg{g, 0, -1, off, E->rank, dr, seg_vids(E->rank, g)};
             sg.rows = (int64_t)sg.rows_vid.size();
             off += sg.rows;
@@ -2131,6 +2137,9 @@ int cognn_engine_create(const cognn_engine_config* cfg, int64_t V, int64_t Ecoun
         if (cfg->num_layers != 2) throw EngineError("cognn_engine_create: num_layers must be 2 (as in every reference config)");
         cognn_engine* E = new cognn_engine();
         E->cfg = *cfg;
+        if (const char* pl = getenv("COGNN_PLACEMENT"))     // for callers that keep the reference's command line (bin/gcn-optimize -c 1)
+            E->cfg.placement = (strcmp(pl, "vertex-set") == 0 || strcmp(pl, "1") == 0) ? COGNN_PLACE_VERTEX_SET : COGNN_PLACE_PARTY;
+        if (E->cfg.placement != COGNN_PLACE_PARTY && E->cfg.placement != COGNN_PLACE_VERTEX_SET) { delete E; throw EngineError("cognn_engine_create: unknown placement"); }
         E->be = cognn_default_backend();
         E->k = cfg->num_parties; E->world = cfg->world; E->rank = cfg->rank; E->m = E->k / E->world;
         if (E->be->cognn_ctx_create(cfg->device, cfg->stream, &E->ctx) != 0) {

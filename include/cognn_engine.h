@@ -41,7 +41,15 @@ typedef struct {
     int32_t undirected;      /* -u */
     int32_t verbose;         /* record per-phase HIP-event timers of every GAS iteration (cognn_engine_get_phase_seconds):
                                 the source of the reference's "::<tag> took X seconds" lines */
+    int32_t placement;       /* world > 1: which rank holds which share.  COGNN_PLACE_PARTY (0): a rank is a set of parties - it holds
+                                their own shares and the co-shares THEY hold of the previous party's vertices, as a party's machine does
+                                in the reference (engine.h:157-201); every two-party opening of an owner / co-party pair on different
+                                ranks crosses the link.  COGNN_PLACE_VERTEX_SET (1): a rank holds BOTH shares of its parties' vertex
+                                sets - the single-GPU co-located mode extended to several GPUs of one trusted node: every two-party
+                                step stays in registers (pair chains) and only Gather traffic (co-share replicas, partial sums)
+                                and the weight average cross the links.  Same results. */
 } cognn_engine_config;
+enum { COGNN_PLACE_PARTY = 0, COGNN_PLACE_VERTEX_SET = 1 };
 
 /* one logical message of an exchange round; buffers are device pointers on this rank */
 typedef struct {

@@ -30,7 +30,8 @@ def main():
     part = np.array([v % k for v in range(V)], dtype=np.int32)
     feats, labels = co.synth_features(V, cfg["in"], cfg["lab"], cfg["gseed"] + 1, density=0.2)
     gp = GnnParam(num_labels=cfg["lab"], input_dim=cfg["in"], hidden_dim=cfg["hid"], num_samples=V, learning_rate=0.5)
-    eng = Engine(k, src, dst, part, gp, seed=cfg["seed"], variant=cfg["variant"], rank=rank, world=world, stream=0)
+    placement = cfg.get("placement", "party")              # "vertex-set": a rank holds both shares of its parties' vertex sets
+    eng = Engine(k, src, dst, part, gp, seed=cfg["seed"], variant=cfg["variant"], rank=rank, world=world, stream=0, placement=placement)
     # asynchronous exchange (begin / wait) unless the case asks for the blocking callback
     mk = cdist.make_exchange if cfg.get("blocking_exchange") else cdist.make_exchange_async
     hostile_stats = None
@@ -63,7 +64,7 @@ def main():
                 out["it%d_o%d_s0" % (it, o)] = eng.shares(o, 0)
                 for l in range(2):
                     out["it%d_o%d_s0_w%d" % (it, o, l)] = eng.weight(o, 0, l)
-            if ((o + 1) % k) // m == rank:
+            if (o if placement == "vertex-set" else (o + 1) % k) // m == rank:
                 out["it%d_o%d_s1" % (it, o)] = eng.shares(o, 1)
                 for l in range(2):
                     out["it%d_o%d_s1_w%d" % (it, o, l)] = eng.weight(o, 1, l)

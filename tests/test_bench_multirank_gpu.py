@@ -13,18 +13,18 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("chunks", [1, 3])
-def test_bench_two_ranks_over_gloo(chunks):
+@pytest.mark.parametrize("chunks,placement", [(1, "vertex-set"), (3, "party"), (1, "party")])
+def test_bench_two_ranks_over_gloo(chunks, placement):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     env = dict(os.environ, COGNN_BENCH_BACKEND="gloo")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                         "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-                        "--workload", "small", "--chunks", str(chunks)], env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+                        "--workload", "small", "--chunks", str(chunks), "--placement", placement], env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-1500:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "strong" and d["higher_is_better"] is True
     assert d["value"] > 0 and d["ms_per_step"] > 0 and d["config"]["parties"] == 8 and d["config"]["exchange"] == "gloo-host-staged"
-    assert d["config"]["exchange_chunks"] == chunks
+    assert d["config"]["exchange_chunks"] == chunks and d["config"]["placement"] == placement
     assert d["cpu_baseline"] is None or isinstance(d["cpu_baseline"], dict)

@@ -114,6 +114,16 @@ def test_whole_epochs_per_call(tmp_path):
     _check(dict(BASE, k=4, iters=12, whole_epochs=True), 2, tmp_path)
 
 
+@pytest.mark.parametrize("k,world,variant,iters,extra", [(2, 2, "optimize-gcn", 6, {}), (4, 2, "optimize-gcn", 6, {}), (3, 3, "optimize-gcn", 12, {}),
+                                                          (4, 4, "optimize-gcn-inference", 2, {}), (4, 2, "optimize-gcn", 12, {"whole_epochs": True}),
+                                                          (4, 2, "optimize-gcn", 6, {"pair_fusion": False}), (6, 3, "optimize-gcn", 6, {"V": 61, "Eu": 200})])
+def test_vertex_set_placement(tmp_path, k, world, variant, iters, extra):
+    """COGNN_PLACE_VERTEX_SET: every rank holds both shares of its parties' vertex sets - all two-party steps are pair chains, only
+    the Gather's replicas / partial sums and the weight average travel - and ends in the oracle's shares and weights like the
+    party placement."""
+    _check(dict(BASE, k=k, variant=variant, iters=iters, placement="vertex-set", **extra), world, tmp_path)
+
+
 def test_single_rank_host_logic_three_parties(tmp_path):
     """world == 1 through the same worker: the engine's co-located path (in-device hand-off) on the CPU backend."""
     _check(dict(BASE, k=3, iters=12), 1, tmp_path)
@@ -130,7 +140,8 @@ def test_original_gcn_single_process(tmp_path, k, extra):
 
 @pytest.mark.parametrize("seed", [1, 2])
 @pytest.mark.parametrize("k,world,variant,iters,extra", [(4, 2, "optimize-gcn", 6, {}), (4, 4, "optimize-gcn", 6, {}), (4, 4, "optimize-gcn-inference", 2, {}),
-                                                        (4, 2, "optimize-gcn", 6, {"exchanged_openings": True}), (6, 2, "optimize-gcn", 12, {"whole_epochs": True})])
+                                                        (4, 2, "optimize-gcn", 6, {"exchanged_openings": True}), (6, 2, "optimize-gcn", 12, {"whole_epochs": True}),
+                                                        (4, 4, "optimize-gcn", 6, {"placement": "vertex-set"}), (6, 2, "optimize-gcn", 12, {"placement": "vertex-set", "whole_epochs": True})])
 def test_hostile_transport(tmp_path, seed, k, world, variant, iters, extra):
     """Late reads of the outboxes, poisoned inboxes until wait(), rounds and messages completed in shuffled order
     (tests/hostile_transport.py): every exchange_wait the engine owes - before it overwrites a buffer it handed to a round,
@@ -141,7 +152,8 @@ def test_hostile_transport(tmp_path, seed, k, world, variant, iters, extra):
 @pytest.mark.parametrize("chunks,k,world,variant,iters,extra", [
     (2, 4, 2, "optimize-gcn", 6, {}), (3, 4, 4, "optimize-gcn", 6, {}), (4, 4, 4, "optimize-gcn-inference", 2, {}),
     (3, 4, 2, "optimize-gcn", 6, {"exchanged_openings": True}), (2, 4, 2, "optimize-gcn", 6, {"pair_fusion": 0}),
-    (8, 3, 3, "optimize-gcn", 6, {}), (2, 4, 2, "optimize-gcn", 6, {"per_round": False}), (3, 4, 2, "optimize-gcn", 6, {"blocking_exchange": True})])
+    (8, 3, 3, "optimize-gcn", 6, {}), (2, 4, 2, "optimize-gcn", 6, {"per_round": False}), (3, 4, 2, "optimize-gcn", 6, {"blocking_exchange": True}),
+    (3, 4, 2, "optimize-gcn", 6, {"placement": "vertex-set"})])
 def test_chunked_exchange_pipeline(tmp_path, chunks, k, world, variant, iters, extra):
     """COGNN_OPT_EXCHANGE_CHUNKS: the open -> exchange -> close steps of the cross-rank sides in row chunks (chunk c's round in
     flight behind chunk c+1's kernels, closes waiting round by round) give the oracle's shares bit for bit - over gloo with the

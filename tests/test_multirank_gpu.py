@@ -45,6 +45,18 @@ def test_four_parties_four_ranks_training_hip(tmp_path):
     _check(cfg, 4, tmp_path)
 
 
+@pytest.mark.parametrize("k,world,variant,iters,shape", [(4, 2, "optimize-gcn", 12, dict(V=2048, Eu=8192, hid=64, lab=16, inn=128)),
+                                                          (8, 4, "optimize-gcn-inference", 2, dict(V=4096, Eu=16384, hid=16, lab=8, inn=32)),
+                                                          (3, 3, "optimize-gcn", 6, dict(V=600, Eu=2000, hid=16, lab=7, inn=33))])
+def test_vertex_set_placement_hip(tmp_path, k, world, variant, iters, shape):
+    """COGNN_PLACE_VERTEX_SET with the HIP kernels: both shares of a vertex set on one rank (pair chains for every two-party step),
+    replicas and partial sums across ranks - kernel-relevant widths, one and two training epochs."""
+    cfg = dict(BASE, k=k, V=shape["V"], Eu=shape["Eu"], hid=shape["hid"], lab=shape["lab"], variant=variant, iters=iters, backend="hip",
+               placement="vertex-set")
+    cfg["in"] = shape["inn"]
+    _check(cfg, world, tmp_path)
+
+
 @pytest.mark.parametrize("k,extra", [(2, {}), (3, {"pair_fusion": 0}), (4, {"V": 700, "Eu": 2500, "in": 33, "hid": 16, "lab": 7}),
                                      (2, {"V": 2708, "Eu": 5278, "in": 300, "hid": 16, "lab": 7}), (3, {"V": 9, "Eu": 5})])
 def test_original_gcn_single_process_hip(tmp_path, k, extra):

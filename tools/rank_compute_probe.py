@@ -31,7 +31,7 @@ sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import numpy as np  # noqa: E402
 
 
-def probe(world, rank, workload, steps, chunks, graph=None):
+def probe(world, rank, workload, steps, chunks, graph=None, placement="party"):
     import torch
     import bench
     from cognn_amd.engine import Engine, GnnParam
@@ -41,7 +41,7 @@ def probe(world, rank, workload, steps, chunks, graph=None):
     src, dst = graph if graph is not None else bench.synth_graph(V, Eu, 0xC06A11)
     part = (np.arange(V) % k).astype(np.int32)
     gp = GnnParam(num_labels=lab, input_dim=in_dim, hidden_dim=hid, num_samples=V, num_edges=len(src))
-    eng = Engine(k, src, dst, part, gp, seed=0xC06A11, variant=variant, rank=rank, world=world, device=0)
+    eng = Engine(k, src, dst, part, gp, seed=0xC06A11, variant=variant, rank=rank, world=world, device=0, placement=placement)
     sent = {}
     rounds = [0]
 
@@ -93,11 +93,13 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--chunks", type=int, default=1)
     ap.add_argument("--table", action="store_true")
+    ap.add_argument("--placement", default="party", choices=["party", "vertex-set"], help="which rank holds which share (cognn_engine_config::placement)")
     ap.add_argument("--link-gbs", type=float, default=77.0, help="xGMI rate per link and direction assumed by the model")
     ap.add_argument("--round-us", type=float, default=20.0, help="fixed cost per exchange round assumed by the model")
     a = ap.parse_args()
     if not a.table:
-        r = probe(a.world, a.rank, a.workload, a.steps, a.chunks)
+        r = probe(a.world, a.rank, a.workload, a.steps, a.chunks, placement=a.placement)
+        print("placement %s: " % a.placement, end="")
         print("rank %d of %d, %s, chunks %d: %.3f ms of kernels per pass (null transport; %.3f ms of it aggregate + partial sums + products), "
               "%d rounds, %.1f MB sent per pass, %.1f MB to the busiest peer"
               % (a.rank, a.world, a.workload, a.chunks, r["kernels_ms"], r["heavy_ms"], r["rounds"], r["sent_mb"], r["busiest_mb"]))
@@ -107,9 +109,9 @@ def main():
     print("| world | kernels ms (C=1 / C=%d) | gather+gemm ms | rounds (C=1 / C=%d) | busiest link MB | t_link ms (C=1 / C=%d) | MODEL pass ms unchunked | MODEL pass ms chunked |" % (C, C, C))
     print("|---|---|---|---|---|---|---|---|")
     for world in (2, 4, 8):
-        r1 = probe(world, 0, a.workload, a.steps, 1, graph)
+        r1 = probe(world, 0, a.workload, a.steps, 1, graph, a.placement)
         graph = r1["graph"]
-        rc = probe(world, 0, a.workload, a.steps, C, graph)
+        rc = probe(world, 0, a.workload, a.steps, C, graph, a.placement)
         link = lambda r: r["busiest_mb"] * 1e6 / (a.link_gbs * 1e9) * 1e3 + r["rounds"] * a.round_us * 1e-3
         t1, tc = link(r1), link(rc)
         ew_c = max(rc["kernels_ms"] - rc["heavy_ms"], 0.0)
@@ -117,8 +119,8 @@ def main():
         chunked = rc["kernels_ms"] + tc - min(ew_c, tc) * (1.0 - 1.0 / C)
         print("| %d | %.2f / %.2f | %.2f | %d / %d | %.0f | %.2f / %.2f | %.2f | %.2f |"
               % (world, r1["kernels_ms"], rc["kernels_ms"], r1["heavy_ms"], r1["rounds"], rc["rounds"], r1["busiest_mb"], t1, tc, unchunked, chunked))
-    print("(model: %.0f GB/s per link and direction, %.0f us per round; kernels measured on one MI355X with a transport that moves nothing)"
-          % (a.link_gbs, a.round_us))
+    print("(placement %s; model: %.0f GB/s per link and direction, %.0f us per round; kernels measured on one MI355X with a transport that moves nothing)"
+          % (a.placement, a.link_gbs, a.round_us))
 
 
 if __name__ == "__main__":
