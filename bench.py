@@ -188,6 +188,50 @@ def cross_path_check(eng, Engine, k, src, dst, part, param, variant, iters, in_d
     return res
 
 
+def multi_rank_check(eng, Engine, dist, rank, world, placement, k, src, dst, part, param, variant, iters, in_dim, lab, passes, device):
+    """After the timed region (N > 1): every rank hashes the shares and weight shares it holds; rank 0 runs the same job as ONE process
+    on its GPU (all parties, one call per GAS iteration, as many passes as the bench ran for a training workload) and compares share by
+    share: the N-rank run (placement, transport, overlap) must end in exactly the single-process bits."""
+    import hashlib
+    m = k // world
+
+    def holder(o, sd):
+        return (o if (placement == "vertex-set" or sd == 0) else (o + 1) % k) // m
+
+    def digest(e, o, sd):
+        h = hashlib.sha256()
+        h.update(np.ascontiguousarray(e.shares(o, sd)).tobytes())
+        for layer in (0, 1):
+            h.update(np.ascontiguousarray(e.weight(o, sd, layer)).tobytes())
+        return h.hexdigest()
+    t0 = time.perf_counter()
+    local = {"%d/%d" % (o, sd): digest(eng, o, sd) for o in range(k) for sd in (0, 1) if holder(o, sd) == rank}
+    gathered = [None] * world
+    dist.all_gather_object(gathered, local)
+    res = None
+    if rank == 0:
+        got = {}
+        for g in gathered:
+            got.update(g)
+        ref = Engine(k, src, dst, part, param, seed=0xC06A11, variant=variant, device=device)
+        for P in ref.hosted:
+            vids = ref.party_vids(P)
+            rng = np.random.default_rng(0xC06A12 + P)
+            ref.set_party_data(P, (rng.random((len(vids), in_dim)) < 0.01).astype(np.float64), rng.integers(0, lab, size=len(vids)))
+        ref.start()
+        for _ in range(passes if "inference" not in variant else 1):
+            for it in range(iters):
+                ref.run(it, it + 1)
+        bad = [key for key in sorted(got) if got[key] != digest(ref, int(key.split("/")[0]), int(key.split("/")[1]))]
+        ref.close()
+        res = {"what": "sha256 of every (party, share) tensor and its weight shares as the %d ranks hold them after the bench's sequence vs a "
+                       "single-process engine on rank 0's GPU running the plain sequence, one call per GAS iteration" % world,
+               "cross_path_identical": len(got) == 2 * k and not bad, "shares_compared": len(got), "mismatches": bad[:8],
+               "seconds": time.perf_counter() - t0}
+    dist.barrier()
+    return res
+
+
 def dealer_streams_leg(eng, torch, args, iters, k, digest_before):
     """The same pass with the dealer values of the co-located pairs' chains and the A masks of the grouped products READ from
     HBM (COGNN_OPT_DEALER_STREAMS) instead of regenerated in registers: what the online phase costs when the offline phase hands
@@ -418,6 +462,13 @@ def main():
             out["check"] = cross_path_check(eng, Engine, k, src, dst, part, param, variant, iters, in_dim, lab, n_warm + args.steps)
         except Exception as ex:  # noqa: BLE001 - e.g. a second engine of an 8x workload does not fit beside the first: the measurement stands
             out["check"] = {"skipped": "the verification engine could not run: %s" % (str(ex)[-200:],)}
+    if not args.no_check and world > 1:
+        try:
+            chk = multi_rank_check(eng, Engine, dist, rank, world, args.placement, k, src, dst, part, param, variant, iters, in_dim, lab,
+                                   n_warm + args.steps, local_rank)
+        except Exception as ex:  # noqa: BLE001 - the measurement stands
+            chk = {"skipped": "the verification could not run: %s" % (str(ex)[-200:],)}
+        out["check"] = chk
     if world == 1 and not args.no_dealer_streams and not recorded:
         try:
             out["dealer_streams"] = dealer_streams_leg(eng, torch, args, iters, k, out.get("check", {}).get("digest"))

@@ -28,3 +28,5 @@ def test_bench_two_ranks_over_gloo(chunks, placement):
     assert d["value"] > 0 and d["ms_per_step"] > 0 and d["config"]["parties"] == 8 and d["config"]["exchange"] == "gloo-host-staged"
     assert d["config"]["exchange_chunks"] == chunks and d["config"]["placement"] == placement
     assert d["cpu_baseline"] is None or isinstance(d["cpu_baseline"], dict)
+    # the N-rank run ends in the single-process bits (rank 0 re-runs the job as one process and compares every rank's share digests)
+    assert d["check"]["cross_path_identical"] is True and d["check"]["shares_compared"] == 16, d["check"]
