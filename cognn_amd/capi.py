@@ -154,6 +154,7 @@ _SIGNATURES = {
     "cognn_scatter_gather_original_u64": (_I, [_P, _P, _P, _P, _P, _P, _P, _KP, _KP, _L, _L, _P, _P, _P, _P, ctypes.POINTER(ScatterPair), ctypes.c_int32]),
     "cognn_gather_pair_chain_u64": (_I, [_P, _P, _P, _P, _L, ctypes.POINTER(GatherPair), ctypes.c_int32]),
     "cognn_gather_pair_chain_takes_softmax": (_I, [_L]),
+    "cognn_gather_pair_chain_base_u64": (_I, [_P, _P, _P, _P, _P, _L, ctypes.POINTER(GatherPair), ctypes.c_int32]),
     "cognn_graph_build_colocated": (_I, [_P, _L, _L, ctypes.c_int32] + [_P] * 6 + [_L] + [_P] * 8),
     "cognn_transpose_u64": (_I, [_P, _P, _P, _L, _L]),
     "cognn_timer_begin": (_I, [_P, _I]),

@@ -171,7 +171,7 @@ __global__ void gather_softmax_zero_kernel(GatherSoftmaxBatch q, int count) {
 // W: u64 per lane and step - 2 (16-byte accesses) for an even width, 1 for an odd one (7 or 3 labels)
 // SMX: the prediction layer follows as a second epilogue (LPR lanes hold a row of F <= LPR * W logits: row reductions by shuffles)
 template <int LPR, int W, bool STREAM, bool SMX = false>
-__device__ __forceinline__ void gather_pair_chain_body(const u64* __restrict__ table, const uint32_t* __restrict__ rowptr,
+__device__ __forceinline__ void gather_pair_chain_body(const u64* __restrict__ table, const u64* __restrict__ base, const uint32_t* __restrict__ rowptr,
                                                        const uint32_t* __restrict__ col, int F, int ntiles, const GatherPairBatch& b,
                                                        uint32_t (&s_rp)[2][kPairTile + 1], uint32_t (&s_col)[2][kPairColCap],
                                                        const GatherSoftmaxBatch* sm = nullptr, unsigned long long* s_cnt = nullptr,
@@ -214,7 +214,7 @@ __device__ __forceinline__ void gather_pair_chain_body(const u64* __restrict__ t
                 for (int sd = 0; sd < 2; ++sd) {
                     const uint32_t e0 = s_rp[sd][0], bq = s_rp[sd][lr], eq = s_rp[sd][lr + 1];
                     Chunk<W> acc;
-                    acc.load(table + (size_t)(rbase[sd] + lr) * F + off);                 // the self row
+                    acc.load((base ? base : table) + (size_t)(rbase[sd] + lr) * F + off);   // the self row (or the sums a first launch left)
                     uint32_t q = bq;
                     if (staged[sd]) {
                         for (; q + 4 <= eq; q += 4) {
@@ -325,21 +325,22 @@ __device__ __forceinline__ void gather_pair_chain_body(const u64* __restrict__ t
 }
 
 template <int LPR, bool STREAM, int W = 2>   // STREAM: every pair brings the dealt slab of its chain (pair_chain.h)
-__global__ __launch_bounds__(kThreads) void gather_pair_chain_kernel(const u64* __restrict__ table, const uint32_t* __restrict__ rowptr,
-                                                                      const uint32_t* __restrict__ col, int F, int ntiles, GatherPairBatch b) {
+__global__ __launch_bounds__(kThreads) void gather_pair_chain_kernel(const u64* __restrict__ table, const u64* __restrict__ base,
+                                                                      const uint32_t* __restrict__ rowptr, const uint32_t* __restrict__ col, int F,
+                                                                      int ntiles, GatherPairBatch b) {
     __shared__ uint32_t s_rp[2][kPairTile + 1];
     __shared__ uint32_t s_col[2][kPairColCap];
-    gather_pair_chain_body<LPR, W, STREAM>(table, rowptr, col, F, ntiles, b, s_rp, s_col);
+    gather_pair_chain_body<LPR, W, STREAM>(table, base, rowptr, col, F, ntiles, b, s_rp, s_col);
 }
 template <int LPR, int W>
-__global__ __launch_bounds__(kThreads) void gather_pair_softmax_kernel(const u64* __restrict__ table, const uint32_t* __restrict__ rowptr,
-                                                                        const uint32_t* __restrict__ col, int F, int ntiles, GatherPairBatch b,
-                                                                        GatherSoftmaxBatch sm) {
+__global__ __launch_bounds__(kThreads) void gather_pair_softmax_kernel(const u64* __restrict__ table, const u64* __restrict__ base,
+                                                                        const uint32_t* __restrict__ rowptr, const uint32_t* __restrict__ col, int F,
+                                                                        int ntiles, GatherPairBatch b, GatherSoftmaxBatch sm) {
     __shared__ uint32_t s_rp[2][kPairTile + 1];
     __shared__ uint32_t s_col[2][kPairColCap];
     __shared__ unsigned long long s_cnt[5];
     __shared__ double s_loss;
-    gather_pair_chain_body<LPR, W, false, true>(table, rowptr, col, F, ntiles, b, s_rp, s_col, &sm, s_cnt, &s_loss);
+    gather_pair_chain_body<LPR, W, false, true>(table, base, rowptr, col, F, ntiles, b, s_rp, s_col, &sm, s_cnt, &s_loss);
 }
 // Grid of the gather kernels: one workgroup per tile up to this cap (the kernels keep their grid-stride loop).  Measured on
 // MI355X (config5, fused F = 64 launch): persistent grids lose to the hardware dispatcher - 1792 workgroups (one per slot)
@@ -491,7 +492,12 @@ int cognn_gather_pair_chain_takes_softmax(int64_t F) {      // the widths cognn_
 }
 int cognn_gather_pair_chain_u64(cognn_ctx* ctx, const uint64_t* table, const uint32_t* rowptr, const uint32_t* col, int64_t F,
                                 const cognn_gather_pair* pairs, int32_t count) {
+    return cognn_gather_pair_chain_base_u64(ctx, table, nullptr, rowptr, col, F, pairs, count);
+}
+int cognn_gather_pair_chain_base_u64(cognn_ctx* ctx, const uint64_t* table, const uint64_t* base, const uint32_t* rowptr, const uint32_t* col, int64_t F,
+                                     const cognn_gather_pair* pairs, int32_t count) {
     { const int rc_flush_ = cg_flush(ctx); if (rc_flush_) return rc_flush_; }
+    CG_REQUIRE(!base || cg_aligned16(base), "cognn_gather_pair_chain_base_u64: misaligned base");
     CG_REQUIRE(ctx && table && rowptr && (count == 0 || pairs) && count >= 0 && count <= kGatherPairsMax, "cognn_gather_pair_chain_u64: bad arguments");
     CG_REQUIRE(F > 0 && F < (1 << 20) && cg_aligned16(table), "cognn_gather_pair_chain_u64: bad width or misaligned table");
     const bool odd = (F & 1) != 0;                           // 8-byte lanes: the row stride is not a multiple of 16 bytes
@@ -549,8 +555,8 @@ int cognn_gather_pair_chain_u64(cognn_ctx* ctx, const uint64_t* table, const uin
         CG_LAUNCH_CHECK();
 #define CG_GS_CASE(L)                                                                                                                              \
     case L:                                                                                                                                        \
-        if (odd) hipLaunchKernelGGL((gather_pair_softmax_kernel<L, 1>), grid, block, 0, ctx->stream, (const u64*)table, rowptr, col, (int)F, ntiles, b, sm); \
-        else hipLaunchKernelGGL((gather_pair_softmax_kernel<L, 2>), grid, block, 0, ctx->stream, (const u64*)table, rowptr, col, (int)F, ntiles, b, sm);    \
+        if (odd) hipLaunchKernelGGL((gather_pair_softmax_kernel<L, 1>), grid, block, 0, ctx->stream, (const u64*)table, (const u64*)base, rowptr, col, (int)F, ntiles, b, sm); \
+        else hipLaunchKernelGGL((gather_pair_softmax_kernel<L, 2>), grid, block, 0, ctx->stream, (const u64*)table, (const u64*)base, rowptr, col, (int)F, ntiles, b, sm);    \
         break;
         switch (lpr) {
             CG_GS_CASE(1) CG_GS_CASE(2) CG_GS_CASE(4) CG_GS_CASE(8) CG_GS_CASE(16) CG_GS_CASE(32)
@@ -562,10 +568,10 @@ int cognn_gather_pair_chain_u64(cognn_ctx* ctx, const uint64_t* table, const uin
     }
 #define CG_GP_CASE(L)                                                                                                                              \
     case L:                                                                                                                                        \
-        if (odd && nstream) hipLaunchKernelGGL((gather_pair_chain_kernel<L, true, 1>), grid, block, 0, ctx->stream, (const u64*)table, rowptr, col, (int)F, ntiles, b); \
-        else if (odd) hipLaunchKernelGGL((gather_pair_chain_kernel<L, false, 1>), grid, block, 0, ctx->stream, (const u64*)table, rowptr, col, (int)F, ntiles, b);    \
-        else if (nstream) hipLaunchKernelGGL((gather_pair_chain_kernel<L, true>), grid, block, 0, ctx->stream, (const u64*)table, rowptr, col, (int)F, ntiles, b); \
-        else hipLaunchKernelGGL((gather_pair_chain_kernel<L, false>), grid, block, 0, ctx->stream, (const u64*)table, rowptr, col, (int)F, ntiles, b);        \
+        if (odd && nstream) hipLaunchKernelGGL((gather_pair_chain_kernel<L, true, 1>), grid, block, 0, ctx->stream, (const u64*)table, (const u64*)base, rowptr, col, (int)F, ntiles, b); \
+        else if (odd) hipLaunchKernelGGL((gather_pair_chain_kernel<L, false, 1>), grid, block, 0, ctx->stream, (const u64*)table, (const u64*)base, rowptr, col, (int)F, ntiles, b);    \
+        else if (nstream) hipLaunchKernelGGL((gather_pair_chain_kernel<L, true>), grid, block, 0, ctx->stream, (const u64*)table, (const u64*)base, rowptr, col, (int)F, ntiles, b); \
+        else hipLaunchKernelGGL((gather_pair_chain_kernel<L, false>), grid, block, 0, ctx->stream, (const u64*)table, (const u64*)base, rowptr, col, (int)F, ntiles, b);        \
         break;
     switch (lpr) {
         CG_GP_CASE(1) CG_GP_CASE(2) CG_GP_CASE(4) CG_GP_CASE(8) CG_GP_CASE(16) CG_GP_CASE(32) CG_GP_CASE(64)

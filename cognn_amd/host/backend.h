@@ -14,7 +14,7 @@
     X(cognn_mask_open_u64) X(cognn_add_u64) X(cognn_sub_u64) X(cognn_sum_u64) X(cognn_fanout_u64) X(cognn_dealer_gemm_c1_u64) X(cognn_beaver_gemm_close_u64) \
     X(cognn_trunc_open_u64) X(cognn_trunc_close_pub_dealt_u64) X(cognn_dealer_trunc_pub_u64) X(cognn_trunc_open_add_u64) X(cognn_beaver_gemm_fusable) X(cognn_beaver_gemm_group_takes_epilogue) X(cognn_beaver_gemm_group_is_whole_k) X(cognn_beaver_gemm_close_raw_u64) X(cognn_beaver_gemm_close2_u64) X(cognn_beaver_gemm_close_group_u64) X(cognn_beaver_gemm_tn_groupable) X(cognn_beaver_gemm_close_group_tn_u64) X(cognn_gemm_presplit_bytes) X(cognn_gemm_presplit_u64) X(cognn_gemm_presplit_tn_bytes) X(cognn_gemm_presplit_tn_u64) X(cognn_trunc_close_u64) X(cognn_trunc_close_open_u64) X(cognn_trunc_close_pub_u64) X(cognn_rowscale_open_u64) X(cognn_rowscale_close_u64)         \
     X(cognn_relu_open_u64) X(cognn_relu_mul_u64) X(cognn_relu_close_u64) X(cognn_mask_select_u64) X(cognn_softmax_u64) \
-    X(cognn_metrics_q16) X(cognn_softmax_jobs_u64) X(cognn_pair_chain_u64) X(cognn_pair_weight_update_u64) X(cognn_pair_chain_dealt_slots) X(cognn_pair_chain_deal_u64) X(cognn_gather_pair_chain_u64) X(cognn_gather_pair_chain_takes_softmax) X(cognn_scatter_gather_original_u64) X(cognn_graph_build_colocated) X(cognn_transpose_u64) X(cognn_timer_begin) X(cognn_timer_end) X(cognn_timer_read)         \
+    X(cognn_metrics_q16) X(cognn_softmax_jobs_u64) X(cognn_pair_chain_u64) X(cognn_pair_weight_update_u64) X(cognn_pair_chain_dealt_slots) X(cognn_pair_chain_deal_u64) X(cognn_gather_pair_chain_u64) X(cognn_gather_pair_chain_takes_softmax) X(cognn_gather_pair_chain_base_u64) X(cognn_scatter_gather_original_u64) X(cognn_graph_build_colocated) X(cognn_transpose_u64) X(cognn_timer_begin) X(cognn_timer_end) X(cognn_timer_read)         \
     X(cognn_timer_reset) X(cognn_last_error)
 
 struct cognn_backend {

@@ -1035,14 +1035,15 @@ u64* table_seg(cognn_engine* E, Side& s, int F) {
     return E->table + off * F;
 }
 
-void message_passing(cognn_engine* E, int F, int64_t it, bool open_scale) {
+// the cross-rank part of a message-passing round on the share table T: both rounds are enqueued and left in flight
+void mp_exchange(cognn_engine* E, int F, u64* T) {
     // replicate the co-party's fresh share of every owner to the other ranks (ss_...h:997-1002 / :982)
     if (E->world > 1) {
         XList xl;
         for (int o = 0; o < E->k; ++o) {
             const int rc = E->holder(o, 1);
             const int64_t bytes = (int64_t)E->G.party[o].localVertexPos.size() * F * 8;
-            u64* seg = E->table + E->B_off[o] * F;
+            u64* seg = T + E->B_off[o] * F;
             if (rc == E->rank) {
                 for (int r = 0; r < E->world; ++r) {
                     if (r == E->rank) continue;
@@ -1058,7 +1059,7 @@ void message_passing(cognn_engine* E, int F, int64_t it, bool open_scale) {
     // partial sums of every hosted party for its remote destinations (ss_...h:827-835, 1063-1067)
     if (E->partRows > 0) {
         if (E->timing) BE(cognn_timer_begin(E->ctx, T_PART));
-        BE(cognn_gather_csr_u64(E->ctx, E->table + E->inboxLocalOff * F, nullptr, E->table, E->part_rowptr, E->part_col, E->partRows, F));
+        BE(cognn_gather_csr_u64(E->ctx, T + E->inboxLocalOff * F, nullptr, T, E->part_rowptr, E->part_col, E->partRows, F));
         if (E->timing) {
             BE(cognn_timer_end(E->ctx, T_PART));
             E->algo[T_PART] += 8.0 * F * ((double)E->partEdges + E->partRows) + 4.0 * E->partEdges + 4.0 * (E->partRows + 1);
@@ -1067,11 +1068,15 @@ void message_passing(cognn_engine* E, int F, int64_t it, bool open_scale) {
     if (E->world > 1) {
         XList xl;
         for (auto& sg : E->segs) {
-            if (sg.src_rank == E->rank && sg.dst_rank != E->rank) xl.send(sg.dst_rank, E->table + sg.out_off * F, sg.rows * F * 8);
-            if (sg.dst_rank == E->rank && sg.src_rank != E->rank) xl.recv(sg.src_rank, E->table + sg.inbox_off * F, sg.rows * F * 8);
+            if (sg.src_rank == E->rank && sg.dst_rank != E->rank) xl.send(sg.dst_rank, T + sg.out_off * F, sg.rows * F * 8);
+            if (sg.dst_rank == E->rank && sg.src_rank != E->rank) xl.recv(sg.src_rank, T + sg.inbox_off * F, sg.rows * F * 8);
         }
         run_exchange(E, xl, true);                          // the replication round may still be in flight: both travel while the
     }                                                       // local part of the aggregate runs
+}
+
+void message_passing(cognn_engine* E, int F, int64_t it, bool open_scale) {
+    mp_exchange(E, F, E->table);
     // aggregate: out = self + local in-edges + replica in-edges (owner rows) / + received partials (co rows).  With several
     // ranks it is split: the entries that read rows held on this rank run now, beside the two exchange rounds; the entries
     // that read received rows (co-share replicas, partial-sum inbox) are added in place once the messages have arrived.
@@ -1112,7 +1117,9 @@ void message_passing(cognn_engine* E, int F, int64_t it, bool open_scale) {
 // epilogue (cognn_gather_pair_chain_u64): the lanes that aggregate vertex r's owner-side row also aggregate its co-party-side
 // row and run the pair chain on the two sums in registers, so the aggregate itself is never written or re-read.
 bool can_fuse_gather_chain(const cognn_engine* E, int F) {
-    if (E->world != 1 || !E->pair_fusion || E->k > 8) return false;
+    // (several ranks: the vertex-set placement - the local part of the aggregate runs while the messages travel, the launch over the
+    // received rows carries the epilogue)
+    if (!E->pair_fusion || E->hosted.size() > 8) return false;
     for (auto& s : E->sides) if (!s.peer) return false;
     return true;
 }
@@ -1178,12 +1185,27 @@ void message_passing_fused(cognn_engine* E, int F, int64_t it, bool scale, bool 
         gp.push_back(g);
     }
     if (streams_on(E)) { bool all = true; for (auto& g : gp) all = all && g.chain.dealt; if (!all) for (auto& g : gp) g.chain.dealt = nullptr; }
+    if (E->world > 1) {
+        // several ranks: both exchange rounds travel while the entries that read rows held here are aggregated (plain launch into aggOut);
+        // the launch over the received rows (co-share replicas, partial-sum inbox) then starts from those sums and carries the epilogue
+        mp_exchange(E, F, const_cast<u64*>(table));
+        if (E->timing) BE(cognn_timer_begin(E->ctx, T_AGG));
+        BE(cognn_gather_csr_u64(E->ctx, E->aggOut, table, table, E->agg_rowptr, E->agg_col, E->aggRows, F));
+        if (E->timing) {
+            BE(cognn_timer_end(E->ctx, T_AGG));
+            E->algo[T_AGG] += 8.0 * F * ((double)E->aggEdges + 2.0 * E->aggRows) + 4.0 * E->aggEdges + 4.0 * (E->aggRows + 1);
+        }
+        exchange_wait(E);
+    }
+    const bool split = E->world > 1;
+    const double edges = split ? (double)E->remEdges : (double)E->aggEdges;
     if (E->timing) BE(cognn_timer_begin(E->ctx, T_AGG));
-    BE(cognn_gather_pair_chain_u64(E->ctx, table, E->agg_rowptr, E->agg_col, F, gp.data(), (int32_t)gp.size()));
+    BE(cognn_gather_pair_chain_base_u64(E->ctx, table, split ? E->aggOut : nullptr, split ? E->rem_rowptr : E->agg_rowptr, split ? E->rem_col : E->agg_col, F,
+                                        gp.data(), (int32_t)gp.size()));
     if (E->timing) {
         BE(cognn_timer_end(E->ctx, T_AGG));
         // source row per entry, base row per output row, u32 col / rowptr + what the epilogue writes
-        E->algo[T_AGG] += 8.0 * F * ((double)E->aggEdges + (double)E->aggRows) + 4.0 * E->aggEdges + 4.0 * (E->aggRows + 1) + out_bytes;
+        E->algo[T_AGG] += 8.0 * F * (edges + (double)E->aggRows) + 4.0 * edges + 4.0 * (E->aggRows + 1) + out_bytes;
     }
     for (auto& s : E->sides) {
         s.cur = relu_follows ? s.h1 : softmax_follows ? s.buf[0] : s.buf[1];

@@ -394,6 +394,12 @@ typedef struct {
     const cognn_softmax_job* softmax[2];
 } cognn_gather_pair;
 int cognn_gather_pair_chain_takes_softmax(int64_t F);
+/* The same with the rows' starting values taken from `base` (same row numbering as `table`) instead of the rows of `table`
+ * themselves: base = the sums a first launch (cognn_gather_csr_u64 over the entries that read rows held by this rank) left, rowptr /
+ * col = the entries that read rows received from other ranks - a multi-rank run aggregates the local part while the messages
+ * travel and lets the launch over the received part carry the epilogue.  base == NULL: cognn_gather_pair_chain_u64. */
+int cognn_gather_pair_chain_base_u64(cognn_ctx*, const uint64_t* table, const uint64_t* base, const uint32_t* rowptr, const uint32_t* col,
+                                     int64_t F, const cognn_gather_pair* pairs, int32_t count);
 int cognn_gather_pair_chain_u64(cognn_ctx*, const uint64_t* table, const uint32_t* rowptr, const uint32_t* col, int64_t F,
                                 const cognn_gather_pair* pairs, int32_t count);
 

@@ -662,6 +662,10 @@ int cognn_scatter_gather_original_u64(cognn_ctx*, uint64_t* outA, uint64_t* outB
 }
 int cognn_gather_pair_chain_u64(cognn_ctx* ctx, const uint64_t* table, const uint32_t* rowptr, const uint32_t* col, int64_t F,
                                 const cognn_gather_pair* pairs, int32_t count) {
+    return cognn_gather_pair_chain_base_u64(ctx, table, nullptr, rowptr, col, F, pairs, count);
+}
+int cognn_gather_pair_chain_base_u64(cognn_ctx* ctx, const uint64_t* table, const uint64_t* base, const uint32_t* rowptr, const uint32_t* col, int64_t F,
+                                     const cognn_gather_pair* pairs, int32_t count) {
     for (int32_t c = 0; c < count; ++c) {
         const cognn_gather_pair& p = pairs[c];
         const int64_t rows = p.chain.rows;
@@ -671,7 +675,7 @@ int cognn_gather_pair_chain_u64(cognn_ctx* ctx, const uint64_t* table, const uin
         for (int sd = 0; sd < 2; ++sd) {
             v[sd].resize((size_t)(rows * F));
             // rowptr is indexed by table row: shift it so that row 0 of the temporary is the segment's first row
-            if (int rc = cognn_gather_csr_u64(ctx, v[sd].data(), table + r0[sd] * F, table, rowptr + r0[sd], col, rows, F)) return rc;
+            if (int rc = cognn_gather_csr_u64(ctx, v[sd].data(), (base ? base : table) + r0[sd] * F, table, rowptr + r0[sd], col, rows, F)) return rc;
         }
         cognn_pair_chain ch = p.chain;
         ch.x[0] = v[0].data(); ch.x[1] = v[1].data(); ch.F = F;
