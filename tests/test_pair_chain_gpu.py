@@ -355,6 +355,70 @@ def test_gather_with_the_prediction_layer_as_second_epilogue(ctx, F, scale, writ
         ctx.call("cognn_gather_pair_chain_u64", ptr(dtab), ptr(drp), ptr(dcl), F, pairs, len(sizes))
 
 
+@pytest.mark.parametrize("F,flags,softmax", [(64, SCALE | RELU, False), (16, SCALE, True), (7, SCALE, True), (16, 0, False)])
+def test_gather_pair_chain_from_a_base_equals_the_one_launch_form(ctx, F, flags, softmax):
+    """cognn_gather_pair_chain_base_u64: the rows' entries split over two launches (a plain cognn_gather_csr_u64 over the first part
+    leaves the sums, the launch over the rest starts from them and carries the epilogue - what a multi-rank run does with the
+    entries that read received rows) gives exactly what one launch over all entries gives: outputs, opening, prediction layer."""
+    from cognn_amd import capi
+    rng = np.random.default_rng(77 + F + flags)
+    sizes = [70, 33]
+    offs, off = [], 0
+    for n in sizes:
+        a = off; off = (off + n + 1) & ~1
+        b = off; off = (off + n + 1) & ~1
+        offs.append((a, b))
+    T = off
+    deg = rng.poisson(6, size=T); deg[rng.random(T) < 0.2] = 0
+    rowptr = np.zeros(T + 1, dtype=np.uint32); rowptr[1:] = np.cumsum(deg)
+    col = rng.integers(0, T, size=int(rowptr[-1]), dtype=np.uint32)
+    cut = np.array([rng.integers(0, d + 1) for d in deg])            # entries [0, cut) of a row are "local", the rest "received"
+    rp1 = np.zeros(T + 1, dtype=np.uint32); rp1[1:] = np.cumsum(cut)
+    rp2 = np.zeros(T + 1, dtype=np.uint32); rp2[1:] = np.cumsum(deg - cut)
+    c1 = np.concatenate([col[rowptr[r]:rowptr[r] + cut[r]] for r in range(T)] + [np.zeros(0, np.uint32)]).astype(np.uint32)
+    c2 = np.concatenate([col[rowptr[r] + cut[r]:rowptr[r + 1]] for r in range(T)] + [np.zeros(0, np.uint32)]).astype(np.uint32)
+    val = rng.integers(-(1 << 17), 1 << 17, size=(T, F)).astype(np.int64).astype(U64)
+    dtab = dev(val)
+    results = []
+    for split in (False, True):
+        pairs = (capi.GatherPair * len(sizes))()
+        jobs = (capi.SoftmaxJob * (2 * len(sizes)))()
+        outs = []
+        for i, (n, (a, b)) in enumerate(zip(sizes, offs)):
+            ks = {nm: _keys(9, i, 4, op) for nm, op in (("scale", co.OP_GA_SCALE), ("strunc", co.OP_GA_SCALE_TRUNC), ("relu", co.OP_AP_RELU), ("smx", co.OP_AP_SOFTMAX))}
+            s0 = co.normalizer(np.arange(n) % 9); s1 = np.zeros(n, dtype=U64)
+            bufs = [dev_empty((n, F)) for _ in range(5)]; cnt, loss = dev_empty(6), dev_empty(1, "f64")
+            labels = dev((np.arange(n) % F).astype(np.int32))
+            p = pairs[i]
+            p.a_row0 = a; p.b_row0 = b
+            c = p.chain
+            c.scale[0] = dev(s0).data_ptr(); c.scale[1] = dev(s1).data_ptr()
+            c.scale_keys = ks["scale"][0]; c.scale_trunc_keys = ks["strunc"][0]; c.relu_keys = ks["relu"][0]
+            c.out[0] = bufs[0].data_ptr(); c.out[1] = bufs[1].data_ptr()
+            if not softmax:
+                c.open[0] = bufs[2].data_ptr(); c.open_key[0] = 5; c.open_key[1] = 6; c.flags = flags | OPEN_SUM
+            else:
+                c.flags = flags
+                for q in (0, 1):
+                    j = jobs[2 * i + q]
+                    j.d_out = bufs[3 + q].data_ptr(); j.keys = ks["smx"][0]; j.p = q; j.rows = n; j.train_rows = n // 2; j.val_rows = n // 4
+                    if q == 0:
+                        j.labels = labels.data_ptr(); j.counts6 = cnt.data_ptr(); j.loss = loss.data_ptr()
+                    p.softmax[q] = ctypes.addressof(j)
+            c.rows = n; c.F = F
+            outs.append((bufs, cnt, labels))
+        if split:
+            base = dev_empty((T, F))
+            ctx.call("cognn_gather_csr_u64", ptr(base), ptr(dtab), ptr(dtab), ptr(dev(rp1.view(np.int32))), ptr(dev(c1.view(np.int32))), T, F)
+            ctx.call("cognn_gather_pair_chain_base_u64", ptr(dtab), ptr(base), ptr(dev(rp2.view(np.int32))), ptr(dev(c2.view(np.int32))), F, pairs, len(sizes))
+        else:
+            ctx.call("cognn_gather_pair_chain_u64", ptr(dtab), ptr(dev(rowptr.view(np.int32))), ptr(dev(col.view(np.int32))), F, pairs, len(sizes))
+        results.append([[host(t) for t in bufs] + [host(cnt, np.int64)[:5]] for bufs, cnt, _ in outs])
+    for one, two in zip(*results):
+        for x, y in zip(one, two):
+            assert np.array_equal(x, y)
+
+
 @pytest.mark.parametrize("n", [1, 7, 16 * 7, 1433 * 16 + 1])
 @pytest.mark.parametrize("pairs,average,avg_scale,post,raw", [(1, 0, 0, 0, 1), (3, 0, 0, 1, 0), (2, 1, 1, 0, 1), (5, 1, 0, 1, 1), (16, 1, 1, 0, 0)])
 def test_pair_weight_update_matches_the_two_party_oracle(ctx, n, pairs, average, avg_scale, post, raw):
