@@ -56,11 +56,13 @@ def _oracle_for(data, dataset, k, setting, iters):
     return o
 
 
-def test_two_rank_launcher_logs_match_oracle(tmp_path):
+@pytest.mark.parametrize("placement", ["party", "vertex-set"])
+def test_two_rank_launcher_logs_match_oracle(tmp_path, placement):
+    """(COGNN_PLACEMENT=vertex-set: every rank holds both shares of its party's vertex set - same logs, same cache files)"""
     data, logs = tmp_path / "data", tmp_path / "log"
     cmd = LAUNCH + ["--dataset", "cora_small", "--parties", "2", "--gpus", "2", "--iterations", "6", "--data-dir", str(data),
                     "--log-dir", str(logs), "--synthetic", "--backend", "gloo", "--worker", CPU_WORKER]
-    env = dict(os.environ, OMP_NUM_THREADS="1")
+    env = dict(os.environ, OMP_NUM_THREADS="1", COGNN_PLACEMENT=placement)
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env, cwd=tmp_path)
     assert res.returncode == 0, res.stderr + res.stdout
     o = _oracle_for(data, "cora_small", 2, "gcn-optimize/cora_small/2s", 6)
