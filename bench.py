@@ -283,7 +283,7 @@ def main():
     ap.add_argument("--chunks", type=int, default=1, help="N > 1: row chunks of the cross-rank open -> exchange -> close steps (COGNN_OPT_EXCHANGE_CHUNKS)")
     ap.add_argument("--placement", default="vertex-set", choices=["vertex-set", "party"],
                     help="N > 1: vertex-set = every GPU holds BOTH shares of its parties' vertex sets (the co-located mode of N = 1 extended: two-party "
-                         "steps stay in registers, only Gather replicas / partial sums and the weight average cross xGMI); party = a GPU is a set of "
+                         "steps stay in registers, only the Gather's share-table replicas and the weight average cross xGMI); party = a GPU is a set of "
                          "parties as in the reference's deployment (every opening of a cross-GPU owner / co-party pair crosses a link)")
     ap.add_argument("--graph", action="store_true", help="training workloads: replay the recorded epoch (hipGraph, COGNN_OPT_GRAPH_EPOCHS) instead of launching every kernel")
     args = ap.parse_args()

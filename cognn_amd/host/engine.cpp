@@ -1053,6 +1053,11 @@ void mp_exchange(cognn_engine* E, int F, u64* T) {
             } else if (!(E->m == 1 && E->rank == E->rank_of(o))) {
                 xl.recv(rc, seg, bytes);
             }
+            if (E->cfg.placement == COGNN_PLACE_VERTEX_SET) {   // ... and the own share likewise (see build_layout)
+                u64* sega = T + E->A_off[o] * F;
+                if (rc == E->rank) { for (int r = 0; r < E->world; ++r) if (r != E->rank) xl.send(r, sega, bytes); }
+                else xl.recv(rc, sega, bytes);
+            }
         }
         run_exchange(E, xl);                                // in flight during the partial-sum launch below (it reads own-share rows only)
     }
@@ -1789,8 +1794,18 @@ void build_layout(cognn_engine* E) {
     even();
     E->aggRows = off;
     for (int o = 0; o < k; ++o) if (E->B_off[o] < 0) { even(); E->B_off[o] = off; off += nrows(o); }
-    // partial-sum segments: (source rank -> g) goes to rank(co(g)); receiver-side order: source rank, then g
     E->segs.clear();
+    if (E->cfg.placement == COGNN_PLACE_VERTEX_SET) {
+        // one trusted node: the own shares of the other ranks' vertex sets are replicated like the co-shares, and a co-share row
+        // aggregates its remote sources' own-share rows directly - no partial-sum launch, no inbox, one exchange round per Gather
+        // (the same bytes on the wire: a partial-sum segment of a dense graph has a row for nearly every vertex)
+        for (int o = 0; o < k; ++o) if (E->A_off[o] < 0) { even(); E->A_off[o] = off; off += nrows(o); }
+        even();
+        E->inboxLocalOff = off; E->inboxRows = 0; E->partRows = 0;
+        E->tableRows = off;
+        return;
+    }
+    // partial-sum segments: (source rank -> g) goes to rank(co(g)); receiver-side order: source rank, then g
     const int64_t inbox0 = off;
     auto seg_vids = [&](int sr, int g) {                    // distinct destination vertices of g reached from any party of rank sr
         std::vector<uint64_t> v;
@@ -1879,9 +1894,12 @@ void build_csrs(cognn_engine* E) {
             for (uint32_t q = self.rowptr[r]; q < self.rowptr[r + 1]; ++q) lists[rbase + r].push_back((uint32_t)(rbase + self.col[q]));
     }
     // in-device exchange: when the producing party is hosted on this rank too, the co-party rows gather the producer's
-    // own-share rows directly (edge by edge) instead of going through materialised partial sums
+    // own-share rows directly (edge by edge) instead of going through materialised partial sums (vertex-set placement: every
+    // producer - the remote ones through the replicas of their own shares)
+    std::vector<int> producers = E->hosted;
+    if (E->cfg.placement == COGNN_PLACE_VERTEX_SET) { producers.clear(); for (int Q = 0; Q < k; ++Q) producers.push_back(Q); }
     for (int g : E->cohosted)
-        for (int Q : E->hosted) {
+        for (int Q : producers) {
             if (Q == g) continue;
             const cognn::EdgeBlock& blk = G.party[Q].out[g];
             const int64_t rbase = E->B_off[g];

@@ -46,7 +46,7 @@ typedef struct {
                                 in the reference (engine.h:157-201); every two-party opening of an owner / co-party pair on different
                                 ranks crosses the link.  COGNN_PLACE_VERTEX_SET (1): a rank holds BOTH shares of its parties' vertex
                                 sets - the single-GPU co-located mode extended to several GPUs of one trusted node: every two-party
-                                step stays in registers (pair chains) and only Gather traffic (co-share replicas, partial sums)
+                                step stays in registers (pair chains) and only Gather traffic (replicas of the share-table segments)
                                 and the weight average cross the links.  Same results. */
 } cognn_engine_config;
 enum { COGNN_PLACE_PARTY = 0, COGNN_PLACE_VERTEX_SET = 1 };
