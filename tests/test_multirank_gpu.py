@@ -87,4 +87,8 @@ def test_multirank_random_configuration_hip(tmp_path, seed):
                variant="optimize-gcn" if seed % 2 else "optimize-gcn-inference", iters=6 if seed % 2 else 2, backend="hip",
                chunks=int(rng.choice([1, 1, 2, 3, 5])))
     cfg["in"] = int(rng.choice([5, 16, 40]))
+    if seed % 3 == 2:                                        # every third: both shares of a vertex set on one rank, whole epochs per call
+        cfg["placement"] = "vertex-set"
+        if cfg["variant"] == "optimize-gcn":
+            cfg.update(iters=12, whole_epochs=True)
     _check(cfg, world, tmp_path)
