@@ -241,6 +241,57 @@ def _single_process_reference(Engine, gathered, digest, k, src, dst, part, param
     return res
 
 
+def placement_leg(torch, dist, Engine, args, placement, backend, rank, world, local_rank, k, src, dst, part, param, variant, iters, in_dim, lab, n_warm, value_of):
+    """N > 1: the same job on a second engine under the other placement (same transport, same timed loop: barrier + synchronize on both
+    sides, max over ranks), with its own N-rank check.  Extra keys only."""
+    from cognn_amd import dist as cdist
+    eng = Engine(k, src, dst, part, param, seed=0xC06A11, variant=variant, rank=rank, world=world, device=local_rank, placement=placement)
+    xch = None
+    if backend == "nccl":
+        xch = cdist.attach_rccl(eng, local_rank)
+    else:
+        eng.set_exchange(cdist.make_exchange_async(torch.device("cuda", local_rank), host_staged=True, per_round=False))
+    for P in eng.hosted:
+        vids = eng.party_vids(P)
+        rng = np.random.default_rng(0xC06A12 + P)
+        eng.set_party_data(P, (rng.random((len(vids), in_dim)) < 0.01).astype(np.float64), rng.integers(0, lab, size=len(vids)))
+    eng.start()
+    eng.retain_offline(True)
+    if "inference" in variant:
+        eng.forward_only(True)
+    eng.offline(0, iters)
+
+    def barrier():
+        torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+    for _ in range(n_warm):
+        eng.run(0, iters)
+    x0 = xch.stats() if xch else None
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        eng.run(0, iters)
+    barrier()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    x1 = xch.stats() if xch else None
+    out = {"placement": placement, "ms_per_step": dt / args.steps * 1e3, "value": value_of(dt / args.steps), "unit": "edges*feat/s"}
+    if xch:
+        out["exchange"] = {"rounds_per_step": (x1["rounds"] - x0["rounds"]) / args.steps, "MB_sent_per_step": (x1["bytes_sent"] - x0["bytes_sent"]) / args.steps / 1e6,
+                           "comm_stream_ms_per_step": (x1["comm_ms"] - x0["comm_ms"]) / args.steps}
+    if not args.no_check:
+        try:
+            out["check"] = multi_rank_check(eng, Engine, dist, rank, world, placement, k, src, dst, part, param, variant, iters, in_dim, lab,
+                                            n_warm + args.steps, local_rank)
+        except Exception as ex:  # noqa: BLE001
+            out["check"] = {"skipped": "the verification could not run: %s" % (str(ex)[-200:],)}
+    eng.close()
+    if xch:
+        xch.close()
+    return out
+
+
 def dealer_streams_leg(eng, torch, args, iters, k, digest_before):
     """The same pass with the dealer values of the co-located pairs' chains and the A masks of the grouped products READ from
     HBM (COGNN_OPT_DEALER_STREAMS) instead of regenerated in registers: what the online phase costs when the offline phase hands
@@ -290,10 +341,13 @@ def main():
     ap.add_argument("--no-check", action="store_true", help="skip the cross-path verification after the timed region")
     ap.add_argument("--no-dealer-streams", action="store_true", help="skip the extra timing of the dealt (memory-streamed dealer) form")
     ap.add_argument("--chunks", type=int, default=1, help="N > 1: row chunks of the cross-rank open -> exchange -> close steps (COGNN_OPT_EXCHANGE_CHUNKS)")
-    ap.add_argument("--placement", default="vertex-set", choices=["vertex-set", "party"],
-                    help="N > 1: vertex-set = every GPU holds BOTH shares of its parties' vertex sets (the co-located mode of N = 1 extended: two-party "
-                         "steps stay in registers, only the Gather's share-table replicas and the weight average cross xGMI); party = a GPU is a set of "
-                         "parties as in the reference's deployment (every opening of a cross-GPU owner / co-party pair crosses a link)")
+    ap.add_argument("--placement", default="party", choices=["party", "vertex-set"],
+                    help="N > 1, the placement `value` is measured on: party = a GPU is a set of parties as BASELINE.json's north_star has it (one party per "
+                         "GPU at N = 8; every Beaver / truncation opening of an owner / co-party pair crosses xGMI over RCCL p2p); vertex-set = every GPU "
+                         "holds BOTH shares of its parties' vertex sets (the co-located mode of N = 1 extended: two-party steps stay in registers, only the "
+                         "Gather's share-table replicas and the weight average cross xGMI).  With the default the other one is measured too and reported "
+                         "under `vertex_set_placement`")
+    ap.add_argument("--no-placement-leg", action="store_true", help="N > 1: skip the extra measurement of the vertex-set placement")
     ap.add_argument("--graph", action="store_true", help="training workloads: replay the recorded epoch (hipGraph, COGNN_OPT_GRAPH_EPOCHS) instead of launching every kernel")
     args = ap.parse_args()
 
@@ -478,6 +532,12 @@ def main():
         except Exception as ex:  # noqa: BLE001 - the measurement stands
             chk = {"skipped": "the verification could not run: %s" % (str(ex)[-200:],)}
         out["check"] = chk
+    if world > 1 and args.placement == "party" and not args.no_placement_leg:
+        try:
+            out["vertex_set_placement"] = placement_leg(torch, dist, Engine, args, "vertex-set", backend, rank, world, local_rank, k, src, dst, part, param,
+                                                        variant, iters, in_dim, lab, n_warm, lambda sec: ef_per_step / sec)
+        except Exception as ex:  # noqa: BLE001 - the measurement of the headline placement stands
+            out["vertex_set_placement"] = {"skipped": "could not run: %s" % (str(ex)[-200:],)}
     if world == 1 and not args.no_dealer_streams and not recorded:
         try:
             out["dealer_streams"] = dealer_streams_leg(eng, torch, args, iters, k, out.get("check", {}).get("digest"))

@@ -30,3 +30,8 @@ def test_bench_two_ranks_over_gloo(chunks, placement):
     assert d["cpu_baseline"] is None or isinstance(d["cpu_baseline"], dict)
     # the N-rank run ends in the single-process bits (rank 0 re-runs the job as one process and compares every rank's share digests)
     assert d["check"]["cross_path_identical"] is True and d["check"]["shares_compared"] == 16, d["check"]
+    if placement == "party":                                 # the other placement is measured (and checked) beside the headline one
+        v = d["vertex_set_placement"]
+        assert v["placement"] == "vertex-set" and v["ms_per_step"] > 0 and v["check"]["cross_path_identical"] is True, v
+    else:
+        assert "vertex_set_placement" not in d
