@@ -533,6 +533,10 @@ def main():
             chk = {"skipped": "the verification could not run: %s" % (str(ex)[-200:],)}
         out["check"] = chk
     if world > 1 and args.placement == "party" and not args.no_placement_leg:
+        eng.close()                               # (the headline engine and its communicator are done: free them before the second one starts)
+        if xch:
+            xch.close()
+        eng, xch = None, None
         try:
             out["vertex_set_placement"] = placement_leg(torch, dist, Engine, args, "vertex-set", backend, rank, world, local_rank, k, src, dst, part, param,
                                                         variant, iters, in_dim, lab, n_warm, lambda sec: ef_per_step / sec)
@@ -549,7 +553,8 @@ def main():
         out["cpu_baseline"] = None
     if rank == 0:
         print(json.dumps(out))
-    eng.close()
+    if eng is not None:
+        eng.close()
     if xch:
         xch.close()
     if world > 1:
