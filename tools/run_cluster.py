@@ -237,7 +237,11 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="transport of Python ranks (--worker)")
     ap.add_argument("--worker", default=None, help="start Python ranks (module or script, e.g. cognn_amd.worker) instead of bin/<executable> -c 1")
     ap.add_argument("--timeout", type=float, default=3600.0, help="seconds per run before the ranks are killed")
+    ap.add_argument("--placement", default=None, choices=["party", "vertex-set"],
+                    help="--gpus N > 1: which rank holds which share (COGNN_PLACEMENT of every rank; default: party, the reference's deployment)")
     a = ap.parse_args()
+    if a.placement:
+        os.environ["COGNN_PLACEMENT"] = a.placement           # inherited by every rank this launcher starts
     for name in UNSUPPORTED:
         if getattr(a, name):
             print("--%s: the FL, plaintext and GraphSC baselines are other programs of the reference, not part of this engine"
