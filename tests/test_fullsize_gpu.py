@@ -132,3 +132,43 @@ def test_config5_full_size_properties():
         assert np.all(prob > -1e-3) and np.all(prob < 1 + 1e-3)
         assert np.allclose(prob.sum(axis=1), 1.0, atol=2e-3)
     print("full-size reconstruction agreement across dealer seeds: max |diff| = %.2e" % worst)
+
+
+def test_config5_training_epoch_call_patterns_agree_at_full_size(monkeypatch):
+    """One optimize-gcn training epoch at the bench's size (2^20 vertices / 2^24 edges, 128-64-16) three ways: one call for the whole
+    epoch (the paths that span GAS iterations of a call: the backward PreScatter scale run ahead by the chain that truncates g, the
+    deferred ReLU' selection), one call per iteration, and the whole-epoch call with the cross-iteration / second-epilogue fusions and the
+    operand images switched off - every party's two weight shares of both layers agree bit for bit (the vertex tensor is empty after
+    an epoch: the weights carry everything the epoch computed)."""
+    import hashlib
+    from cognn_amd.engine import Engine, GnnParam
+    graph, feats = _inputs()
+    src, dst = graph
+    V = 1 << LV
+    part = (np.arange(V) % K).astype(np.int32)
+
+    def epoch(whole):
+        eng = Engine(K, src, dst, part, GnnParam(num_labels=LAB, input_dim=IN, hidden_dim=HID, num_samples=V, num_edges=len(src)), seed=21)
+        for P in eng.hosted:
+            eng.set_party_data(P, *feats[P])
+        eng.start()
+        if whole:
+            eng.run(0, 6)
+        else:
+            for it in range(6):
+                eng.run(it, it + 1)
+        h = hashlib.sha256()
+        for P in range(K):
+            for sd in (0, 1):
+                for layer in (0, 1):
+                    h.update(np.ascontiguousarray(eng.weight(P, sd, layer)).tobytes())
+        m = [eng.metrics(P)["loss"] for P in range(K)]
+        eng.close()
+        return h.hexdigest(), m
+    a, ma = epoch(True)
+    b, mb = epoch(False)
+    for name in ("COGNN_NO_BACKWARD_FUSION", "COGNN_NO_SOFTMAX_FUSION", "COGNN_GEMM_NO_MASK_IMAGE"):
+        monkeypatch.setenv(name, "1")
+    c, mc = epoch(True)
+    assert a == b == c
+    assert np.allclose(ma, mb, rtol=1e-9) and np.allclose(ma, mc, rtol=1e-9)      # the loss is a floating-point sum: order of the additions
