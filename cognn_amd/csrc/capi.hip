@@ -13,6 +13,11 @@ int cognn_set_error(const char* fmt, ...) {
     return 1;
 }
 
+// The device-side epoch salt is ONE set of symbols per process (cognn_spec.h), so at most one context may hold it non-zero at a
+// time, and while it does every entry point of every OTHER context is refused (cg_flush / launch_ew check cg_salt_owner): a
+// second context never silently evaluates dealer streams under a foreign salt.  The engine only uses it for recorded epochs
+// (COGNN_OPT_GRAPH_EPOCHS); eager launches carry the salt in their keys.
+std::atomic<cognn_ctx*> cg_salt_owner{nullptr};
 void* cg_salt_symbol_kernels_elementwise();
 void* cg_salt_symbol_kernels_gather();
 void* cg_salt_symbol_kernels_gemm();
@@ -52,6 +57,7 @@ int cognn_ctx_create_private(int device, cognn_ctx** out) {
 }
 int cognn_ctx_destroy(cognn_ctx* ctx) {
     if (!ctx) return 0;
+    if (cg_salt_owner.load() == ctx) (void)cognn_set_epoch_salt(ctx, 0);
     (void)cognn_timer_reset(ctx);
     if (ctx->lanes_active) ctx->stream = ctx->main_stream;
     for (auto st : ctx->lanes) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
@@ -194,7 +200,7 @@ int cognn_timer_read(cognn_ctx* ctx, int kind, int64_t* launches, double* total_
 }
 int cognn_timer_reset(cognn_ctx* ctx) {
     CG_REQUIRE(ctx, "cognn_timer_reset: null ctx");
-    for (int k = 0; k < 8; ++k) {
+    for (size_t k = 0; k < sizeof(ctx->timers) / sizeof(ctx->timers[0]); ++k) {
         for (auto& pr : ctx->timers[k]) { (void)hipEventDestroy(pr.b); (void)hipEventDestroy(pr.e); }
         ctx->timers[k].clear();
         for (auto& ev : ctx->open_begin[k]) (void)hipEventDestroy(ev);
@@ -211,8 +217,17 @@ int cognn_set_epoch_salt(cognn_ctx* ctx, uint64_t salt) {
         ctx->salt_sym[2] = (unsigned long long*)cg_salt_symbol_kernels_gemm();
         CG_REQUIRE(ctx->salt_sym[0] && ctx->salt_sym[1] && ctx->salt_sym[2], "cognn_set_epoch_salt: cannot resolve the salt symbols");
     }
+    if (salt != 0) {
+        cognn_ctx* none = nullptr;
+        if (!cg_salt_owner.compare_exchange_strong(none, ctx) && none != ctx)
+            return cognn_set_error("cognn_set_epoch_salt: another context holds a non-zero epoch salt (one recorded-epoch engine per process at a time)");
+    }
     hipLaunchKernelGGL(salt_set_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->salt_sym[0], ctx->salt_sym[1], ctx->salt_sym[2], (unsigned long long)salt);
     CG_LAUNCH_CHECK();
+    if (salt == 0 && cg_salt_owner.load() == ctx) {
+        CG_HIP(hipStreamSynchronize(ctx->stream));          // the symbols read 0 again before any other context may launch
+        cg_salt_owner.store(nullptr);
+    }
     return 0;
 }
 // ---- a recorded sequence of launches (hipGraph): the engine records one epoch and replays it (COGNN_OPT_GRAPH_EPOCHS) ----------

@@ -6,6 +6,7 @@
 #include <stdio.h>
 #include "cognn_spec.h"
 
+#include <atomic>
 #include <vector>
 struct cognn_timer_pair { hipEvent_t b, e; };
 struct cognn_ctx;
@@ -35,8 +36,16 @@ struct cognn_ctx {
     int chunk_c = 0, chunk_C = 1;                                    // chunk window of the element-wise entry points (cognn_ctx_set_chunk)
 };
 int cognn_set_error(const char* fmt, ...);
+extern std::atomic<cognn_ctx*> cg_salt_owner;      // the context that holds a non-zero device-side epoch salt, if any (capi.hip)
+static inline int cg_salt_guard(cognn_ctx* ctx) {
+    cognn_ctx* o = cg_salt_owner.load(std::memory_order_relaxed);
+    return (o && o != ctx) ? cognn_set_error("another context's epoch salt is set on the device (a recorded epoch is in flight): refused") : 0;
+}
 // launches whatever is queued
-static inline int cg_flush_pending(cognn_ctx* ctx) { return (ctx && ctx->pending.flush) ? ctx->pending.flush(ctx) : 0; }
+static inline int cg_flush_pending(cognn_ctx* ctx) {
+    if (int rc = cg_salt_guard(ctx)) return rc;
+    return (ctx && ctx->pending.flush) ? ctx->pending.flush(ctx) : 0;
+}
 // ... as every entry point other than the element-wise ones does first, so that stream order is preserved; those take no chunk window
 static inline int cg_flush(cognn_ctx* ctx) {
     if (ctx && ctx->chunk_C > 1) return cognn_set_error("a chunk window is set (cognn_ctx_set_chunk): only the element-wise entry points may be called");

@@ -11,6 +11,7 @@
 #include <sys/socket.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <chrono>
 #include <thread>
 #include <utility>
@@ -119,36 +120,44 @@ int cognn_rccl_rendezvous_tcp(const char* addr, int port, int rank, int world, d
         // A stray or garbled connection (port scanner, a client that dies mid-handshake) is dropped and accepting goes on until
         // the deadline; a rank is counted once however often it connects (a retry gets the id again).
         std::vector<char> seen((size_t)world, 0);
+        auto remaining = [&] { return std::chrono::duration<double>(deadline - std::chrono::steady_clock::now()).count(); };
         for (int served = 0; served < world - 1;) {
+            if (remaining() <= 0) { close(ls); return xerr("cognn_rccl_rendezvous_tcp: %d of %d ranks connected before the timeout", served, world - 1); }
             int c = accept(ls, nullptr, nullptr);
-            if (c < 0) {
-                if (std::chrono::steady_clock::now() > deadline) { close(ls); return xerr("cognn_rccl_rendezvous_tcp: %d of %d ranks connected before the timeout", served, world - 1); }
-                continue;
-            }
-            timeval ctv; ctv.tv_sec = 10; ctv.tv_usec = 0;          // the accepted socket inherits the listener's 1 s: too short for a slow client
+            if (c < 0) continue;                                    // (woken once a second: the deadline is checked at the top)
+            // the accepted socket inherits the listener's 1 s: too short for a slow client; but never longer than what is left
+            const double left = std::min(10.0, std::max(0.05, remaining()));
+            timeval ctv; ctv.tv_sec = (long)left; ctv.tv_usec = (long)((left - (double)(long)left) * 1e6);
             setsockopt(c, SOL_SOCKET, SO_RCVTIMEO, &ctv, sizeof(ctv));
             setsockopt(c, SOL_SOCKET, SO_SNDTIMEO, &ctv, sizeof(ctv));
             int32_t peer = -1;
             const int bad = read_all(c, &peer, sizeof(peer)) || peer <= 0 || peer >= world || write_all(c, id128, COGNN_RCCL_ID_BYTES);
             close(c);
-            if (bad) continue;
+            if (bad) continue;                                      // the client connects again (below) until the deadline
             if (!seen[(size_t)peer]) { seen[(size_t)peer] = 1; ++served; }
         }
         close(ls);
         return 0;
     }
+    // a client whose connection is refused (rank 0 not listening yet) or whose hand-shake is dropped half-way connects again until
+    // the deadline: the server counts a rank once however often it is served
     for (;;) {
         int s = socket(AF_INET, SOCK_STREAM, 0);
         X_REQUIRE(s >= 0, "cognn_rccl_rendezvous_tcp: socket: %s", strerror(errno));
+        const char* what = "not reachable";
         if (connect(s, (sockaddr*)&sa, sizeof(sa)) == 0) {
+            timeval ctv; ctv.tv_sec = 10; ctv.tv_usec = 0;
+            setsockopt(s, SOL_SOCKET, SO_RCVTIMEO, &ctv, sizeof(ctv));
+            setsockopt(s, SOL_SOCKET, SO_SNDTIMEO, &ctv, sizeof(ctv));
             int32_t me = rank;
             const int bad = write_all(s, &me, sizeof(me)) || read_all(s, id128, COGNN_RCCL_ID_BYTES);
             close(s);
-            X_REQUIRE(!bad, "cognn_rccl_rendezvous_tcp: hand-shake with rank 0 failed");
-            return 0;
+            if (!bad) return 0;
+            what = "dropped the hand-shake";
+        } else {
+            close(s);
         }
-        close(s);
-        if (std::chrono::steady_clock::now() > deadline) return xerr("cognn_rccl_rendezvous_tcp: rank 0 at %s:%d not reachable: %s", addr, port, strerror(errno));
+        if (std::chrono::steady_clock::now() > deadline) return xerr("cognn_rccl_rendezvous_tcp: rank 0 at %s:%d %s: %s", addr, port, what, strerror(errno));
         std::this_thread::sleep_for(std::chrono::milliseconds(50));
     }
 }

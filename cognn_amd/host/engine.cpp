@@ -124,7 +124,8 @@ struct cognn_engine {
     bool graph_warm = false, graph_unsupported = false;
     void* graph_exec = nullptr;
     int64_t graph_epoch = -1;                       // the epoch the recorded graph was captured in (retained products are tied to it)
-    u64 salt_now = 0;                               // the epoch salt currently set on the device (cognn_set_epoch_salt)
+    u64 salt_now = 0;                               // the epoch salt of the iteration being issued (added to the keys on the host, or - recorded epochs - on the device)
+    u64 salt_on_device = 0;                         // what cognn_set_epoch_salt last set (recorded epochs only)
     bool dealer_streams = false;                    // COGNN_OPT_DEALER_STREAMS: dealt values of the pair chains / grouped products read from HBM
     std::map<std::tuple<int, int64_t, int>, u64*> dealt;   // (owner, iteration, place) -> slab, filled at first use, kept (retain_offline)
     int64_t dealt_bytes = 0;
@@ -247,12 +248,16 @@ int epoch_len(const cognn_engine* E) { return (original(E) ? 2 : 3) * E->cfg.num
 cognn_keys keys(cognn_engine* E, u64 owner, int64_t it, int op) {
     cognn_keys k;
     cognn_opkeys o = cognn_make_opkeys(E->cfg.seed, owner, (u64)(it % epoch_len(E)), (u64)op);
-    for (int i = 0; i < COGNN_SL_COUNT; ++i) k.k[i] = o.k[i];
+    // eager launches: the epoch salt is added to the keys here, on the host, and the device-side salt stays 0 - nothing
+    // process-global changes, so any number of engines / contexts may run side by side.  Recorded epochs need epoch-independent
+    // kernel arguments: there the device adds it (cognn_set_epoch_salt, exclusive to one context at a time).
+    const u64 add = E->graph_epochs ? 0 : E->salt_now;
+    for (int i = 0; i < COGNN_SL_COUNT; ++i) k.k[i] = o.k[i] + add;
     return k;
 }
 void set_salt_value(cognn_engine* E, u64 salt) {
     if (E->salt_now == salt) return;
-    BE(cognn_set_epoch_salt(E->ctx, salt));
+    if (E->graph_epochs) { BE(cognn_set_epoch_salt(E->ctx, salt)); E->salt_on_device = salt; }
     E->salt_now = salt;
 }
 void set_salt(cognn_engine* E, int64_t it) { set_salt_value(E, (u64)(it / epoch_len(E)) * COGNN_GAMMA); }
@@ -2111,8 +2116,36 @@ void open_features(cognn_engine* E) {
     }
 }
 
+// Ranks that disagree on what they run (placement, variant, dimensions, seed, graph) would issue mismatched send / receive lists
+// and hang in the transport: every rank swaps a fingerprint of its configuration with every other rank first and fails fast.
+// (The receive slots start out holding this rank's own value, so a transport that moves nothing - tools/rank_compute_probe.py -
+// passes.)
+void config_handshake(cognn_engine* E) {
+    if (E->world == 1) return;
+    u64 h = 0xcbf29ce484222325ull;
+    auto mix = [&](u64 v) { for (int b = 0; b < 8; ++b) { h ^= (v >> (8 * b)) & 0xff; h *= 0x100000001b3ull; } };
+    mix((u64)E->k); mix((u64)E->world); mix((u64)E->cfg.variant); mix((u64)E->cfg.placement); mix((u64)E->in()); mix((u64)E->hid());
+    mix((u64)E->lab()); mix(E->cfg.seed); mix((u64)E->G.num_edges); mix((u64)E->G.row_of_vid.size()); mix((u64)E->cfg.undirected);
+    std::vector<u64> host((size_t)E->world + 1, h);
+    u64* d = upload(E, host);
+    XList xl;
+    for (int r = 0; r < E->world; ++r) {
+        if (r == E->rank) continue;
+        xl.send(r, d + E->world, 8);
+        xl.recv(r, d + r, 8);
+    }
+    run_exchange_sync(E, xl);
+    BE(cognn_ctx_sync(E->ctx));
+    BE(cognn_memcpy_d2h(E->ctx, host.data(), d, host.size() * 8));
+    for (int r = 0; r < E->world; ++r)
+        if (host[(size_t)r] != h)
+            throw EngineError("engine: rank " + std::to_string(r) + " runs a different configuration than rank " + std::to_string(E->rank) +
+                              " (placement, variant, dimensions, seed or graph differ)");
+}
+
 void start(cognn_engine* E) {
     const int in = E->in(), hid = E->hid(), lab = E->lab();
+    config_handshake(E);
     if (E->w0.empty()) { E->w0 = glorot(in, hid); E->w1 = glorot(hid, lab); }
     std::vector<u64> wfx[2];
     for (double v : E->w0) wfx[0].push_back(fx_llround(v));
@@ -2177,8 +2210,6 @@ int cognn_engine_create(const cognn_engine_config* cfg, int64_t V, int64_t Ecoun
         if (cfg->num_layers != 2) throw EngineError("cognn_engine_create: num_layers must be 2 (as in every reference config)");
         cognn_engine* E = new cognn_engine();
         E->cfg = *cfg;
-        if (const char* pl = getenv("COGNN_PLACEMENT"))     // for callers that keep the reference's command line (bin/gcn-optimize -c 1)
-            E->cfg.placement = (strcmp(pl, "vertex-set") == 0 || strcmp(pl, "1") == 0) ? COGNN_PLACE_VERTEX_SET : COGNN_PLACE_PARTY;
         if (E->cfg.placement != COGNN_PLACE_PARTY && E->cfg.placement != COGNN_PLACE_VERTEX_SET) { delete E; throw EngineError("cognn_engine_create: unknown placement"); }
         E->be = cognn_default_backend();
         E->k = cfg->num_parties; E->world = cfg->world; E->rank = cfg->rank; E->m = E->k / E->world;
@@ -2217,7 +2248,7 @@ int cognn_engine_destroy(cognn_engine* E) {
     if (!E) return 0;
     if (E->ctx) {
         if (E->graph_exec) E->be->cognn_graph_destroy(E->ctx, E->graph_exec);
-        if (E->salt_now) E->be->cognn_set_epoch_salt(E->ctx, 0);
+        if (E->salt_on_device) E->be->cognn_set_epoch_salt(E->ctx, 0);
         for (void* p : E->allocs) E->be->cognn_free(E->ctx, p);
         E->be->cognn_ctx_destroy(E->ctx);
     }
@@ -2360,7 +2391,7 @@ int cognn_engine_run(cognn_engine* E, int64_t it0, int64_t it1) {
     return guard([&] {
         if (!E || !E->started) throw EngineError("cognn_engine_run: engine not started");
         const int ep = epoch_len(E);
-        struct SaltReset { cognn_engine* E; ~SaltReset() { if (E->salt_now) { E->be->cognn_set_epoch_salt(E->ctx, 0); E->salt_now = 0; } } } salt_reset{E};
+        struct SaltReset { cognn_engine* E; ~SaltReset() { if (E->salt_on_device) { E->be->cognn_set_epoch_salt(E->ctx, 0); E->salt_on_device = 0; } E->salt_now = 0; } } salt_reset{E};
         E->run_end = it1;
         E->prescaled_it = -1;                               // (nothing is carried from one call to the next)
         for (int64_t it = it0; it < it1; ++it) {

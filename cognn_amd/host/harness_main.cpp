@@ -199,6 +199,13 @@ int main(int argc, char* argv[]) {
         cfg.num_layers = gp.num_layers; cfg.num_labels = gp.num_labels; cfg.input_dim = gp.input_dim; cfg.hidden_dim = gp.hidden_dim;
         cfg.learning_rate = gp.learning_rate; cfg.train_ratio = gp.train_ratio; cfg.val_ratio = gp.val_ratio; cfg.test_ratio = gp.test_ratio;
         cfg.seed = fnv1a(setting); cfg.device = device; cfg.stream = nullptr; cfg.undirected = undirected; cfg.verbose = 1;
+        // which rank holds which share (multi-rank runs): the reference's command line has no switch for it, so the CLI - and only
+        // the CLI - reads it from the environment; anything but the two names is an error, not a silent default
+        if (const char* pl = getenv("COGNN_PLACEMENT")) {
+            if (!strcmp(pl, "party") || !strcmp(pl, "0")) cfg.placement = COGNN_PLACE_PARTY;
+            else if (!strcmp(pl, "vertex-set") || !strcmp(pl, "1")) cfg.placement = COGNN_PLACE_VERTEX_SET;
+            else { std::cerr << "COGNN_PLACEMENT must be 'party' or 'vertex-set' (got '" << pl << "')." << std::endl; return -1; }
+        }
         cognn_engine* e = nullptr;
         if (cognn_engine_create(&cfg, (int64_t)part.size(), (int64_t)src.size(), src.data(), dst.data(), part.data(), &e)) {
             std::cerr << cognn_engine_last_error() << std::endl;

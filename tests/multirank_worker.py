@@ -28,9 +28,11 @@ def main():
     k = cfg["k"]; V = cfg["V"]
     src, dst = co.synth_graph(V, cfg["Eu"], cfg["gseed"])
     part = np.array([v % k for v in range(V)], dtype=np.int32)
-    feats, labels = co.synth_features(V, cfg["in"], cfg["lab"], cfg["gseed"] + 1, density=0.2)
-    gp = GnnParam(num_labels=cfg["lab"], input_dim=cfg["in"], hidden_dim=cfg["hid"], num_samples=V, learning_rate=0.5)
+    feats, labels = co.synth_features(V, cfg["in"], cfg["lab"], cfg["gseed"] + 1, density=cfg.get("density", 0.2))
+    gp = GnnParam(**dict(dict(num_labels=cfg["lab"], input_dim=cfg["in"], hidden_dim=cfg["hid"], num_samples=V, learning_rate=0.5), **cfg.get("param", {})))
     placement = cfg.get("placement", "party")              # "vertex-set": a rank holds both shares of its parties' vertex sets
+    if "placement_by_rank" in cfg:                         # a deliberately inconsistent launch (test_mismatched_configuration_fails_fast)
+        placement = cfg["placement_by_rank"][rank]
     eng = Engine(k, src, dst, part, gp, seed=cfg["seed"], variant=cfg["variant"], rank=rank, world=world, stream=0, placement=placement)
     # asynchronous exchange (begin / wait) unless the case asks for the blocking callback
     mk = cdist.make_exchange if cfg.get("blocking_exchange") else cdist.make_exchange_async
@@ -48,7 +50,16 @@ def main():
     if cfg.get("chunks", 1) > 1:                           # open -> exchange -> close of the cross-rank sides in row chunks
         eng.exchange_chunks(cfg["chunks"])
     eng.set_global_data(feats, labels)
-    eng.start()
+    if "placement_by_rank" in cfg:
+        try:
+            eng.start()
+        except capi.CognnError as ex:
+            print("START FAILED: %s" % ex, flush=True)
+            eng.close()
+            dist.destroy_process_group()
+            sys.exit(7)
+    else:
+        eng.start()
     if cfg.get("exchanged_openings"):                      # every opening travels as two shares (COGNN_OPT_PUBLIC_OPENINGS off)
         eng.public_openings(False)
     if "pair_fusion" in cfg:

@@ -114,6 +114,9 @@ def test_cli_argument_errors(tmp_path):
     (tmp_path / "bad.txt").write_text("0 x\n")
     r = subprocess.run(base + ["-r", "1", str(tmp_path / "bad.txt")] + files[1:], capture_output=True, text=True)
     assert r.returncode != 0 and "Invalid format in graph topology input files." in r.stderr
+    # a misspelt placement is an error, not a silent fall-back to the party placement (ranks that disagree would hang in the transport)
+    r = subprocess.run(base + ["-r", "1"] + files, capture_output=True, text=True, env=dict(os.environ, COGNN_PLACEMENT="vertexset"), cwd=tmp_path)
+    assert r.returncode != 0 and "COGNN_PLACEMENT must be" in r.stderr
 
 
 @pytest.mark.gpu

@@ -29,7 +29,15 @@ def _run(cfg, world, tmp_path):
     cfg = dict(cfg, out=str(tmp_path / "shares"))
     port = _free_port()
     procs = []
-    for r in range(world):
+    if cfg.get("inproc"):                                  # the ranks as threads of ONE process over a mailbox transport (tests/inproc_worker.py)
+        env = dict(os.environ, OMP_NUM_THREADS="1")
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "inproc_worker.py"), json.dumps(dict(cfg, world=world))], env=env,
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+        world_procs = 0
+    else:
+        world_procs = world
+    for r in range(world_procs):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    OMP_NUM_THREADS="1")
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "multirank_worker.py"), json.dumps(cfg)], env=env))
@@ -39,8 +47,8 @@ def _run(cfg, world, tmp_path):
     for r in range(world):
         with np.load(cfg["out"] + ".rank%d.npz" % r) as z:
             for key in z.files:
-                if key == "hostile_rounds":
-                    got.setdefault("hostile_rounds", []).append(z[key])
+                if key in ("hostile_rounds", "exchange_stats"):
+                    got.setdefault(key, []).append(z[key])
                     continue
                 assert key not in got
                 got[key] = z[key]
@@ -51,8 +59,8 @@ def _check(cfg, world, tmp_path):
     k, V = cfg["k"], cfg["V"]
     src, dst = co.synth_graph(V, cfg["Eu"], cfg["gseed"])
     part = [v % k for v in range(V)]
-    feats, labels = co.synth_features(V, cfg["in"], cfg["lab"], cfg["gseed"] + 1, density=0.2)
-    p = co.GnnParam(num_labels=cfg["lab"], input_dim=cfg["in"], hidden_dim=cfg["hid"], num_samples=V, learning_rate=0.5)
+    feats, labels = co.synth_features(V, cfg["in"], cfg["lab"], cfg["gseed"] + 1, density=cfg.get("density", 0.2))
+    p = co.GnnParam(**dict(dict(num_labels=cfg["lab"], input_dim=cfg["in"], hidden_dim=cfg["hid"], num_samples=V, learning_rate=0.5), **cfg.get("param", {})))
     if cfg["variant"] == "original-gcn":
         import original_gcn
         o = original_gcn.OriginalOracleEngine(k, src, dst, part, feats, labels, p, seed=cfg["seed"])
@@ -188,3 +196,50 @@ def test_hostile_transport_detects_a_missing_round_wait(tmp_path):
     """... and with the chunked pipeline: a per-round wait that completes nothing leaves that chunk's inbox poisoned."""
     with pytest.raises(AssertionError):
         _check(dict(BASE, k=4, variant="optimize-gcn-inference", iters=2, hostile=1, hostile_skip_waits=2, chunks=3), 2, tmp_path)
+
+
+# ---- world 8, k = 8, one party per rank: the north-star layout (the reference's k x k mesh, include/engine.h:157-201, and its
+# per-peer threads, ss_...h:702-704,926-928) ----
+W8 = dict(BASE, k=8, V=96, Eu=260)
+
+
+@pytest.mark.parametrize("variant,iters,extra", [("optimize-gcn", 12, {}), ("optimize-gcn-inference", 2, {}),
+                                                 ("optimize-gcn", 12, {"placement": "vertex-set"}), ("optimize-gcn-inference", 2, {"placement": "vertex-set"}),
+                                                 ("optimize-gcn", 12, {"whole_epochs": True}), ("optimize-gcn", 6, {"exchanged_openings": True}),
+                                                 ("optimize-gcn", 6, {"chunks": 3})])
+def test_eight_parties_eight_ranks(tmp_path, variant, iters, extra):
+    """One party per rank at world 8 over gloo (plain-C++ backend): every owner / co-party pair crosses a rank boundary, every
+    owner's co-share is replicated to six other ranks, partial sums travel between all 56 ordered rank pairs, the weight average
+    gathers from six ranks onto ranks 0 and 1 (gcn.h:747-802) - two training epochs / an inference pass, both placements, every
+    party's two shares and weight shares against the oracle after every GAS iteration."""
+    _check(dict(W8, variant=variant, iters=iters, **extra), 8, tmp_path)
+
+
+@pytest.mark.parametrize("variant,iters,extra", [("optimize-gcn", 12, {}), ("optimize-gcn", 12, {"placement": "vertex-set", "whole_epochs": True}),
+                                                 ("optimize-gcn-inference", 2, {"chunks": 2})])
+def test_eight_parties_eight_ranks_in_one_process(tmp_path, variant, iters, extra):
+    """The same layout with the eight ranks as threads of ONE process (tests/inproc_worker.py): eight engines and contexts side by
+    side in one address space, two epochs - nothing process-global (the epoch salt, error strings) may leak from one to another."""
+    _check(dict(W8, variant=variant, iters=iters, inproc=True, **extra), 8, tmp_path)
+
+
+@pytest.mark.parametrize("seed,variant,iters,extra", [(1, "optimize-gcn", 6, {}), (2, "optimize-gcn-inference", 2, {}),
+                                                      (3, "optimize-gcn", 6, {"placement": "vertex-set"}), (4, "optimize-gcn", 6, {"chunks": 2})])
+def test_eight_parties_eight_ranks_hostile_transport(tmp_path, seed, variant, iters, extra):
+    """The same layout over the hostile asynchronous transport (late reads, poisoned inboxes, shuffled completion)."""
+    _check(dict(W8, variant=variant, iters=iters, hostile=seed, **extra), 8, tmp_path)
+
+
+def test_mismatched_configuration_fails_fast(tmp_path):
+    """Two ranks launched with different placements: start() swaps a configuration fingerprint with every other rank, so both
+    stop with an error instead of hanging later in mismatched send / receive lists."""
+    cfg = dict(BASE, k=4, placement_by_rank=["party", "vertex-set"], out=str(tmp_path / "x"))
+    port = _free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "multirank_worker.py"), json.dumps(cfg)], env=env,
+                                      stdout=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=120)[0] for p in procs]
+    assert [p.returncode for p in procs] == [7, 7], outs
+    assert all("runs a different configuration" in o for o in outs), outs

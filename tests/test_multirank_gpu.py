@@ -92,3 +92,39 @@ def test_multirank_random_configuration_hip(tmp_path, seed):
         if cfg["variant"] == "optimize-gcn":
             cfg.update(iters=12, whole_epochs=True)
     _check(cfg, world, tmp_path)
+
+
+# ---- the north-star layout on the HIP kernels: 8 parties, one per rank, world 8.  A GPU box admits at most 6 processes on its card,
+# so the eight ranks run as threads of one process over a mailbox transport (tests/inproc_worker.py): eight engines / contexts on
+# the one GPU, every owner / co-party pair across a rank boundary ----
+SMALL = dict(BASE, k=8, V=1 << 14, Eu=1 << 17, hid=64, lab=16, density=0.01, backend="hip", inproc=True)   # bench.py's `small` workload shape
+SMALL["in"] = 128
+
+
+@pytest.mark.parametrize("variant,iters,extra", [("optimize-gcn-inference", 2, {}), ("optimize-gcn-inference", 2, {"placement": "vertex-set"}),
+                                                 ("optimize-gcn", 6, {}), ("optimize-gcn", 6, {"placement": "vertex-set", "whole_epochs": True})])
+def test_eight_parties_eight_ranks_small_workload_hip(tmp_path, variant, iters, extra):
+    """Inference pass and training epoch of the `small` workload shape (2^14 vertices / 2^18 directed edges, in = 128, hid = 64,
+    labels = 16: grouped MFMA products, 16-byte Gather lanes) at world 8, both placements, bit-exact vs the oracle."""
+    _check(dict(SMALL, variant=variant, iters=iters, **extra), 8, tmp_path)
+
+
+@pytest.mark.parametrize("variant,iters,extra", [("optimize-gcn", 12, {}), ("optimize-gcn", 12, {"placement": "vertex-set"}),
+                                                 ("optimize-gcn", 12, {"chunks": 3}), ("optimize-gcn-inference", 2, {"exchanged_openings": True})])
+def test_eight_parties_eight_ranks_hip(tmp_path, variant, iters, extra):
+    """Two training epochs (weight average across eight ranks, epoch salt past epoch 0 in eight contexts at once) at hid = 16."""
+    cfg = dict(BASE, k=8, V=4096, Eu=16384, hid=16, lab=8, variant=variant, iters=iters, backend="hip", inproc=True, **extra)
+    cfg["in"] = 32
+    _check(cfg, 8, tmp_path)
+
+
+# ---- BASELINE.json configs[2] and [3] in their stated layouts: 2-party CiteSeer-shaped on 2 ranks, 4-party PubMed-shaped on 4 ranks
+# (one party per rank; HIP kernels, ranks share the GPU, gloo host-staged), one training epoch vs the oracle ----
+@pytest.mark.parametrize("name,k,V,E,inn,lab,lr,tr,placement", [
+    ("citeseer-2p", 2, 3312, 10016, 3703, 6, 0.8, 0.2, "party"), ("pubmed-4p", 4, 19717, 128146, 500, 3, 8.0, 0.05, "party"),
+    ("citeseer-2p", 2, 3312, 10016, 3703, 6, 0.8, 0.2, "vertex-set"), ("pubmed-4p", 4, 19717, 128146, 500, 3, 8.0, 0.05, "vertex-set")])
+def test_baseline_configs_3_and_4_one_party_per_rank_hip(tmp_path, name, k, V, E, inn, lab, lr, tr, placement):
+    cfg = dict(BASE, k=k, V=V, Eu=E // 2, hid=16, lab=lab, density=0.01, variant="optimize-gcn", iters=6, backend="hip", placement=placement,
+               param=dict(learning_rate=lr, train_ratio=tr, val_ratio=0.2 if tr == 0.2 else 0.15, test_ratio=0.6 if tr == 0.2 else 0.8))
+    cfg["in"] = inn
+    _check(cfg, k, tmp_path)
