@@ -2,6 +2,9 @@
 #include "common.h"
 #include "../../include/cognn_hip.h"
 #include <string.h>
+#include <map>
+#include <mutex>
+#include <utility>
 
 static thread_local char g_err[1024] = "";
 
@@ -18,6 +21,18 @@ int cognn_set_error(const char* fmt, ...) {
 // second context never silently evaluates dealer streams under a foreign salt.  The engine only uses it for recorded epochs
 // (COGNN_OPT_GRAPH_EPOCHS); eager launches carry the salt in their keys.
 std::atomic<cognn_ctx*> cg_salt_owner{nullptr};
+int cg_ensure_dynamic_lds(const void* kernel, int bytes) {
+    static std::mutex mu;
+    static std::map<std::pair<int, const void*>, int> raised;
+    int dev = 0;
+    CG_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(mu);
+    int& cur = raised[{dev, kernel}];
+    if (bytes <= cur) return 0;
+    CG_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    cur = bytes;
+    return 0;
+}
 void* cg_salt_symbol_kernels_elementwise();
 void* cg_salt_symbol_kernels_gather();
 void* cg_salt_symbol_kernels_gemm();

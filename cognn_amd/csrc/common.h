@@ -66,6 +66,12 @@ static inline int cg_flush(cognn_ctx* ctx) {
 
 #define CG_LAUNCH_CHECK() CG_HIP(hipGetLastError())
 
+// Dynamic LDS beyond the default limit needs hipFuncAttributeMaxDynamicSharedMemorySize on the kernel.  The attribute is process-wide
+// state of the runtime: it is raised once per (device, kernel) to the largest size asked for so far, under a lock - not re-set before
+// every launch (one runtime call less per launch, and several host threads launching the same kernel from their own contexts
+// never lower it under each other's launches).
+int cg_ensure_dynamic_lds(const void* kernel, int bytes);          // capi.hip
+
 typedef unsigned long long u64;
 typedef ulonglong2 u64x2;
 

@@ -290,6 +290,22 @@ int cognn_rccl_exchange_time(cognn_rccl_exchange* x, double* comm_ms) {
     return 0;
 }
 
+int cognn_rccl_exchange_ranks(cognn_rccl_exchange* x, int32_t* comm_count, int32_t* comm_rank, int64_t* ones_summed) {
+    X_REQUIRE(x && comm_count && comm_rank && ones_summed, "cognn_rccl_exchange_ranks: bad arguments");
+    int c = 0, r = -1;
+    X_NCCL(ncclCommCount(x->comm, &c));
+    X_NCCL(ncclCommUserRank(x->comm, &r));
+    const uint64_t one = 1;
+    X_HIP(hipStreamSynchronize(x->compute));
+    X_HIP(hipMemcpyAsync(x->scratch, &one, 8, hipMemcpyHostToDevice, x->comm_stream));
+    X_NCCL(ncclAllReduce(x->scratch, x->scratch + 1, 1, ncclUint64, ncclSum, x->comm, x->comm_stream));
+    uint64_t sum = 0;
+    X_HIP(hipMemcpyAsync(&sum, x->scratch + 1, 8, hipMemcpyDeviceToHost, x->comm_stream));
+    X_HIP(hipStreamSynchronize(x->comm_stream));
+    *comm_count = c; *comm_rank = r; *ones_summed = (int64_t)sum;
+    return 0;
+}
+
 int cognn_rccl_exchange_barrier(cognn_rccl_exchange* x) {
     X_REQUIRE(x, "cognn_rccl_exchange_barrier: null exchange");
     X_HIP(hipEventRecord(x->ready, x->compute));

@@ -840,7 +840,11 @@ __global__ __launch_bounds__(256) void presplit_e_kernel(u64x2* out, const u64* 
 // SPLITK (few row tiles, long K: the dataset-sized graphs - Cora's 1354 x 1433): a workgroup serves (job, group of row tiles,
 // K range of g.ksteps steps), builds the B fragments of its K range only and adds its partial tiles into the zeroed Z with
 // uint64 atomics (exact: integer adds commute).
-template <int NT, int WAVES, bool FULL, bool KEVEN, bool PRE = false, bool SPLITK = false, bool EPI = false, bool PREA = false>
+// DEALT: the party's mask is READ from J.Amask (COGNN_OPT_DEALER_STREAMS) instead of regenerated.  A compile-time switch on purpose: as
+// a run-time branch the two forms shared registers and the compiler put an `s_waitcnt vmcnt(0)` in front of every PRNG block - the
+// next K step's operand loads, issued just before, had to land before any mask arithmetic started (round 3's one-column-tile
+// products ran at 35 % MFMA pipe utilisation, neither VALU- nor HBM-bound: they were waiting for their own prefetch).
+template <int NT, int WAVES, bool FULL, bool KEVEN, bool PRE = false, bool SPLITK = false, bool EPI = false, bool PREA = false, bool DEALT = false>
 __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(2, NT == 1 ? 4 : 2)))
 void beaver_gemm_group_kernel(GemmGroup g, GemmEpi epi) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -963,7 +967,7 @@ void beaver_gemm_group_kernel(GemmGroup g, GemmEpi epi) {
         for (int jj = 0; jj < 4; ++jj) {
             if (PREA) break;
             const u64 x = (u64)m * (u64)K + (u64)(st * 32 + 8 * jj + 2 * b);
-            if (Amask) {                                     // (uniform) dealt mask: a memory stream instead of the counter PRNG
+            if (DEALT) {                                     // dealt mask: a memory stream instead of the counter PRNG
                 const size_t xc = FULL ? (size_t)x : (size_t)min((u64)x, (u64)M * (u64)K - 2);
                 if (KEVEN) { const u64x2 t = *reinterpret_cast<const u64x2*>(Amask + xc); w[2 * jj] = t.x; w[2 * jj + 1] = t.y; }
                 else { w[2 * jj] = Amask[xc]; w[2 * jj + 1] = Amask[xc + 1]; }
@@ -1574,11 +1578,11 @@ int launch_tn_d16(cognn_ctx* ctx, u64* Z, const u64* E0, const u64* E1, const u6
 #define CG_TND16_LAUNCH(NT_, W_)                                                                                                        \
     do {                                                                                                                                 \
         if (E1 || F1) {                                                                                                                  \
-            CG_HIP(hipFuncSetAttribute((const void*)beaver_gemm_tn_d16_kernel<NT_, W_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            if (int rc_lds_ = cg_ensure_dynamic_lds((const void*)beaver_gemm_tn_d16_kernel<NT_, W_, true>, (int)lds)) return rc_lds_; \
             hipLaunchKernelGGL((beaver_gemm_tn_d16_kernel<NT_, W_, true>), dim3((unsigned)gx, (unsigned)splits), dim3(W_ * 64), lds, ctx->stream, Z, E0, E1, \
                                F, F1, keyA, keyB, p, (int)M, (int)N, (int)K, nst, ksteps, mtiles, a_storage);                            \
         } else {                                                                                                                         \
-            CG_HIP(hipFuncSetAttribute((const void*)beaver_gemm_tn_d16_kernel<NT_, W_, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            if (int rc_lds_ = cg_ensure_dynamic_lds((const void*)beaver_gemm_tn_d16_kernel<NT_, W_, false>, (int)lds)) return rc_lds_; \
             hipLaunchKernelGGL((beaver_gemm_tn_d16_kernel<NT_, W_, false>), dim3((unsigned)gx, (unsigned)splits), dim3(W_ * 64), lds, ctx->stream, Z, E0,   \
                                E1, F, F1, keyA, keyB, p, (int)M, (int)N, (int)K, nst, ksteps, mtiles, a_storage);                        \
         }                                                                                                                                \
@@ -1602,7 +1606,7 @@ int launch_tn_ws(cognn_ctx* ctx, u64* Z, const u64* E0, const u64* E1, const u64
     const size_t lds = 3 * 2 * (size_t)(8 * 2048);
 #define CG_TN_LAUNCH(D)                                                                                                            \
     do {                                                                                                                            \
-        CG_HIP(hipFuncSetAttribute((const void*)beaver_gemm_tn_ws_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        if (int rc_lds_ = cg_ensure_dynamic_lds((const void*)beaver_gemm_tn_ws_kernel<D>, (int)lds)) return rc_lds_; \
         hipLaunchKernelGGL(beaver_gemm_tn_ws_kernel<D>, dim3((unsigned)nmb, (unsigned)splits), dim3(512), lds, ctx->stream, Z, E0, E1, F, F1,   \
                            keyA, keyB, p, (int)M, (int)N, (int)K, sps, a_storage);                                                  \
     } while (0)
@@ -1630,7 +1634,7 @@ int launch_tn(cognn_ctx* ctx, u64* Z, const u64* A1, const u64* A2, const u64* B
     const int sps = (nkt + splits - 1) / splits;
     splits = (nkt + sps - 1) / sps;
     const size_t lds = (size_t)(8 * 2 * 128 * 16) + (size_t)kBStage;
-    CG_HIP(hipFuncSetAttribute((const void*)ring_gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (int rc_lds_ = cg_ensure_dynamic_lds((const void*)ring_gemm_tn_kernel, (int)lds)) return rc_lds_;
     hipLaunchKernelGGL(ring_gemm_tn_kernel, dim3((unsigned)nmb, (unsigned)splits), dim3(512), lds, ctx->stream, Z, A1, A2, B, (int)M, (int)N,
                        (int)K, sps);
     CG_LAUNCH_CHECK();
@@ -1681,10 +1685,10 @@ int gemm_dispatch(cognn_ctx* ctx, u64* C, const u64* A, const u64* A2, const u64
             const int nmb = (int)((M + BM - 1) / BM);
             dim3 grid((unsigned)std::min(nmb, 256), (unsigned)((N + BN - 1) / BN));
             if (BN == 32) {
-                CG_HIP(hipFuncSetAttribute((const void*)ring_gemm_mfma_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                if (int rc_lds_ = cg_ensure_dynamic_lds((const void*)ring_gemm_mfma_kernel<32>, (int)lds)) return rc_lds_;
                 hipLaunchKernelGGL(ring_gemm_mfma_kernel<32>, grid, dim3(kGemmThreads), lds, ctx->stream, C, A, A2, B, (int)M, (int)N, (int)K, accumulate);
             } else {
-                CG_HIP(hipFuncSetAttribute((const void*)ring_gemm_mfma_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                if (int rc_lds_ = cg_ensure_dynamic_lds((const void*)ring_gemm_mfma_kernel<64>, (int)lds)) return rc_lds_;
                 hipLaunchKernelGGL(ring_gemm_mfma_kernel<64>, grid, dim3(kGemmThreads), lds, ctx->stream, C, A, A2, B, (int)M, (int)N, (int)K, accumulate);
             }
             CG_LAUNCH_CHECK();
@@ -1846,7 +1850,7 @@ int beaver_close_impl(cognn_ctx* ctx, uint64_t* Z, const uint64_t* E, const uint
             const dim3 grid((unsigned)std::min((tiles + 7) / 8, 256));
 #define CG_D16N_LAUNCH(...)                                                                                                  \
     do {                                                                                                                      \
-        CG_HIP(hipFuncSetAttribute((const void*)beaver_gemm_d16n_kernel<__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        if (int rc_lds_ = cg_ensure_dynamic_lds((const void*)beaver_gemm_d16n_kernel<__VA_ARGS__>, (int)lds)) return rc_lds_; \
         hipLaunchKernelGGL((beaver_gemm_d16n_kernel<__VA_ARGS__>), grid, dim3(512), lds, ctx->stream, (u64*)Z, (const u64*)E, (const u64*)E1, planes,  \
                            keyA_, (int)M, (int)N, (int)K, nst32, tiles);                                                      \
     } while (0)
@@ -1891,7 +1895,7 @@ int beaver_close_impl(cognn_ctx* ctx, uint64_t* Z, const uint64_t* E, const uint
         const bool full = (M % bm == 0) && (K % 16 == 0), kal = (K % 4 == 0);
 #define CG_WS_LAUNCH(...)                                                                                                          \
     do {                                                                                                                            \
-        CG_HIP(hipFuncSetAttribute((const void*)beaver_gemm_ws_kernel<__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        if (int rc_lds_ = cg_ensure_dynamic_lds((const void*)beaver_gemm_ws_kernel<__VA_ARGS__>, (int)lds)) return rc_lds_; \
         hipLaunchKernelGGL((beaver_gemm_ws_kernel<__VA_ARGS__>), dim3((unsigned)std::min(nmb, 256), (unsigned)ksplits), dim3(512), lds,    \
                            ctx->stream, (u64*)Z, (const u64*)E, (const u64*)E1, planes, keys->k[p == 0 ? COGNN_SL_A0 : COGNN_SL_A1],       \
                            (int)M, (int)N, (int)K, nst, ksteps);                                                                    \
@@ -1972,15 +1976,21 @@ int beaver_close_impl(cognn_ctx* ctx, uint64_t* Z, const uint64_t* E, const uint
 // ---- grouped launch of one phase's products ------------------------------------------------------------------------------
 namespace {
 template <int NT, int WAVES>
-int launch_group(cognn_ctx* ctx, const GemmGroup& g, int wgs, size_t lds, bool full, bool keven, bool pre, bool splitk, const GemmEpi* epi, bool prea = false) {
+int launch_group(cognn_ctx* ctx, const GemmGroup& g, int wgs, size_t lds, bool full, bool keven, bool pre, bool splitk, const GemmEpi* epi, bool prea = false,
+                 bool dealt = false) {
     static const GemmEpi no_epi = GemmEpi();
     const GemmEpi& ep = epi ? *epi : no_epi;
 #define CG_GROUP_LAUNCH(...)                                                                                                     \
     do {                                                                                                                          \
-        CG_HIP(hipFuncSetAttribute((const void*)beaver_gemm_group_kernel<NT, WAVES, __VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        if (int rc_lds_ = cg_ensure_dynamic_lds((const void*)beaver_gemm_group_kernel<NT, WAVES, __VA_ARGS__>, (int)lds)) return rc_lds_; \
         hipLaunchKernelGGL((beaver_gemm_group_kernel<NT, WAVES, __VA_ARGS__>), dim3((unsigned)wgs), dim3(WAVES * 64), lds, ctx->stream, g, ep);         \
     } while (0)
-    if (prea && pre && !splitk && !epi) {                    // both halves of the A fragment come as images: no producer arithmetic at all
+    if (dealt) {                                             // (whole-K form, even K: cognn_beaver_gemm_close_group_u64 passes `dealt` for nothing else)
+        if (pre) { if (full) CG_GROUP_LAUNCH(true, true, true, false, false, false, true); else CG_GROUP_LAUNCH(false, true, true, false, false, false, true); }
+        else if (full) CG_GROUP_LAUNCH(true, true, false, false, false, false, true);
+        else CG_GROUP_LAUNCH(false, true, false, false, false, false, true);
+    }
+    else if (prea && pre && !splitk && !epi) {               // both halves of the A fragment come as images: no producer arithmetic at all
         if (full) CG_GROUP_LAUNCH(true, true, true, false, false, true); else CG_GROUP_LAUNCH(false, true, true, false, false, true);
     }
     else if (epi) {                                          // (whole-K form only)
@@ -2047,7 +2057,7 @@ extern "C" int cognn_beaver_gemm_close_group_u64(cognn_ctx* ctx, const cognn_gem
     for (int32_t j = 0; j < count; ++j) { any_dealt = any_dealt || jobs[j].A_dealt != nullptr; nepi_any = nepi_any || jobs[j].epilogue != nullptr; }
     // every job brings its fragment-ordered image (else none is used); the image form reads no operand element by element, so an odd K
     // (Cora's 1433, CiteSeer's 3703 features) is fine - unless a dealt mask is streamed too, whose vector loads assume an even K
-    const bool pre = npre == count && count > 0 && (K % 2 == 0 || !any_dealt);
+    const bool pre = npre == count && count > 0;
     int nprea = 0;
     for (int32_t j = 0; j < count; ++j) if (jobs[j].A_presplit) ++nprea;
     // the masks' image too (every job or none; whole-K form, see launch_group) - for more than one column tile only: at N <= 16 the product
@@ -2058,6 +2068,11 @@ extern "C" int cognn_beaver_gemm_close_group_u64(cognn_ctx* ctx, const cognn_gem
     // or - few row tiles, or a K too long for LDS: the dataset-sized graphs - workgroups take K ranges and add partial tiles
     // into the zeroed outputs (split K).
     const bool whole_k = group_whole_k(N, K, tiles_all);
+    // the dealt mask is streamed by the whole-K form with an even K and no chain epilogue, when every job brings one; any other form
+    // regenerates the mask - the same values (a dealt stream holds exactly what the counter PRNG yields)
+    int ndealt = 0;
+    for (int32_t j = 0; j < count; ++j) if (jobs[j].A_dealt) ++ndealt;
+    const bool dealt = ndealt == count && count > 0 && whole_k && K % 2 == 0 && !nepi_any;
     const bool grouped = !no_group && count > 0 && N <= kFusedBN && K >= 1 && aligned && tiles_all > 0;
     int nepi = 0;
     for (int32_t j = 0; j < count; ++j) if (jobs[j].epilogue) ++nepi;
@@ -2123,7 +2138,7 @@ extern "C" int cognn_beaver_gemm_close_group_u64(cognn_ctx* ctx, const cognn_gem
         d.Z = (u64*)J.Z; d.E0 = (const u64*)J.E0; d.E1 = (const u64*)J.E1; d.F0 = (const u64*)J.F0; d.F1 = (const u64*)J.F1;
         d.Epl = pre ? (const u64x2*)J.E_presplit : nullptr;
         d.Apl = prea ? (const u64x2*)J.A_presplit : nullptr;
-        d.Amask = (const u64*)J.A_dealt;
+        d.Amask = dealt ? (const u64*)J.A_dealt : nullptr;
         d.keyA = J.keys.k[J.p == 0 ? COGNN_SL_A0 : COGNN_SL_A1]; d.keyB = J.keys.k[J.p == 0 ? COGNN_SL_B0 : COGNN_SL_B1];
         d.p = J.p; d.M = (int)J.M; d.tiles = tiles;
         if (whole_k) {
@@ -2147,10 +2162,10 @@ extern "C" int cognn_beaver_gemm_close_group_u64(cognn_ctx* ctx, const cognn_gem
     const bool keven = (K % 2 == 0);
     int rc;
     const GemmEpi* ep = nepi ? &epi : nullptr;
-    if (NT == 1) rc = launch_group<1, 4>(ctx, g, wg_end, lds, full, keven, pre, !whole_k, ep, prea);
-    else if (NT == 2) rc = launch_group<2, 8>(ctx, g, wg_end, lds, full, keven, pre, !whole_k, ep, prea);
-    else if (NT == 3) rc = launch_group<3, 8>(ctx, g, wg_end, lds, full, keven, pre, !whole_k, ep, prea);
-    else rc = launch_group<4, 8>(ctx, g, wg_end, lds, full, keven, pre, !whole_k, ep, prea);
+    if (NT == 1) rc = launch_group<1, 4>(ctx, g, wg_end, lds, full, keven, pre, !whole_k, ep, prea, dealt);
+    else if (NT == 2) rc = launch_group<2, 8>(ctx, g, wg_end, lds, full, keven, pre, !whole_k, ep, prea, dealt);
+    else if (NT == 3) rc = launch_group<3, 8>(ctx, g, wg_end, lds, full, keven, pre, !whole_k, ep, prea, dealt);
+    else rc = launch_group<4, 8>(ctx, g, wg_end, lds, full, keven, pre, !whole_k, ep, prea, dealt);
     if (rc || raw) return rc;
     for (int32_t j = 0; j < count; ++j) {                      // C_p joins here when the caller did not ask for the raw product
         const cognn_gemm_job& J = jobs[j];
@@ -2223,13 +2238,13 @@ extern "C" int cognn_beaver_gemm_close_group_tn_u64(cognn_ctx* ctx, const cognn_
 #define CG_TNG_LAUNCH(NT_, W_)                                                                                                           \
     do {                                                                                                                                  \
         if (prea) {                                                                                                                       \
-            CG_HIP(hipFuncSetAttribute((const void*)beaver_gemm_tn_group_kernel<NT_, W_, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            if (int rc_lds_ = cg_ensure_dynamic_lds((const void*)beaver_gemm_tn_group_kernel<NT_, W_, false, true>, (int)lds)) return rc_lds_; \
             hipLaunchKernelGGL((beaver_gemm_tn_group_kernel<NT_, W_, false, true>), dim3((unsigned)wg_end), dim3(W_ * 64), lds, ctx->stream, g);       \
         } else if (two) {                                                                                                                 \
-            CG_HIP(hipFuncSetAttribute((const void*)beaver_gemm_tn_group_kernel<NT_, W_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            if (int rc_lds_ = cg_ensure_dynamic_lds((const void*)beaver_gemm_tn_group_kernel<NT_, W_, true>, (int)lds)) return rc_lds_; \
             hipLaunchKernelGGL((beaver_gemm_tn_group_kernel<NT_, W_, true>), dim3((unsigned)wg_end), dim3(W_ * 64), lds, ctx->stream, g);              \
         } else {                                                                                                                          \
-            CG_HIP(hipFuncSetAttribute((const void*)beaver_gemm_tn_group_kernel<NT_, W_, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            if (int rc_lds_ = cg_ensure_dynamic_lds((const void*)beaver_gemm_tn_group_kernel<NT_, W_, false>, (int)lds)) return rc_lds_; \
             hipLaunchKernelGGL((beaver_gemm_tn_group_kernel<NT_, W_, false>), dim3((unsigned)wg_end), dim3(W_ * 64), lds, ctx->stream, g);             \
         }                                                                                                                                 \
     } while (0)

@@ -34,6 +34,13 @@ class RcclExchange:
             raise RuntimeError(self.lib.cognn_exchange_last_error().decode())
         return {"rounds": r.value, "bytes_sent": s.value, "bytes_received": v.value, "comm_ms": ms.value}
 
+    def ranks(self):
+        """(ncclCommCount, ncclCommUserRank, sum of an all-reduce of ones over the communicator); collective."""
+        c = ctypes.c_int32(); r = ctypes.c_int32(); ones = ctypes.c_int64()
+        if self.lib.cognn_rccl_exchange_ranks(self.h, ctypes.byref(c), ctypes.byref(r), ctypes.byref(ones)) != 0:
+            raise RuntimeError(self.lib.cognn_exchange_last_error().decode())
+        return c.value, r.value, ones.value
+
     def barrier(self):
         if self.lib.cognn_rccl_exchange_barrier(self.h) != 0:
             raise RuntimeError(self.lib.cognn_exchange_last_error().decode())

@@ -67,6 +67,7 @@ _EXCHANGE_SIGNATURES = {
     "cognn_rccl_exchange_stats": (ctypes.c_int, [_P, ctypes.POINTER(_L), ctypes.POINTER(_L), ctypes.POINTER(_L)]),
     "cognn_rccl_exchange_time": (ctypes.c_int, [_P, ctypes.POINTER(_D)]),
     "cognn_rccl_exchange_barrier": (ctypes.c_int, [_P]),
+    "cognn_rccl_exchange_ranks": (ctypes.c_int, [_P, ctypes.POINTER(_I), ctypes.POINTER(_I), ctypes.POINTER(_L)]),
 }
 RCCL_ID_BYTES = 128
 

@@ -17,6 +17,7 @@
 #include <cstring>
 #include <functional>
 #include <map>
+#include <mutex>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -38,7 +39,9 @@ struct EngineError : std::runtime_error {
     using std::runtime_error::runtime_error;
 };
 
-enum { T_AGG = 0, T_PART = 1, T_GEMM = 2, T_PH_PRESCATTER = 3, T_PH_MP = 4, T_PH_GATHER = 5, T_PH_APPLY = 6, T_PH_WAVG = 7, T_GEMM_EPI = 8 };
+// T_AGG / T_AGG_LAB: the aggregate launches of the message-passing rounds at the first forward round's width (hidden_dim) and at the
+// other width (num_labels) - two different kernels in the fused form (pair chain epilogue / prediction-layer epilogue)
+enum { T_AGG = 0, T_PART = 1, T_GEMM = 2, T_PH_PRESCATTER = 3, T_PH_MP = 4, T_PH_GATHER = 5, T_PH_APPLY = 6, T_PH_WAVG = 7, T_GEMM_EPI = 8, T_AGG_LAB = 9 };
 
 struct Side {
     int owner = 0, p = 0, n = 0;
@@ -163,7 +166,8 @@ struct cognn_engine {
     std::vector<std::vector<double>> hostFeat;
     std::vector<std::vector<int32_t>> hostLabels;
     std::vector<double> w0, w1;
-    double algo[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    double algo[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    int agg_timer = T_AGG;                          // which of the two aggregate timers the current round's launches count under
     u64* wa[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // weight-averaging temporaries
     u64* wa_recv[2] = {nullptr, nullptr};                                    // [world x wa_stride] each
     size_t wa_stride = 0;                                                     // even element count: every rank's slot is 16-byte aligned
@@ -1102,14 +1106,14 @@ void message_passing(cognn_engine* E, int F, int64_t it, bool open_scale) {
         }
     }
     auto aggregate = [&](const u64* base, const uint32_t* rowptr, const uint32_t* col, int64_t edges, bool last) {
-        if (E->timing) BE(cognn_timer_begin(E->ctx, T_AGG));
+        if (E->timing) BE(cognn_timer_begin(E->ctx, E->agg_timer));
         if (last && !sb.empty())
             BE(cognn_gather_csr_open_u64(E->ctx, E->aggOut, base, E->table, rowptr, col, E->aggRows, F, (int32_t)sb.size(), sb.data(), se.data(), sk.data()));
         else
             BE(cognn_gather_csr_u64(E->ctx, E->aggOut, base, E->table, rowptr, col, E->aggRows, F));
         if (E->timing) {
-            BE(cognn_timer_end(E->ctx, T_AGG));
-            E->algo[T_AGG] += 8.0 * F * ((double)edges + 2.0 * E->aggRows) + 4.0 * edges + 4.0 * (E->aggRows + 1);
+            BE(cognn_timer_end(E->ctx, E->agg_timer));
+            E->algo[E->agg_timer] += 8.0 * F * ((double)edges + 2.0 * E->aggRows) + 4.0 * edges + 4.0 * (E->aggRows + 1);
         }
     };
     const bool split = E->world > 1 && E->remEdges > 0;
@@ -1199,23 +1203,23 @@ void message_passing_fused(cognn_engine* E, int F, int64_t it, bool scale, bool 
         // several ranks: both exchange rounds travel while the entries that read rows held here are aggregated (plain launch into aggOut);
         // the launch over the received rows (co-share replicas, partial-sum inbox) then starts from those sums and carries the epilogue
         mp_exchange(E, F, const_cast<u64*>(table));
-        if (E->timing) BE(cognn_timer_begin(E->ctx, T_AGG));
+        if (E->timing) BE(cognn_timer_begin(E->ctx, E->agg_timer));
         BE(cognn_gather_csr_u64(E->ctx, E->aggOut, table, table, E->agg_rowptr, E->agg_col, E->aggRows, F));
         if (E->timing) {
-            BE(cognn_timer_end(E->ctx, T_AGG));
-            E->algo[T_AGG] += 8.0 * F * ((double)E->aggEdges + 2.0 * E->aggRows) + 4.0 * E->aggEdges + 4.0 * (E->aggRows + 1);
+            BE(cognn_timer_end(E->ctx, E->agg_timer));
+            E->algo[E->agg_timer] += 8.0 * F * ((double)E->aggEdges + 2.0 * E->aggRows) + 4.0 * E->aggEdges + 4.0 * (E->aggRows + 1);
         }
         exchange_wait(E);
     }
     const bool split = E->world > 1;
     const double edges = split ? (double)E->remEdges : (double)E->aggEdges;
-    if (E->timing) BE(cognn_timer_begin(E->ctx, T_AGG));
+    if (E->timing) BE(cognn_timer_begin(E->ctx, E->agg_timer));
     BE(cognn_gather_pair_chain_base_u64(E->ctx, table, split ? E->aggOut : nullptr, split ? E->rem_rowptr : E->agg_rowptr, split ? E->rem_col : E->agg_col, F,
                                         gp.data(), (int32_t)gp.size()));
     if (E->timing) {
-        BE(cognn_timer_end(E->ctx, T_AGG));
+        BE(cognn_timer_end(E->ctx, E->agg_timer));
         // source row per entry, base row per output row, u32 col / rowptr + what the epilogue writes
-        E->algo[T_AGG] += 8.0 * F * (edges + (double)E->aggRows) + 4.0 * edges + 4.0 * (E->aggRows + 1) + out_bytes;
+        E->algo[E->agg_timer] += 8.0 * F * (edges + (double)E->aggRows) + 4.0 * edges + 4.0 * (E->aggRows + 1) + out_bytes;
     }
     for (auto& s : E->sides) {
         s.cur = relu_follows ? s.h1 : softmax_follows ? s.buf[0] : s.buf[1];
@@ -1463,6 +1467,7 @@ void run_iteration(cognn_engine* E, int64_t it) {
         // ---- Scatter / PreMerge / Gather ----
         const bool gscale = (it + 1) % I.ep != 0;          // gcn.h:470
         const bool fuse_open = gscale && E->sides.size() <= 32;
+        E->agg_timer = (I.e == I.f - 1 || I.e == I.f + 1) ? T_AGG_LAB : T_AGG;   // the label-wide rounds of an epoch (widths {hid, lab, -, lab, -, hid})
         relu_opened = false;
         if (can_fuse_gather_chain(E, F)) {                 // (no scale <=> last iteration of an epoch, a backward one)
             // the scale (and ReLU) of the co-located pairs rides in the aggregate launch's epilogue; in a backward iteration
@@ -2044,6 +2049,10 @@ void alloc_sides(cognn_engine* E) {
 }
 
 std::vector<double> glorot(int d0, int d1) {               // gcn.h:838-852, libc rand() re-seeded per matrix
+    // libc's generator is ONE state per process: two engines starting side by side (one per host thread) would interleave their
+    // srand / rand sequences and end up with different weights - the whole sequence of a matrix runs under one lock
+    static std::mutex libc_rand_mu;
+    std::lock_guard<std::mutex> lock(libc_rand_mu);
     std::vector<double> w((size_t)d0 * d1);
     std::srand(42);
     const double limit = std::sqrt(6.0 / (d0 + d1));
@@ -2504,13 +2513,13 @@ int cognn_engine_enable_timing(cognn_engine* E, int32_t on) {
         if (!E) throw EngineError("null engine");
         E->timing = on != 0;
         BE(cognn_timer_reset(E->ctx));
-        E->algo[0] = E->algo[1] = E->algo[2] = E->algo[T_GEMM_EPI] = 0;
+        E->algo[0] = E->algo[1] = E->algo[2] = E->algo[T_GEMM_EPI] = E->algo[T_AGG_LAB] = 0;
     });
 }
 int cognn_engine_get_timing(cognn_engine* E, int32_t kind, int64_t* launches, double* total_ms, double* algo) {
     return guard([&] {
-        if (!E || kind < 0 || kind > 3) throw EngineError("cognn_engine_get_timing: bad arguments");
-        const int t = kind == 3 ? T_GEMM_EPI : kind;
+        if (!E || kind < 0 || kind > 4) throw EngineError("cognn_engine_get_timing: bad arguments");
+        const int t = kind == 3 ? T_GEMM_EPI : kind == 4 ? T_AGG_LAB : kind;
         BE(cognn_timer_read(E->ctx, t, launches, total_ms));
         if (algo) *algo = E->algo[t];
     });

@@ -158,7 +158,8 @@ int cognn_engine_get_weight(cognn_engine* e, int32_t owner, int32_t side, int32_
 /* metrics of the last prediction layer of a hosted party: out[0..4] = accuracies (full, train, border-train,
  * test, border-test), out[5] = cross-entropy loss, out[6] = #vertices, out[7] = #border (gcn.h:620-632) */
 int cognn_engine_get_metrics(cognn_engine* e, int32_t party, double* out8);
-/* kernel timing (HIP events on the engine's stream). kind: 0 gather-aggregate launches, 1 gather-partials launches, 2 the
+/* kernel timing (HIP events on the engine's stream). kind: 0 gather-aggregate launches of the hidden-wide message-passing rounds,
+ * 4 those of the label-wide rounds (a different kernel when the prediction layer rides in the launch), 1 gather-partials launches, 2 the
  * Beaver product phase of a GAS iteration (all hosted sides' products; they overlap each other on two launch lanes, so the unit
  * timed is the phase, `launches` = number of phases; the launches that are products and nothing else), 3 the product launches that
  * carry the co-located pairs' truncation chain as their epilogue (cognn_gemm_job::epilogue; algo = the product's operations) */

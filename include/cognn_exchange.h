@@ -49,6 +49,9 @@ int cognn_rccl_exchange_stats(cognn_rccl_exchange* x, int64_t* rounds, int64_t* 
 /* total time the p2p groups of all rounds so far took on the communication stream (HIP events around every group; waits
  * for the stream to drain).  bytes / this time = the achieved xGMI rate of this rank. */
 int cognn_rccl_exchange_time(cognn_rccl_exchange* x, double* comm_ms);
+/* what the communicator itself says about the job: ncclCommCount, ncclCommUserRank and the sum of an all-reduce of ones over it
+ * (= the number of ranks that took part) - bench.py prints them so that a multi-GPU record shows RCCL saw N ranks.  Collective. */
+int cognn_rccl_exchange_ranks(cognn_rccl_exchange* x, int32_t* comm_count, int32_t* comm_rank, int64_t* ones_summed);
 /* an all-ranks barrier on the communication stream followed by a host wait (end-of-run hand-shake, sendFinish/recvFinish
  * of ss_...h:270-272) */
 int cognn_rccl_exchange_barrier(cognn_rccl_exchange* x);

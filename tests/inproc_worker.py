@@ -2,7 +2,8 @@
 `world`) and an in-process mailbox transport.  A GPU box admits only a handful of processes on its card, so this is how the
 north-star layout - 8 parties, one per rank, world 8 (the reference's k x k mesh, include/engine.h:157-201) - runs the real HIP
 kernels on one GPU; it also puts eight engines / contexts side by side in one address space (nothing process-global may differ
-between them: dealer keys carry the epoch salt, errors are thread-local).  Output format = tests/multirank_worker.py's, one file
+between them: dealer keys carry the epoch salt, errors are thread-local, libc's rand() - the Glorot initialisation - runs under a lock;
+that last one was found by this worker: two engines interleaving srand(42) / rand() started from different weights).  Output format = tests/multirank_worker.py's, one file
 per rank."""
 import ctypes
 import json
@@ -21,6 +22,7 @@ sys.path.insert(0, os.path.join(ROOT, "oracle"))
 def make_mailbox_exchange(rank, boxes, device, wrap, stats):
     """(begin, wait, wait_round): a send is copied out of the engine's buffer at begin() and posted to the (rank -> peer) queue;
     receives are filled at wait() in issue order - messages between two ranks match by order, as RCCL matches them."""
+    import torch
     from cognn_amd.engine_api import EXCHANGE_FN, EXCHANGE_WAIT_FN, EXCHANGE_WAIT_ROUND_FN
     pending = []                                            # rounds begun and not completed: (round number, [(ptr, bytes, peer)])
     count = [0]
@@ -31,7 +33,12 @@ def make_mailbox_exchange(rank, boxes, device, wrap, stats):
             for i in range(n):
                 x = xfers[i]
                 if x.is_send:
-                    boxes[(rank, int(x.peer))].put(wrap(x.ptr, x.bytes, device).cpu().clone())
+                    # snapshot at begin(); on the GPU the message stays on the device (a device-to-device copy on this rank's
+                    # stream, complete before it is posted - what a peer-to-peer transport does)
+                    snap = wrap(x.ptr, x.bytes, device).clone()
+                    if device.type == "cuda":
+                        torch.cuda.current_stream().synchronize()
+                    boxes[(rank, int(x.peer))].put(snap)
                     stats["bytes"] += int(x.bytes)
                 else:
                     recvs.append((int(x.ptr), int(x.bytes), int(x.peer)))
@@ -51,6 +58,8 @@ def make_mailbox_exchange(rank, boxes, device, wrap, stats):
                     data = boxes[(peer, rank)].get(timeout=300)
                     assert data.numel() == nbytes, (rank, peer, data.numel(), nbytes)
                     wrap(ptr, nbytes, device).copy_(data)
+            if device.type == "cuda":
+                torch.cuda.current_stream().synchronize()
             return 0
         except Exception as ex:  # noqa: BLE001
             print("mailbox exchange (wait) failed on rank %d: %r" % (rank, ex), flush=True)
@@ -86,14 +95,21 @@ def main():
 
     def rank_main(rank):
         try:
+            stream = 0
             if hip:
                 torch.cuda.set_device(0)
-            eng = Engine(k, src, dst, part, gp, seed=cfg["seed"], variant=cfg["variant"], rank=rank, world=world, stream=0, placement=placement)
+                if cfg.get("private_streams", True):        # one stream per rank (as every rank of a real run has): the engine's launches and
+                    ts = torch.cuda.Stream(device=0)        # the transport's copies of this thread are ordered on it, not on the shared null stream
+                    torch.cuda.set_stream(ts)
+                    stream = ts.cuda_stream
+            eng = Engine(k, src, dst, part, gp, seed=cfg["seed"], variant=cfg["variant"], rank=rank, world=world, stream=stream, placement=placement)
             eng.set_exchange(make_mailbox_exchange(rank, boxes, device, cdist._wrap, stats[rank]))
             if cfg.get("chunks", 1) > 1:
                 eng.exchange_chunks(cfg["chunks"])
             eng.set_global_data(feats, labels)
             eng.start()
+            if "pair_fusion" in cfg:
+                eng.pair_fusion(bool(cfg["pair_fusion"]))
             if cfg.get("exchanged_openings"):
                 eng.public_openings(False)
             if cfg.get("packed_openings") is not None and hasattr(eng, "packed_openings"):

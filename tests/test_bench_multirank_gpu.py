@@ -35,3 +35,29 @@ def test_bench_two_ranks_over_gloo(chunks, placement):
         assert v["placement"] == "vertex-set" and v["ms_per_step"] > 0 and v["check"]["cross_path_identical"] is True, v
     else:
         assert "vertex_set_placement" not in d
+
+
+def test_bench_started_bare_launches_its_own_ranks():
+    """`python bench.py --gpus 2` without torch.distributed.run (no WORLD_SIZE in the environment) - how the driver starts the N = 1
+    bench: the process becomes the launcher before it touches a GPU, starts the two ranks as child processes and relays rank 0's
+    single JSON line; the record shows how many ranks the transport's own all-reduce saw."""
+    env = {key: val for key, val in os.environ.items() if key not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["COGNN_BENCH_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--workload", "small",
+                        "--no-placement-leg"], env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-1500:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["check"]["cross_path_identical"] is True
+    assert d["exchange"]["ranks"] == 2 and d["exchange"]["allreduce_of_ones"] == 2
+    assert d["switches"].get("COGNN_BENCH_BACKEND") == "gloo"
+
+
+def test_bench_started_bare_reports_a_failing_rank():
+    """... and a rank that dies takes the launcher's exit code with it (no JSON line, the other rank is stopped)."""
+    env = {key: val for key, val in os.environ.items() if key not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["COGNN_BENCH_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--steps", "1", "--warmup", "0", "--workload", "small"],
+                       env=env, capture_output=True, text=True, timeout=300, cwd=ROOT)       # 8 parties do not divide over 3 ranks
+    assert r.returncode != 0 and not [l for l in r.stdout.splitlines() if l.startswith("{")]

@@ -30,7 +30,7 @@ def _run(cfg, world, tmp_path):
     port = _free_port()
     procs = []
     if cfg.get("inproc"):                                  # the ranks as threads of ONE process over a mailbox transport (tests/inproc_worker.py)
-        env = dict(os.environ, OMP_NUM_THREADS="1")
+        env = dict(os.environ, OMP_NUM_THREADS="1", **cfg.get("env", {}))
         r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "inproc_worker.py"), json.dumps(dict(cfg, world=world))], env=env,
                            capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
@@ -243,3 +243,12 @@ def test_mismatched_configuration_fails_fast(tmp_path):
     outs = [p.communicate(timeout=120)[0] for p in procs]
     assert [p.returncode for p in procs] == [7, 7], outs
     assert all("runs a different configuration" in o for o in outs), outs
+
+
+def test_engines_starting_side_by_side_get_the_reference_weights(tmp_path):
+    """Four engines started at the same moment in one process (threads): the Glorot weights come from libc's srand(42) / rand()
+    (gcn.h:838-852), ONE generator state per process - the engine runs each matrix's sequence under a lock, so every rank starts from
+    the weights the oracle has (wide matrices: tens of thousands of rand() calls per matrix, which interleaved before the lock)."""
+    cfg = dict(BASE, k=4, V=64, Eu=150, hid=64, lab=8, variant="optimize-gcn-inference", iters=2, inproc=True)
+    cfg["in"] = 400
+    _check(cfg, 4, tmp_path)

@@ -43,7 +43,10 @@ def main():
         head = ""
     # "build": what the passes were collected on - the tag of the gpurun directory and the commit checked out when the raw
     # outputs were reduced (the builder's PMC pass, not a measurement of whoever reads the number later)
-    pmc = {"method": __doc__.split("usage")[0].strip().split("\n", 3)[-1].strip(), "build": {"tag": os.path.basename(os.path.normpath(src)), "git_head": head}}
+    sys.path.insert(0, ROOT)
+    import bench                                            # (kernel_source_hash: the same digest every bench line carries)
+    pmc = {"method": __doc__.split("usage")[0].strip().split("\n", 3)[-1].strip(),
+           "build": {"tag": os.path.basename(os.path.normpath(src)), "git_head": head, "kernel_source_hash": bench.kernel_source_hash()}}
     for wl in workloads:
         d = os.path.join(src, wl)
         if not os.path.isdir(d):
