@@ -327,14 +327,17 @@ def placement_leg(torch, dist, Engine, args, placement, backend, rank, world, lo
     return out
 
 
-def dealer_streams_leg(eng, torch, args, iters, k, digest_before):
+def dealer_streams_leg(eng, torch, args, iters, k, digest_before, minimal=False):
     """The same pass with the dealer values of the co-located pairs' chains and the A masks of the grouped products READ from
     HBM (COGNN_OPT_DEALER_STREAMS) instead of regenerated in registers: what the online phase costs when the offline phase hands
     each party its correlations in memory, as the reference's does (README.md:215-216).  Extra keys only: the headline stays the
     in-register form.  The first passes deal (materialise) the values; the timed ones read them."""
     import hashlib
     mem0 = eng.memory()[1]
-    eng.dealer_streams(True)
+    if minimal:
+        eng.dealer_minimal(True)                  # (reads the slabs the streamed leg materialised, when that leg ran first)
+    else:
+        eng.dealer_streams(True)
     for _ in range(2):
         eng.run(0, iters)
     eng.enable_timing(True)
@@ -348,8 +351,11 @@ def dealer_streams_leg(eng, torch, args, iters, k, digest_before):
     n_gemm, ms_gemm, ops_gemm = eng.timing(2)
     n_gepi, ms_gepi, ops_gepi = eng.timing(3)
     eng.enable_timing(False)
-    res = {"what": "dealer values of the pair chains (truncations, row scales, ReLUs, openings: what each party receives) and the A masks of the "
-                   "grouped products read from HBM instead of regenerated from the counter PRNG; same shares",
+    res = {"what": ("the dealer-minimal form: every party regenerates what it derives from its own seed (a_p, b_p, c_0, C_0, r_0, r'_0, opening and product "
+                    "masks) and READS only what a PRG-compressed dealer must send - party 1's corrections c_1, r_1, r'_1 and the ReLU's published g "
+                    "(7 of the 22 per-element slots of the pair chains; the products' C_1 as in every form); same shares") if minimal else
+                   ("dealer values of the pair chains (truncations, row scales, ReLUs, openings: what each party receives) and the A masks of the "
+                    "grouped products read from HBM instead of regenerated from the counter PRNG; same shares"),
            "ms_per_step": dt / args.steps * 1e3, "dealt_GB_resident": (eng.memory()[1] - mem0) / 1e9,
            "gather_avg_ms": ms_agg / max(n_agg, 1), "gather_bytes_per_launch_incl_dealt": bytes_agg / max(n_agg, 1),
            "gather_GBps_incl_dealt": (bytes_agg / 1e9) / (ms_agg / 1e3) if ms_agg > 0 else None,
@@ -649,10 +655,13 @@ def main():
         except Exception as ex:  # noqa: BLE001 - the measurement of the headline placement stands
             out["vertex_set_placement"] = {"skipped": "could not run: %s" % (str(ex)[-200:],)}
     if world == 1 and not args.no_dealer_streams and not recorded:
-        try:
-            out["dealer_streams"] = dealer_streams_leg(eng, torch, args, iters, k, out.get("check", {}).get("digest"))
-        except Exception as ex:  # noqa: BLE001 - the dealt values of a large workload may not fit
-            out["dealer_streams"] = {"skipped": "the dealt form could not run: %s" % (str(ex)[-200:],)}
+        # three forms of the same online phase side by side: masks regenerated in registers (the headline), every dealt value streamed
+        # from HBM, and the dealer-minimal form in between (only what a PRG-compressed dealer must send is read)
+        for key, minimal in (("dealer_streams", False), ("dealer_minimal", True)):
+            try:
+                out[key] = dealer_streams_leg(eng, torch, args, iters, k, out.get("check", {}).get("digest"), minimal=minimal)
+            except Exception as ex:  # noqa: BLE001 - the dealt values of a large workload may not fit
+                out[key] = {"skipped": "the dealt form could not run: %s" % (str(ex)[-200:],)}
     if "inference" not in variant and not recorded and eng is not None:
         # What a real multi-epoch run pays per epoch: the dealer (offline) phase of the epoch's Beaver products + the online epoch
         # (the timed region above replays epoch 0 with its product shares retained).  Later epochs, dealt product shares recycled

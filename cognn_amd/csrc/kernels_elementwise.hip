@@ -603,7 +603,7 @@ struct PairBatch {
     unsigned blk_end[kPairBatchMax];
     int count;
 };
-template <bool STREAM>   // STREAM: every chain of the batch brings its dealt slab (pair_chain.h)
+template <int STREAM>   // STREAM 1 / 2: every chain of the batch brings its dealt slab and reads all of it / the dealer's corrections only (pair_chain.h)
 __global__ __launch_bounds__(kThreads) void pair_chain_kernel(PairBatch b) {
     const unsigned blk = blockIdx.x;
     int seg = 0;
@@ -633,7 +633,7 @@ __global__ __launch_bounds__(kThreads) void pair_chain_kernel(PairBatch b) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const u64 idx = (u64)(i + j);
-            if (addc) { v0[j] += STREAM ? d.slab[(u64)(SB.ti + PCS_TI_C0) * (u64)d.n + idx] : cognn_prng(d.keyC0, idx); v1[j] += cc[j]; }     // TruncOpenAdd: x + C_p
+            if (addc) { v0[j] += STREAM == 1 ? d.slab[(u64)(SB.ti + PCS_TI_C0) * (u64)d.n + idx] : cognn_prng(d.keyC0, idx); v1[j] += cc[j]; }     // TruncOpenAdd: x + C_p
             if (j < w) pair_trunc<STREAM>(d, SB.ti + PCS_TI_R0, d.tiR, d.tiR0, d.tiRP0, idx, v0[j], v1[j]);
         }
     }
@@ -967,12 +967,15 @@ int cognn_pair_chain_u64(cognn_ctx* ctx, const cognn_pair_chain* chains, int32_t
     PairBatch b;
     b.count = 0;
     int nstream = 0;
-    for (int32_t c = 0; c < count; ++c) if (chains[c].dealt) ++nstream;
+    int nminimal = 0;
+    for (int32_t c = 0; c < count; ++c) { if (chains[c].dealt) ++nstream; if (chains[c].dealt && (chains[c].flags & COGNN_PC_DEALT_MINIMAL)) ++nminimal; }
     CG_REQUIRE(nstream == 0 || nstream == count, "cognn_pair_chain_u64: either every chain of a call brings its dealt values or none does");
+    CG_REQUIRE(nminimal == 0 || nminimal == count, "cognn_pair_chain_u64: COGNN_PC_DEALT_MINIMAL on every chain of a call or on none");
     auto launch = [&]() -> int {
         if (b.count == 0) return 0;
-        if (nstream) hipLaunchKernelGGL(pair_chain_kernel<true>, dim3(b.blk_end[b.count - 1]), dim3(kThreads), 0, ctx->stream, b);
-        else hipLaunchKernelGGL(pair_chain_kernel<false>, dim3(b.blk_end[b.count - 1]), dim3(kThreads), 0, ctx->stream, b);
+        if (nstream && nminimal) hipLaunchKernelGGL(pair_chain_kernel<2>, dim3(b.blk_end[b.count - 1]), dim3(kThreads), 0, ctx->stream, b);
+        else if (nstream) hipLaunchKernelGGL(pair_chain_kernel<1>, dim3(b.blk_end[b.count - 1]), dim3(kThreads), 0, ctx->stream, b);
+        else hipLaunchKernelGGL(pair_chain_kernel<0>, dim3(b.blk_end[b.count - 1]), dim3(kThreads), 0, ctx->stream, b);
         b.count = 0;
         CG_LAUNCH_CHECK();
         return 0;

@@ -170,7 +170,7 @@ __global__ void gather_softmax_zero_kernel(GatherSoftmaxBatch q, int count) {
 }
 // W: u64 per lane and step - 2 (16-byte accesses) for an even width, 1 for an odd one (7 or 3 labels)
 // SMX: the prediction layer follows as a second epilogue (LPR lanes hold a row of F <= LPR * W logits: row reductions by shuffles)
-template <int LPR, int W, bool STREAM, bool SMX = false>
+template <int LPR, int W, int STREAM, bool SMX = false>
 __device__ __forceinline__ void gather_pair_chain_body(const u64* __restrict__ table, const u64* __restrict__ base, const uint32_t* __restrict__ rowptr,
                                                        const uint32_t* __restrict__ col, int F, int ntiles, const GatherPairBatch& b,
                                                        uint32_t (&s_rp)[2][kPairTile + 1], uint32_t (&s_col)[2][kPairColCap],
@@ -324,7 +324,7 @@ __device__ __forceinline__ void gather_pair_chain_body(const u64* __restrict__ t
     }
 }
 
-template <int LPR, bool STREAM, int W = 2>   // STREAM: every pair brings the dealt slab of its chain (pair_chain.h)
+template <int LPR, int STREAM, int W = 2>   // STREAM 1 / 2: every pair brings the dealt slab of its chain, read whole / the corrections only (pair_chain.h)
 __global__ __launch_bounds__(kThreads) void gather_pair_chain_kernel(const u64* __restrict__ table, const u64* __restrict__ base,
                                                                       const uint32_t* __restrict__ rowptr, const uint32_t* __restrict__ col, int F,
                                                                       int ntiles, GatherPairBatch b) {
@@ -340,7 +340,7 @@ __global__ __launch_bounds__(kThreads) void gather_pair_softmax_kernel(const u64
     __shared__ uint32_t s_col[2][kPairColCap];
     __shared__ unsigned long long s_cnt[5];
     __shared__ double s_loss;
-    gather_pair_chain_body<LPR, W, false, true>(table, base, rowptr, col, F, ntiles, b, s_rp, s_col, &sm, s_cnt, &s_loss);
+    gather_pair_chain_body<LPR, W, 0, true>(table, base, rowptr, col, F, ntiles, b, s_rp, s_col, &sm, s_cnt, &s_loss);
 }
 // Grid of the gather kernels: one workgroup per tile up to this cap (the kernels keep their grid-stride loop).  Measured on
 // MI355X (config5, fused F = 64 launch): persistent grids lose to the hardware dispatcher - 1792 workgroups (one per slot)
@@ -504,7 +504,7 @@ int cognn_gather_pair_chain_base_u64(cognn_ctx* ctx, const uint64_t* table, cons
     GatherPairBatch b;
     GatherSoftmaxBatch sm;
     b.count = 0;
-    int ntiles = 0, nstream = 0, nsoftmax = 0;
+    int ntiles = 0, nstream = 0, nsoftmax = 0, nminimal = 0;
     for (int32_t c = 0; c < count; ++c) {
         const cognn_gather_pair& p = pairs[c];
         const cognn_pair_chain& s = p.chain;
@@ -540,6 +540,7 @@ int cognn_gather_pair_chain_base_u64(cognn_ctx* ctx, const uint64_t* table, cons
         d.n = s.rows * F; d.F = (uint32_t)F; d.flags = (uint32_t)fl;
         d.slab = (const u64*)s.dealt;
         if (d.slab) ++nstream;
+        if (d.slab && (fl & COGNN_PC_DEALT_MINIMAL)) ++nminimal;
         g.a_row0 = (int)p.a_row0; g.b_row0 = (int)p.b_row0; g.rows = (int)s.rows;
         ntiles += (int)((s.rows + kPairTile - 1) / kPairTile);
         g.tile_end = ntiles;
@@ -549,6 +550,7 @@ int cognn_gather_pair_chain_base_u64(cognn_ctx* ctx, const uint64_t* table, cons
     const int lpr = pick_lpr(odd ? (int)F : (int)(F / 2));
     dim3 grid((unsigned)gather_grid(ntiles)), block(kThreads);
     CG_REQUIRE(nstream == 0 || nstream == b.count, "cognn_gather_pair_chain_u64: either every pair brings its dealt values or none does");
+    CG_REQUIRE(nminimal == 0 || (nminimal == b.count && !odd), "cognn_gather_pair_chain_u64: COGNN_PC_DEALT_MINIMAL on every pair or on none (even widths)");
     CG_REQUIRE(nsoftmax == 0 || nsoftmax == b.count, "cognn_gather_pair_chain_u64: either every pair brings its softmax jobs or none does");
     if (nsoftmax) {
         hipLaunchKernelGGL(gather_softmax_zero_kernel, dim3(1), dim3(64), 0, ctx->stream, sm, b.count);
@@ -568,10 +570,11 @@ int cognn_gather_pair_chain_base_u64(cognn_ctx* ctx, const uint64_t* table, cons
     }
 #define CG_GP_CASE(L)                                                                                                                              \
     case L:                                                                                                                                        \
-        if (odd && nstream) hipLaunchKernelGGL((gather_pair_chain_kernel<L, true, 1>), grid, block, 0, ctx->stream, (const u64*)table, (const u64*)base, rowptr, col, (int)F, ntiles, b); \
-        else if (odd) hipLaunchKernelGGL((gather_pair_chain_kernel<L, false, 1>), grid, block, 0, ctx->stream, (const u64*)table, (const u64*)base, rowptr, col, (int)F, ntiles, b);    \
-        else if (nstream) hipLaunchKernelGGL((gather_pair_chain_kernel<L, true>), grid, block, 0, ctx->stream, (const u64*)table, (const u64*)base, rowptr, col, (int)F, ntiles, b); \
-        else hipLaunchKernelGGL((gather_pair_chain_kernel<L, false>), grid, block, 0, ctx->stream, (const u64*)table, (const u64*)base, rowptr, col, (int)F, ntiles, b);        \
+        if (odd && nstream) hipLaunchKernelGGL((gather_pair_chain_kernel<L, 1, 1>), grid, block, 0, ctx->stream, (const u64*)table, (const u64*)base, rowptr, col, (int)F, ntiles, b); \
+        else if (odd) hipLaunchKernelGGL((gather_pair_chain_kernel<L, 0, 1>), grid, block, 0, ctx->stream, (const u64*)table, (const u64*)base, rowptr, col, (int)F, ntiles, b);    \
+        else if (nstream && nminimal) hipLaunchKernelGGL((gather_pair_chain_kernel<L, 2>), grid, block, 0, ctx->stream, (const u64*)table, (const u64*)base, rowptr, col, (int)F, ntiles, b); \
+        else if (nstream) hipLaunchKernelGGL((gather_pair_chain_kernel<L, 1>), grid, block, 0, ctx->stream, (const u64*)table, (const u64*)base, rowptr, col, (int)F, ntiles, b); \
+        else hipLaunchKernelGGL((gather_pair_chain_kernel<L, 0>), grid, block, 0, ctx->stream, (const u64*)table, (const u64*)base, rowptr, col, (int)F, ntiles, b);        \
         break;
     switch (lpr) {
         CG_GP_CASE(1) CG_GP_CASE(2) CG_GP_CASE(4) CG_GP_CASE(8) CG_GP_CASE(16) CG_GP_CASE(32) CG_GP_CASE(64)

@@ -52,14 +52,24 @@ inline void pair_chain_fill_keys(PairChainDev& d, const cognn_pair_chain& s) {
     d.rB1 = s.relu_keys.k[COGNN_SL_B1]; d.rC0 = s.relu_keys.k[COGNN_SL_C0]; d.rT = s.relu_keys.k[COGNN_SL_T];
 }
 
+// STREAM (how the chain gets its dealer values): 0 = every value regenerated from the counter PRNG in registers; 1 = every value read
+// from the slab (COGNN_OPT_DEALER_STREAMS: all a party receives, streamed); 2 = the dealer-minimal form: what a PRG-compressed dealer
+// must SEND is read - the correction shares of party 1 (c_1 of every element-wise Beaver triple, r_1 and r'_1 of every truncation)
+// and the published g of the ReLU - while everything a party derives from its own seed (a_p, b_p, c_0, C_0, r_0, r'_0, the
+// masks of the next opening) is regenerated.  7 of the 22 slots.  Same values in all three forms.
+//
 // dealer-assisted truncation of the pair (v0, v1 = the two sides' values before their masks are added)
-// STREAM: r_0, r_1, r'_0, r'_1 are read from the slab (slots sb .. sb + 3) instead of being derived from the three streams
-template <bool STREAM>
+// STREAM 1: r_0, r_1, r'_0, r'_1 are read from the slab (slots sb .. sb + 3) instead of being derived from the three streams
+template <int STREAM>
 __device__ __forceinline__ void pair_trunc(const PairChainDev& d, int sb, u64 kR, u64 kR0, u64 kRP0, u64 idx, u64& v0, u64& v1) {
     u64 r0, r1, rp0, rp1;
-    if (STREAM) {
+    if (STREAM == 1) {
         const u64* s = d.slab + (u64)sb * (u64)d.n + idx;
         r0 = s[0]; r1 = s[d.n]; rp0 = s[2 * d.n]; rp1 = s[3 * d.n];
+    } else if (STREAM == 2) {
+        const u64* s = d.slab + (u64)sb * (u64)d.n + idx;
+        r0 = cognn_prng(kR0, idx); rp0 = cognn_prng(kRP0, idx);
+        r1 = s[d.n]; rp1 = s[3 * d.n];
     } else {
         const u64 rfull = cognn_prng(kR, idx) & COGNN_TRUNC_MASK;
         r0 = cognn_prng(kR0, idx); r1 = rfull - r0;
@@ -80,13 +90,16 @@ __device__ __forceinline__ PairRow pair_row(const PairChainDev& d, u64 row) {
     return r;
 }
 // row scale by the shared vector (sc0, sc1) + truncation of element idx of row `rw`
-template <bool STREAM>
+template <int STREAM>
 __device__ __forceinline__ void pair_scale(const PairChainDev& d, int sb, u64 idx, const PairRow& rw, bool opened, u64& v0, u64& v1) {
     u64 a0, a1, c0m, c1m;
     const u64 b0 = rw.b0, b1 = rw.b1, g = rw.g;
-    if (STREAM) {
+    if (STREAM == 1) {
         const u64* s = d.slab + (u64)(sb + PCS_SC_A0) * (u64)d.n + idx;
         a0 = s[0]; a1 = s[d.n]; c0m = s[2 * d.n]; c1m = s[3 * d.n];
+    } else if (STREAM == 2) {
+        a0 = cognn_prng(d.sA0, idx); a1 = cognn_prng(d.sA1, idx); c0m = cognn_prng(d.sC0, idx);
+        c1m = d.slab[(u64)(sb + PCS_SC_C1) * (u64)d.n + idx];
     } else {
         a0 = cognn_prng(d.sA0, idx); a1 = cognn_prng(d.sA1, idx); c0m = cognn_prng(d.sC0, idx);
         c1m = (a0 + a1) * (b0 + b1) - c0m;
@@ -98,12 +111,18 @@ __device__ __forceinline__ void pair_scale(const PairChainDev& d, int sb, u64 id
     pair_trunc<STREAM>(d, sb + PCS_SC_R0, d.stR, d.stR0, d.stRP0, idx, v0, v1);
 }
 // masked-sign ReLU of element idx; returns the public sign
-template <bool STREAM>
+template <int STREAM>
 __device__ __forceinline__ bool pair_relu(const PairChainDev& d, int sb, u64 idx, u64& v0, u64& v1) {
     u64 a0, a1, b0, b1, c0m, c1m, g;
-    if (STREAM) {
+    if (STREAM == 1) {
         const u64* s = d.slab + (u64)sb * (u64)d.n + idx;
         a0 = s[0]; a1 = s[d.n]; b0 = s[2 * d.n]; b1 = s[3 * d.n]; c0m = s[4 * d.n]; c1m = s[5 * d.n]; g = s[6 * d.n];
+    } else if (STREAM == 2) {
+        const u64* s = d.slab + (u64)sb * (u64)d.n + idx;
+        a0 = cognn_prng(d.rA0, idx); a1 = cognn_prng(d.rA1, idx);
+        b0 = cognn_prng(d.rB0, idx); b1 = cognn_prng(d.rB1, idx);
+        c0m = cognn_prng(d.rC0, idx);
+        c1m = s[5 * d.n]; g = s[6 * d.n];
     } else {
         a0 = cognn_prng(d.rA0, idx); a1 = cognn_prng(d.rA1, idx);
         b0 = cognn_prng(d.rB0, idx); b1 = cognn_prng(d.rB1, idx);
@@ -119,9 +138,9 @@ __device__ __forceinline__ bool pair_relu(const PairChainDev& d, int sb, u64 idx
     return pos;
 }
 // the masks of the opening that follows the chain
-template <bool STREAM>
+template <int STREAM>
 __device__ __forceinline__ void pair_open_masks(const PairChainDev& d, int sb, u64 idx, u64& a0, u64& a1) {
-    if (STREAM) { const u64* s = d.slab + (u64)sb * (u64)d.n + idx; a0 = s[0]; a1 = s[d.n]; }
+    if (STREAM == 1) { const u64* s = d.slab + (u64)sb * (u64)d.n + idx; a0 = s[0]; a1 = s[d.n]; }
     else { a0 = cognn_prng(d.open_key0, idx); a1 = cognn_prng(d.open_key1, idx); }
 }
 // fills the slab of one chain: slot by slot exactly the values the PRNG forms above derive (element idx of every slot in use)

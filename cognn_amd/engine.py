@@ -152,6 +152,11 @@ class Engine:
         read from there instead of being regenerated from the counter PRNG (cognn_engine.h: COGNN_OPT_DEALER_STREAMS)."""
         _check(self.lib.cognn_engine_set_option(self.h, 5, int(on)))
 
+    def dealer_minimal(self, on=True):
+        """The corrections-only dealt form (COGNN_OPT_DEALER_STREAMS = 2): every party regenerates what it derives from its own seed and reads
+        from HBM only what a PRG-compressed dealer must send it - c_1, r_1, r'_1 and the ReLU's published g."""
+        _check(self.lib.cognn_engine_set_option(self.h, 5, 2 if on else 0))
+
     def graph_epochs(self, on=True):
         """Whole epochs per run() call are recorded once (hipGraph) and replayed (cognn_engine.h: COGNN_OPT_GRAPH_EPOCHS)."""
         _check(self.lib.cognn_engine_set_option(self.h, 6, int(on)))

@@ -129,7 +129,7 @@ struct cognn_engine {
     int64_t graph_epoch = -1;                       // the epoch the recorded graph was captured in (retained products are tied to it)
     u64 salt_now = 0;                               // the epoch salt of the iteration being issued (added to the keys on the host, or - recorded epochs - on the device)
     u64 salt_on_device = 0;                         // what cognn_set_epoch_salt last set (recorded epochs only)
-    bool dealer_streams = false;                    // COGNN_OPT_DEALER_STREAMS: dealt values of the pair chains / grouped products read from HBM
+    int dealer_streams = 0;                         // COGNN_OPT_DEALER_STREAMS: 1 = dealt values of the pair chains / grouped products read from HBM; 2 = only the dealer's corrections
     std::map<std::tuple<int, int64_t, int>, u64*> dealt;   // (owner, iteration, place) -> slab, filled at first use, kept (retain_offline)
     int64_t dealt_bytes = 0;
     double phase_s[6] = {0, 0, 0, 0, 0, 0};         // cognn_engine_get_phase_seconds
@@ -507,11 +507,12 @@ struct PairChains {
 };
 // COGNN_OPT_DEALER_STREAMS: the dealt slab of a chain / the dealt A mask of a product, materialised at first use
 enum { DEAL_GEMM_CHAIN = 0, DEAL_SCALE_CHAIN = 1, DEAL_GATHER_CHAIN = 2, DEAL_RELU_CHAIN = 3, DEAL_GEMM_A0 = 4, DEAL_GEMM_A1 = 5 };
-bool streams_on(const cognn_engine* E) { return E->dealer_streams && E->retain_offline; }
+bool streams_on(const cognn_engine* E) { return E->dealer_streams != 0 && E->retain_offline; }
 void attach_dealt(cognn_engine* E, cognn_pair_chain& c, int owner, int64_t it, int place) {
     if (!streams_on(E)) return;
     const int64_t slots = E->be->cognn_pair_chain_dealt_slots(c.flags, (c.open[0] || c.open[1]) ? 1 : 0);
     if (slots <= 0 || c.rows * c.F <= 0) return;
+    if (E->dealer_streams == 2 && (c.F & 1)) return;       // (the corrections-only form is built for the 16-byte lanes; an odd width regenerates - same values)
     auto key = std::make_tuple(owner, it, place);
     auto f = E->dealt.find(key);
     if (f == E->dealt.end()) {
@@ -521,9 +522,17 @@ void attach_dealt(cognn_engine* E, cognn_pair_chain& c, int owner, int64_t it, i
         f = E->dealt.emplace(key, slab).first;
     }
     c.dealt = f->second;
+    if (E->dealer_streams == 2) c.flags |= COGNN_PC_DEALT_MINIMAL;
+}
+// slots of a chain's slab that the launch reads per element: all of them, or (corrections-only form) r_1, r'_1 per truncation, c_1 per
+// element-wise triple, c_1 and g of the ReLU
+double dealt_slots_read(cognn_engine* E, const cognn_pair_chain& c) {
+    if (!c.dealt) return 0.0;
+    if (!(c.flags & COGNN_PC_DEALT_MINIMAL)) return (double)E->be->cognn_pair_chain_dealt_slots(c.flags, (c.open[0] || c.open[1]) ? 1 : 0);
+    return ((c.flags & COGNN_PC_TRUNC_IN) ? 2.0 : 0.0) + ((c.flags & COGNN_PC_SCALE) ? 3.0 : 0.0) + ((c.flags & COGNN_PC_RELU) ? 2.0 : 0.0);
 }
 const u64* dealt_mask(cognn_engine* E, int owner, int64_t it, int place, u64 key, int64_t elems) {
-    if (!streams_on(E) || elems <= 0) return nullptr;
+    if (!streams_on(E) || elems <= 0 || E->dealer_streams == 2) return nullptr;   // (a product's A mask is the party's own PRG stream: the corrections-only form regenerates it)
     auto k = std::make_tuple(owner, it, place);
     auto f = E->dealt.find(k);
     if (f == E->dealt.end()) {
@@ -1195,7 +1204,7 @@ void message_passing_fused(cognn_engine* E, int F, int64_t it, bool scale, bool 
         out_bytes += 8.0 * elems * ((c.out[0] ? 2 : 0) + (c.open[0] ? ((c.flags & COGNN_PC_OPEN_SUM) ? 1 : 2) : 0)) + (c.mask ? elems : 0.0);
         if (softmax_follows) out_bytes += 8.0 * elems * 2 + 4.0 * (double)s.n;      // both sides' d_out, the labels
         if (!softmax_follows) attach_dealt(E, c, s.owner, it, DEAL_GATHER_CHAIN);
-        if (c.dealt) out_bytes += 8.0 * elems * (double)E->be->cognn_pair_chain_dealt_slots(c.flags, c.open[0] ? 1 : 0);   // the dealt values it reads
+        out_bytes += 8.0 * elems * dealt_slots_read(E, c);   // the dealt values it reads
         gp.push_back(g);
     }
     if (streams_on(E)) { bool all = true; for (auto& g : gp) all = all && g.chain.dealt; if (!all) for (auto& g : gp) g.chain.dealt = nullptr; }
@@ -2444,7 +2453,10 @@ int cognn_engine_set_option(cognn_engine* E, int32_t option, int64_t value) {
         else if (option == COGNN_OPT_PAIR_FUSION) E->pair_fusion = value != 0;
         else if (option == COGNN_OPT_FORWARD_ONLY) E->forward_only = value != 0;
         else if (option == COGNN_OPT_PUBLIC_OPENINGS) E->public_openings = value != 0;
-        else if (option == COGNN_OPT_DEALER_STREAMS) E->dealer_streams = value != 0;
+        else if (option == COGNN_OPT_DEALER_STREAMS) {
+            if (value < 0 || value > 2) throw EngineError("cognn_engine_set_option: COGNN_OPT_DEALER_STREAMS takes 0, 1 (every dealt value streamed) or 2 (the dealer's corrections only)");
+            E->dealer_streams = (int)value;
+        }
         else if (option == COGNN_OPT_GRAPH_EPOCHS) {
             if (value != 0 && original(E)) throw EngineError("cognn_engine_set_option: recorded epochs are not supported for original-gcn");
             if (value != 0 && !E->graph_epochs) BE(cognn_ctx_use_private_stream(E->ctx));   // (the caller's stream may be the default stream, which cannot record)

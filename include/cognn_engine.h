@@ -118,6 +118,9 @@ int cognn_engine_offline(cognn_engine* e, int64_t iter_begin, int64_t iter_end);
  * openings) and the A masks of the grouped products are materialised in HBM the first time an iteration runs and READ from
  * there afterwards: +8 bytes per dealt value, shares bit-identical.  A measurement mode (bench.py reports it beside the
  * headline): the per-side kernels of multi-rank runs and the weight-sized operands keep regenerating theirs.
+ * Value 2 = the corrections-only form: each party regenerates whatever it derives from its own seed (a_p, b_p, c_0, C_0, r_0, r'_0,
+ * the masks of the next opening, the products' A masks) and reads only what a PRG-compressed dealer must SEND it - party 1's
+ * correction shares c_1 (element-wise triples), r_1 and r'_1 (truncations), and the ReLU's published g: 7 of the 22 slots.
  * COGNN_OPT_GRAPH_EPOCHS (default 0; single process): cognn_engine_run calls that cover whole epochs (first iteration a multiple
  * of the epoch length) run each such epoch as ONE recorded launch sequence (hipGraph): the first epoch eagerly, the second while
  * it is recorded, every later one as a replay under its own epoch salt (cognn_set_epoch_salt) - dataset-sized graphs spend

@@ -321,7 +321,10 @@ enum { COGNN_PC_TRUNC_IN = 1, COGNN_PC_SCALE = 2, COGNN_PC_RELU = 4, COGNN_PC_IN
        /* with COGNN_PC_TRUNC_IN and mask_in: the selection applies to the truncated product (mask_in[i] ? v_p : 0 on both sides after
         * the truncation) instead of the raw input - g = (p - y) . W^T truncated, then the backward ReLU' (gcn.h:702-708), then the
         * steps that follow, in one chain */
-       COGNN_PC_MASK_AFTER_TRUNC = 256 };
+       COGNN_PC_MASK_AFTER_TRUNC = 256,
+       /* with `dealt`: read only what a PRG-compressed dealer must send - party 1's correction shares (c_1 of the element-wise triples,
+        * r_1 and r'_1 of the truncations) and the ReLU's published g - and regenerate what each party derives from its own seed */
+       COGNN_PC_DEALT_MINIMAL = 512 };
 typedef struct cognn_pair_chain_s {
     const uint64_t* x[2];        /* the two sides' input shares [rows x F] */
     const uint64_t* c1;          /* side 1's dealt product share (COGNN_PC_TRUNC_IN without COGNN_PC_NO_C) */

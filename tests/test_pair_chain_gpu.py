@@ -96,6 +96,28 @@ def test_pair_chain_matches_the_two_party_oracle(ctx, flags, rows, F):
         assert np.array_equal(host(dp0), host(op0)) and np.array_equal(host(dp1), host(op1))
         if flags & RELU:
             assert np.array_equal(host(dmask, np.uint8), host(mask, np.uint8))
+        # the corrections-only form (COGNN_PC_DEALT_MINIMAL): only party 1's c_1 / r_1 / r'_1 and the ReLU's g are read - every other slot
+        # of the slab is overwritten with garbage first, the chain must not notice
+        sl = host(slab).reshape(slots, rows * F).copy()
+        keep_rows, base = set(), 0
+        if flags & TRUNC_IN:
+            keep_rows |= {base + 2, base + 4}; base += 5              # r_1, r'_1
+        if flags & SCALE:
+            keep_rows |= {base + 3, base + 5, base + 7}; base += 8     # c_1, r_1, r'_1
+        if flags & RELU:
+            keep_rows |= {base + 5, base + 6}; base += 7              # c_1, g
+        for r in range(slots):
+            if r not in keep_rows:
+                sl[r] = 0xDEADBEEFDEADBEEF
+        slab2 = dev(sl.reshape(-1))
+        if F % 2 == 0:
+            for t in (d0, d1, dp0, dp1):
+                t.zero_()
+            c.dealt = slab2.data_ptr(); c.flags = flags | 512
+            ctx.call("cognn_pair_chain_u64", ctypes.byref(c), 1)
+            assert np.array_equal(host(d0), e0) and np.array_equal(host(d1), e1)
+            assert np.array_equal(host(dp0), host(op0)) and np.array_equal(host(dp1), host(op1))
+            c.flags = flags
         c.dealt = None
         c.out[0] = out0.data_ptr(); c.out[1] = out1.data_ptr(); c.open[0] = op0.data_ptr(); c.open[1] = op1.data_ptr(); c.mask = mask.data_ptr()
     with np.errstate(over="ignore"):

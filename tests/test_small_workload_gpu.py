@@ -74,3 +74,11 @@ def test_small_workload_matches_the_oracle_on_every_row(hid):
     for P in range(k):
         assert np.array_equal(d.shares(P, 0), want[-1][P][0]) and np.array_equal(d.shares(P, 1), want[-1][P][1]), "dealer streams, party %d" % P
     d.close()
+    # ... and the corrections-only form (COGNN_OPT_DEALER_STREAMS = 2): own-seed values regenerated, c_1 / r_1 / r'_1 / g read
+    m = engine()
+    m.retain_offline(True); m.forward_only(True); m.dealer_minimal(True); m.offline(0, iters)
+    for _ in range(2):
+        m.run(0, iters)
+    for P in range(k):
+        assert np.array_equal(m.shares(P, 0), want[-1][P][0]) and np.array_equal(m.shares(P, 1), want[-1][P][1]), "dealer-minimal form, party %d" % P
+    m.close()
