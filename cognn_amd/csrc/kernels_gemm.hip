@@ -844,7 +844,9 @@ __global__ __launch_bounds__(256) void presplit_e_kernel(u64x2* out, const u64* 
 // a run-time branch the two forms shared registers and the compiler put an `s_waitcnt vmcnt(0)` in front of every PRNG block - the
 // next K step's operand loads, issued just before, had to land before any mask arithmetic started (round 3's one-column-tile
 // products ran at 35 % MFMA pipe utilisation, neither VALU- nor HBM-bound: they were waiting for their own prefetch).
-template <int NT, int WAVES, bool FULL, bool KEVEN, bool PRE = false, bool SPLITK = false, bool EPI = false, bool PREA = false, bool DEALT = false>
+// DBG (timing experiments only, `make ABLATION=1`, results wrong): 1 no operand loads, 2 no PRNG, 4 no MFMA, 8 no limb split of the mask,
+// 16 B fragments not read from LDS, 32 no epilogue
+template <int NT, int WAVES, bool FULL, bool KEVEN, bool PRE = false, bool SPLITK = false, bool EPI = false, bool PREA = false, bool DEALT = false, int DBG = 0>
 __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(2, NT == 1 ? 4 : 2)))
 void beaver_gemm_group_kernel(GemmGroup g, GemmEpi epi) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -901,8 +903,8 @@ void beaver_gemm_group_kernel(GemmGroup g, GemmEpi epi) {
     u64 nx0[8], nx1[PRE ? 1 : 8], nm0[PREA ? 8 : 1];
     const u64x2* __restrict__ Epl = J.Epl;
     const u64x2* __restrict__ Apl = J.Apl;
-    auto load_step = [&](int it) {
-        const int tile = wid + (it / nst) * nw, st = st_lo + it % nst;
+    auto load_step = [&](int tile, int st) {
+        if (DBG & 1) { for (int e = 0; e < 8; ++e) nx0[e] = (u64)(tile + st + e); return; }
         if (PRE) {                                           // fragment-ordered image: four coalesced 16-byte pieces
             const size_t off = (((size_t)tile * g.nst + st) * 4 << 6) + lane;
             const u64x2* src = Epl + off;
@@ -944,17 +946,23 @@ void beaver_gemm_group_kernel(GemmGroup g, GemmEpi epi) {
             }
         }
     };
-    load_step(0);
+    load_step(wid, st_lo);
     v4i acc[NT][8];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int s2 = 0; s2 < 8; ++s2) acc[t][s2] = v4i{0, 0, 0, 0};
+    // (tile, ls) of the current step, advanced incrementally (ls = step inside this workgroup's K range, i.e. of its LDS image).  The
+    // accumulators are cleared behind the stores of a tile's last step, in a block the compiler cannot fold away: cleared
+    // `if (ls == 0)` it turned the clearing into 32 x NT selects in EVERY step.
+    // (Two operand register sets used alternately, the loop unrolled by two, saves the 16 copies per step - and costs registers: one
+    // column tile went from 126 to 136, four column tiles spilled: 1.04 -> 3.3 ms.  Not done.)
+    int tile = wid, ls = 0;
     for (int it = 0; it < total; ++it) {
-        const int tile = wid + (it / nst) * nw, ls = it % nst, st = st_lo + ls;   // ls: step inside this workgroup's K range (its LDS image)
+        const int st = st_lo + ls;
         const int m = tile * 16 + r;
-        if (ls == 0) {
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
-#pragma unroll
-                for (int s2 = 0; s2 < 8; ++s2) acc[t][s2] = v4i{0, 0, 0, 0};
-        }
+        int ls_n = ls + 1, tile_n = tile;
+        if (ls_n == nst) { ls_n = 0; tile_n += nw; }
         u64 v[8], w[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = (!PRE && two) ? nx0[e] + nx1[PRE ? 0 : e] : nx0[e];
@@ -962,7 +970,7 @@ void beaver_gemm_group_kernel(GemmGroup g, GemmEpi epi) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) w[e] = nm0[e];
         }
-        if (it + 1 < total) load_step(it + 1);             // the next step's opened shares are in flight during this step's arithmetic
+        if (it + 1 < total) load_step(tile_n, st_lo + ls_n);   // the next step's opened shares are in flight during this step's arithmetic
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
             if (PREA) break;
@@ -972,8 +980,8 @@ void beaver_gemm_group_kernel(GemmGroup g, GemmEpi epi) {
                 if (KEVEN) { const u64x2 t = *reinterpret_cast<const u64x2*>(Amask + xc); w[2 * jj] = t.x; w[2 * jj + 1] = t.y; }
                 else { w[2 * jj] = Amask[xc]; w[2 * jj + 1] = Amask[xc + 1]; }
             } else if (FULL || st * 32 + 8 * jj < K) {      // (uniform: a ragged K - the hidden_dim = 16 layer-1 product - skips the k values past it)
-                w[2 * jj] = cognn_prng(keyA, x);
-                w[2 * jj + 1] = cognn_prng(keyA, x + 1);
+                w[2 * jj] = (DBG & 2) ? x ^ keyA : cognn_prng(keyA, x);
+                w[2 * jj + 1] = (DBG & 2) ? (x + 1) ^ keyA : cognn_prng(keyA, x + 1);
             } else {
                 w[2 * jj] = 0; w[2 * jj + 1] = 0;
             }
@@ -993,7 +1001,7 @@ void beaver_gemm_group_kernel(GemmGroup g, GemmEpi epi) {
         } else {
             split4(v, pe0); split4(v + 4, pe1);
         }
-        if (PREA) {
+        if (PREA || (DBG & 8)) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) { pm0[i] = (uint32_t)w[i]; pm1[i] = (uint32_t)(w[i] >> 32); }
         } else {
@@ -1006,13 +1014,19 @@ void beaver_gemm_group_kernel(GemmGroup g, GemmEpi epi) {
         for (int t = 0; t < NT; ++t) {
             v4i bf[8];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) bf[i] = bp[(size_t)((ls * NT + t) * 8 + i) * 64];
+            for (int i = 0; i < 8; ++i) bf[i] = (DBG & 16) ? af[(i + t + 1) & 7] : bp[(size_t)((ls * NT + t) * 8 + i) * 64];
+            if (DBG & 4) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { acc[t][i][0] ^= af[i][0] ^ bf[i][1]; acc[t][i][1] ^= af[i][2] ^ bf[i][3]; acc[t][i][2] ^= af[i][1]; acc[t][i][3] ^= af[i][3] ^ bf[i][0] ^ bf[i][2]; }
+                continue;
+            }
 #pragma unroll
             for (int i = 0; i < 8; ++i)
 #pragma unroll
                 for (int jj = 0; jj + i < 8; ++jj) acc[t][i + jj] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[i], bf[jj], acc[t][i + jj], 0, 0, 0);
         }
-        if (EPI && ls == nst - 1) {
+        if (ls == nst - 1 && !(DBG & 32)) {
+        if (EPI) {
             // the pair's chain on this tile: own accumulators = side 1's raw product, side 0's comes from the earlier launch
             const PairChainDev& d = epi.d[job];
             const bool addc = !(d.flags & COGNN_PC_NO_C), scale = (d.flags & COGNN_PC_SCALE) != 0;
@@ -1039,7 +1053,7 @@ void beaver_gemm_group_kernel(GemmGroup g, GemmEpi epi) {
                     }
                 }
             }
-        } else if (ls == nst - 1) {
+        } else {
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 const int col = t * 16 + (lane & 15);        // C/D map of the 16x16 MFMA family: col = lane & 15, row = 4 * (lane >> 4) + reg
@@ -1056,6 +1070,13 @@ void beaver_gemm_group_kernel(GemmGroup g, GemmEpi epi) {
                 }
             }
         }
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int s2 = 0; s2 < 8; ++s2) acc[t][s2] = v4i{0, 0, 0, 0};
+        asm volatile("; accumulators cleared for the next row tile");
+        }
+        tile = tile_n; ls = ls_n;
     }
 }
 
@@ -1985,6 +2006,19 @@ int launch_group(cognn_ctx* ctx, const GemmGroup& g, int wgs, size_t lds, bool f
         if (int rc_lds_ = cg_ensure_dynamic_lds((const void*)beaver_gemm_group_kernel<NT, WAVES, __VA_ARGS__>, (int)lds)) return rc_lds_; \
         hipLaunchKernelGGL((beaver_gemm_group_kernel<NT, WAVES, __VA_ARGS__>), dim3((unsigned)wgs), dim3(WAVES * 64), lds, ctx->stream, g, ep);         \
     } while (0)
+#ifdef COGNN_GEMM_ABLATION   // timing experiments only (`make ABLATION=1`): these variants compute wrong results
+    static const int dbg_env = getenv("COGNN_GEMM_DBG") ? atoi(getenv("COGNN_GEMM_DBG")) : 0;
+    if (dbg_env && pre && full && !splitk && !epi && !prea && !dealt && NT == 1) {
+        switch (dbg_env) {
+#define CG_DBG_CASE(D) case D: CG_GROUP_LAUNCH(true, true, true, false, false, false, false, D); break;
+            CG_DBG_CASE(1) CG_DBG_CASE(2) CG_DBG_CASE(4) CG_DBG_CASE(8) CG_DBG_CASE(16) CG_DBG_CASE(10) CG_DBG_CASE(11) CG_DBG_CASE(27) CG_DBG_CASE(20) CG_DBG_CASE(32)
+#undef CG_DBG_CASE
+            default: return cognn_set_error("COGNN_GEMM_DBG=%d is not built for the grouped product", dbg_env);
+        }
+        CG_LAUNCH_CHECK();
+        return 0;
+    }
+#endif
     if (dealt) {                                             // (whole-K form, even K: cognn_beaver_gemm_close_group_u64 passes `dealt` for nothing else)
         if (pre) { if (full) CG_GROUP_LAUNCH(true, true, true, false, false, false, true); else CG_GROUP_LAUNCH(false, true, true, false, false, false, true); }
         else if (full) CG_GROUP_LAUNCH(true, true, false, false, false, false, true);

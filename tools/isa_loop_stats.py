@@ -1,56 +1,60 @@
 #!/usr/bin/env python3
-"""Instruction mix of the MFMA loop of one kernel, from the gfx950 assembly hipcc -save-temps leaves behind.
-usage: tools/isa_loop_stats.py <file.s> <mangled-name-substring>  (e.g. 'beaver_gemm_group_kernelILi1ELi4ELb1ELb1ELb1ELb0ELb0ELb0E')
-Prints, for the innermost basic-block run that contains the kernel's MFMAs (from the first label before the first MFMA that is
-the target of a backward branch to the branch itself), the count of MFMA / VALU / SALU / vector-memory / LDS instructions."""
+"""Instruction mix per K step of one kernel, from the gfx950 assembly `hipcc -save-temps` leaves behind.
+usage: tools/isa_loop_stats.py <file.s> <mangled-name-substring> [mfma-per-step]
+Counts the instructions from the kernel's first MFMA to its last loop back edge, leaving out the basic blocks that store to global
+memory (the per-tile epilogues), and divides by the number of K steps in that range (MFMAs / mfma-per-step, default 36)."""
 import collections
 import re
 import sys
 
 
+def classify(op):
+    if op.startswith("v_mfma"): return "mfma"
+    if op.startswith(("global_", "buffer_", "flat_", "scratch_")): return "vmem"
+    if op.startswith("ds_"): return "lds"
+    if op.startswith("v_"): return "valu"
+    if op.startswith("s_waitcnt"): return "waitcnt"
+    if op.startswith("s_"): return "salu"
+    return "other"
+
+
 def main():
     path, key = sys.argv[1], sys.argv[2]
+    per = int(sys.argv[3]) if len(sys.argv) > 3 else 36
     txt = open(path).read().split("\n")
-    starts = [i for i, l in enumerate(txt) if l.startswith("_Z") and l.split(":")[0].find(key) >= 0 and ":" in l]
+    starts = [i for i, l in enumerate(txt) if l.startswith("_Z") and ":" in l and key in l.split(":")[0]]
     if not starts:
         sys.exit("kernel not found")
     i0 = starts[0]
     end = next(i for i in range(i0, len(txt)) if "s_endpgm" in txt[i])
     body = txt[i0:end + 1]
-    labels = {l.split(":")[0]: i for i, l in enumerate(body) if re.match(r"^\.LBB\d+_\d+:", l)}
+    vg = [l for l in txt if key in l and ".num_vgpr" in l]
     mf = [i for i, l in enumerate(body) if "v_mfma" in l]
-    print("kernel lines", len(body), "mfma", len(mf))
-    # loops: backward branches
-    loops = []
-    for i, l in enumerate(body):
-        m = re.search(r"s_cbranch_\w+\s+(\.LBB\d+_\d+)|s_branch\s+(\.LBB\d+_\d+)", l)
-        if m:
-            tgt = m.group(1) or m.group(2)
-            if tgt in labels and labels[tgt] < i:
-                loops.append((labels[tgt], i))
-    cand = [(a, b) for a, b in loops if any(a <= x <= b for x in mf)]
-    if not cand:
-        print("no loop around the MFMAs"); return
-    a, b = min(cand, key=lambda ab: ab[1] - ab[0])
-    cls = collections.Counter()
-    detail = collections.Counter()
-    for l in body[a:b + 1]:
-        t = l.strip().split()
-        if not t or t[0].startswith((".", ";")) or t[0].endswith(":"):
+    labels = {l.split(":")[0]: i for i, l in enumerate(body) if re.match(r"^\.LBB\d+_\d+:", l)}
+    back = [i for i, l in enumerate(body) for m in [re.search(r"s_c?branch\w*\s+(\.LBB\d+_\d+)", l)] if m and m.group(1) in labels and labels[m.group(1)] < i]
+    lo = min([labels[re.search(r"(\.LBB\d+_\d+)", body[i]).group(1)] for i in back if i > mf[-1]] or [mf[0]])
+    hi = max([i for i in back if i > mf[-1]] or [mf[-1]])
+    blocks, cur = [], []
+    for i in range(lo, hi + 1):
+        if re.match(r"^\.LBB\d+_\d+:", body[i]) and cur:
+            blocks.append(cur); cur = []
+        cur.append(body[i])
+    blocks.append(cur)
+    cls, detail = collections.Counter(), collections.Counter()
+    for blk in blocks:
+        ops = [l.strip().split()[0] for l in blk if l.strip() and not l.strip().startswith((".", ";")) and not l.strip().endswith(":")]
+        if any(o.startswith(("global_store", "global_atomic")) for o in ops):
+            cls["epilogue_blocks"] += 1
             continue
-        op = t[0]
-        if op.startswith("v_mfma"): c = "mfma"
-        elif op.startswith(("global_", "buffer_", "flat_", "scratch_")): c = "vmem"
-        elif op.startswith("ds_"): c = "lds"
-        elif op.startswith("v_"): c = "valu"
-        elif op.startswith("s_waitcnt"): c = "waitcnt"
-        elif op.startswith("s_"): c = "salu"
-        else: c = "other"
-        cls[c] += 1
-        if c == "valu":
-            detail[re.sub(r"_e(32|64)$", "", op)] += 1
-    print("loop lines %d..%d:" % (a, b), dict(cls))
-    print("valu detail:", detail.most_common(14))
+        for o in ops:
+            c = classify(o)
+            cls[c] += 1
+            if c == "valu":
+                detail[re.sub(r"_e(32|64)$", "", o)] += 1
+    steps = max(1, cls["mfma"] // per)
+    print("vgprs:", vg[0].split(",")[-1].strip() if vg else "?", " loop lines %d..%d, %d K steps in the loop body" % (lo, hi, steps))
+    print("per K step:", {k: round(v / steps, 1) for k, v in cls.items() if k != "epilogue_blocks"}, " epilogue blocks left out:", cls["epilogue_blocks"])
+    print("valu detail per K step:", [(k, round(v / steps, 1)) for k, v in detail.most_common(14)])
 
 
 if __name__ == "__main__":
