@@ -66,6 +66,17 @@ class GemmJob(ctypes.Structure):
                 ("E_presplit", ctypes.c_void_p), ("A_presplit", ctypes.c_void_p), ("A_dealt", ctypes.c_void_p), ("K", ctypes.c_int64), ("epilogue", ctypes.c_void_p), ("Z_zeroed", ctypes.c_int32)]
 
 
+class DealerJob(ctypes.Structure):
+    """cognn_dealer_job (include/cognn_hip.h)."""
+    _fields_ = [("C1", ctypes.c_void_p), ("keys", Keys), ("M", ctypes.c_int64)]
+
+
+class DealerTnJob(ctypes.Structure):
+    """cognn_dealer_tn_job (include/cognn_hip.h)."""
+    _fields_ = [("C1", ctypes.c_void_p), ("keys", Keys), ("M", ctypes.c_int64), ("N", ctypes.c_int64), ("K", ctypes.c_int64), ("transA", ctypes.c_int32),
+                ("scratchA", ctypes.c_void_p), ("scratchB", ctypes.c_void_p)]
+
+
 class CognnError(RuntimeError):
     pass
 
@@ -106,6 +117,7 @@ _SIGNATURES = {
     "cognn_fx_encode_f64": (_I, [_P, _P, _P, _P, _L, _L]),
     "cognn_share_split_u64": (_I, [_P, _P, _U, _P, _P, _L]),
     "cognn_prng_fill_u64": (_I, [_P, _P, _U, _L]),
+    "cognn_gemm_mask_fill_u64": (_I, [_P, _P, _U, _L]),
     "cognn_gather_csr_u64": (_I, [_P, _P, _P, _P, _P, _P, _L, _L]),
     "cognn_gather_csr_open_u64": (_I, [_P, _P, _P, _P, _P, _P, _L, _L, ctypes.c_int32, _P, _P, _P]),
     "cognn_relu_close_open_u64": (_I, [_P, _P, _P, _P, _P, _P, _P, _U, _L]),
@@ -118,6 +130,9 @@ _SIGNATURES = {
     "cognn_sum_u64": (_I, [_P, _P, _P, ctypes.c_int32, _L]),
     "cognn_fanout_u64": (_I, [_P, _P, ctypes.c_int32, _P, _L]),
     "cognn_dealer_gemm_c1_u64": (_I, [_P, _P, _KP, _L, _L, _L, _I, _P, _P]),
+    "cognn_dealer_gemm_c1_groupable": (_I, [_L, _L]),
+    "cognn_dealer_gemm_c1_group_u64": (_I, [_P, _P, ctypes.c_int32, _L, _L]),
+    "cognn_dealer_gemm_c1_tn_group_u64": (_I, [_P, _P, ctypes.c_int32]),
     "cognn_beaver_gemm_close_u64": (_I, [_P, _P, _P, _P, _P, _P, _KP, _I, _L, _L, _L, _I, _P]),
     "cognn_trunc_open_u64": (_I, [_P, _P, _P, _U, _KP, _I, _L]),
     "cognn_trunc_open_add_u64": (_I, [_P, _P, _P, _P, _KP, _KP, _I, _L]),

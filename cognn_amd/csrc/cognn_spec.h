@@ -89,6 +89,15 @@ COGNN_HD uint64_t cognn_prng(uint64_t key, uint64_t idx) {
     key += COGNN_SALT;
     return cognn_prng_z(idx ^ key, (uint32_t)(key >> 32));
 }
+/* Beaver A masks of the ring products are defined in LIMB FORM: the mask of element idx is the signed-digit reading
+ * of the PRNG word w = prng(key, idx),  a = sum_i int8(byte_i(w)) * 256^i  (mod 2^64)  =  w - (((w >> 7) & 0x0101...01) << 8).
+ * w -> a is a bijection of the 64-bit words (the signed-digit decomposition is unique), so the mask is as uniform as the word.  The
+ * product kernels split every operand into signed 8-bit limbs for the i8 MFMAs: for this mask the limbs ARE the bytes of w - the
+ * producer of the mask half of an A fragment only byte-transposes PRNG words (no bias add, no carry) - and every other user of the
+ * stream (openings X - a, the dealer's product share, operand images) pays three integer ops to form the value. */
+COGNN_HD uint64_t cognn_limb_value(uint64_t w) { return w - (((w >> 7) & 0x0101010101010101ull) << 8); }
+COGNN_HD uint64_t cognn_gemm_mask(uint64_t key, uint64_t idx);
+COGNN_HD uint64_t cognn_gemm_mask(uint64_t key, uint64_t idx) { return cognn_limb_value(cognn_prng(key, idx)); }
 COGNN_HD uint64_t cognn_derive(uint64_t key, uint64_t tag) {
     return cognn_mix64((key ^ cognn_mix64(tag + COGNN_GAMMA)) + COGNN_GAMMA);
 }

@@ -115,9 +115,10 @@ int launch_ew(cognn_ctx* ctx, int64_t n_all, F f) {
 }
 
 struct PrngFill {
-    u64* out; u64 key;
+    u64* out; u64 key; int limb;
     __device__ void operator()(int64_t i, int w) const {
         u64 v[2] = {cognn_prng(key, (u64)i), cognn_prng(key, (u64)i + 1)};
+        if (limb) { v[0] = cognn_limb_value(v[0]); v[1] = cognn_limb_value(v[1]); }
         st2(out, i, w, v);
     }
 };
@@ -131,14 +132,15 @@ struct ShareSplit {
         if (s1) st2(s1, i, w, b);
     }
 };
-struct MaskOpen {       // E = X - prng(key, logical idx)
-    u64* E; const u64* X; u64 key; int64_t rows, cols; int transposed;
+struct MaskOpen {       // E = X - prng(key, logical idx); limb: the stream is a product's A mask (limb form, cognn_gemm_mask)
+    u64* E; const u64* X; u64 key; int64_t rows, cols; int transposed; int limb;
+    __device__ u64 mask(u64 idx) const { const u64 w = cognn_prng(key, idx); return limb ? cognn_limb_value(w) : w; }
     __device__ void operator()(int64_t i, int w) const {
         u64 x[2], e[2];
         if (transposed == 3) {             // X stored [cols x rows], E written in logical [rows x cols] order (a small weight matrix)
             for (int j = 0; j < w; ++j) {
                 const u64 idx = (u64)(i + j), m = idx / (u64)cols, k = idx % (u64)cols;
-                e[j] = X[k * (u64)rows + m] - cognn_prng(key, idx);
+                e[j] = X[k * (u64)rows + m] - mask(idx);
             }
             st2(E, i, w, e);
             return;
@@ -150,7 +152,7 @@ struct MaskOpen {       // E = X - prng(key, logical idx)
                 u64 k = idx / (u64)rows, m = idx % (u64)rows;
                 idx = m * (u64)cols + k;
             }
-            e[j] = x[j] - cognn_prng(key, idx);
+            e[j] = x[j] - mask(idx);
         }
         st2(E, i, w, e);
     }
@@ -371,7 +373,7 @@ struct ReluClose {
         }
         st2(h, i, w, r);
         if (E) {
-            u64 e[2] = {r[0] - cognn_prng(key_open, (u64)i), r[1] - cognn_prng(key_open, (u64)i + 1)};
+            u64 e[2] = {r[0] - cognn_gemm_mask(key_open, (u64)i), r[1] - cognn_gemm_mask(key_open, (u64)i + 1)};   // the next product's A mask
             st2(E, i, w, e);
         }
     }
@@ -776,7 +778,11 @@ extern "C" {
 
 int cognn_prng_fill_u64(cognn_ctx* ctx, uint64_t* out, uint64_t key, int64_t n) {
     CG_REQUIRE(ctx && out && al(out), "cognn_prng_fill_u64: bad arguments");
-    return launch_ew(ctx, n, PrngFill{(u64*)out, key});
+    return launch_ew(ctx, n, PrngFill{(u64*)out, key, 0});
+}
+int cognn_gemm_mask_fill_u64(cognn_ctx* ctx, uint64_t* out, uint64_t key, int64_t n) {
+    CG_REQUIRE(ctx && out && al(out), "cognn_gemm_mask_fill_u64: bad arguments");
+    return launch_ew(ctx, n, PrngFill{(u64*)out, key, 1});
 }
 int cognn_share_split_u64(cognn_ctx* ctx, const uint64_t* fx, uint64_t key, uint64_t* s0, uint64_t* s1, int64_t n) {
     CG_REQUIRE(ctx && fx && al(fx) && al(s0) && al(s1), "cognn_share_split_u64: bad arguments");
@@ -789,7 +795,10 @@ int cognn_fx_encode_f64(cognn_ctx* ctx, const double* in, const double* rowscale
 }
 int cognn_mask_open_u64(cognn_ctx* ctx, uint64_t* E, const uint64_t* X, uint64_t key, int64_t rows, int64_t cols, int transposed) {
     CG_REQUIRE(ctx && E && X && al(E) && al(X), "cognn_mask_open_u64: bad arguments");
-    return launch_ew(ctx, rows * cols, MaskOpen{(u64*)E, (const u64*)X, key, rows, cols, transposed});
+    const int limb = (transposed & COGNN_MASK_OPEN_LIMB) ? 1 : 0;
+    transposed &= ~COGNN_MASK_OPEN_LIMB;
+    CG_REQUIRE(transposed >= 0 && transposed <= 3, "cognn_mask_open_u64: bad `transposed`");
+    return launch_ew(ctx, rows * cols, MaskOpen{(u64*)E, (const u64*)X, key, rows, cols, transposed, limb});
 }
 int cognn_add_u64(cognn_ctx* ctx, uint64_t* out, const uint64_t* a, const uint64_t* b, int64_t n) {
     CG_REQUIRE(ctx && out && a && b && al(out) && al(a) && al(b), "cognn_add_u64: bad arguments");

@@ -72,6 +72,22 @@ __device__ __forceinline__ void split4(const u64 v[4], uint32_t plane[8]) {
     plane[6] = __builtin_amdgcn_perm(d, b, 0x05040100u); plane[7] = __builtin_amdgcn_perm(d, b, 0x07060302u);
 }
 
+// The same planes for four words whose BYTES are the limbs: the limb-form Beaver A mask (cognn_spec.h, cognn_limb_value) - byte
+// transposes only, no bias add and no carry chain
+__device__ __forceinline__ void split4_limb(const u64 w[4], uint32_t plane[8]) {
+    uint32_t lo[4], hi[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { lo[j] = (uint32_t)w[j]; hi[j] = (uint32_t)(w[j] >> 32); }
+    uint32_t a = __builtin_amdgcn_perm(lo[1], lo[0], 0x05010400u), b = __builtin_amdgcn_perm(lo[1], lo[0], 0x07030602u);
+    uint32_t c = __builtin_amdgcn_perm(lo[3], lo[2], 0x05010400u), d = __builtin_amdgcn_perm(lo[3], lo[2], 0x07030602u);
+    plane[0] = __builtin_amdgcn_perm(c, a, 0x05040100u); plane[1] = __builtin_amdgcn_perm(c, a, 0x07060302u);
+    plane[2] = __builtin_amdgcn_perm(d, b, 0x05040100u); plane[3] = __builtin_amdgcn_perm(d, b, 0x07060302u);
+    a = __builtin_amdgcn_perm(hi[1], hi[0], 0x05010400u); b = __builtin_amdgcn_perm(hi[1], hi[0], 0x07030602u);
+    c = __builtin_amdgcn_perm(hi[3], hi[2], 0x05010400u); d = __builtin_amdgcn_perm(hi[3], hi[2], 0x07030602u);
+    plane[4] = __builtin_amdgcn_perm(c, a, 0x05040100u); plane[5] = __builtin_amdgcn_perm(c, a, 0x07060302u);
+    plane[6] = __builtin_amdgcn_perm(d, b, 0x05040100u); plane[7] = __builtin_amdgcn_perm(d, b, 0x07060302u);
+}
+
 // BN: output columns per workgroup (32 or 64). Waves are arranged kWavesM x (BN/32).
 template <int BN>
 __global__ __launch_bounds__(kWavesM * (BN / 32) * 64) void ring_gemm_mfma_kernel(u64* C, const u64* __restrict__ A,
@@ -446,7 +462,7 @@ void beaver_gemm_ws_kernel(u64* Z, const u64* __restrict__ E0, const u64* __rest
             }                                                                                                             \
             if (DBG & 8) { if ((v_[0] ^ w_[0]) == 0x1234567ull) Z[0] = v_[1] ^ v_[2] ^ v_[3] ^ w_[1] ^ w_[2] ^ w_[3]; continue; } \
             uint32_t pe_[8], pm_[8];                                                                                      \
-            split4(v_, pe_); split4(w_, pm_);                                                                             \
+            split4(v_, pe_); split4_limb(w_, pm_);                                                                        \
             unsigned char* d_ = dst_ + (trow + 64 * r) * 16;                                                              \
             _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                               \
                 *reinterpret_cast<uint32_t*>(d_ + i * kPlane) = pe_[i];                                                   \
@@ -612,7 +628,7 @@ __global__ __launch_bounds__(256) void beaver_gemm_d16_kernel(u64* Z, const u64*
             }
         }
         uint32_t pe0[8], pe1[8], pm0[8], pm1[8];
-        split4(v, pe0); split4(v + 4, pe1); split4(w, pm0); split4(w + 4, pm1);
+        split4(v, pe0); split4(v + 4, pe1); split4_limb(w, pm0); split4_limb(w + 4, pm1);
         v4i af[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) af[i] = v4i{(int)pe0[i], (int)pe1[i], (int)pm0[i], (int)pm1[i]};
@@ -732,7 +748,7 @@ void beaver_gemm_d16n_kernel(u64* Z, const u64* __restrict__ E0, const u64* __re
 #pragma unroll
             for (int i = 0; i < 8; ++i) { pe0[i] = (uint32_t)v[i]; pe1[i] = (uint32_t)(v[i] >> 32); pm0[i] = (uint32_t)w[i]; pm1[i] = (uint32_t)(w[i] >> 32); }
         } else {
-            split4(v, pe0); split4(v + 4, pe1); split4(w, pm0); split4(w + 4, pm1);
+            split4(v, pe0); split4(v + 4, pe1); split4_limb(w, pm0); split4_limb(w + 4, pm1);
         }
         v4i af[8];
 #pragma unroll
@@ -791,6 +807,7 @@ struct GemmGroupJob {
     const u64x2* Apl;                                        // PREA: the party's mask A_p of that operand in the same order (a mask that is dealt once)
     const u64* Amask;                                        // the party's mask A_p as dealt [M x K] (COGNN_OPT_DEALER_STREAMS): read, not regenerated
     u64 keyA, keyB;
+    u64 keyA1, keyB1, keyC0;                                 // DEAL: the other party's A / B mask keys and the C_0 key of the triple
     int p, M, tiles, wg_end;                                 // wg_end: exclusive prefix of the workgroups assigned to the jobs
     int ngroups;                                             // SPLITK: workgroups per K range (the job has ngroups x splits workgroups)
 };
@@ -846,7 +863,12 @@ __global__ __launch_bounds__(256) void presplit_e_kernel(u64x2* out, const u64* 
 // products ran at 35 % MFMA pipe utilisation, neither VALU- nor HBM-bound: they were waiting for their own prefetch).
 // DBG (timing experiments only, `make ABLATION=1`, results wrong): 1 no operand loads, 2 no PRNG, 4 no MFMA, 8 no limb split of the mask,
 // 16 B fragments not read from LDS, 32 no epilogue
-template <int NT, int WAVES, bool FULL, bool KEVEN, bool PRE = false, bool SPLITK = false, bool EPI = false, bool PREA = false, bool DEALT = false, int DBG = 0>
+// DEAL: the DEALER's product share of the same triple, C_1 = (A_0 + A_1) . (B_0 + B_1) - C_0 (cognn_dealer_gemm_c1_group_u64): both
+// halves of the A fragment are generated - limb bytes of prng(A_0 key) and of prng(A_1 key) over the same (row, k) set - against B
+// fragments that hold B_0 + B_1 in BOTH segments, and the epilogue subtracts the C_0 stream: no operand is read, nothing is
+// materialised, and the offline phase of an epoch is a handful of grouped launches on the same MFMA path as the online one.
+template <int NT, int WAVES, bool FULL, bool KEVEN, bool PRE = false, bool SPLITK = false, bool EPI = false, bool PREA = false, bool DEALT = false, int DBG = 0,
+          bool DEAL = false>
 __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(2, NT == 1 ? 4 : 2)))
 void beaver_gemm_group_kernel(GemmGroup g, GemmEpi epi) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -876,8 +898,12 @@ void beaver_gemm_group_kernel(GemmGroup g, GemmEpi epi) {
                 const int k = d16_k(st, b, (q & 1) * 4 + jj);
                 u64 x = 0;
                 if (k < K && n < N) {
-                    const u64 f = F0[(size_t)k * N + n] + (F1 ? F1[(size_t)k * N + n] : 0ull);
-                    x = seg == 0 ? cognn_prng(keyB, (u64)k * (u64)N + (u64)n) + (p == 1 ? f : 0ull) : f;
+                    if (DEAL) {
+                        x = cognn_prng(keyB, (u64)k * (u64)N + (u64)n) + cognn_prng(J.keyB1, (u64)k * (u64)N + (u64)n);
+                    } else {
+                        const u64 f = F0[(size_t)k * N + n] + (F1 ? F1[(size_t)k * N + n] : 0ull);
+                        x = seg == 0 ? cognn_prng(keyB, (u64)k * (u64)N + (u64)n) + (p == 1 ? f : 0ull) : f;
+                    }
                 }
                 v[jj] = x;
             }
@@ -904,6 +930,7 @@ void beaver_gemm_group_kernel(GemmGroup g, GemmEpi epi) {
     const u64x2* __restrict__ Epl = J.Epl;
     const u64x2* __restrict__ Apl = J.Apl;
     auto load_step = [&](int tile, int st) {
+        if (DEAL) return;                                    // (both operand halves are generated)
         if (DBG & 1) { for (int e = 0; e < 8; ++e) nx0[e] = (u64)(tile + st + e); return; }
         if (PRE) {                                           // fragment-ordered image: four coalesced 16-byte pieces
             const size_t off = (((size_t)tile * g.nst + st) * 4 << 6) + lane;
@@ -965,7 +992,7 @@ void beaver_gemm_group_kernel(GemmGroup g, GemmEpi epi) {
         if (ls_n == nst) { ls_n = 0; tile_n += nw; }
         u64 v[8], w[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = (!PRE && two) ? nx0[e] + nx1[PRE ? 0 : e] : nx0[e];
+        for (int e = 0; e < 8; ++e) v[e] = DEAL ? 0ull : (!PRE && two) ? nx0[e] + nx1[PRE ? 0 : e] : nx0[e];
         if (PREA) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) w[e] = nm0[e];
@@ -982,6 +1009,7 @@ void beaver_gemm_group_kernel(GemmGroup g, GemmEpi epi) {
             } else if (FULL || st * 32 + 8 * jj < K) {      // (uniform: a ragged K - the hidden_dim = 16 layer-1 product - skips the k values past it)
                 w[2 * jj] = (DBG & 2) ? x ^ keyA : cognn_prng(keyA, x);
                 w[2 * jj + 1] = (DBG & 2) ? (x + 1) ^ keyA : cognn_prng(keyA, x + 1);
+                if (DEAL) { v[2 * jj] = cognn_prng(J.keyA1, x); v[2 * jj + 1] = cognn_prng(J.keyA1, x + 1); }   // the other party's mask
             } else {
                 w[2 * jj] = 0; w[2 * jj + 1] = 0;
             }
@@ -995,7 +1023,9 @@ void beaver_gemm_group_kernel(GemmGroup g, GemmEpi epi) {
             }
         }
         uint32_t pe0[8], pe1[8], pm0[8], pm1[8];
-        if (PRE) {
+        if (DEAL) {
+            split4_limb(v, pe0); split4_limb(v + 4, pe1);    // (PRNG words of A_1: the bytes are the limbs)
+        } else if (PRE) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) { pe0[i] = (uint32_t)v[i]; pe1[i] = (uint32_t)(v[i] >> 32); }
         } else {
@@ -1005,7 +1035,8 @@ void beaver_gemm_group_kernel(GemmGroup g, GemmEpi epi) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) { pm0[i] = (uint32_t)w[i]; pm1[i] = (uint32_t)(w[i] >> 32); }
         } else {
-            split4(w, pm0); split4(w + 4, pm1);
+            if (DEALT) { split4(w, pm0); split4(w + 4, pm1); }      // (a dealt mask is stored as VALUES)
+            else { split4_limb(w, pm0); split4_limb(w + 4, pm1); }
         }
         v4i af[8];
 #pragma unroll
@@ -1064,8 +1095,10 @@ void beaver_gemm_group_kernel(GemmGroup g, GemmEpi epi) {
                     const long long lo = (long long)acc[t][0][q] + (long long)acc[t][1][q] * 256 + (long long)acc[t][2][q] * 65536 +
                                          (long long)acc[t][3][q] * 16777216;
                     if ((FULL || row < M) && col < N) {
-                        if (SPLITK) atomicAdd((unsigned long long*)&Z[(size_t)row * N + col], (u64)lo + ((u64)hi << 32));
-                        else Z[(size_t)row * N + col] = (u64)lo + ((u64)hi << 32);
+                        u64 val = (u64)lo + ((u64)hi << 32);
+                        if (DEAL && (!SPLITK || st_lo == 0)) val -= cognn_prng(J.keyC0, (u64)row * (u64)N + (u64)col);   // C_1 = S_A . S_B - C_0
+                        if (SPLITK) atomicAdd((unsigned long long*)&Z[(size_t)row * N + col], val);
+                        else Z[(size_t)row * N + col] = val;
                     }
                 }
             }
@@ -1294,7 +1327,7 @@ void beaver_gemm_tn_ws_kernel(u64* Z, const u64* __restrict__ E0, const u64* __r
         }                                                                                                                 \
         if (DBG & 8) { if ((v_[0] ^ w_[1] ^ bp_[2] ^ ff_[3]) == 0x1234567ull) Z[0] = v_[1] ^ w_[0] ^ bp_[0] ^ ff_[0]; break; } \
         uint32_t pe_[8], pm_[8], pb_[8], pf_[8];                                                                          \
-        split4(v_, pe_); split4(w_, pm_); split4(bp_, pb_); split4(ff_, pf_);                                             \
+        split4(v_, pe_); split4_limb(w_, pm_); split4(bp_, pb_); split4(ff_, pf_);                                        \
         unsigned char* da_ = sA + (slot_) * kStage;                                                                       \
         unsigned char* db_ = sB + (slot_) * kStage;                                                                       \
         _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                                   \
@@ -1473,7 +1506,7 @@ __device__ __forceinline__ void tn_d16_body(u64* Z, const u64* __restrict__ E0, 
                     w[e] = cognn_prng(keyA, x) & keep;
                     x += xs;
                 }
-                split4(v, pe0); split4(v + 4, pe1); split4(w, pm0); split4(w + 4, pm1);
+                split4(v, pe0); split4(v + 4, pe1); split4_limb(w, pm0); split4_limb(w + 4, pm1);
             }
             v4i af[8];
 #pragma unroll
@@ -1559,7 +1592,7 @@ __global__ __launch_bounds__(256) void presplit_tn_kernel(u64x2* out, const u64*
             u64 x = 0;
             if (m < M && k < K) {
                 if (src) x = src[(size_t)k * M + m] + (src1 ? src1[(size_t)k * M + m] : 0ull);
-                else x = cognn_prng(key, a_storage ? (u64)k * (u64)M + (u64)m : (u64)m * (u64)K + (u64)k);
+                else x = cognn_gemm_mask(key, a_storage ? (u64)k * (u64)M + (u64)m : (u64)m * (u64)K + (u64)k);   // (a product's A mask: limb form)
             }
             v[e] = x;
         }
@@ -1664,14 +1697,15 @@ int launch_tn(cognn_ctx* ctx, u64* Z, const u64* A1, const u64* A2, const u64* B
 
 // element-wise helpers used by the Beaver composites -------------------------------------------
 __global__ __launch_bounds__(256) void prng_fill2_kernel(u64* out, u64 k0, u64 k1, int64_t rows, int64_t cols, int transposed,
-                                                          int two, const u64* addend) {
-    // out (storage layout) = prng(k0, lidx) [+ prng(k1, lidx)] [+ addend]; transposed: storage [cols x rows]
+                                                          int two, const u64* addend, int limb) {
+    // out (storage layout) = prng(k0, lidx) [+ prng(k1, lidx)] [+ addend]; transposed: storage [cols x rows]; limb: the streams are
+    // Beaver A masks of a product (limb form, cognn_limb_value)
     const int64_t n = rows * cols;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         u64 idx = (u64)i;
         if (transposed == 1) { const u64 k = idx / (u64)rows, m = idx % (u64)rows; idx = m * (u64)cols + k; }   // 2: storage order
-        u64 v = cognn_prng(k0, idx);
-        if (two) v += cognn_prng(k1, idx);
+        u64 v = limb ? cognn_gemm_mask(k0, idx) : cognn_prng(k0, idx);
+        if (two) v += limb ? cognn_gemm_mask(k1, idx) : cognn_prng(k1, idx);
         if (addend) v += addend[i];
         out[i] = v;
     }
@@ -1680,11 +1714,11 @@ __global__ __launch_bounds__(256) void sub_prng_kernel(u64* out, u64 key, int64_
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) out[i] -= cognn_prng(key, (u64)i);
 }
 
-int fill(cognn_ctx* ctx, u64* out, u64 k0, u64 k1, int64_t rows, int64_t cols, int transposed, int two, const u64* addend) {
+int fill(cognn_ctx* ctx, u64* out, u64 k0, u64 k1, int64_t rows, int64_t cols, int transposed, int two, const u64* addend, int limb = 0) {
     const int64_t n = rows * cols;
     if (n <= 0) return 0;
     dim3 grid((unsigned)std::min<int64_t>((n + 255) / 256, 256 * 32));
-    hipLaunchKernelGGL(prng_fill2_kernel, grid, dim3(256), 0, ctx->stream, out, k0, k1, rows, cols, transposed, two, addend);
+    hipLaunchKernelGGL(prng_fill2_kernel, grid, dim3(256), 0, ctx->stream, out, k0, k1, rows, cols, transposed, two, addend, limb);
     CG_LAUNCH_CHECK();
     return 0;
 }
@@ -1764,7 +1798,7 @@ int cognn_dealer_gemm_c1_u64(cognn_ctx* ctx, uint64_t* C1, const cognn_keys* key
     { const int rc_flush_ = cg_flush(ctx); if (rc_flush_) return rc_flush_; }
     CG_REQUIRE(ctx && C1 && keys && scratchA && scratchB, "cognn_dealer_gemm_c1_u64: null argument");
     int rc;
-    if ((rc = fill(ctx, (u64*)scratchA, keys->k[COGNN_SL_A0], keys->k[COGNN_SL_A1], M, K, transA, 1, nullptr))) return rc;
+    if ((rc = fill(ctx, (u64*)scratchA, keys->k[COGNN_SL_A0], keys->k[COGNN_SL_A1], M, K, transA, 1, nullptr, 1))) return rc;
     if ((rc = fill(ctx, (u64*)scratchB, keys->k[COGNN_SL_B0], keys->k[COGNN_SL_B1], K, N, 0, 1, nullptr))) return rc;
     if ((rc = gemm_dispatch(ctx, (u64*)C1, (const u64*)scratchA, nullptr, (const u64*)scratchB, M, N, K, transA, 0))) return rc;
     const int64_t n = M * N;
@@ -1978,7 +2012,7 @@ int beaver_close_impl(cognn_ctx* ctx, uint64_t* Z, const uint64_t* E, const uint
     u64* Ap = (u64*)scratch;
     u64* Bp = Ap + (size_t)M * K;
     // A_p (storage layout of E), B_p (+F for p==1), Z <- C_p
-    if ((rc = fill(ctx, Ap, keys->k[p == 0 ? COGNN_SL_A0 : COGNN_SL_A1], 0, M, K, transA, 0, nullptr))) return rc;
+    if ((rc = fill(ctx, Ap, keys->k[p == 0 ? COGNN_SL_A0 : COGNN_SL_A1], 0, M, K, transA, 0, nullptr, 1))) return rc;
     if ((rc = fill(ctx, Bp, keys->k[p == 0 ? COGNN_SL_B0 : COGNN_SL_B1], 0, K, N, 0, 0, p == 1 ? (const u64*)F : nullptr))) return rc;
     if (p == 0) { if ((rc = fill(ctx, (u64*)Z, keys->k[COGNN_SL_C0], 0, M, N, 0, 0, nullptr))) return rc; }
     else CG_HIP(hipMemcpyAsync(Z, c1, (size_t)M * N * 8, hipMemcpyDeviceToDevice, ctx->stream));
@@ -1998,7 +2032,7 @@ int beaver_close_impl(cognn_ctx* ctx, uint64_t* Z, const uint64_t* E, const uint
 namespace {
 template <int NT, int WAVES>
 int launch_group(cognn_ctx* ctx, const GemmGroup& g, int wgs, size_t lds, bool full, bool keven, bool pre, bool splitk, const GemmEpi* epi, bool prea = false,
-                 bool dealt = false) {
+                 bool dealt = false, bool deal = false) {
     static const GemmEpi no_epi = GemmEpi();
     const GemmEpi& ep = epi ? *epi : no_epi;
 #define CG_GROUP_LAUNCH(...)                                                                                                     \
@@ -2006,6 +2040,13 @@ int launch_group(cognn_ctx* ctx, const GemmGroup& g, int wgs, size_t lds, bool f
         if (int rc_lds_ = cg_ensure_dynamic_lds((const void*)beaver_gemm_group_kernel<NT, WAVES, __VA_ARGS__>, (int)lds)) return rc_lds_; \
         hipLaunchKernelGGL((beaver_gemm_group_kernel<NT, WAVES, __VA_ARGS__>), dim3((unsigned)wgs), dim3(WAVES * 64), lds, ctx->stream, g, ep);         \
     } while (0)
+    if (deal) {                                              // the dealer's product share: both operand halves generated (no loads)
+        if (splitk) { if (full) CG_GROUP_LAUNCH(true, true, false, true, false, false, false, 0, true); else CG_GROUP_LAUNCH(false, true, false, true, false, false, false, 0, true); }
+        else if (full) CG_GROUP_LAUNCH(true, true, false, false, false, false, false, 0, true);
+        else CG_GROUP_LAUNCH(false, true, false, false, false, false, false, 0, true);
+        CG_LAUNCH_CHECK();
+        return 0;
+    }
 #ifdef COGNN_GEMM_ABLATION   // timing experiments only (`make ABLATION=1`): these variants compute wrong results
     static const int dbg_env = getenv("COGNN_GEMM_DBG") ? atoi(getenv("COGNN_GEMM_DBG")) : 0;
     if (dbg_env && pre && full && !splitk && !epi && !prea && !dealt && NT == 1) {
@@ -2210,6 +2251,137 @@ extern "C" int cognn_beaver_gemm_close_group_u64(cognn_ctx* ctx, const cognn_gem
         CG_LAUNCH_CHECK();
     }
     return 0;
+}
+
+// ---- the dealer's product shares of triples with a transposed left operand (the weight-gradient products): the operand fills of
+// ALL jobs in one launch (A_0 + A_1 in limb form, B_0 + B_1, and C_1 initialised to -C_0), then one K-split product per job that
+// accumulates onto it - 1 + n launches instead of 5 n -----------------------------------------------------------------------------
+namespace {
+constexpr int kFillJobsMax = 48;
+struct FillJobs {
+    u64* out[kFillJobsMax]; u64 k0[kFillJobsMax], k1[kFillJobsMax]; long long rows[kFillJobsMax], cols[kFillJobsMax];
+    int mode[kFillJobsMax];                                  // bits 0-1: transposed (prng_fill2_kernel), 4: two streams, 8: limb form, 16: negate
+    int count;
+};
+__global__ __launch_bounds__(256) void prng_fill_jobs_kernel(FillJobs f) {
+    const int j = blockIdx.y;
+    const long long rows = f.rows[j], cols = f.cols[j], n = rows * cols;
+    const int mode = f.mode[j], tr = mode & 3;
+    const u64 k0 = f.k0[j], k1 = f.k1[j];
+    u64* out = f.out[j];
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        u64 idx = (u64)i;
+        if (tr == 1) { const u64 k = idx / (u64)rows, m = idx % (u64)rows; idx = m * (u64)cols + k; }
+        u64 v = (mode & 8) ? cognn_gemm_mask(k0, idx) : cognn_prng(k0, idx);
+        if (mode & 4) v += (mode & 8) ? cognn_gemm_mask(k1, idx) : cognn_prng(k1, idx);
+        out[i] = (mode & 16) ? 0ull - v : v;
+    }
+}
+}  // namespace
+extern "C" int cognn_dealer_gemm_c1_tn_group_u64(cognn_ctx* ctx, const cognn_dealer_tn_job* jobs, int32_t count) {
+    { const int rc_flush_ = cg_flush(ctx); if (rc_flush_) return rc_flush_; }
+    CG_REQUIRE(ctx && (count == 0 || jobs) && count >= 0 && count <= kFillJobsMax / 3, "cognn_dealer_gemm_c1_tn_group_u64: bad arguments (at most %d jobs)", kFillJobsMax / 3);
+    FillJobs f;
+    memset(&f, 0, sizeof(f));
+    long long nmax = 0;
+    for (int32_t j = 0; j < count; ++j) {
+        const cognn_dealer_tn_job& J = jobs[j];
+        CG_REQUIRE(J.M >= 0 && J.N >= 0 && J.K >= 0 && J.M < (1ll << 31) && J.N < (1ll << 31) && J.K < (1ll << 31) && (J.transA == 1 || J.transA == 2),
+                   "cognn_dealer_gemm_c1_tn_group_u64: job %d: bad shape or transA", j);
+        if (J.M * J.N == 0) continue;
+        CG_REQUIRE(J.C1 && J.scratchA && J.scratchB && cg_aligned16(J.C1) && cg_aligned16(J.scratchA) && cg_aligned16(J.scratchB), "cognn_dealer_gemm_c1_tn_group_u64: job %d: null or misaligned buffer", j);
+        auto add = [&](u64* out, u64 k0, u64 k1, long long rows, long long cols, int mode) {
+            f.out[f.count] = out; f.k0[f.count] = k0; f.k1[f.count] = k1; f.rows[f.count] = rows; f.cols[f.count] = cols; f.mode[f.count] = mode;
+            nmax = std::max(nmax, rows * cols); ++f.count;
+        };
+        add((u64*)J.scratchA, J.keys.k[COGNN_SL_A0], J.keys.k[COGNN_SL_A1], J.M, J.K, (J.transA & 3) | 4 | 8);
+        add((u64*)J.scratchB, J.keys.k[COGNN_SL_B0], J.keys.k[COGNN_SL_B1], J.K, J.N, 4);
+        add((u64*)J.C1, J.keys.k[COGNN_SL_C0], 0, J.M, J.N, 16);
+    }
+    if (f.count == 0) return 0;
+    hipLaunchKernelGGL(prng_fill_jobs_kernel, dim3((unsigned)std::min<long long>((nmax + 255) / 256, 4096), (unsigned)f.count), dim3(256), 0, ctx->stream, f);
+    CG_LAUNCH_CHECK();
+    // the products are independent (own buffers): small ones - a few microseconds of work behind a long K - run side by side on the
+    // context's launch lanes instead of one after the other
+    const int lanes = (count > 1 && !ctx->lanes_active && !ctx->capturing) ? std::min<int>(4, count) : 0;
+    if (lanes) { if (int rc = cognn_lane_begin(ctx, lanes)) return rc; }
+    int rc = 0, next = 0;
+    for (int32_t j = 0; j < count && !rc; ++j) {
+        const cognn_dealer_tn_job& J = jobs[j];
+        if (J.M * J.N == 0) continue;
+        if (lanes) { rc = cognn_lane_select(ctx, next); next = (next + 1) % lanes; }
+        if (!rc) rc = gemm_dispatch(ctx, (u64*)J.C1, (const u64*)J.scratchA, nullptr, (const u64*)J.scratchB, J.M, J.N, J.K, J.transA, 1);
+    }
+    if (lanes) { const int rc2 = cognn_lane_end(ctx); if (!rc) rc = rc2; }
+    return rc;
+}
+
+// ---- the dealer's product shares of several triples of one (N, K) in one launch (offline phase) ---------------------------------
+extern "C" int cognn_dealer_gemm_c1_groupable(int64_t N, int64_t K) { return (N >= 1 && N <= kFusedBN && K >= 1) ? 1 : 0; }
+extern "C" int cognn_dealer_gemm_c1_group_u64(cognn_ctx* ctx, const cognn_dealer_job* jobs, int32_t count, int64_t N, int64_t K) {
+    { const int rc_flush_ = cg_flush(ctx); if (rc_flush_) return rc_flush_; }
+    CG_REQUIRE(ctx && (count == 0 || jobs) && count >= 0 && count <= kGroupMax, "cognn_dealer_gemm_c1_group_u64: bad arguments (at most %d jobs)", kGroupMax);
+    CG_REQUIRE(cognn_dealer_gemm_c1_groupable(N, K) && K < (1ll << 31), "cognn_dealer_gemm_c1_group_u64: shape not served (N <= %d)", kFusedBN);
+    int64_t tiles_all = 0;
+    bool full = (K % 32 == 0);
+    for (int32_t j = 0; j < count; ++j) {
+        CG_REQUIRE(jobs[j].M >= 0 && jobs[j].M < (1ll << 31) && (jobs[j].M == 0 || (jobs[j].C1 && cg_aligned16(jobs[j].C1))), "cognn_dealer_gemm_c1_group_u64: job %d is malformed", j);
+        tiles_all += (jobs[j].M + 15) / 16;
+        full = full && (jobs[j].M % 16 == 0);
+    }
+    if (tiles_all == 0) return 0;
+    const int nst = (int)((K + 31) / 32), NT = (int)((N + 15) / 16);
+    const bool whole_k = group_whole_k(N, K, tiles_all);
+    GemmGroup g;
+    memset(&g, 0, sizeof(g));
+    g.N = (int)N; g.K = (int)K; g.nst = nst;
+    const int waves = NT == 1 ? 4 : 8;
+    const int budget = NT == 1 ? 768 : 256;
+    int64_t groups_all = 0;
+    for (int32_t j = 0; j < count; ++j) groups_all += ((jobs[j].M + 15) / 16 + waves - 1) / waves;
+    int ksteps = nst;
+    if (!whole_k) {
+        const int ksteps_max = std::max(1, (int)(((NT == 1 ? 48 : 128) * 1024) / ((size_t)NT * kD16Stage)));
+        const int want_splits = (int)std::max<int64_t>(1, (2 * budget + groups_all - 1) / groups_all);
+        ksteps = std::min(ksteps_max, std::max(std::min(2, nst), (nst + want_splits - 1) / want_splits));
+    }
+    const int splits = (nst + ksteps - 1) / ksteps;
+    g.ksteps = ksteps;
+    const size_t lds = (size_t)ksteps * NT * kD16Stage;
+    int wg_end = 0;
+    ZeroJobs z;
+    memset(&z, 0, sizeof(z));
+    unsigned zmax = 0;
+    for (int32_t j = 0; j < count; ++j) {
+        const cognn_dealer_job& J = jobs[j];
+        const int tiles = (int)((J.M + 15) / 16);
+        if (tiles == 0) continue;
+        GemmGroupJob& d = g.j[g.count++];
+        d.Z = (u64*)J.C1;
+        d.keyA = J.keys.k[COGNN_SL_A0]; d.keyA1 = J.keys.k[COGNN_SL_A1]; d.keyB = J.keys.k[COGNN_SL_B0]; d.keyB1 = J.keys.k[COGNN_SL_B1];
+        d.keyC0 = J.keys.k[COGNN_SL_C0];
+        d.p = 0; d.M = (int)J.M; d.tiles = tiles;
+        if (whole_k) {
+            int share = (int)(((int64_t)budget * tiles + tiles_all - 1) / tiles_all);
+            share = std::max(1, std::min(share, (tiles + waves - 1) / waves));
+            d.ngroups = share;
+            wg_end += share;
+        } else {
+            d.ngroups = (tiles + waves - 1) / waves;
+            wg_end += d.ngroups * splits;
+            CG_REQUIRE(J.M * N < (1ll << 32), "cognn_dealer_gemm_c1_group_u64: job %d: output too large for the split-K form", j);
+            z.p[z.count] = (u64*)J.C1; z.n[z.count] = (unsigned)(J.M * N); zmax = std::max(zmax, z.n[z.count]); ++z.count;
+        }
+        d.wg_end = wg_end;
+    }
+    if (z.count) {
+        hipLaunchKernelGGL(zero_jobs_kernel, dim3(std::min(256u, (zmax + 255) / 256), (unsigned)z.count), dim3(256), 0, ctx->stream, z);
+        CG_LAUNCH_CHECK();
+    }
+    if (NT == 1) return launch_group<1, 4>(ctx, g, wg_end, lds, full, true, false, !whole_k, nullptr, false, false, true);
+    if (NT == 2) return launch_group<2, 8>(ctx, g, wg_end, lds, full, true, false, !whole_k, nullptr, false, false, true);
+    if (NT == 3) return launch_group<3, 8>(ctx, g, wg_end, lds, full, true, false, !whole_k, nullptr, false, false, true);
+    return launch_group<4, 8>(ctx, g, wg_end, lds, full, true, false, !whole_k, nullptr, false, false, true);
 }
 
 // ---- grouped launch of one phase's weight-gradient products (A stored transposed, K = #vertices of the job's party) ----------

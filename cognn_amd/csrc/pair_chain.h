@@ -141,7 +141,10 @@ __device__ __forceinline__ bool pair_relu(const PairChainDev& d, int sb, u64 idx
 template <int STREAM>
 __device__ __forceinline__ void pair_open_masks(const PairChainDev& d, int sb, u64 idx, u64& a0, u64& a1) {
     if (STREAM == 1) { const u64* s = d.slab + (u64)sb * (u64)d.n + idx; a0 = s[0]; a1 = s[d.n]; }
-    else { a0 = cognn_prng(d.open_key0, idx); a1 = cognn_prng(d.open_key1, idx); }
+    else {
+        a0 = cognn_prng(d.open_key0, idx); a1 = cognn_prng(d.open_key1, idx);
+        if (d.flags & COGNN_PC_OPEN_LIMB) { a0 = cognn_limb_value(a0); a1 = cognn_limb_value(a1); }   // the opening of a product's left operand
+    }
 }
 // fills the slab of one chain: slot by slot exactly the values the PRNG forms above derive (element idx of every slot in use)
 __device__ __forceinline__ void pair_deal_element(const PairChainDev& d, u64* slab, u64 idx, u64 row, bool has_open) {
@@ -171,6 +174,8 @@ __device__ __forceinline__ void pair_deal_element(const PairChainDev& d, u64* sl
     }
     if (has_open) {
         u64* s = slab + (u64)B.op * n + idx;
-        s[PCS_OP_A0 * n] = cognn_prng(d.open_key0, idx); s[PCS_OP_A1 * n] = cognn_prng(d.open_key1, idx);
+        const bool limb = (d.flags & COGNN_PC_OPEN_LIMB) != 0;      // (the slab holds mask VALUES)
+        s[PCS_OP_A0 * n] = limb ? cognn_gemm_mask(d.open_key0, idx) : cognn_prng(d.open_key0, idx);
+        s[PCS_OP_A1 * n] = limb ? cognn_gemm_mask(d.open_key1, idx) : cognn_prng(d.open_key1, idx);
     }
 }

@@ -129,6 +129,7 @@ struct cognn_engine {
     int64_t graph_epoch = -1;                       // the epoch the recorded graph was captured in (retained products are tied to it)
     u64 salt_now = 0;                               // the epoch salt of the iteration being issued (added to the keys on the host, or - recorded epochs - on the device)
     u64 salt_on_device = 0;                         // what cognn_set_epoch_salt last set (recorded epochs only)
+    bool dealer_group = getenv("COGNN_NO_DEALER_GROUP") == nullptr;   // offline phase: the product shares of one shape in one grouped MFMA launch
     int dealer_streams = 0;                         // COGNN_OPT_DEALER_STREAMS: 1 = dealt values of the pair chains / grouped products read from HBM; 2 = only the dealer's corrections
     std::map<std::tuple<int, int64_t, int>, u64*> dealt;   // (owner, iteration, place) -> slab, filled at first use, kept (retain_offline)
     int64_t dealt_bytes = 0;
@@ -538,7 +539,7 @@ const u64* dealt_mask(cognn_engine* E, int owner, int64_t it, int place, u64 key
     if (f == E->dealt.end()) {
         u64* m = dalloc<u64>(E, (size_t)elems);
         E->dealt_bytes += elems * 8;
-        BE(cognn_prng_fill_u64(E->ctx, m, key, elems));
+        BE(cognn_gemm_mask_fill_u64(E->ctx, m, key, elems));   // (a product's A mask: limb-form values)
         f = E->dealt.emplace(k, m).first;
     }
     return f->second;
@@ -644,7 +645,7 @@ bool gemm_stage(cognn_engine* E, int64_t it, XFn X, WFn Wm, SpecFn spec, DstFn d
         GemmSpec g = spec(s);
         cognn_keys k = gkeys(s, g);
         if (xsrc == X_OPEN_HERE && !feature)
-            BE(cognn_mask_open_u64(E->ctx, s.ob[0], X(s), k.k[s.p == 0 ? COGNN_SL_A0 : COGNN_SL_A1], g.M, g.K, g.transA));
+            BE(cognn_mask_open_u64(E->ctx, s.ob[0], X(s), k.k[s.p == 0 ? COGNN_SL_A0 : COGNN_SL_A1], g.M, g.K, g.transA | COGNN_MASK_OPEN_LIMB));
         if (!w_opened) BE(cognn_mask_open_u64(E->ctx, s.ob[1], Wm(s), k.k[s.p == 0 ? COGNN_SL_B0 : COGNN_SL_B1], g.K, g.N, g.transB ? 3 : 0));
         e0[i] = g.M * g.K; e1[i] = g.K * g.N; eo[i] = g.M * g.N;
     });
@@ -919,7 +920,7 @@ void rowscale_stage(cognn_engine* E, int64_t it, int op, int top, int F, XFn X, 
                 c.out[0] = s.h1; c.out[1] = t.h1;
                 c.open[0] = s.h1E; c.flags |= COGNN_PC_OPEN_SUM;      // E_0 + E_1 once, into the owner side's buffer (pair_opening)
                 E->h1e_pairs_summed = true;
-                c.open_key[0] = nk.k[COGNN_SL_A0]; c.open_key[1] = nk.k[COGNN_SL_A1];
+                c.open_key[0] = nk.k[COGNN_SL_A0]; c.open_key[1] = nk.k[COGNN_SL_A1]; c.flags |= COGNN_PC_OPEN_LIMB;   // (a product's A masks: limb form)
                 if (E->forward_only) {                       // inference: the next product only reads the opening; h_t and the sign mask
                     c.out[0] = c.out[1] = nullptr;           // serve the backward pass, which will not run
                     c.mask = nullptr;
@@ -977,7 +978,7 @@ void relu_stage(cognn_engine* E, int64_t it, bool e_opened, bool pairs_done) {
             c.out[0] = s.h1; c.out[1] = t.h1;
             c.open[0] = s.h1E; c.flags |= COGNN_PC_OPEN_SUM;      // E_0 + E_1 once, into the owner side's buffer (pair_opening)
                 E->h1e_pairs_summed = true;
-            c.open_key[0] = nk.k[COGNN_SL_A0]; c.open_key[1] = nk.k[COGNN_SL_A1];
+            c.open_key[0] = nk.k[COGNN_SL_A0]; c.open_key[1] = nk.k[COGNN_SL_A1]; c.flags |= COGNN_PC_OPEN_LIMB;   // (a product's A masks: limb form)
             if (E->forward_only) { c.out[0] = c.out[1] = nullptr; c.mask = nullptr; }
         }
         pc.launch(E);
@@ -1178,7 +1179,7 @@ void message_passing_fused(cognn_engine* E, int F, int64_t it, bool scale, bool 
             c.out[0] = s.h1; c.out[1] = t.h1;
             c.open[0] = s.h1E; c.flags |= COGNN_PC_OPEN_SUM;      // E_0 + E_1 once, into the owner side's buffer (pair_opening)
                 E->h1e_pairs_summed = true;
-            c.open_key[0] = nk.k[COGNN_SL_A0]; c.open_key[1] = nk.k[COGNN_SL_A1];
+            c.open_key[0] = nk.k[COGNN_SL_A0]; c.open_key[1] = nk.k[COGNN_SL_A1]; c.flags |= COGNN_PC_OPEN_LIMB;   // (a product's A masks: limb form)
             if (E->forward_only) { c.out[0] = c.out[1] = nullptr; c.mask = nullptr; }
         } else if (softmax_follows) {
             for (Side* x : {&s, &t}) {
@@ -1449,7 +1450,7 @@ void run_iteration(cognn_engine* E, int64_t it) {
                 for (auto& s : E->sides) {
                     BE(cognn_memcpy_d2d(E->ctx, s.h1, s.cur, (size_t)s.n * E->hid() * 8));   // h_t[1]
                     cognn_keys k = keys(E, s.owner, it, COGNN_OP_PS_GEMM);
-                    BE(cognn_mask_open_u64(E->ctx, s.h1E, s.cur, k.k[s.p == 0 ? COGNN_SL_A0 : COGNN_SL_A1], s.n, E->hid(), 0));
+                    BE(cognn_mask_open_u64(E->ctx, s.h1E, s.cur, k.k[s.p == 0 ? COGNN_SL_A0 : COGNN_SL_A1], s.n, E->hid(), COGNN_MASK_OPEN_LIMB));
                 }
                 x_opened = true;
             }
@@ -1724,22 +1725,52 @@ bool gemm_of_iteration(cognn_engine* E, Side& s, int64_t it, GemmSpec& g) {
     return false;
 }
 
-// dealer phase: product shares of every Beaver GEMM in [it0,it1)
+// dealer phase: product shares of every Beaver GEMM in [it0,it1).  The products of one shape (N, K) - all sides' triples of a protocol
+// phase, and the same phase of later iterations - go to the grouped MFMA launch (cognn_dealer_gemm_c1_group_u64: operands
+// generated in registers, nothing materialised), up to 16 per launch; the weight-gradient triples (transposed left operand,
+// K = #vertices) stay on the per-triple path (a K-split MFMA kernel of its own).
 void run_offline(cognn_engine* E, int64_t it0, int64_t it1) {
     // recorded epochs deal their product shares inside the recording (on demand), unless the caller replays ONE epoch and keeps them
     if (E->graph_epochs && !E->retain_offline) return;
     if (original(E)) return;                               // original-gcn: every product share is dealt when its product runs
+    struct Pending { std::vector<cognn_dealer_job> jobs; };
+    std::map<std::pair<int64_t, int64_t>, Pending> groups;  // (N, K) -> jobs waiting for a launch
+    auto flush = [&](std::pair<int64_t, int64_t> nk, Pending& p) {
+        if (p.jobs.empty()) return;
+        BE(cognn_dealer_gemm_c1_group_u64(E->ctx, p.jobs.data(), (int32_t)p.jobs.size(), nk.first, nk.second));
+        p.jobs.clear();
+    };
+    std::vector<cognn_dealer_tn_job> tn_jobs;
     for (int64_t it = it0; it < it1; ++it) {
+        const u64 salt_before = E->salt_now;
         set_salt(E, it);
+        if (E->graph_epochs && E->salt_now != salt_before)  // (recorded epochs: the salt lives on the device - jobs of two epochs cannot share a launch)
+            for (auto& g : groups) flush(g.first, g.second);
         for (auto& s : E->sides) {
             GemmSpec g;
             if (s.p != 1 || !gemm_of_iteration(E, s, it, g) || s.c1.count({it, g.op})) continue;
             cognn_keys k = gemm_keys(E, s, it, g);
             u64* c = c1_alloc(E, g.M * g.N);
-            BE(cognn_dealer_gemm_c1_u64(E->ctx, c, &k, g.M, g.N, g.K, g.transA, s.scratch, s.scratch + g.M * g.K));
             s.c1[{it, g.op}] = Side::C1{c, g.M * g.N};
+            if (g.transA == 0 && E->dealer_group && E->be->cognn_dealer_gemm_c1_groupable(g.N, g.K)) {
+                Pending& p = groups[{g.N, g.K}];
+                cognn_dealer_job j;
+                j.C1 = c; j.keys = k; j.M = g.M;
+                p.jobs.push_back(j);
+                if (p.jobs.size() == 16) flush({g.N, g.K}, p);
+            } else if (g.transA != 0 && E->dealer_group) {  // (every side has scratch of its own: the jobs of one iteration share their fills)
+                cognn_dealer_tn_job j;
+                j.C1 = c; j.keys = k; j.M = g.M; j.N = g.N; j.K = g.K; j.transA = g.transA; j.scratchA = s.scratch; j.scratchB = s.scratch + g.M * g.K;
+                tn_jobs.push_back(j);
+            } else {
+                BE(cognn_dealer_gemm_c1_u64(E->ctx, c, &k, g.M, g.N, g.K, g.transA, s.scratch, s.scratch + g.M * g.K));
+            }
         }
+        for (size_t b = 0; b < tn_jobs.size(); b += 16)
+            BE(cognn_dealer_gemm_c1_tn_group_u64(E->ctx, tn_jobs.data() + b, (int32_t)std::min<size_t>(16, tn_jobs.size() - b)));
+        tn_jobs.clear();
     }
+    for (auto& g : groups) flush(g.first, g.second);
     set_salt_value(E, 0);
 }
 
@@ -2076,7 +2107,7 @@ void open_features(cognn_engine* E) {
     const int in = E->in();
     for (auto& s : E->sides) {
         cognn_keys fk = feature_gemm_keys(E, s.owner, 0);
-        BE(cognn_mask_open_u64(E->ctx, s.featE, s.feat, fk.k[s.p == 0 ? COGNN_SL_A0 : COGNN_SL_A1], (int64_t)s.n, in, 0));
+        BE(cognn_mask_open_u64(E->ctx, s.featE, s.feat, fk.k[s.p == 0 ? COGNN_SL_A0 : COGNN_SL_A1], (int64_t)s.n, in, COGNN_MASK_OPEN_LIMB));
     }
     {
         XList xl;
@@ -2113,7 +2144,7 @@ void open_features(cognn_engine* E) {
                 if (bytes <= 0 || !s.featPl) continue;
                 cognn_keys fk = feature_gemm_keys(E, s.owner, 0);
                 if (!s.featMaskPl) s.featMaskPl = dalloc<unsigned char>(E, (size_t)bytes);
-                BE(cognn_prng_fill_u64(E->ctx, s.ob[0], fk.k[s.p == 0 ? COGNN_SL_A0 : COGNN_SL_A1], (int64_t)s.n * in));
+                BE(cognn_gemm_mask_fill_u64(E->ctx, s.ob[0], fk.k[s.p == 0 ? COGNN_SL_A0 : COGNN_SL_A1], (int64_t)s.n * in));   // mask VALUES (limb form)
                 BE(cognn_gemm_presplit_u64(E->ctx, (void*)s.featMaskPl, s.ob[0], nullptr, (int64_t)s.n, in));
             }
         // the layer-0 weight gradient X^T . g reads the same opening and the same mask along the other axis: its kernel's A fragments,

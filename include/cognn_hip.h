@@ -121,7 +121,12 @@ int cognn_ring_gemm2_u64(cognn_ctx*, uint64_t* C, const uint64_t* A1, const uint
                          int64_t M, int64_t N, int64_t K, int transA, int accumulate);
 /* Beaver reveal share: E_p = X_p - prng(key, logical idx). transposed: X is stored [cols x rows]
  * while the logical (masked) matrix is its transpose [rows x cols]. */
+#define COGNN_MASK_OPEN_LIMB 16   /* OR into `transposed`: the stream is the A mask of a Beaver product - limb form: mask value = signed-digit
+                                    * reading of the PRNG word, a = w - (((w >> 7) & 0x0101..01) << 8) (cognn_spec.h), what the product
+                                    * kernels generate for their A operand; plain prng(key, idx) otherwise (B masks, element-wise masks) */
 int cognn_mask_open_u64(cognn_ctx*, uint64_t* E, const uint64_t* X, uint64_t key, int64_t rows, int64_t cols, int transposed);
+/* out[i] = the A mask VALUE of a product (limb form) for element i: what a dealt A mask / a mask image holds */
+int cognn_gemm_mask_fill_u64(cognn_ctx*, uint64_t* out, uint64_t key, int64_t n);
 int cognn_add_u64(cognn_ctx*, uint64_t* out, const uint64_t* a, const uint64_t* b, int64_t n);
 int cognn_sub_u64(cognn_ctx*, uint64_t* out, const uint64_t* a, const uint64_t* b, int64_t n);
 /* out = in[0] + ... + in[count-1]  /  out[0..count) = in; count <= 16 (weight averaging, gcn.h:753-778: the weight shares of all
@@ -131,6 +136,29 @@ int cognn_fanout_u64(cognn_ctx*, uint64_t* const* out, int32_t count, const uint
 /* dealer (offline): C1 = (A0+A1).(B0+B1) - C0 with all five streams evaluated from keys */
 int cognn_dealer_gemm_c1_u64(cognn_ctx*, uint64_t* C1, const cognn_keys* keys, int64_t M, int64_t N, int64_t K, int transA,
                              uint64_t* scratchA /*MxK*/, uint64_t* scratchB /*KxN*/);
+/* ... of several triples that share (N, K) in ONE launch of the grouped MFMA kernel (K ranges split over workgroups when there are few
+ * row tiles or K is long: the dataset-shaped layer-0 products): every operand is generated in registers - the limb bytes of the
+ * two parties' A masks are the two halves of the A fragment, B_0 + B_1 fills both segments of the B fragments, the epilogue subtracts
+ * the C_0 stream - so nothing is read or materialised.  keys: the triple's (A0, A1, B0, B1, C0).  transA = 0 only. */
+typedef struct {
+    uint64_t* C1;        /* [M x N] out */
+    cognn_keys keys;
+    int64_t M;
+} cognn_dealer_job;
+int cognn_dealer_gemm_c1_groupable(int64_t N, int64_t K);
+/* ... and of triples whose left operand is used transposed (transA = 1 or 2 as in cognn_dealer_gemm_c1_u64: the weight-gradient
+ * products, K = #vertices): the operand fills of all jobs are one launch, each product then accumulates onto its C_1 = -C_0.
+ * scratchA: M x K, scratchB: K x N u64 per job (distinct per job). */
+typedef struct {
+    uint64_t* C1;
+    cognn_keys keys;
+    int64_t M, N, K;
+    int32_t transA;
+    uint64_t* scratchA;
+    uint64_t* scratchB;
+} cognn_dealer_tn_job;
+int cognn_dealer_gemm_c1_tn_group_u64(cognn_ctx*, const cognn_dealer_tn_job* jobs, int32_t count);
+int cognn_dealer_gemm_c1_group_u64(cognn_ctx*, const cognn_dealer_job* jobs, int32_t count, int64_t N, int64_t K);
 /* Z_p = p*E.F + E.B_p + A_p.F + C_p with E = E0 + E1 (the two parties' opened shares; E1 may be NULL) [MxK]
  * and F [KxN] the opened sum; A_p/B_p/C_0 come from keys, C_1 from `c1` (p==1).  transA: E is stored [KxM]
  * (as produced by cognn_mask_open_u64 with transposed=1).  scratch: MxK + KxN u64. */
@@ -324,7 +352,10 @@ enum { COGNN_PC_TRUNC_IN = 1, COGNN_PC_SCALE = 2, COGNN_PC_RELU = 4, COGNN_PC_IN
        COGNN_PC_MASK_AFTER_TRUNC = 256,
        /* with `dealt`: read only what a PRG-compressed dealer must send - party 1's correction shares (c_1 of the element-wise triples,
         * r_1 and r'_1 of the truncations) and the ReLU's published g - and regenerate what each party derives from its own seed */
-       COGNN_PC_DEALT_MINIMAL = 512 };
+       COGNN_PC_DEALT_MINIMAL = 512,
+       /* the opening written by the chain (open / open_key) is the left operand of a Beaver PRODUCT: its masks are in limb form
+        * (cognn_spec.h, cognn_gemm_mask) like every A mask the product kernels generate */
+       COGNN_PC_OPEN_LIMB = 1024 };
 typedef struct cognn_pair_chain_s {
     const uint64_t* x[2];        /* the two sides' input shares [rows x F] */
     const uint64_t* c1;          /* side 1's dealt product share (COGNN_PC_TRUNC_IN without COGNN_PC_NO_C) */

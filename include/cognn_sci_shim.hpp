@@ -430,7 +430,7 @@ inline DevMat matmul(Session& s, const DevMat& A, const DevMat& B) {
     cognn_keys k = s.keys(OP_GEMM);
     DevMat E(s.ctx, M, K), Ep(s.ctx, M, K), F(s.ctx, K, N), Fp(s.ctx, K, N), Z(s.ctx, M, N), O(s.ctx, M, N);
     Dev scratch(s.ctx, M * K + K * N);
-    check(cognn_mask_open_u64(s.ctx, E.u64(), A.u64(), k.k[p ? SL_A1 : SL_A0], (int64_t)M, (int64_t)K, 0), "cognn_mask_open_u64");
+    check(cognn_mask_open_u64(s.ctx, E.u64(), A.u64(), k.k[p ? SL_A1 : SL_A0], (int64_t)M, (int64_t)K, COGNN_MASK_OPEN_LIMB), "cognn_mask_open_u64");
     check(cognn_mask_open_u64(s.ctx, F.u64(), B.u64(), k.k[p ? SL_B1 : SL_B0], (int64_t)K, (int64_t)N, 0), "cognn_mask_open_u64");
     s.swap_mat(E, Ep);                                       // Beaver reveal
     s.swap_mat(F, Fp);

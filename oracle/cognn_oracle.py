@@ -100,6 +100,20 @@ def prng_shape(key, shape):
     return prng(key, n).reshape(shape)
 
 
+def limb_value(w):
+    """The signed-digit reading of 64-bit words: sum_i int8(byte_i(w)) * 256^i mod 2^64 = w - (((w >> 7) & 0x0101..01) << 8).
+    A bijection of the words.  The Beaver A masks of the ring products are DEFINED this way: the GPU product kernels
+    split operands into signed 8-bit limbs, and for a mask defined like this the limbs are the bytes of the PRNG word."""
+    w = np.asarray(w, dtype=U64)
+    with np.errstate(over="ignore"):
+        return w - (((w >> U64(7)) & U64(0x0101010101010101)) << U64(8))
+
+
+def gemm_mask_shape(key, shape):
+    """A mask of a Beaver product's left operand (limb form), logical row-major element order."""
+    return limb_value(prng_shape(key, shape))
+
+
 def fx_encode(x):
     """CryptoUtil::encodeDoubleAsFixedPoint stand-in (gcn.h:220): llround(x*2^f), two's complement."""
     a = np.asarray(x, dtype=np.float64) * FX_ONE
@@ -170,9 +184,9 @@ def beaver_gemm_pair(x0, x1, w0, w1, key_of, a_of_transposed=False):
     assert K == K2
     with np.errstate(over="ignore"):
         if a_of_transposed:
-            a0 = prng_shape(key_of(SL_A0), (K, M)).T.copy(); a1 = prng_shape(key_of(SL_A1), (K, M)).T.copy()
+            a0 = gemm_mask_shape(key_of(SL_A0), (K, M)).T.copy(); a1 = gemm_mask_shape(key_of(SL_A1), (K, M)).T.copy()
         else:
-            a0 = prng_shape(key_of(SL_A0), (M, K)); a1 = prng_shape(key_of(SL_A1), (M, K))
+            a0 = gemm_mask_shape(key_of(SL_A0), (M, K)); a1 = gemm_mask_shape(key_of(SL_A1), (M, K))
         b0 = prng_shape(key_of(SL_B0), (K, N)); b1 = prng_shape(key_of(SL_B1), (K, N))
         c0 = prng_shape(key_of(SL_C0), (M, N))
         c1 = ring_matmul(a0 + a1, b0 + b1) - c0               # dealer, offline

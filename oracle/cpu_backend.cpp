@@ -131,6 +131,11 @@ int cognn_prng_fill_u64(cognn_ctx*, uint64_t* out, uint64_t key, int64_t n) {
     for (int64_t i = 0; i < n; ++i) out[i] = cognn_prng(key, (u64)i);
     return 0;
 }
+int cognn_gemm_mask_fill_u64(cognn_ctx*, uint64_t* out, uint64_t key, int64_t n) {   // a product's A mask: limb-form values (cognn_spec.h)
+    CG_PAR
+    for (int64_t i = 0; i < n; ++i) out[i] = cognn_gemm_mask(key, (u64)i);
+    return 0;
+}
 int cognn_gather_csr_u64(cognn_ctx*, uint64_t* out, const uint64_t* base, const uint64_t* table, const uint32_t* rowptr,
                          const uint32_t* col, int64_t n_rows, int64_t F) {
     CG_PAR
@@ -173,12 +178,15 @@ int cognn_ring_gemm_u64(cognn_ctx*, uint64_t* C, const uint64_t* A, const uint64
     return 0;
 }
 int cognn_mask_open_u64(cognn_ctx*, uint64_t* E, const uint64_t* X, uint64_t key, int64_t rows, int64_t cols, int tr) {
+    const bool limb = (tr & COGNN_MASK_OPEN_LIMB) != 0;     // the A mask of a product: limb form
+    tr &= ~COGNN_MASK_OPEN_LIMB;
+    auto mask = [&](u64 idx) { return limb ? cognn_gemm_mask(key, idx) : cognn_prng(key, idx); };
     if (tr == 3) {                                         // X stored [cols x rows], E in logical order
-        for (int64_t i = 0; i < rows * cols; ++i) E[i] = X[(i % cols) * rows + i / cols] - cognn_prng(key, (u64)i);
+        for (int64_t i = 0; i < rows * cols; ++i) E[i] = X[(i % cols) * rows + i / cols] - mask((u64)i);
         return 0;
     }
     CG_PAR
-    for (int64_t i = 0; i < rows * cols; ++i) E[i] = X[i] - cognn_prng(key, lidx(i, rows, cols, tr));
+    for (int64_t i = 0; i < rows * cols; ++i) E[i] = X[i] - mask(lidx(i, rows, cols, tr));
     return 0;
 }
 int cognn_add_u64(cognn_ctx*, uint64_t* o, const uint64_t* a, const uint64_t* b, int64_t n) {
@@ -208,13 +216,26 @@ int cognn_dealer_gemm_c1_u64(cognn_ctx* c, uint64_t* C1, const cognn_keys* keys,
     CG_PAR
     for (int64_t i = 0; i < M * K; ++i) {
         const u64 li = lidx(i, M, K, transA);
-        sa[i] = cognn_prng(keys->k[COGNN_SL_A0], li) + cognn_prng(keys->k[COGNN_SL_A1], li);
+        sa[i] = cognn_gemm_mask(keys->k[COGNN_SL_A0], li) + cognn_gemm_mask(keys->k[COGNN_SL_A1], li);   // A masks: limb form
     }
     CG_PAR
     for (int64_t i = 0; i < K * N; ++i) sb[i] = cognn_prng(keys->k[COGNN_SL_B0], (u64)i) + cognn_prng(keys->k[COGNN_SL_B1], (u64)i);
     cognn_ring_gemm_u64(c, C1, sa, sb, M, N, K, transA, 0);
     CG_PAR
     for (int64_t i = 0; i < M * N; ++i) C1[i] -= cognn_prng(keys->k[COGNN_SL_C0], (u64)i);
+    return 0;
+}
+int cognn_dealer_gemm_c1_tn_group_u64(cognn_ctx* c, const cognn_dealer_tn_job* jobs, int32_t count) {
+    for (int32_t j = 0; j < count; ++j)
+        if (int rc = cognn_dealer_gemm_c1_u64(c, jobs[j].C1, &jobs[j].keys, jobs[j].M, jobs[j].N, jobs[j].K, jobs[j].transA, jobs[j].scratchA, jobs[j].scratchB)) return rc;
+    return 0;
+}
+int cognn_dealer_gemm_c1_groupable(int64_t, int64_t) { return 0; }       // the reference backend deals job by job
+int cognn_dealer_gemm_c1_group_u64(cognn_ctx* c, const cognn_dealer_job* jobs, int32_t count, int64_t N, int64_t K) {
+    for (int32_t j = 0; j < count; ++j) {
+        std::vector<u64> scratch((size_t)(jobs[j].M * K + K * N));
+        if (int rc = cognn_dealer_gemm_c1_u64(c, jobs[j].C1, &jobs[j].keys, jobs[j].M, N, K, 0, scratch.data(), scratch.data() + jobs[j].M * K)) return rc;
+    }
     return 0;
 }
 int cognn_ring_gemm2_u64(cognn_ctx* c, uint64_t* C, const uint64_t* A1, const uint64_t* A2, const uint64_t* B, int64_t M, int64_t N,
@@ -230,7 +251,7 @@ int cognn_beaver_gemm_close_u64(cognn_ctx* c, uint64_t* Z, const uint64_t* E, co
     REQ(p == 0 || c1, "beaver_gemm_close: p=1 needs c1");
     u64* Ap = scratch; u64* Bp = scratch + M * K;
     CG_PAR
-    for (int64_t i = 0; i < M * K; ++i) Ap[i] = cognn_prng(keys->k[p == 0 ? COGNN_SL_A0 : COGNN_SL_A1], lidx(i, M, K, transA));
+    for (int64_t i = 0; i < M * K; ++i) Ap[i] = cognn_gemm_mask(keys->k[p == 0 ? COGNN_SL_A0 : COGNN_SL_A1], lidx(i, M, K, transA));
     CG_PAR
     for (int64_t i = 0; i < K * N; ++i) Bp[i] = cognn_prng(keys->k[p == 0 ? COGNN_SL_B0 : COGNN_SL_B1], (u64)i) + (p == 1 ? F[i] : 0);
     CG_PAR
@@ -245,7 +266,7 @@ int cognn_beaver_gemm_close_raw_u64(cognn_ctx* c, uint64_t* Z, const uint64_t* E
                                     int p, int64_t M, int64_t N, int64_t K, uint64_t* scratch) {
     u64* Ap = scratch; u64* Bp = scratch + M * K;
     CG_PAR
-    for (int64_t i = 0; i < M * K; ++i) Ap[i] = cognn_prng(keys->k[p == 0 ? COGNN_SL_A0 : COGNN_SL_A1], (u64)i);
+    for (int64_t i = 0; i < M * K; ++i) Ap[i] = cognn_gemm_mask(keys->k[p == 0 ? COGNN_SL_A0 : COGNN_SL_A1], (u64)i);
     CG_PAR
     for (int64_t i = 0; i < K * N; ++i) Bp[i] = cognn_prng(keys->k[p == 0 ? COGNN_SL_B0 : COGNN_SL_B1], (u64)i) + (p == 1 ? F[i] : 0);
     cognn_ring_gemm2_u64(c, Z, E, E1, Bp, M, N, K, 0, 0);
@@ -416,7 +437,7 @@ int cognn_relu_close_open_u64(cognn_ctx* c, uint64_t* h, uint64_t* E, uint8_t* m
     CHUNK(n)
     cognn_relu_close_u64(c, h, mask, z, w0, w1, n);
     CG_PAR
-    for (int64_t i = lo_; i < hi_; ++i) E[i] = h[i] - cognn_prng(key_open, (u64)i);
+    for (int64_t i = lo_; i < hi_; ++i) E[i] = h[i] - cognn_gemm_mask(key_open, (u64)i);   // the next product's A mask
     return 0;
 }
 int cognn_mask_select_u64(cognn_ctx*, uint64_t* out, const uint64_t* in, const uint8_t* mask, int64_t n) {
@@ -549,15 +570,17 @@ int cognn_pair_chain_u64(cognn_ctx* ctx, const cognn_pair_chain* chains, int32_t
             }
             for (int p = 0; p < 2; ++p) cur[p].swap(h[p]);
         }
+        const bool limb = (s.flags & COGNN_PC_OPEN_LIMB) != 0;    // the opening of a product's left operand: limb-form masks
+        auto omask = [&](int p, int64_t i) { return limb ? cognn_gemm_mask(s.open_key[p], (u64)i) : cognn_prng(s.open_key[p], (u64)i); };
         if (s.flags & COGNN_PC_OPEN_SUM) {                  // what each party holds after exchanging the two openings
             REQ(!s.open[1], "pair_chain: COGNN_PC_OPEN_SUM writes open[0] only");
             if (s.open[0])
                 for (int64_t i = 0; i < n; ++i)
-                    s.open[0][i] = (cur[0][(size_t)i] - cognn_prng(s.open_key[0], (u64)i)) + (cur[1][(size_t)i] - cognn_prng(s.open_key[1], (u64)i));
+                    s.open[0][i] = (cur[0][(size_t)i] - omask(0, i)) + (cur[1][(size_t)i] - omask(1, i));
         }
         for (int p = 0; p < 2; ++p) {
             if (s.open[p] && !(s.flags & COGNN_PC_OPEN_SUM))
-                for (int64_t i = 0; i < n; ++i) s.open[p][i] = cur[p][(size_t)i] - cognn_prng(s.open_key[p], (u64)i);
+                for (int64_t i = 0; i < n; ++i) s.open[p][i] = cur[p][(size_t)i] - omask(p, i);
             if (s.out[p]) memcpy(s.out[p], cur[p].data(), (size_t)n * 8);
         }
     }

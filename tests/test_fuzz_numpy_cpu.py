@@ -71,6 +71,19 @@ def test_prng_sharing_and_mask_streams(cpu, seed):
         assert np.array_equal(et.T, x - co.prng_shape(key, (rows, F)))
         call(cpu, "cognn_mask_open_u64", hp(et), hp(xt), ctypes.c_uint64(key), rows, F, 2)     # storage-order mask index
         assert np.array_equal(et, xt - co.prng_shape(key, (F, rows)))
+        # COGNN_MASK_OPEN_LIMB (16): the stream as a product's A mask - the signed-digit reading of every PRNG word
+        call(cpu, "cognn_mask_open_u64", hp(e), hp(x), ctypes.c_uint64(key), rows, F, 16)
+        assert np.array_equal(e, x - co.gemm_mask_shape(key, (rows, F)))
+        call(cpu, "cognn_mask_open_u64", hp(et), hp(xt), ctypes.c_uint64(key), rows, F, 1 | 16)
+        assert np.array_equal(et.T, x - co.gemm_mask_shape(key, (rows, F)))
+        m = np.zeros(n, dtype=U64)
+        call(cpu, "cognn_gemm_mask_fill_u64", hp(m), ctypes.c_uint64(key), n)
+        w = co.prng(key, n)
+        digits = w.view(np.int8).reshape(n, 8).astype(np.int64)            # little-endian bytes of w read as signed limbs
+        want = np.zeros(n, dtype=U64)
+        for i in range(8):
+            want += (digits[:, i].astype(U64)) << U64(8 * i)
+        assert np.array_equal(m, want) and np.array_equal(m, co.limb_value(w))
     # key derivation
     from cognn_amd import capi
     k = capi.make_keys(seed + 1, 3, 9, co.OP_AP_GEMM)
@@ -118,7 +131,7 @@ def test_gemm_family(cpu, seed):
     stor = (lambda a: np.ascontiguousarray(a.T)) if tA else (lambda a: a)
     E = [np.zeros(stor(X0).shape, dtype=U64) for _ in range(2)]; Fm = [np.zeros((K, N), dtype=U64) for _ in range(2)]
     for p, (xp, wp) in enumerate(((X0, W0), (X1, W1))):
-        call(cpu, "cognn_mask_open_u64", hp(E[p]), hp(stor(xp)), ctypes.c_uint64(kf(co.SL_A0 + p)), M, K, tA)
+        call(cpu, "cognn_mask_open_u64", hp(E[p]), hp(stor(xp)), ctypes.c_uint64(kf(co.SL_A0 + p)), M, K, tA | 16)     # | COGNN_MASK_OPEN_LIMB: a product's A mask
         call(cpu, "cognn_mask_open_u64", hp(Fm[p]), hp(wp), ctypes.c_uint64(kf(co.SL_B0 + p)), K, N, 0)
     c1 = np.zeros((M, N), dtype=U64); sa = np.zeros(M * K + K * N + 16, dtype=U64)
     call(cpu, "cognn_dealer_gemm_c1_u64", hp(c1), ctypes.byref(k), M, N, K, tA, hp(sa), ctypes.c_void_p(sa.ctypes.data + 8 * M * K))

@@ -427,7 +427,7 @@ def test_beaver_gemm_pair(ctx, M, N, K, transA):
     stor = (lambda a: a.T.copy()) if transA else (lambda a: a)
     E = [dev_empty(stor(X0).shape) for _ in range(2)]; Fm = [dev_empty((K, N)) for _ in range(2)]
     for p, (xp, wp) in enumerate(((X0, W0), (X1, W1))):
-        ctx.call("cognn_mask_open_u64", ptr(E[p]), ptr(dev(stor(xp))), ctypes.c_uint64(kf(co.SL_A0 + p)), M, K, transA)
+        ctx.call("cognn_mask_open_u64", ptr(E[p]), ptr(dev(stor(xp))), ctypes.c_uint64(kf(co.SL_A0 + p)), M, K, transA | 16)   # | COGNN_MASK_OPEN_LIMB: a product's A mask
         ctx.call("cognn_mask_open_u64", ptr(Fm[p]), ptr(dev(wp)), ctypes.c_uint64(kf(co.SL_B0 + p)), K, N, 0)
     Fs = dev_empty((K, N))
     ctx.call("cognn_add_u64", ptr(Fs), ptr(Fm[0]), ptr(Fm[1]), K * N)
@@ -479,7 +479,7 @@ def test_beaver_gemm_group(ctx, N, K, Ms, two, presplit):
         k, kf = keys_of(11, q, 4, co.OP_PS_GEMM)
         E = [dev_empty((M, K)) for _ in range(2)]; Fm = [dev_empty((K, N)) for _ in range(2)]
         for p, (xp, wp) in enumerate(((X0, W0), (X1, W1))):
-            ctx.call("cognn_mask_open_u64", ptr(E[p]), ptr(dev(xp)), ctypes.c_uint64(kf(co.SL_A0 + p)), M, K, 0)
+            ctx.call("cognn_mask_open_u64", ptr(E[p]), ptr(dev(xp)), ctypes.c_uint64(kf(co.SL_A0 + p)), M, K, 16)
             ctx.call("cognn_mask_open_u64", ptr(Fm[p]), ptr(dev(wp)), ctypes.c_uint64(kf(co.SL_B0 + p)), K, N, 0)
         Es = dev_empty((M, K)); Fs = dev_empty((K, N))
         ctx.call("cognn_add_u64", ptr(Es), ptr(E[0]), ptr(E[1]), M * K)
@@ -494,7 +494,7 @@ def test_beaver_gemm_group(ctx, N, K, Ms, two, presplit):
         if presplit == "masks":                              # ... and each side's mask A_p in the same order (a mask that is dealt once)
             for p in range(2):
                 tmp = dev_empty((M, K)); mimg[p] = dev_empty(capi.load().cognn_gemm_presplit_bytes(M, K) // 8)
-                ctx.call("cognn_prng_fill_u64", ptr(tmp), ctypes.c_uint64(kf(co.SL_A0 + p)), M * K)
+                ctx.call("cognn_gemm_mask_fill_u64", ptr(tmp), ctypes.c_uint64(kf(co.SL_A0 + p)), M * K)
                 ctx.call("cognn_gemm_presplit_u64", ptr(mimg[p]), ptr(tmp), None, M, K)
                 keep.append(tmp)
         z0, z1 = co.beaver_gemm_pair(X0, X1, W0, W1, kf)
@@ -560,7 +560,7 @@ def test_beaver_gemm_group_tn(ctx, M, N, Ks, stor_mask, images):
         X0 = rand_u64(rng, (M, Kc)); X1 = rand_u64(rng, (M, Kc)); W0 = rand_u64(rng, (Kc, N)); W1 = rand_u64(rng, (Kc, N))
         E = [dev_empty((Kc, M)) for _ in range(2)]; Fm = [dev_empty((Kc, N)) for _ in range(2)]
         for p, (xp, wp) in enumerate(((X0, W0), (X1, W1))):     # the operand is stored [K x M]; transA 1: mask addressed (m, k), 2: (k, m)
-            ctx.call("cognn_mask_open_u64", ptr(E[p]), ptr(dev(xp.T.copy())), ctypes.c_uint64(kf(co.SL_A0 + p)), M, Kc, 2 if stor_mask else 1)
+            ctx.call("cognn_mask_open_u64", ptr(E[p]), ptr(dev(xp.T.copy())), ctypes.c_uint64(kf(co.SL_A0 + p)), M, Kc, (2 if stor_mask else 1) | 16)
             ctx.call("cognn_mask_open_u64", ptr(Fm[p]), ptr(dev(wp)), ctypes.c_uint64(kf(co.SL_B0 + p)), Kc, N, 0)
         Es = dev_empty((Kc, M)); Fs = dev_empty((Kc, N))
         ctx.call("cognn_add_u64", ptr(Es), ptr(E[0]), ptr(E[1]), M * Kc)
@@ -638,7 +638,7 @@ def test_relu_close_open(ctx):
     with np.errstate(over="ignore"):
         pos = (w0 + w1).astype(np.int64) > 0
         hw = np.where(pos, z, U64(0))
-        assert np.array_equal(host(h), hw) and np.array_equal(host(E), hw - co.prng(key, n))
+        assert np.array_equal(host(h), hw) and np.array_equal(host(E), hw - co.limb_value(co.prng(key, n)))   # the next product's A mask
     assert np.array_equal(host(mask, np.uint8).astype(bool), pos)
 
 
@@ -802,3 +802,68 @@ def test_beaver_gemm_group_with_the_pair_chain_as_epilogue(ctx, N, K, Ms, scale,
         ctx.call("cognn_beaver_gemm_close_group_u64", jobs1, P, N, K, 1)
     assert lib.cognn_beaver_gemm_group_takes_epilogue(32, 1433, 170) == 0           # the split-K shapes take none
     assert lib.cognn_beaver_gemm_group_takes_epilogue(16, 64, 65536) == 0           # ... nor one-column-tile products (VALU-bound: the chain is cheaper alone)
+
+
+@pytest.mark.parametrize("N,K,Ms", [(16, 128, (40000, 39999)), (16, 1433, (1354, 1354)), (64, 128, (16384, 16400, 5)), (7, 16, (300,)), (3, 500, (4929, 4930, 4929, 4929)),
+                                    (16, 3703, (1656,)), (64, 33, tuple([257] * 17)), (1, 1, (1, 0))])
+def test_dealer_product_shares_as_one_grouped_launch(ctx, N, K, Ms):
+    """cognn_dealer_gemm_c1_group_u64 (offline phase): C_1 = (A_0 + A_1) . (B_0 + B_1) - C_0 of several triples of one (N, K) in one
+    launch of the grouped MFMA kernel - every operand generated in registers (the A masks in limb form), K ranges split over
+    workgroups for the dataset shapes (Cora's 1354 x 1433, CiteSeer's 1656 x 3703) - against numpy and against the per-triple
+    entry point; more than 16 triples are rejected (the engine launches 16 at a time)."""
+    from cognn_amd import capi
+    lib = capi.load()
+    jobs = (capi.DealerJob * len(Ms))()
+    outs, want = [], []
+    for q, M in enumerate(Ms):
+        k, kf = keys_of(23, q, 1, co.OP_PS_GEMM)
+        c1 = dev_empty((M, N))
+        if M:
+            c1.fill_(0x5555)                                 # (the split-K form adds into the output: it must clear it itself)
+        jobs[q].C1 = c1.data_ptr(); jobs[q].keys = k; jobs[q].M = M
+        outs.append(c1)
+        with np.errstate(over="ignore"):
+            a = co.gemm_mask_shape(kf(co.SL_A0), (M, K)) + co.gemm_mask_shape(kf(co.SL_A1), (M, K))
+            b = co.prng_shape(kf(co.SL_B0), (K, N)) + co.prng_shape(kf(co.SL_B1), (K, N))
+            want.append(co.ring_matmul(a, b) - co.prng_shape(kf(co.SL_C0), (M, N)))
+    if len(Ms) > 16:
+        with pytest.raises(capi.CognnError):
+            ctx.call("cognn_dealer_gemm_c1_group_u64", jobs, len(jobs), N, K)
+        return
+    assert lib.cognn_dealer_gemm_c1_groupable(N, K) == 1
+    ctx.call("cognn_dealer_gemm_c1_group_u64", jobs, len(jobs), N, K)
+    for q, M in enumerate(Ms):
+        assert np.array_equal(host(outs[q]), want[q]), q
+        if M:                                                # the per-triple entry point deals the same share
+            one = dev_empty((M, N)); sa = dev_empty(M * K + K * N)
+            ctx.call("cognn_dealer_gemm_c1_u64", ptr(one), ctypes.byref(jobs[q].keys), M, N, K, 0, ptr(sa), ctypes.c_void_p(sa.data_ptr() + 8 * M * K))
+            assert np.array_equal(host(one), want[q]), q
+
+
+@pytest.mark.parametrize("shapes", [[(128, 16, 4929, 2), (128, 16, 4930, 2), (16, 3, 4929, 1)], [(64, 7, 1354, 1)], [(33, 5, 300, 2), (5, 1, 1, 1), (8, 8, 0, 2)]])
+def test_dealer_product_shares_with_a_transposed_operand(ctx, shapes):
+    """cognn_dealer_gemm_c1_tn_group_u64: the weight-gradient triples (A used transposed: transA 1 = logical mask index, 2 = the mask
+    in storage order) - all fills in one launch, C_1 = -C_0 + (A_0 + A_1)^T-form product - against numpy and the per-triple call."""
+    from cognn_amd import capi
+    jobs = (capi.DealerTnJob * len(shapes))()
+    keep, want = [], []
+    for q, (M, N, K, tA) in enumerate(shapes):
+        k, kf = keys_of(31, q, 2, co.OP_AP_GEMM)
+        c1 = dev_empty((M, N)); sa = dev_empty(M * K + 2); sb = dev_empty(K * N + 2)
+        jobs[q].C1 = c1.data_ptr(); jobs[q].keys = k; jobs[q].M = M; jobs[q].N = N; jobs[q].K = K; jobs[q].transA = tA
+        jobs[q].scratchA = sa.data_ptr(); jobs[q].scratchB = sb.data_ptr()
+        keep += [c1, sa, sb]
+        with np.errstate(over="ignore"):
+            if tA == 2:                                      # the mask of the [K x M] tensor, indexed in storage order
+                a = (co.gemm_mask_shape(kf(co.SL_A0), (K, M)) + co.gemm_mask_shape(kf(co.SL_A1), (K, M))).T
+            else:
+                a = co.gemm_mask_shape(kf(co.SL_A0), (M, K)) + co.gemm_mask_shape(kf(co.SL_A1), (M, K))
+            b = co.prng_shape(kf(co.SL_B0), (K, N)) + co.prng_shape(kf(co.SL_B1), (K, N))
+            want.append(co.ring_matmul(a, b) - co.prng_shape(kf(co.SL_C0), (M, N)))
+    ctx.call("cognn_dealer_gemm_c1_tn_group_u64", jobs, len(jobs))
+    for q, (M, N, K, tA) in enumerate(shapes):
+        assert np.array_equal(host(keep[3 * q]), want[q]), q
+        if M * N:
+            one = dev_empty((M, N)); sa = dev_empty(M * K + K * N + 2)
+            ctx.call("cognn_dealer_gemm_c1_u64", ptr(one), ctypes.byref(jobs[q].keys), M, N, K, tA, ptr(sa), ctypes.c_void_p(sa.data_ptr() + 8 * M * K))
+            assert np.array_equal(host(one), want[q]), q
