@@ -424,6 +424,7 @@ def main():
                          "holds BOTH shares of its parties' vertex sets (the co-located mode of N = 1 extended: two-party steps stay in registers, only the "
                          "Gather's share-table replicas and the weight average cross xGMI).  With the default the other one is measured too and reported "
                          "under `vertex_set_placement`")
+    ap.add_argument("--packed", action="store_true", help="N > 1: opened truncation / ReLU-product shares cross ranks as 6 bytes per element (COGNN_OPT_PACKED_OPENINGS)")
     ap.add_argument("--no-placement-leg", action="store_true", help="N > 1: skip the extra measurement of the vertex-set placement")
     ap.add_argument("--graph", action="store_true", help="training workloads: replay the recorded epoch (hipGraph, COGNN_OPT_GRAPH_EPOCHS) instead of launching every kernel")
     args = ap.parse_args()
@@ -475,6 +476,8 @@ def main():
             eng.set_exchange(cdist.make_exchange_async(torch.device("cuda", local_rank), host_staged=True, per_round=args.chunks > 1))
         if args.chunks > 1:
             eng.exchange_chunks(args.chunks)
+        if args.packed:
+            eng.packed_openings(True)
     for P in eng.hosted:                      # Bernoulli(0.01) bag-of-words features, uniform labels
         vids = eng.party_vids(P)
         rng = np.random.default_rng(0xC06A12 + P)
@@ -591,7 +594,7 @@ def main():
                                "partition vid %% %d, input_dim=%d hidden_dim=%d num_labels=%d, %d part%s per GPU"
                                % (k, variant, iters - 1, V, 2 * Eu, k, in_dim, hid, lab, k // world, "y" if k // world == 1 else "ies"),
                    "name": args.workload, "parties": k, "exchange": "in-device" if world == 1 else ("rccl-p2p" if backend == "nccl" else backend + "-host-staged"),
-                   "exchange_chunks": args.chunks if world > 1 else None,
+                   "exchange_chunks": args.chunks if world > 1 else None, "packed_openings": bool(args.packed) if world > 1 else None,
                    "placement": (args.placement if world > 1 else "all parties and both share-holders of every vertex set on the one GPU")},
         "epoch_time_s": dt / args.steps,
         "edges_feat_per_s_per_party": value / k,

@@ -118,6 +118,8 @@ _SIGNATURES = {
     "cognn_share_split_u64": (_I, [_P, _P, _U, _P, _P, _L]),
     "cognn_prng_fill_u64": (_I, [_P, _P, _U, _L]),
     "cognn_gemm_mask_fill_u64": (_I, [_P, _P, _U, _L]),
+    "cognn_pack48_u64": (_I, [_P, _P, _P, _L]),
+    "cognn_unpack48_u64": (_I, [_P, _P, _P, _L]),
     "cognn_gather_csr_u64": (_I, [_P, _P, _P, _P, _P, _P, _L, _L]),
     "cognn_gather_csr_open_u64": (_I, [_P, _P, _P, _P, _P, _P, _L, _L, ctypes.c_int32, _P, _P, _P]),
     "cognn_relu_close_open_u64": (_I, [_P, _P, _P, _P, _P, _P, _P, _U, _L]),

@@ -89,6 +89,16 @@ COGNN_HD uint64_t cognn_prng(uint64_t key, uint64_t idx) {
     key += COGNN_SALT;
     return cognn_prng_z(idx ^ key, (uint32_t)(key >> 32));
 }
+/* What both parties form from the two opened shares of a truncation, c = c_0 + c_1 with c_p = x_p + mask_p: the TOP 48 BITS of each
+ * share, added mod 2^48 - the carry out of the low 16 bits is dropped.  Only 6 bytes of an opened share therefore ever matter
+ * (COGNN_OPT_PACKED_OPENINGS ships exactly those between ranks); the result is (c >> 16) - {0, 1}, i.e. the truncation is
+ * floor(x / 2^16) + {-1, 0, +1}.  The masked-sign ReLU reads its opened product w = w_0 + w_1 the same way: the sign
+ * of the 48-bit sum of the top 48 bits - exact, because the multiplier t is at least 2^17 (COGNN_RELU_T_MIN). */
+#define COGNN_HI48_MASK 0xFFFFFFFFFFFFull
+#define COGNN_RELU_T_MIN (1ull << 17)           /* the ReLU's dealer multiplier t lies in [2^17, 2^20): |z t| >= 2^17 whenever z != 0, so the 48-bit
+                                                 * reading of the opened w = z t has exactly the sign of z */
+COGNN_HD uint64_t cognn_open_hi48(uint64_t c0, uint64_t c1) { return ((c0 >> COGNN_FX_BITS) + (c1 >> COGNN_FX_BITS)) & COGNN_HI48_MASK; }
+COGNN_HD bool cognn_relu_positive(uint64_t w0, uint64_t w1) { return (long long)(cognn_open_hi48(w0, w1) << 16) > 0; }
 /* Beaver A masks of the ring products are defined in LIMB FORM: the mask of element idx is the signed-digit reading
  * of the PRNG word w = prng(key, idx),  a = sum_i int8(byte_i(w)) * 256^i  (mod 2^64)  =  w - (((w >> 7) & 0x0101...01) << 8).
  * w -> a is a bijection of the 64-bit words (the signed-digit decomposition is unique), so the mask is as uniform as the word.  The

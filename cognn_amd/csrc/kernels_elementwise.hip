@@ -166,7 +166,7 @@ struct TruncClosePubDealt {
         ld2(c0, i, w, a); ld2(c1, i, w, b); ld2(t, i, w, tt);
         if (out) ld2(rp, i, w, r);
         for (int j = 0; j < 2; ++j) {
-            const u64 hi = ((a[j] + b[j]) >> COGNN_FX_BITS) - (COGNN_TRUNC_OFFSET >> COGNN_FX_BITS);
+            const u64 hi = cognn_open_hi48(a[j], b[j]) - (COGNN_TRUNC_OFFSET >> COGNN_FX_BITS);
             e[j] = hi - tt[j];
             y[j] = (p == 0 ? hi : 0ull) - r[j];
         }
@@ -250,7 +250,7 @@ struct TruncClose {
             u64 a[2], b[2];
             ld2(c0, i, w, a); ld2(c1, i, w, b);
             for (int j = 0; j < 2; ++j) {
-                const u64 hi = ((a[j] + b[j]) >> COGNN_FX_BITS) - (COGNN_TRUNC_OFFSET >> COGNN_FX_BITS);
+                const u64 hi = cognn_open_hi48(a[j], b[j]) - (COGNN_TRUNC_OFFSET >> COGNN_FX_BITS);
                 if (pub) yt[j] = hi - ((cognn_prng(k.k[COGNN_SL_R], (u64)(i + j)) & COGNN_TRUNC_MASK) >> COGNN_FX_BITS);
                 y[j] = p == 0 ? hi - trunc_rp(k, 0, (u64)(i + j)) : 0ull - trunc_rp(k, 1, (u64)(i + j));
             }
@@ -331,7 +331,7 @@ struct ReluOpen {        // E = z - a_p ; G = t_p - b_p (G optional: the dealer 
             if (G) {
                 u64 t0 = cognn_prng(k.k[COGNN_SL_T0], idx);
                 u64 tp = t0;
-                if (p == 1) tp = ((cognn_prng(k.k[COGNN_SL_T], idx) & 0xFFFFFull) | 1ull) - t0;
+                if (p == 1) tp = ((cognn_prng(k.k[COGNN_SL_T], idx) & 0xFFFFFull) | COGNN_RELU_T_MIN) - t0;
                 g[j] = tp - cognn_prng(k.k[p == 0 ? COGNN_SL_B0 : COGNN_SL_B1], idx);
             }
         }
@@ -353,7 +353,7 @@ struct ReluMul {
         } else {
             for (int j = 0; j < 2; ++j) {
                 u64 idx = (u64)(i + j);
-                g[j] = ((cognn_prng(k.k[COGNN_SL_T], idx) & 0xFFFFFull) | 1ull) - cognn_prng(k.k[COGNN_SL_B0], idx) -
+                g[j] = ((cognn_prng(k.k[COGNN_SL_T], idx) & 0xFFFFFull) | COGNN_RELU_T_MIN) - cognn_prng(k.k[COGNN_SL_B0], idx) -
                        cognn_prng(k.k[COGNN_SL_B1], idx);
             }
         }
@@ -367,7 +367,7 @@ struct ReluClose {
         u64 a[2], b[2], v[2], r[2] = {0, 0};
         ld2(w0, i, w, a); ld2(w1, i, w, b); ld2(z, i, w, v);
         for (int j = 0; j < w; ++j) {
-            bool pos = (long long)(a[j] + b[j]) > 0;
+            bool pos = cognn_relu_positive(a[j], b[j]);
             r[j] = pos ? v[j] : 0ull;
             if (mask) mask[i + j] = pos ? 1 : 0;
         }
@@ -779,6 +779,38 @@ extern "C" {
 int cognn_prng_fill_u64(cognn_ctx* ctx, uint64_t* out, uint64_t key, int64_t n) {
     CG_REQUIRE(ctx && out && al(out), "cognn_prng_fill_u64: bad arguments");
     return launch_ew(ctx, n, PrngFill{(u64*)out, key, 0});
+}
+// Packed openings (COGNN_OPT_PACKED_OPENINGS): of an opened truncation share only the top 48 bits matter (cognn_open_hi48), so between
+// ranks 6 bytes per element travel: a plane of n 32-bit words (bits 16..47) followed by a plane of n 16-bit words (bits 48..63).
+namespace {
+__global__ __launch_bounds__(256) void pack48_kernel(uint32_t* mid, uint16_t* top, const u64* __restrict__ src, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const u64 v = src[i];
+        mid[i] = (uint32_t)(v >> 16); top[i] = (uint16_t)(v >> 48);
+    }
+}
+__global__ __launch_bounds__(256) void unpack48_kernel(u64* dst, const uint32_t* __restrict__ mid, const uint16_t* __restrict__ top, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        dst[i] = ((u64)mid[i] << 16) | ((u64)top[i] << 48);
+}
+}  // namespace
+int cognn_pack48_u64(cognn_ctx* ctx, void* packed, const uint64_t* src, int64_t n) {
+    { const int rc_flush_ = cg_flush_pending(ctx); if (rc_flush_) return rc_flush_; }
+    CG_REQUIRE(ctx && n >= 0 && (n == 0 || (packed && src && (((uintptr_t)packed) & 3u) == 0)), "cognn_pack48_u64: bad arguments");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(pack48_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 16384)), dim3(256), 0, ctx->stream, (uint32_t*)packed,
+                       (uint16_t*)((unsigned char*)packed + 4 * n), (const u64*)src, n);
+    CG_LAUNCH_CHECK();
+    return 0;
+}
+int cognn_unpack48_u64(cognn_ctx* ctx, uint64_t* dst, const void* packed, int64_t n) {
+    { const int rc_flush_ = cg_flush_pending(ctx); if (rc_flush_) return rc_flush_; }
+    CG_REQUIRE(ctx && n >= 0 && (n == 0 || (packed && dst && (((uintptr_t)packed) & 3u) == 0)), "cognn_unpack48_u64: bad arguments");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(unpack48_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 16384)), dim3(256), 0, ctx->stream, (u64*)dst, (const uint32_t*)packed,
+                       (const uint16_t*)((const unsigned char*)packed + 4 * n), n);
+    CG_LAUNCH_CHECK();
+    return 0;
 }
 int cognn_gemm_mask_fill_u64(cognn_ctx* ctx, uint64_t* out, uint64_t key, int64_t n) {
     CG_REQUIRE(ctx && out && al(out), "cognn_gemm_mask_fill_u64: bad arguments");

@@ -77,7 +77,7 @@ __device__ __forceinline__ void pair_trunc(const PairChainDev& d, int sb, u64 kR
     }
     const u64 c0 = v0 + r0 + COGNN_TRUNC_OFFSET;            // side 0's opening (TruncOpen, p = 0)
     const u64 c1 = v1 + r1;                                 // side 1's opening
-    v0 = ((c0 + c1) >> COGNN_FX_BITS) - (COGNN_TRUNC_OFFSET >> COGNN_FX_BITS) - rp0;     // TruncClose, p = 0
+    v0 = cognn_open_hi48(c0, c1) - (COGNN_TRUNC_OFFSET >> COGNN_FX_BITS) - rp0;         // TruncClose, p = 0
     v1 = 0ull - rp1;                                                                     // TruncClose, p = 1
 }
 // the per-row values of the row scale: the dealer's b shares and the opened g = (s_0 - b_0) + (s_1 - b_1) - once per row, not
@@ -126,14 +126,14 @@ __device__ __forceinline__ bool pair_relu(const PairChainDev& d, int sb, u64 idx
     } else {
         a0 = cognn_prng(d.rA0, idx); a1 = cognn_prng(d.rA1, idx);
         b0 = cognn_prng(d.rB0, idx); b1 = cognn_prng(d.rB1, idx);
-        g = ((cognn_prng(d.rT, idx) & 0xFFFFFull) | 1ull) - b0 - b1;                              // dealer-published g (ReluMul)
+        g = ((cognn_prng(d.rT, idx) & 0xFFFFFull) | COGNN_RELU_T_MIN) - b0 - b1;                              // dealer-published g (ReluMul)
         c0m = cognn_prng(d.rC0, idx);
         c1m = (a0 + a1) * (b0 + b1) - c0m;
     }
     const u64 e = (v0 - a0) + (v1 - a1);                                                          // ReluOpen, both sides
     const u64 w0 = e * b0 + a0 * g + c0m;
     const u64 w1 = e * g + e * b1 + a1 * g + c1m;
-    const bool pos = (long long)(w0 + w1) > 0;                                                    // ReluClose
+    const bool pos = cognn_relu_positive(w0, w1);                                                 // ReluClose
     v0 = pos ? v0 : 0ull; v1 = pos ? v1 : 0ull;
     return pos;
 }
@@ -170,7 +170,7 @@ __device__ __forceinline__ void pair_deal_element(const PairChainDev& d, u64* sl
         const u64 c0m = cognn_prng(d.rC0, idx);
         s[PCS_RE_A0 * n] = a0; s[PCS_RE_A1 * n] = a1; s[PCS_RE_B0 * n] = b0; s[PCS_RE_B1 * n] = b1;
         s[PCS_RE_C0 * n] = c0m; s[PCS_RE_C1 * n] = (a0 + a1) * (b0 + b1) - c0m;
-        s[PCS_RE_G * n] = ((cognn_prng(d.rT, idx) & 0xFFFFFull) | 1ull) - b0 - b1;
+        s[PCS_RE_G * n] = ((cognn_prng(d.rT, idx) & 0xFFFFFull) | COGNN_RELU_T_MIN) - b0 - b1;
     }
     if (has_open) {
         u64* s = slab + (u64)B.op * n + idx;

@@ -166,6 +166,10 @@ class Engine:
         chunks, each chunk's messages in flight behind the next chunk's kernels (cognn_engine.h: COGNN_OPT_EXCHANGE_CHUNKS)."""
         _check(self.lib.cognn_engine_set_option(self.h, 7, int(chunks)))
 
+    def packed_openings(self, on=True):
+        """Opened truncation / ReLU-product shares cross ranks as 6 bytes per element (cognn_engine.h: COGNN_OPT_PACKED_OPENINGS)."""
+        _check(self.lib.cognn_engine_set_option(self.h, 8, int(on)))
+
     def public_openings(self, on=True):
         """Share-holders outside pair chains derive the opening that follows a truncation themselves (default) instead of
         exchanging it as two shares (cognn_engine.h: COGNN_OPT_PUBLIC_OPENINGS)."""

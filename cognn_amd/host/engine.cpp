@@ -336,6 +336,7 @@ int cognn_engine_set_option(cognn_engine* E, int32_t option, int64_t value) {
             if (E->graph_exec) { E->be->cognn_graph_destroy(E->ctx, E->graph_exec); E->graph_exec = nullptr; }
             E->graph_epochs = value != 0; E->graph_warm = false;
         }
+        else if (option == COGNN_OPT_PACKED_OPENINGS) { exchange_wait(E); E->packed_openings = value != 0; }
         else if (option == COGNN_OPT_EXCHANGE_CHUNKS) {
             if (value < 1 || value > 8) throw EngineError("cognn_engine_set_option: COGNN_OPT_EXCHANGE_CHUNKS takes 1..8");
             E->chunks = (int)value;

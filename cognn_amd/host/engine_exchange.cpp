@@ -5,19 +5,22 @@
 namespace cognn_eng {
 
 // completes the round that is still in flight (asynchronous exchange); a no-op otherwise
+static void unpack_completed(cognn_engine* E);
 void exchange_wait(cognn_engine* E) {
-    if (!E->xpending) return;
+    if (!E->xpending) { unpack_completed(E); return; }     // (a blocking transport completes its rounds inside run_exchange)
     E->xpending = false;
     E->xdone = E->xbegun;
     if (E->xwait(E->xuser) != 0) throw EngineError("engine: exchange wait function failed");
+    unpack_completed(E);
 }
 // completes the rounds up to and including `round` (numbered by xbegun at their start); later rounds stay in flight when the
 // transport can tell them apart (cognn_exchange_wait_round_fn) - otherwise everything enqueued is completed
 void exchange_wait_round(cognn_engine* E, int64_t round) {
-    if (!E->xpending || round < E->xdone) return;
+    if (!E->xpending || round < E->xdone) { unpack_completed(E); return; }
     if (!E->xwait_round || round + 1 >= E->xbegun) { exchange_wait(E); return; }
     E->xdone = round + 1;
     if (E->xwait_round(E->xuser, round) != 0) throw EngineError("engine: exchange wait function failed");
+    unpack_completed(E);
 }
 // starts a round.  With a wait function registered the call only enqueues the messages; whoever consumes received data - or
 // overwrites a buffer that is being sent - calls exchange_wait first (for_sides does, before it touches a side whose peer is remote).
@@ -31,7 +34,7 @@ void run_exchange(cognn_engine* E, XList& xl, bool keep_inflight) {
     ++E->rounds;
     ++E->xbegun;
     if (E->xwait) E->xpending = true;
-    else E->xdone = E->xbegun;
+    else { E->xdone = E->xbegun; unpack_completed(E); }
 }
 void run_exchange_sync(cognn_engine* E, XList& xl) {
     run_exchange(E, xl);
@@ -66,11 +69,41 @@ std::vector<int64_t> per_side(cognn_engine* E, int64_t (*f)(cognn_engine*, Side&
     for (auto& s : E->sides) r.push_back(f(E, s));
     return r;
 }
-void msg_range(XList& xl, Side& s, u64* out, u64* in, int64_t elems, int c, int C) {
+// packable (an opened truncation share, or the ReLU's opened product: only the top 48 bits enter the close, cognn_open_hi48) with
+// COGNN_OPT_PACKED_OPENINGS: the chunk is packed to 6 bytes per element into the outbox's wire buffer, the wire buffers travel, and the
+// received one is restored into the inbox once its round has completed (exchange_wait / exchange_wait_round)
+void msg_range(cognn_engine* E, XList& xl, Side& s, u64* out, u64* in, int64_t elems, int c, int C, bool packable) {
     int64_t lo, hi;
     cognn_chunk_range(elems, c, C, &lo, &hi);
-    xl.send(s.peer_rank, out + lo, (hi - lo) * 8);
-    xl.recv(s.peer_rank, in + lo, (hi - lo) * 8);
+    if (hi <= lo) return;
+    if (!packable || !E->packed_openings) {
+        xl.send(s.peer_rank, out + lo, (hi - lo) * 8);
+        xl.recv(s.peer_rank, in + lo, (hi - lo) * 8);
+        return;
+    }
+    auto f = E->wire.find(out);
+    if (f == E->wire.end() || f->second.elems < elems) {
+        cognn_engine::Wire w;
+        w.elems = elems;
+        w.out = dalloc<unsigned char>(E, (size_t)elems * 6 + 16);
+        w.in = dalloc<unsigned char>(E, (size_t)elems * 6 + 16);
+        f = E->wire.insert_or_assign(out, w).first;       // (a grown buffer replaces the old one; the old one is freed with the engine)
+    }
+    const int64_t n = hi - lo;                             // (chunk bounds are even: lo * 6 is a multiple of 4)
+    BE(cognn_pack48_u64(E->ctx, f->second.out + lo * 6, out + lo, n));
+    xl.send(s.peer_rank, f->second.out + lo * 6, n * 6);
+    xl.recv(s.peer_rank, f->second.in + lo * 6, n * 6);
+    E->unpacks.push_back(cognn_engine::Unpack{E->xbegun, in + lo, f->second.in + lo * 6, n});   // the round about to begin
+}
+// restores the packed messages of the rounds that have completed
+static void unpack_completed(cognn_engine* E) {
+    if (E->unpacks.empty()) return;
+    std::vector<cognn_engine::Unpack> later;
+    for (auto& u : E->unpacks) {
+        if (u.round < E->xdone) BE(cognn_unpack48_u64(E->ctx, u.dst, u.src, u.n));
+        else later.push_back(u);
+    }
+    E->unpacks.swap(later);
 }
 void chunked_rounds(cognn_engine* E, const std::vector<Step>& steps, bool skip_paired) {
     bool remote = false;

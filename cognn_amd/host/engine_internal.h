@@ -123,6 +123,11 @@ struct cognn_engine {
     u64 salt_now = 0;                               // the epoch salt of the iteration being issued (added to the keys on the host, or - recorded epochs - on the device)
     u64 salt_on_device = 0;                         // what cognn_set_epoch_salt last set (recorded epochs only)
     bool dealer_group = getenv("COGNN_NO_DEALER_GROUP") == nullptr;   // offline phase: the product shares of one shape in one grouped MFMA launch
+    bool packed_openings = false;                   // COGNN_OPT_PACKED_OPENINGS: opened truncation / ReLU-product shares cross ranks as 6 bytes
+    struct Wire { unsigned char* out; unsigned char* in; int64_t elems; };
+    std::map<const u64*, Wire> wire;               // wire buffers of an outbox (keyed by the outbox), allocated at first use
+    struct Unpack { int64_t round; u64* dst; const unsigned char* src; int64_t n; };
+    std::vector<Unpack> unpacks;                    // received packed messages, restored once their round has completed
     int dealer_streams = 0;                         // COGNN_OPT_DEALER_STREAMS: 1 = dealt values of the pair chains / grouped products read from HBM; 2 = only the dealer's corrections
     std::map<std::tuple<int, int64_t, int>, u64*> dealt;   // (owner, iteration, place) -> slab, filled at first use, kept (retain_offline)
     int64_t dealt_bytes = 0;
@@ -343,7 +348,7 @@ void run_exchange_sync(cognn_engine* E, XList& xl);
 void exchange_ob(cognn_engine* E, int j, const std::vector<int64_t>& elems);
 void exchange_ob2(cognn_engine* E, int j0, const std::vector<int64_t>& e0, int j1, const std::vector<int64_t>& e1);
 std::vector<int64_t> per_side(cognn_engine* E, int64_t (*f)(cognn_engine*, Side&));
-void msg_range(XList& xl, Side& s, u64* out, u64* in, int64_t elems, int c, int C);
+void msg_range(cognn_engine* E, XList& xl, Side& s, u64* out, u64* in, int64_t elems, int c, int C, bool packable = false);
 void chunked_rounds(cognn_engine* E, const std::vector<Step>& steps, bool skip_paired = false);
 void mp_exchange(cognn_engine* E, int F, u64* T);
 void config_handshake(cognn_engine* E);
@@ -450,7 +455,7 @@ void trunc_stage(cognn_engine* E, int64_t it, int op, u64 mul, const std::vector
         cognn_keys k = keys(E, owner_override == ~0ull ? (u64)s.owner : owner_override, it, op);
         BE(cognn_trunc_open_u64(E->ctx, s.ob[2], x[i], mul, &k, s.p, elems[i]));
     };
-    steps[0].msg = [&](XList& xl, Side& s, size_t i, int c, int C) { msg_range(xl, s, s.ob[2], s.ib[2], elems[i], c, C); };
+    steps[0].msg = [&](XList& xl, Side& s, size_t i, int c, int C) { msg_range(E, xl, s, s.ob[2], s.ib[2], elems[i], c, C, true); };   // an opened truncation share: 6 bytes matter
     steps[1].fn = [&](Side& s, size_t i) {
         cognn_keys k = keys(E, owner_override == ~0ull ? (u64)s.owner : owner_override, it, op);
         BE(cognn_trunc_close_u64(E->ctx, dst(s), s.p == 0 ? s.ob[2] : nullptr, s.p == 0 ? s.ib[2] : nullptr, &k, s.p, mode, elems[i]));
@@ -482,7 +487,7 @@ void trunc_exchange_close(cognn_engine* E, int64_t it, int top, DstFn dst, const
                           bool skip_paired, std::function<void(Side&, size_t)> open = nullptr) {
     std::vector<Step> steps(2);
     steps[0].fn = open;
-    steps[0].msg = [&](XList& xl, Side& s, size_t i, int c, int C) { msg_range(xl, s, s.ob[2], s.ib[2], elems[i], c, C); };
+    steps[0].msg = [&](XList& xl, Side& s, size_t i, int c, int C) { msg_range(E, xl, s, s.ob[2], s.ib[2], elems[i], c, C, true); };   // an opened truncation share: 6 bytes matter
     steps[1].fn = [&](Side& s, size_t i) { trunc_close_one(E, it, top, dst, elems, open_next, s, i); };
     chunked_rounds(E, steps, skip_paired);
 }

@@ -39,14 +39,14 @@ void relu_stage(cognn_engine* E, int64_t it, bool e_opened, bool pairs_done) {
             // only E = z - a is opened online: g = t - b is input-independent and published by the dealer offline
             if (!e_opened) BE(cognn_relu_open_u64(E->ctx, s.ob[0], nullptr, s.cur, &k, s.p, eF[i]));
         };
-        steps.back().msg = [&](XList& xl, Side& s, size_t i, int c, int C) { msg_range(xl, s, s.ob[0], s.ib[0], eF[i], c, C); };
+        steps.back().msg = [&](XList& xl, Side& s, size_t i, int c, int C) { msg_range(E, xl, s, s.ob[0], s.ib[0], eF[i], c, C); };
     }
     steps.emplace_back();
     steps.back().fn = [&](Side& s, size_t i) {
         cognn_keys k = keys(E, s.owner, it, COGNN_OP_AP_RELU);
         BE(cognn_relu_mul_u64(E->ctx, s.ob[2], s.ob[0], e_public ? nullptr : s.ib[0], nullptr, nullptr, &k, s.p, eF[i]));
     };
-    steps.back().msg = [&](XList& xl, Side& s, size_t i, int c, int C) { msg_range(xl, s, s.ob[2], s.ib[2], eF[i], c, C); };
+    steps.back().msg = [&](XList& xl, Side& s, size_t i, int c, int C) { msg_range(E, xl, s, s.ob[2], s.ib[2], eF[i], c, C, true); };   // the opened product w: its top 48 bits carry the sign
     // H is the next iteration's PreScatter GEMM input (layer 1): write it straight into its h_t slot and emit the
     // Beaver opening E_p = H_p - A_p of that product in the same pass (gcn.h:230-239 of iteration it+1)
     steps.emplace_back();

@@ -322,8 +322,8 @@ void rowscale_stage(cognn_engine* E, int64_t it, int op, int top, int F, XFn X, 
         BE(cognn_rowscale_open_u64(E->ctx, e_mode == E_FROM_X ? s.ob[0] : nullptr, s.ob[1], X(s), s.svec, &k, s.p, s.n, F));
     };
     steps[0].msg = [&](XList& xl, Side& s, size_t i, int c, int C) {
-        if (!e_public) msg_range(xl, s, e_opened ? X(s) : s.ob[0], s.ib[0], eF[i], c, C);   // (public: ob[0] holds E itself, only the scale openings travel)
-        if (c == 0) msg_range(xl, s, s.ob[1], s.ib[1], e1[i], 0, 1);
+        if (!e_public) msg_range(E, xl, s, e_opened ? X(s) : s.ob[0], s.ib[0], eF[i], c, C);   // (public: ob[0] holds E itself, only the scale openings travel)
+        if (c == 0) msg_range(E, xl, s, s.ob[1], s.ib[1], e1[i], 0, 1);
     };
     steps[1].fn = [&](Side& s, size_t) {                    // the opened sums E0+E1, G0+G1 are formed inside the kernel
         cognn_keys k = keys(E, s.owner, it, op), tk = keys(E, s.owner, it, top);
@@ -331,7 +331,7 @@ void rowscale_stage(cognn_engine* E, int64_t it, int op, int top, int F, XFn X, 
         const u64* e_peer = e_public ? nullptr : e_opened ? (s.peer ? X(*s.peer) : s.ib[0]) : s.ib[0];
         BE(cognn_rowscale_close_u64(E->ctx, s.ob[2], e_own, e_peer, s.ob[1], s.ib[1], &k, &tk, s.p, s.n, F));
     };
-    steps[1].msg = [&](XList& xl, Side& s, size_t i, int c, int C) { msg_range(xl, s, s.ob[2], s.ib[2], eF[i], c, C); };
+    steps[1].msg = [&](XList& xl, Side& s, size_t i, int c, int C) { msg_range(E, xl, s, s.ob[2], s.ib[2], eF[i], c, C, true); };
     steps.emplace_back();
     steps.back().fn = [&](Side& s, size_t i) { trunc_close_one(E, it, top, dst, eF, open_next, s, i); };
     chunked_rounds(E, steps, true);

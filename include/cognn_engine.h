@@ -131,9 +131,15 @@ int cognn_engine_offline(cognn_engine* e, int64_t iter_begin, int64_t iter_end);
  * open -> exchange -> close steps of those sides (product truncation, row scale, ReLU) run in that many row chunks
  * (cognn_ctx_set_chunk): chunk c's messages are enqueued as their own round as soon as chunk c is opened and travel while
  * chunk c+1 is opened and chunk c-1 closed, so those kernels hide behind the link instead of waiting for it.  More, smaller
- * rounds (C times as many for the chunked steps); shares bit-identical for every value. */
+ * rounds (C times as many for the chunked steps); shares bit-identical for every value. 
+ * COGNN_OPT_PACKED_OPENINGS (default 0; matters only between ranks): the opened shares of every truncation and of the ReLU's masked
+ * product cross the link as 6 bytes per element instead of 8 - both parties form the opened value from the TOP 48 BITS of the two
+ * shares (cognn_spec.h, cognn_open_hi48; the ReLU's multiplier is at least 2^17 so that the sign survives), so the low 16 bits never
+ * matter: the open kernels' outboxes are packed into wire buffers (cognn_pack48_u64), those travel, and the inboxes are restored
+ * after the round's wait.  Shares bit-identical with and without.  240 of the 471 units a crossing pair exchanges per inference pass
+ * are such shares: 494 -> 431 MB per pair and direction on config5. */
 enum { COGNN_OPT_RETAIN_OFFLINE = 1, COGNN_OPT_PAIR_FUSION = 2, COGNN_OPT_FORWARD_ONLY = 3, COGNN_OPT_PUBLIC_OPENINGS = 4,
-       COGNN_OPT_DEALER_STREAMS = 5, COGNN_OPT_GRAPH_EPOCHS = 6, COGNN_OPT_EXCHANGE_CHUNKS = 7 };
+       COGNN_OPT_DEALER_STREAMS = 5, COGNN_OPT_GRAPH_EPOCHS = 6, COGNN_OPT_EXCHANGE_CHUNKS = 7, COGNN_OPT_PACKED_OPENINGS = 8 };
 int cognn_engine_set_option(cognn_engine* e, int32_t option, int64_t value);
 /* Offline-phase cache on disk, the counterpart of the reference's preprocess/<setting>/ directory reused with `-n 1`
  * (include/harness.h:140-146, README.md:215-216): save writes every dealt product share currently held on this rank to

@@ -125,6 +125,12 @@ int cognn_ring_gemm2_u64(cognn_ctx*, uint64_t* C, const uint64_t* A1, const uint
                                     * reading of the PRNG word, a = w - (((w >> 7) & 0x0101..01) << 8) (cognn_spec.h), what the product
                                     * kernels generate for their A operand; plain prng(key, idx) otherwise (B masks, element-wise masks) */
 int cognn_mask_open_u64(cognn_ctx*, uint64_t* E, const uint64_t* X, uint64_t key, int64_t rows, int64_t cols, int transposed);
+/* The 6-byte wire form of an opened truncation share (or of the ReLU's opened product): only its top 48 bits enter the close
+ * (cognn_spec.h, cognn_open_hi48).  packed = n 32-bit words (bits 16..47) followed by n 16-bit words (bits 48..63); unpack restores
+ * the share with its low 16 bits zero, which closes to exactly the same result.  packed must be 4-byte aligned.  Not chunk-windowed:
+ * the caller passes the range. */
+int cognn_pack48_u64(cognn_ctx*, void* packed, const uint64_t* src, int64_t n);
+int cognn_unpack48_u64(cognn_ctx*, uint64_t* dst, const void* packed, int64_t n);
 /* out[i] = the A mask VALUE of a product (limb form) for element i: what a dealt A mask / a mask image holds */
 int cognn_gemm_mask_fill_u64(cognn_ctx*, uint64_t* out, uint64_t key, int64_t n);
 int cognn_add_u64(cognn_ctx*, uint64_t* out, const uint64_t* a, const uint64_t* b, int64_t n);

@@ -35,6 +35,7 @@ FX_ONE = 1 << SCALER_BIT_LENGTH
 GAMMA = 0x9E3779B97F4A7C15
 M1 = 0xBF58476D1CE4E5B9
 M2 = 0x94D049BB133111EB
+RELU_T_MIN = 1 << 17              # the ReLU's multiplier t is at least 2^17: |z t| >= 2^17 for z != 0, so the 48-bit reading of w = z t has z's sign
 TRUNC_OFFSET = 1 << 61            # makes x+offset non-negative for |x| < 2^61
 TRUNC_MASK = (1 << 62) - 1
 
@@ -152,6 +153,13 @@ def normalizer(deg):
 # each side computes depend only on its own share, its own dealer streams and the opened
 # (exchanged) values, exactly as in the HIP engine.
 # ----------------------------------------------------------------------------------------
+def open_hi48(c0, c1):
+    """What both parties form from two opened shares of a truncation (or of the ReLU's masked product): the top 48 bits of each,
+    added mod 2^48."""
+    with np.errstate(over="ignore"):
+        return ((np.asarray(c0, dtype=U64) >> U64(SCALER_BIT_LENGTH)) + (np.asarray(c1, dtype=U64) >> U64(SCALER_BIT_LENGTH))) & U64(0xFFFFFFFFFFFF)
+
+
 def trunc_pair(x0, x1, key_of):
     """Dealer-assisted truncation by f bits (T2, bounded mask). key_of(slot)->stream key."""
     shape = x0.shape
@@ -164,8 +172,9 @@ def trunc_pair(x0, x1, key_of):
         rp1 = rp - rp0
         c0 = x0 + r0 + U64(TRUNC_OFFSET)
         c1 = x1 + r1
-        c = c0 + c1                                           # opened
-        o0 = (c >> U64(SCALER_BIT_LENGTH)) - U64(TRUNC_OFFSET >> SCALER_BIT_LENGTH) - rp0
+        # opened: both parties add the TOP 48 BITS of the two shares mod 2^48 (the carry out of the low 16 bits is dropped, so 6 bytes
+        # of an opened share are all that ever travels): (c >> f) - {0, 1}
+        o0 = open_hi48(c0, c1) - U64(TRUNC_OFFSET >> SCALER_BIT_LENGTH) - rp0
         o1 = U64(0) - rp1
     return o0, o1
 
@@ -216,10 +225,10 @@ def beaver_rowscale_pair(v0, v1, s0, s1, key_of):
 
 def relu_pair(z0, z1, key_of):
     """sci::twoPartyGCNRelu stand-in (gcn.h:549): masked-sign ReLU (R1). Opens w = z*t with a
-    dealer-shared random t in [1,2^20); the sign of z becomes public (stated leak)."""
+    dealer-shared random t in [2^17,2^20); the sign of z becomes public (stated leak)."""
     shape = z0.shape
     with np.errstate(over="ignore"):
-        t = (prng_shape(key_of(SL_T), shape) & U64(0xFFFFF)) | U64(1)
+        t = (prng_shape(key_of(SL_T), shape) & U64(0xFFFFF)) | U64(RELU_T_MIN)     # t in [2^17, 2^20)
         t0 = prng_shape(key_of(SL_T0), shape)
         t1 = t - t0
         a0 = prng_shape(key_of(SL_A0), shape); a1 = prng_shape(key_of(SL_A1), shape)
@@ -230,8 +239,7 @@ def relu_pair(z0, z1, key_of):
         g = (t0 - b0) + (t1 - b1)
         w0 = e * b0 + a0 * g + c0
         w1 = e * g + e * b1 + a1 * g + c1
-        w = w0 + w1                                           # opened
-    pos = w.astype(np.int64) > 0
+        pos = (open_hi48(w0, w1) << U64(16)).astype(np.int64) > 0     # opened, read through its top 48 bits like a truncation
     h0 = np.where(pos, z0, U64(0))
     h1 = np.where(pos, z1, U64(0))
     return h0, h1, pos

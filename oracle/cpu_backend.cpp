@@ -131,6 +131,16 @@ int cognn_prng_fill_u64(cognn_ctx*, uint64_t* out, uint64_t key, int64_t n) {
     for (int64_t i = 0; i < n; ++i) out[i] = cognn_prng(key, (u64)i);
     return 0;
 }
+int cognn_pack48_u64(cognn_ctx*, void* packed, const uint64_t* src, int64_t n) {     // the 6-byte wire form of an opened truncation share
+    uint32_t* mid = (uint32_t*)packed; uint16_t* top = (uint16_t*)((unsigned char*)packed + 4 * n);
+    for (int64_t i = 0; i < n; ++i) { mid[i] = (uint32_t)(src[i] >> 16); top[i] = (uint16_t)(src[i] >> 48); }
+    return 0;
+}
+int cognn_unpack48_u64(cognn_ctx*, uint64_t* dst, const void* packed, int64_t n) {
+    const uint32_t* mid = (const uint32_t*)packed; const uint16_t* top = (const uint16_t*)((const unsigned char*)packed + 4 * n);
+    for (int64_t i = 0; i < n; ++i) dst[i] = ((u64)mid[i] << 16) | ((u64)top[i] << 48);
+    return 0;
+}
 int cognn_gemm_mask_fill_u64(cognn_ctx*, uint64_t* out, uint64_t key, int64_t n) {   // a product's A mask: limb-form values (cognn_spec.h)
     CG_PAR
     for (int64_t i = 0; i < n; ++i) out[i] = cognn_gemm_mask(key, (u64)i);
@@ -325,7 +335,7 @@ int cognn_trunc_close_u64(cognn_ctx*, uint64_t* out, const uint64_t* c0, const u
     const cognn_opkeys k = K(keys);
     CG_PAR
     for (int64_t i = lo_; i < hi_; ++i) {
-        u64 y = p == 0 ? ((c0[i] + c1[i]) >> COGNN_FX_BITS) - (COGNN_TRUNC_OFFSET >> COGNN_FX_BITS) - trunc_rp(k, 0, (u64)i)
+        u64 y = p == 0 ? cognn_open_hi48(c0[i], c1[i]) - (COGNN_TRUNC_OFFSET >> COGNN_FX_BITS) - trunc_rp(k, 0, (u64)i)
                        : 0ull - trunc_rp(k, 1, (u64)i);
         out[i] = mode == 1 ? out[i] - y : y;
     }
@@ -361,7 +371,7 @@ int cognn_trunc_close_pub_dealt_u64(cognn_ctx*, uint64_t* out, uint64_t* E, cons
     CHUNK(n)
     REQ(E && c0 && c1 && t && (!out || rp_own), "trunc_close_pub_dealt: missing tensor");
     for (int64_t i = lo_; i < hi_; ++i) {
-        const u64 hi = ((c0[i] + c1[i]) >> COGNN_FX_BITS) - (COGNN_TRUNC_OFFSET >> COGNN_FX_BITS);
+        const u64 hi = cognn_open_hi48(c0[i], c1[i]) - (COGNN_TRUNC_OFFSET >> COGNN_FX_BITS);
         E[i] = hi - t[i];
         if (out) out[i] = (p == 0 ? hi : 0ull) - rp_own[i];
     }
@@ -402,7 +412,7 @@ int cognn_relu_open_u64(cognn_ctx*, uint64_t* E, uint64_t* G, const uint64_t* z,
     CG_PAR
     for (int64_t i = lo_; i < hi_; ++i) {
         const u64 t0 = cognn_prng(keys->k[COGNN_SL_T0], (u64)i);
-        const u64 tp = p == 0 ? t0 : ((cognn_prng(keys->k[COGNN_SL_T], (u64)i) & 0xFFFFFull) | 1ull) - t0;
+        const u64 tp = p == 0 ? t0 : ((cognn_prng(keys->k[COGNN_SL_T], (u64)i) & 0xFFFFFull) | COGNN_RELU_T_MIN) - t0;
         E[i] = z[i] - cognn_prng(keys->k[p == 0 ? COGNN_SL_A0 : COGNN_SL_A1], (u64)i);
         if (G) G[i] = tp - cognn_prng(keys->k[p == 0 ? COGNN_SL_B0 : COGNN_SL_B1], (u64)i);
     }
@@ -416,7 +426,7 @@ int cognn_relu_mul_u64(cognn_ctx*, uint64_t* w, const uint64_t* E, const uint64_
     for (int64_t i = lo_; i < hi_; ++i) {
         // G == NULL: dealer-published g = t - (b0 + b1)
         const u64 g = G ? G[i] + (G1 ? G1[i] : 0)
-                        : ((cognn_prng(keys->k[COGNN_SL_T], (u64)i) & 0xFFFFFull) | 1ull) - cognn_prng(keys->k[COGNN_SL_B0], (u64)i) -
+                        : ((cognn_prng(keys->k[COGNN_SL_T], (u64)i) & 0xFFFFFull) | COGNN_RELU_T_MIN) - cognn_prng(keys->k[COGNN_SL_B0], (u64)i) -
                               cognn_prng(keys->k[COGNN_SL_B1], (u64)i);
         w[i] = beaver_mul(k, p, E[i] + (E1 ? E1[i] : 0), g, (u64)i, (u64)i);
     }
@@ -426,7 +436,7 @@ int cognn_relu_close_u64(cognn_ctx*, uint64_t* h, uint8_t* mask, const uint64_t*
     CHUNK(n)
     CG_PAR
     for (int64_t i = lo_; i < hi_; ++i) {
-        const bool pos = (long long)(w0[i] + w1[i]) > 0;
+        const bool pos = cognn_relu_positive(w0[i], w1[i]);
         h[i] = pos ? z[i] : 0;
         if (mask) mask[i] = pos;
     }
@@ -656,7 +666,7 @@ static void cpu_scale_trunc_pair(const cognn_keys& sk, const cognn_keys& tk, u64
     const u64 e = (v0 - a0) + (v1 - a1);
     const u64 z0 = e * b0 + a0 * g + c0m, z1 = e * g + e * b1 + a1 * g + c1m;
     const u64 c0 = z0 + trunc_r(t, 0, idx) + COGNN_TRUNC_OFFSET, c1 = z1 + trunc_r(t, 1, idx);
-    v0 = ((c0 + c1) >> COGNN_FX_BITS) - (COGNN_TRUNC_OFFSET >> COGNN_FX_BITS) - trunc_rp(t, 0, idx);
+    v0 = cognn_open_hi48(c0, c1) - (COGNN_TRUNC_OFFSET >> COGNN_FX_BITS) - trunc_rp(t, 0, idx);
     v1 = 0ull - trunc_rp(t, 1, idx);
 }
 int cognn_scatter_gather_original_u64(cognn_ctx*, uint64_t* outA, uint64_t* outB, const uint64_t* selfA, const uint64_t* selfB,

@@ -64,6 +64,8 @@ def main():
         eng.public_openings(False)
     if "pair_fusion" in cfg:
         eng.pair_fusion(bool(cfg["pair_fusion"]))
+    if cfg.get("packed_openings"):                         # opened truncation shares as 6 bytes on the wire
+        eng.packed_openings(True)
     out = {}
     m = k // world
     step = 6 if cfg.get("whole_epochs") else 1             # whole epochs per call: nothing is read between their GAS iterations

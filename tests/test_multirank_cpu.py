@@ -252,3 +252,16 @@ def test_engines_starting_side_by_side_get_the_reference_weights(tmp_path):
     cfg = dict(BASE, k=4, V=64, Eu=150, hid=64, lab=8, variant="optimize-gcn-inference", iters=2, inproc=True)
     cfg["in"] = 400
     _check(cfg, 4, tmp_path)
+
+
+@pytest.mark.parametrize("k,world,variant,iters,extra", [
+    (4, 2, "optimize-gcn", 12, {}), (4, 4, "optimize-gcn-inference", 2, {}), (8, 8, "optimize-gcn", 6, {"V": 96, "Eu": 260}),
+    (8, 8, "optimize-gcn-inference", 2, {"V": 96, "Eu": 260}), (4, 2, "optimize-gcn", 6, {"chunks": 3}), (4, 2, "optimize-gcn", 6, {"exchanged_openings": True}),
+    (4, 2, "optimize-gcn", 6, {"blocking_exchange": True}), (4, 4, "optimize-gcn", 6, {"hostile": 5}), (8, 8, "optimize-gcn", 6, {"V": 96, "Eu": 260, "hostile": 6, "chunks": 2}),
+    (6, 3, "optimize-gcn", 6, {"V": 61, "Eu": 200, "pair_fusion": False})])
+def test_packed_openings(tmp_path, k, world, variant, iters, extra):
+    """COGNN_OPT_PACKED_OPENINGS: the opened shares of every truncation and of the ReLU's masked product cross ranks as 6 bytes per
+    element (both parties form the opened value from the top 48 bits of the two shares, so the low 16 never matter): the same shares as
+    the oracle bit for bit - over gloo, the blocking callback, the chunked pipeline, the hostile transport (inboxes poisoned until the
+    wait: a restore before the round's completion would unpack poison), worlds 2 / 3 / 4 / 8."""
+    _check(dict(BASE, k=k, variant=variant, iters=iters, packed_openings=True, **extra), world, tmp_path)

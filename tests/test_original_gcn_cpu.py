@@ -55,8 +55,8 @@ def test_scatter_scales_each_edge_by_both_normalisers():
             n0 = co.normalizer(gs.updateSrcOutDeg[i]).astype(np.int64)
             din = gs.updateDstInDeg[i] if i == P else o.states[i].remoteUpdateDstInDeg[P]
             n1 = co.normalizer(din).astype(np.int64)
-            step = (x.astype(np.int64) * n0[:, None]) >> 16                    # each truncation yields floor or floor + 1
-            lo = (step * n1[:, None]) >> 16                                    # normalisers are >= 0: monotone in step
+            step = (x.astype(np.int64) * n0[:, None]) >> 16                    # each truncation yields floor + {-1, 0, +1}
+            lo = (((step - 1) * n1[:, None]) >> 16) - 1                        # normalisers are >= 0: monotone in step
             hi = (((step + 1) * n1[:, None]) >> 16) + 1
             assert ((y >= lo) & (y <= hi)).all()
             if i != P:

