@@ -177,7 +177,7 @@ def cpu_baseline(args, wl):
                       "in=%d hid=%d labels=%d, %.2f s" % (k, variant, lv2, le2, in_dim, hid, lab, dt)}
 
 
-def cross_path_check(eng, Engine, k, src, dst, part, param, variant, iters, in_dim, lab, passes):
+def cross_path_check(eng, Engine, k, src, dst, part, param, variant, iters, in_dim, lab, passes, recorded=False):
     """After the timed region (N = 1): the shares the bench's own sequence left behind - forward-only stores, retained offline
     products, the pass replayed warmup + steps times - must equal, bit for bit and for every party, those of a fresh engine
     that runs the pass once the plain way; for an inference pass the revealed rows must also be probability vectors.  (Parity
@@ -200,6 +200,8 @@ def cross_path_check(eng, Engine, k, src, dst, part, param, variant, iters, in_d
         rng = np.random.default_rng(0xC06A12 + P)
         ref.set_party_data(P, (rng.random((len(vids), in_dim)) < 0.01).astype(np.float64), rng.integers(0, lab, size=len(vids)))
     ref.start()
+    if recorded:                                            # (recorded epochs deal the feature operand's mask anew every epoch: the plain run does too;
+        ref.graph_epochs(True)                              #  one GAS iteration per call never records anything)
     for _ in range(passes if "inference" not in variant else 1):   # a training pass updates the weights: as many passes as the bench ran
         for it in range(iters):                             # one call per GAS iteration: none of the paths that span iterations of a call
             ref.run(it, it + 1)
@@ -637,7 +639,7 @@ def main():
         out["exchange"] = dict(ranks_seen, transport="torch.distributed %s, host-staged (rehearsal transport)" % backend)
     if not args.no_check and world == 1:
         try:
-            out["check"] = cross_path_check(eng, Engine, k, src, dst, part, param, variant, iters, in_dim, lab, n_warm + args.steps)
+            out["check"] = cross_path_check(eng, Engine, k, src, dst, part, param, variant, iters, in_dim, lab, n_warm + args.steps, recorded=recorded)
         except Exception as ex:  # noqa: BLE001 - e.g. a second engine of an 8x workload does not fit beside the first: the measurement stands
             out["check"] = {"skipped": "the verification engine could not run: %s" % (str(ex)[-200:],)}
     if not args.no_check and world > 1:

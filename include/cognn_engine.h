@@ -126,7 +126,10 @@ int cognn_engine_offline(cognn_engine* e, int64_t iter_begin, int64_t iter_end);
  * it is recorded, every later one as a replay under its own epoch salt (cognn_set_epoch_salt) - dataset-sized graphs spend
  * their epoch in launch overhead.  The engine moves to a private stream, deals product shares inside the recording (the
  * offline call becomes a no-op unless COGNN_OPT_RETAIN_OFFLINE keeps one epoch's products for replays of that epoch) and
- * renews the feature opening every epoch.  Shares, weights and metrics are bit-identical to the eager run.
+ * renews the feature operand's Beaver mask and opening every epoch (the eager form deals that mask once).  Shares, weights and
+ * metrics are bit-identical to an eager run that does the same (set the option and call one GAS iteration at a time); against the
+ * deal-once form they differ by single LSBs - the carry the 48-bit truncation opening drops depends on how a product is split into
+ * shares.
  * COGNN_OPT_EXCHANGE_CHUNKS (default 1; 1..8; matters only for share-holders whose peer is on another rank): the element-wise
  * open -> exchange -> close steps of those sides (product truncation, row scale, ReLU) run in that many row chunks
  * (cognn_ctx_set_chunk): chunk c's messages are enqueued as their own round as soon as chunk c is opened and travel while

@@ -514,8 +514,13 @@ class OracleEngine:
     """Sequential emulation of k CoGNN parties running gcn-optimize / gcn-inference-optimize."""
 
     def __init__(self, k, src, dst, part, features, labels, param, seed=0xC06A11, variant="optimize-gcn",
-                 weights=None):
+                 weights=None, renew_feature_mask=False):
+        """renew_feature_mask: the Beaver mask of the (constant) feature operand is dealt anew in every epoch - what the engine's
+        recorded epochs do (COGNN_OPT_GRAPH_EPOCHS: kernel arguments may not depend on the epoch, so the mask's key carries the
+        epoch salt like every other stream) - instead of once.  The product is the same; its two SHARES, and with them the carry the
+        48-bit truncation opening drops (open_hi48), are not: the two forms differ by single LSBs."""
         self.k = k; self.param = param; self.seed = seed; self.variant = variant
+        self.renew_feature_mask = renew_feature_mask
         self.part = [int(t) for t in part]
         self.states = [preprocess_party(P, k, src, dst, self.part) for P in range(k)]
         exchange_pos_vecs(self.states, k)
@@ -536,13 +541,17 @@ class OracleEngine:
         """Layer-0 PreScatter product X.W0: X (the input features) is the same tensor in every epoch, so its Beaver mask A
         is dealt once (iteration 0) and E = X - A is opened once; W0's mask B and the product share C stay per-iteration
         (fixed-operand mask reuse)."""
-        return lambda slot: (stream_key(self.seed, owner, 0, OP_PS_GEMM, slot) if slot in (SL_A0, SL_A1)
+        return lambda slot: (self._feature_mask_key(owner, it, slot) if slot in (SL_A0, SL_A1)
                              else self.key_of(owner, it, OP_PS_GEMM)(slot))
+
+    def _feature_mask_key(self, owner, it, slot):
+        salt = (it // self.epoch_len()) * GAMMA if self.renew_feature_mask else 0
+        return (stream_key(self.seed, owner, 0, OP_PS_GEMM, slot) + salt) & MASK64
 
     def key_of_feature_wgrad(self, owner, it):
         """Layer-0 weight gradient X^T.g (gcn.h:710): the left operand is the same feature tensor, transposed, so it keeps the
         A mask of key_of_feature_gemm (indexed in storage order); B and C come from this iteration's OP_AP_GEMM streams."""
-        return lambda slot: (stream_key(self.seed, owner, 0, OP_PS_GEMM, slot) if slot in (SL_A0, SL_A1)
+        return lambda slot: (self._feature_mask_key(owner, it, slot) if slot in (SL_A0, SL_A1)
                              else self.key_of(owner, it, OP_AP_GEMM)(slot))
 
     def key_of_hidden_wgrad(self, owner, it, it_fwd):

@@ -112,8 +112,8 @@ def main():
                 eng.pair_fusion(bool(cfg["pair_fusion"]))
             if cfg.get("exchanged_openings"):
                 eng.public_openings(False)
-            if cfg.get("packed_openings") is not None and hasattr(eng, "packed_openings"):
-                eng.packed_openings(bool(cfg["packed_openings"]))
+            if cfg.get("packed_openings"):
+                eng.packed_openings(True)
             out = {}
             for it0 in range(0, cfg["iters"], step):
                 eng.run(it0, it0 + step)

@@ -8,13 +8,13 @@ import cognn_oracle as co
 pytestmark = pytest.mark.gpu
 
 
-def _setup(k, V, Eu, in_dim, hid, lab, variant="optimize-gcn", seed=7, gseed=1):
+def _setup(k, V, Eu, in_dim, hid, lab, variant="optimize-gcn", seed=7, gseed=1, **oracle_kw):
     from cognn_amd.engine import Engine, GnnParam
     src, dst = co.synth_graph(V, Eu, gseed)
     part = np.array([v % k for v in range(V)], dtype=np.int32)
     feats, labels = co.synth_features(V, in_dim, lab, gseed + 1, density=0.2)
     op = co.GnnParam(num_labels=lab, input_dim=in_dim, hidden_dim=hid, num_samples=V, learning_rate=0.5)
-    oracle = co.OracleEngine(k, src, dst, part, feats, labels, op, seed=seed, variant=variant)
+    oracle = co.OracleEngine(k, src, dst, part, feats, labels, op, seed=seed, variant=variant, **oracle_kw)
     gp = GnnParam(num_labels=lab, input_dim=in_dim, hidden_dim=hid, num_samples=V, learning_rate=0.5)
     eng = Engine(k, src, dst, part, gp, seed=seed, variant=variant)
     eng.set_global_data(feats, labels)
@@ -67,10 +67,11 @@ def test_training_two_epochs_bit_exact(k, pair_fusion):
 @pytest.mark.parametrize("k,V,Eu,in_dim,hid,lab", [(2, 70, 170, 20, 8, 4), (3, 120, 400, 33, 16, 7), (8, 400, 1500, 24, 16, 6)])
 def test_recorded_epochs_bit_exact(k, V, Eu, in_dim, hid, lab):
     """COGNN_OPT_GRAPH_EPOCHS: epoch 0 runs eagerly, epoch 1 while it is recorded (hipGraph), epochs 2-4 as replays of that
-    recording under their own epoch salt; also several epochs per call.  Shares, weights and metrics after every epoch are the
-    oracle's - whose feature mask is the one of iteration 0 in every epoch while the recorded epochs renew theirs: the truncated
-    product does not depend on it."""
-    oracle, eng = _setup(k, V, Eu, in_dim, hid, lab, seed=33)
+    recording under their own epoch salt; also several epochs per call.  Shares, weights and metrics after every epoch are those of
+    the oracle that renews the feature operand's Beaver mask every epoch, as recorded epochs do (their kernel arguments may not depend
+    on the epoch).  (The eager form deals that mask once; the two forms differ by single LSBs - the carry the 48-bit truncation opening
+    drops depends on how the product is split into shares.)"""
+    oracle, eng = _setup(k, V, Eu, in_dim, hid, lab, seed=33, renew_feature_mask=True)
     eng.graph_epochs(True)
 
     def check(ep):

@@ -128,3 +128,25 @@ def test_baseline_configs_3_and_4_one_party_per_rank_hip(tmp_path, name, k, V, E
                param=dict(learning_rate=lr, train_ratio=tr, val_ratio=0.2 if tr == 0.2 else 0.15, test_ratio=0.6 if tr == 0.2 else 0.8))
     cfg["in"] = inn
     _check(cfg, k, tmp_path)
+
+
+@pytest.mark.parametrize("cfg_extra,world", [(dict(k=4, V=2048, Eu=8192, hid=64, lab=16, variant="optimize-gcn", iters=6, inn=128), 2),
+                                             (dict(k=4, V=1500, Eu=6000, hid=16, lab=7, variant="optimize-gcn", iters=6, inn=64, chunks=3), 4),
+                                             (dict(k=8, V=1 << 14, Eu=1 << 17, hid=64, lab=16, density=0.01, variant="optimize-gcn-inference", iters=2, inn=128, inproc=True), 8),
+                                             (dict(k=8, V=4096, Eu=16384, hid=16, lab=8, variant="optimize-gcn", iters=12, inn=32, inproc=True), 8)])
+def test_packed_openings_hip(tmp_path, cfg_extra, world):
+    """COGNN_OPT_PACKED_OPENINGS on the HIP kernels: pack / unpack launches around the exchange of every opened truncation share and
+    of the ReLU's opened product (6 bytes per element on the wire), chunk windows included; one party per rank at world 8."""
+    extra = dict(cfg_extra)
+    inn = extra.pop("inn")
+    cfg = dict(BASE, backend="hip", packed_openings=True, **extra)
+    cfg["in"] = inn
+    _check(cfg, world, tmp_path)
+    if cfg.get("inproc"):                                   # the wire really is shorter: bytes counted by the mailbox transport of every rank
+        import numpy as np
+        packed_bytes = sum(int(np.load(str(tmp_path / "shares") + ".rank%d.npz" % r)["exchange_stats"][1]) for r in range(world))
+        import shutil
+        plain = tmp_path / "plain"; plain.mkdir()
+        _check(dict(cfg, packed_openings=False), world, plain)
+        plain_bytes = sum(int(np.load(str(plain / "shares") + ".rank%d.npz" % r)["exchange_stats"][1]) for r in range(world))
+        assert packed_bytes < 0.93 * plain_bytes, (packed_bytes, plain_bytes)
