@@ -512,6 +512,9 @@ class GnnParam:
 
 class OracleEngine:
     """Sequential emulation of k CoGNN parties running gcn-optimize / gcn-inference-optimize."""
+    # the weight-gradient products reuse the Beaver mask of the forward product's left operand, indexed in that tensor's storage order
+    # (DESIGN.md 3.5); a caller that deals a fresh mask for the transposed operand (the sci:: shim: tests/shim_util.py) sets it False
+    WGRAD_MASK_REUSED = True
 
     def __init__(self, k, src, dst, part, features, labels, param, seed=0xC06A11, variant="optimize-gcn",
                  weights=None, renew_feature_mask=False):
@@ -726,11 +729,11 @@ class OracleEngine:
                 if layer == 0:
                     # h_t is the transposed input-feature tensor (gcn.h:230-231): its mask and opening are those of the
                     # layer-0 forward product (dealt once, iteration 0); B and C are fresh
-                    zA, zB = beaver_gemm_pair(hA, hB, inA, inB, self.key_of_feature_wgrad(P, it), a_of_transposed=True)
+                    zA, zB = beaver_gemm_pair(hA, hB, inA, inB, self.key_of_feature_wgrad(P, it), a_of_transposed=self.WGRAD_MASK_REUSED)
                 else:
                     # h_t is the transposed hidden activation of this epoch: mask and opening of the layer-1 forward product
                     # (GAS iteration it - e + layer) are reused the same way
-                    zA, zB = beaver_gemm_pair(hA, hB, inA, inB, self.key_of_hidden_wgrad(P, it, it - e + layer), a_of_transposed=True)
+                    zA, zB = beaver_gemm_pair(hA, hB, inA, inB, self.key_of_hidden_wgrad(P, it, it - e + layer), a_of_transposed=self.WGRAD_MASK_REUSED)
                 dA, dB = trunc_pair(zA, zB, self.key_of(P, it, OP_AP_GEMM_TRUNC))
                 gscale = fx_encode_trunc(1.0 / train) if train > 0 else U64(0)
                 dA, dB = const_scale_trunc_pair(dA, dB, gscale, self.key_of(P, it, OP_AP_GSCALE_TRUNC))

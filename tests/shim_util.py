@@ -68,6 +68,7 @@ def shim_calls(owner, iters, inference=False):
 class ShimKeyedOracle(co.OracleEngine):
     """The oracle with the shim's dealer addressing: call number c of owner P draws from (seed, P, c, shim op)."""
     MAX_ITERS = 24
+    WGRAD_MASK_REUSED = False      # every shim product deals a fresh mask for its left operand as passed (logical order of the transposed tensor)
 
     def key_of(self, owner, it, op):
         if owner == co.OWNER_WAVG:                           # twoPartyGCNMatrixScale(..., 1 - tileIndex, tileIndex + 1): the pair of party 0
@@ -79,8 +80,9 @@ class ShimKeyedOracle(co.OracleEngine):
         c, sop = self._calls[owner][(it, op)]
         return lambda slot: co.stream_key(self.seed, owner, c, sop, slot)
 
-    # the masks of a product's operands do not survive its truncation (the truncated shares depend on the exact product and on
-    # the truncation streams only), so the engine's mask reuse and the shim's fresh masks give the same bits
+    # the shim deals fresh masks per product call (the engine reuses the forward product's): the oracle follows the shim here, mask
+    # for mask - since the truncation opening is formed from the top 48 bits of the two shares, the way a product is split into its two
+    # shares reaches the truncated result (a dropped carry), so the masks matter
     def key_of_feature_gemm(self, owner, it):
         return self.key_of(owner, it, co.OP_PS_GEMM)
 

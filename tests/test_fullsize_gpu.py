@@ -78,7 +78,7 @@ def test_config5_hidden_layer_at_full_size():
             hc = (c[P][0] + c[P][1]).astype(np.int64)
         assert ha.min() >= 0 and hc.min() >= 0
         d = np.abs(ha - hc)
-        assert d.max() <= 4, (P, int(d.max()))               # three probabilistic truncations feed h: a few ulps of 2^-16
+        assert d.max() <= 8, (P, int(d.max()))               # three probabilistic truncations (floor + {-1, 0, +1} each) feed h, the first two through a row scale: a few ulps of 2^-16
         assert (ha > 0).mean() > 0.05                        # (not all zero)
 
 

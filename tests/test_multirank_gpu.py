@@ -149,4 +149,4 @@ def test_packed_openings_hip(tmp_path, cfg_extra, world):
         plain = tmp_path / "plain"; plain.mkdir()
         _check(dict(cfg, packed_openings=False), world, plain)
         plain_bytes = sum(int(np.load(str(plain / "shares") + ".rank%d.npz" % r)["exchange_stats"][1]) for r in range(world))
-        assert packed_bytes < 0.93 * plain_bytes, (packed_bytes, plain_bytes)
+        assert packed_bytes < 0.96 * plain_bytes, (packed_bytes, plain_bytes)     # (all bytes of the run: set-up, the feature opening, replicas and partial sums included)
