@@ -203,15 +203,16 @@ def test_hostile_transport_detects_a_missing_round_wait(tmp_path):
 W8 = dict(BASE, k=8, V=96, Eu=260)
 
 
-@pytest.mark.parametrize("variant,iters,extra", [("optimize-gcn", 12, {}), ("optimize-gcn-inference", 2, {}),
-                                                 ("optimize-gcn", 12, {"placement": "vertex-set"}), ("optimize-gcn-inference", 2, {"placement": "vertex-set"}),
-                                                 ("optimize-gcn", 12, {"whole_epochs": True}), ("optimize-gcn", 6, {"exchanged_openings": True}),
+@pytest.mark.parametrize("variant,iters,extra", [("optimize-gcn", 12, {}), ("optimize-gcn-inference", 2, {"placement": "vertex-set"}),
+                                                 ("optimize-gcn-inference", 2, {"inproc": True}), ("optimize-gcn", 12, {"placement": "vertex-set", "inproc": True}),
+                                                 ("optimize-gcn", 12, {"whole_epochs": True, "inproc": True}), ("optimize-gcn", 6, {"exchanged_openings": True, "inproc": True}),
                                                  ("optimize-gcn", 6, {"chunks": 3})])
 def test_eight_parties_eight_ranks(tmp_path, variant, iters, extra):
     """One party per rank at world 8 over gloo (plain-C++ backend): every owner / co-party pair crosses a rank boundary, every
     owner's co-share is replicated to six other ranks, partial sums travel between all 56 ordered rank pairs, the weight average
     gathers from six ranks onto ranks 0 and 1 (gcn.h:747-802) - two training epochs / an inference pass, both placements, every
-    party's two shares and weight shares against the oracle after every GAS iteration."""
+    party's two shares and weight shares against the oracle after every GAS iteration.  (Three cases as eight gloo processes, the
+    others as eight threads of one process over the mailbox transport - same engine code, a fraction of the start-up time.)"""
     _check(dict(W8, variant=variant, iters=iters, **extra), 8, tmp_path)
 
 
@@ -256,7 +257,7 @@ def test_engines_starting_side_by_side_get_the_reference_weights(tmp_path):
 
 @pytest.mark.parametrize("k,world,variant,iters,extra", [
     (4, 2, "optimize-gcn", 12, {}), (4, 4, "optimize-gcn-inference", 2, {}), (8, 8, "optimize-gcn", 6, {"V": 96, "Eu": 260}),
-    (8, 8, "optimize-gcn-inference", 2, {"V": 96, "Eu": 260}), (4, 2, "optimize-gcn", 6, {"chunks": 3}), (4, 2, "optimize-gcn", 6, {"exchanged_openings": True}),
+    (8, 8, "optimize-gcn-inference", 2, {"V": 96, "Eu": 260, "inproc": True}), (4, 2, "optimize-gcn", 6, {"chunks": 3}), (4, 2, "optimize-gcn", 6, {"exchanged_openings": True}),
     (4, 2, "optimize-gcn", 6, {"blocking_exchange": True}), (4, 4, "optimize-gcn", 6, {"hostile": 5}), (8, 8, "optimize-gcn", 6, {"V": 96, "Eu": 260, "hostile": 6, "chunks": 2}),
     (6, 3, "optimize-gcn", 6, {"V": 61, "Eu": 200, "pair_fusion": False})])
 def test_packed_openings(tmp_path, k, world, variant, iters, extra):
