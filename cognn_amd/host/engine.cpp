@@ -173,7 +173,7 @@ int cognn_engine_create(const cognn_engine_config* cfg, int64_t V, int64_t Ecoun
         }
         try {
             // COGNN_HOST_GRAPH_BUILD forces the host builder (tests compare the two)
-            if (original(E) && E->world != 1) throw EngineError("cognn_engine_create: original-gcn runs as a single process (world = 1)");
+
             if (original(E) && E->k > 16) throw EngineError("cognn_engine_create: original-gcn takes at most 16 parties");
             const bool device_build = E->world == 1 && !getenv("COGNN_HOST_GRAPH_BUILD") && !original(E);   // (original-gcn indexes single edges: host builder)
             if (device_build) {
@@ -185,7 +185,8 @@ int cognn_engine_create(const cognn_engine_config* cfg, int64_t V, int64_t Ecoun
                 build_layout(E);
                 build_csrs(E);
             }
-            if (original(E)) build_original_index(E);
+            if (original(E) && E->world == 1) build_original_index(E);
+            if (original(E) && E->world > 1) build_original_ranks(E);
             alloc_sides(E);
             E->hostFeat.resize(E->hosted.size());
             E->hostLabels.resize(E->hosted.size());

@@ -146,6 +146,20 @@ struct cognn_engine {
     struct OrigPair { u64* n0 = nullptr; u64* n1 = nullptr; int64_t edges = 0; };
     std::vector<OrigDst> orig_dst;             // [g]
     std::vector<OrigPair> orig_pair;           // [P * k + g]
+    // original-gcn across ranks (engine_original.cpp, build_original_ranks): the Scatter instances (client P -> destination party g) in
+    // which this rank plays a role - the client (it holds A_P) or the server (B_P: the co-party of P for g == P, party g with its
+    // replica otherwise) - as row ranges of ONE per-edge tensor
+    struct OrigRole { int P = 0, g = 0, p = 0, peer_rank = 0, peer_role = -1; int64_t edges = 0, row0 = 0; u64* s[2] = {nullptr, nullptr}; };
+    std::vector<OrigRole> orig_roles;          // canonical order: (P, g), client before server
+    int64_t orig_rows = 0, orig_tab_rows = 0, orig_out_rows = 0;
+    uint32_t *orig_id_rowptr = nullptr, *orig_src_col = nullptr;      // edge tensor <- one source row of the share table per edge
+    uint32_t *orig_agg_rowptr = nullptr, *orig_agg_col = nullptr;     // hosted destination rows <- scaled edge rows
+    uint32_t *orig_out_rowptr = nullptr, *orig_out_col = nullptr;     // client results for destination owners whose co-party is elsewhere
+    struct OrigBlock { int g = 0, rank = 0; int64_t rows = 0, off = 0; };
+    std::vector<OrigBlock> orig_send, orig_recv;                      // per (destination owner, peer rank), pre-summed over the rank's parties
+    u64 *orig_tab = nullptr, *orig_acc = nullptr, *orig_edge = nullptr, *orig_out = nullptr, *orig_inb = nullptr;
+    u64* orig_w[4] = {nullptr, nullptr, nullptr, nullptr};           // openings: E out / in, c out / in  [orig_rows x F]
+    u64* orig_g[2] = {nullptr, nullptr};                              // scale openings out / in [orig_rows]
     bool started = false, timing = false;
     int64_t gemm_x_opened_for = -1;    // iteration whose PreScatter GEMM input was already opened by the previous ReLU close
     // share table of the current message-passing round
@@ -372,6 +386,7 @@ void run_iteration(cognn_engine* E, int64_t it);
 void run_epoch(cognn_engine* E, int64_t it);
 // engine_original.cpp
 void build_original_index(cognn_engine* E);
+void build_original_ranks(cognn_engine* E);
 u64 scatter_tag(int P, int g);
 void run_iteration_original(cognn_engine* E, int64_t it);
 // engine_offline.cpp

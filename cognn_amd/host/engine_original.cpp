@@ -91,6 +91,232 @@ void original_message_passing(cognn_engine* E, int64_t it, int F, bool fwd, SrcF
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// original-gcn across ranks (party placement; the reference runs it as k processes, original-gcn/gcn.h:224-251, ss_...h:748-856 /
+// :1005-1080).  The two roles of a Scatter instance (P -> g) - client P with its own share of P's rows, server with the co-share:
+// the co-party of P for the local edges, party g with its replica (ss_...h:997-1002) otherwise - may sit on different ranks, so the
+// per-edge scales run as per-side launches with their openings exchanged: every role hosted here is a row range of one per-edge
+// tensor [edges x F]; one gather fills it from the share table, the two Beaver row scales (+ truncations) run range by range
+// (batched launches, one exchange round per opening), one gather adds the scaled rows to the hosted destination rows - the
+// client's result share of a remote instance crosses to the co-party side of the destination, the server's to its owner side
+// (ss_...h:1063-1100) - and the client results for destination owners whose co-party lives elsewhere travel pre-summed per rank.
+// ---------------------------------------------------------------------------------------------
+void build_original_ranks(cognn_engine* E) {
+    const int k = E->k;
+    auto& G = E->G;
+    if (E->cfg.placement != COGNN_PLACE_PARTY) throw EngineError("cognn_engine_create: original-gcn across ranks runs in the party placement");
+    auto norm = [](uint32_t deg) { return deg == 0 ? (u64)0 : fx_llround(std::pow((double)deg + 1.0, -0.5)); };
+    auto nrows = [&](int o) { return (int64_t)G.party[o].localVertexPos.size(); };
+    E->orig_tab_rows = 0;
+    for (int o = 0; o < k; ++o) {
+        if (E->A_off[o] >= 0) E->orig_tab_rows = std::max(E->orig_tab_rows, E->A_off[o] + nrows(o));
+        E->orig_tab_rows = std::max(E->orig_tab_rows, E->B_off[o] + nrows(o));
+    }
+    E->orig_roles.clear();
+    std::vector<uint32_t> src_col;
+    // destination rows of this rank (the aggregate's layout): entries = scaled edge rows
+    std::vector<std::vector<uint32_t>> agg((size_t)E->aggRows);
+    std::map<int, std::vector<std::vector<uint32_t>>> out_rows;     // destination owner g (co-party elsewhere) -> per vertex of g: edge rows
+    for (int P = 0; P < k; ++P)
+        for (int g = 0; g < k; ++g) {
+            const int server_party = g == P ? E->co(P) : g;
+            const int rc = E->rank_of(P), rs = E->rank_of(server_party);
+            for (int p = 0; p < 2; ++p) {
+                if ((p == 0 ? rc : rs) != E->rank) continue;
+                const cognn::EdgeBlock& blk = G.party[P].out[g];
+                cognn_engine::OrigRole R;
+                if (src_col.size() & 1) src_col.push_back(0);              // ranges start on even rows: the kernels move 16-byte element pairs
+                R.P = P; R.g = g; R.p = p; R.peer_rank = p == 0 ? rs : rc; R.row0 = (int64_t)src_col.size();
+                std::vector<u64> s0, s1;
+                const int64_t tab0 = p == 0 ? E->A_off[P] : E->B_off[P];   // the rows this role reads: P's own share / the co-share (replica)
+                for (size_t r = 0; r + 1 < blk.rowptr.size(); ++r) {
+                    const uint32_t dr = G.row_of_vid[blk.rows_vid[r]];
+                    if (g == P && blk.rowptr[r + 1] == blk.rowptr[r]) {  // the dummy self entry keeps its position in the list and contributes nothing
+                        src_col.push_back((uint32_t)(tab0 + dr)); s0.push_back(0); s1.push_back(0);
+                        continue;
+                    }
+                    for (uint32_t e = blk.rowptr[r]; e < blk.rowptr[r + 1]; ++e) {
+                        const uint32_t erow = (uint32_t)src_col.size();
+                        src_col.push_back((uint32_t)(tab0 + blk.col[e]));
+                        const u64 n0 = norm(G.party[P].outDeg[blk.col[e]]), n1 = norm(G.party[g].inDeg[dr]);
+                        // the client supplies the source normaliser and, for its local edges, the destination normaliser; the server the
+                        // destination normaliser of remote edges (gcn.h:228-229, ss_...h:800,1041-1043); the other party's share is 0
+                        s0.push_back(p == 0 ? n0 : 0);
+                        s1.push_back(g == P ? (p == 0 ? n1 : 0) : (p == 0 ? 0 : n1));
+                        // where the role's result share of this edge goes: local edges stay on their side, remote ones cross
+                        const bool to_owner_side = (g == P) ? (p == 0) : (p == 1);
+                        if (to_owner_side) agg[(size_t)(E->A_off[g] + dr)].push_back(erow);            // (the owner side of g is hosted wherever this role runs)
+                        else if (E->holder(g, 1) == E->rank) agg[(size_t)(E->B_off[g] + dr)].push_back(erow);
+                        else {
+                            auto& v = out_rows[g];
+                            if (v.empty()) v.resize((size_t)nrows(g));
+                            v[dr].push_back(erow);
+                        }
+                    }
+                }
+                R.edges = (int64_t)src_col.size() - R.row0;
+                R.s[0] = upload(E, s0); R.s[1] = upload(E, s1);
+                E->orig_roles.push_back(R);
+            }
+        }
+    for (size_t a = 0; a < E->orig_roles.size(); ++a)           // both roles of an instance on this rank: they read each other's openings in place
+        for (size_t b = 0; b < E->orig_roles.size(); ++b)
+            if (a != b && E->orig_roles[a].P == E->orig_roles[b].P && E->orig_roles[a].g == E->orig_roles[b].g) E->orig_roles[a].peer_role = (int)b;
+    E->orig_rows = (int64_t)src_col.size();
+    std::vector<uint32_t> idp((size_t)E->orig_rows + 1);
+    for (size_t i = 0; i < idp.size(); ++i) idp[i] = (uint32_t)i;
+    E->orig_id_rowptr = upload(E, idp); E->orig_src_col = upload(E, src_col);
+    auto flatten = [&](const std::vector<std::vector<uint32_t>>& rows, std::vector<uint32_t>& rp, std::vector<uint32_t>& col) {
+        for (auto& r : rows) { col.insert(col.end(), r.begin(), r.end()); rp.push_back((uint32_t)col.size()); }
+    };
+    {
+        std::vector<uint32_t> rp{0}, col;
+        flatten(agg, rp, col);
+        E->orig_agg_rowptr = upload(E, rp); E->orig_agg_col = upload(E, col);
+    }
+    // outgoing client results, one block per destination owner (receiver: rank of its co-party), in ascending owner order on both ends
+    E->orig_send.clear(); E->orig_recv.clear();
+    {
+        std::vector<uint32_t> rp{0}, col;
+        int64_t off = 0;
+        for (auto& kv : out_rows) {
+            cognn_engine::OrigBlock b;
+            b.g = kv.first; b.rank = E->holder(kv.first, 1); b.rows = nrows(kv.first); b.off = off;
+            flatten(kv.second, rp, col);
+            off += b.rows;
+            E->orig_send.push_back(b);
+        }
+        E->orig_out_rows = off;
+        E->orig_out_rowptr = upload(E, rp); E->orig_out_col = upload(E, col);
+    }
+    {   // incoming: for every co-hosted owner g, one block from every other rank that hosts a party with edges into g
+        int64_t off = 0;
+        for (int r = 0; r < E->world; ++r) {
+            if (r == E->rank) continue;
+            std::vector<int> owners(E->cohosted.begin(), E->cohosted.end());
+            std::sort(owners.begin(), owners.end());
+            for (int g : owners) {
+                bool any = false;
+                for (int P = r * E->m; P < (r + 1) * E->m; ++P)
+                    if (P != g) for (size_t q = 0; q + 1 < G.party[P].out[g].rowptr.size(); ++q) any = any || G.party[P].out[g].rowptr[q + 1] > G.party[P].out[g].rowptr[q];
+                if (!any) continue;
+                cognn_engine::OrigBlock b;
+                b.g = g; b.rank = r; b.rows = nrows(g); b.off = off;
+                off += b.rows;
+                E->orig_recv.push_back(b);
+            }
+        }
+        const int fm = std::max(E->in(), std::max(E->hid(), E->lab()));
+        E->orig_inb = dalloc<u64>(E, (size_t)std::max<int64_t>(off, 1) * fm);
+        E->orig_out = dalloc<u64>(E, (size_t)std::max<int64_t>(E->orig_out_rows, 1) * fm);
+        E->orig_tab = dalloc<u64>(E, (size_t)E->orig_tab_rows * fm);
+        E->orig_acc = dalloc<u64>(E, (size_t)std::max<int64_t>(E->aggRows, 1) * fm);
+        E->orig_edge = dalloc<u64>(E, (size_t)std::max<int64_t>(E->orig_rows, 1) * fm);
+        for (int j = 0; j < 4; ++j) E->orig_w[j] = dalloc<u64>(E, (size_t)std::max<int64_t>(E->orig_rows, 1) * fm);
+        for (int j = 0; j < 2; ++j) E->orig_g[j] = dalloc<u64>(E, (size_t)std::max<int64_t>(E->orig_rows, 1) + 2);
+    }
+    // a sender lists a block only when it has edges into g: the receiver's `any` test above is the same predicate
+}
+
+// One message-passing round of the unoptimised kernel across ranks: every side's tensor src(side) [n x F] -> dst(side)
+template <class SrcFn, class DstFn>
+void original_message_passing_ranks(cognn_engine* E, int64_t it, int F, bool fwd, SrcFn src, DstFn dst) {
+    auto seg = [&](u64* base, Side& s) { return base + (s.p == 0 ? E->A_off[s.owner] : E->B_off[s.owner]) * (int64_t)F; };
+    // the share table of the round: every hosted side's tensor, the co-shares replicated to the ranks whose parties serve remote edges
+    for (auto& s : E->sides) BE(cognn_memcpy_d2d(E->ctx, seg(E->orig_tab, s), src(s), (size_t)s.n * F * 8));
+    {
+        XList xl;
+        for (int o = 0; o < E->k; ++o) {
+            const int rc = E->holder(o, 1);
+            const int64_t bytes = (int64_t)E->G.party[o].localVertexPos.size() * F * 8;
+            u64* sg = E->orig_tab + E->B_off[o] * (int64_t)F;
+            if (rc == E->rank) {
+                for (int r = 0; r < E->world; ++r) {
+                    if (r == E->rank || (E->m == 1 && r == E->rank_of(o))) continue;   // (that rank hosts only the owner itself)
+                    xl.send(r, sg, bytes);
+                }
+            } else if (!(E->m == 1 && E->rank == E->rank_of(o))) xl.recv(rc, sg, bytes);
+        }
+        run_exchange(E, xl);                                // in flight during the self-row scale below
+    }
+    // the accumulators start from the self rows - scaled by the owner-known normaliser in a forward iteration (:365-381)
+    if (fwd)
+        rowscale_stage(E, it, COGNN_OP_GA_SCALE, COGNN_OP_GA_SCALE_TRUNC, F, [&](Side& s) { return (u64*)src(s); }, [&](Side& s) { return seg(E->orig_acc, s); });
+    else
+        for (auto& s : E->sides) BE(cognn_memcpy_d2d(E->ctx, seg(E->orig_acc, s), src(s), (size_t)s.n * F * 8));
+    exchange_wait(E);
+    if (E->orig_rows > 0) BE(cognn_gather_csr_u64(E->ctx, E->orig_edge, nullptr, E->orig_tab, E->orig_id_rowptr, E->orig_src_col, E->orig_rows, F));
+    // the two per-edge scales: share x shared normaliser (Beaver, one triple per element, b per edge) + truncation, range by range
+    for (int t = 0; t < 2; ++t) {
+        const int op = t == 0 ? COGNN_OP_SC_SCALE0 : COGNN_OP_SC_SCALE1, top = t == 0 ? COGNN_OP_SC_SCALE0_TRUNC : COGNN_OP_SC_SCALE1_TRUNC;
+        auto kof = [&](const cognn_engine::OrigRole& R, int o) { return keys(E, scatter_tag(R.P, R.g), it, o); };
+        auto peer_ptr = [&](const cognn_engine::OrigRole& R, u64* own_out, u64* own_in, int64_t stride) {
+            return R.peer_role >= 0 ? own_out + E->orig_roles[(size_t)R.peer_role].row0 * stride : own_in + R.row0 * stride;
+        };
+        {   // E_p = V_p - a_p, G_p = s_p - b_p
+            Batch batch(E);
+            for (auto& R : E->orig_roles) {
+                if (!R.edges) continue;
+                cognn_keys kk = kof(R, op);
+                BE(cognn_rowscale_open_u64(E->ctx, E->orig_w[0] + R.row0 * F, E->orig_g[0] + R.row0, E->orig_edge + R.row0 * F, R.s[t], &kk, R.p, R.edges, F));
+            }
+        }
+        {
+            XList xl;
+            for (auto& R : E->orig_roles) {
+                if (!R.edges || R.peer_role >= 0) continue;
+                xl.send(R.peer_rank, E->orig_w[0] + R.row0 * F, R.edges * F * 8); xl.recv(R.peer_rank, E->orig_w[1] + R.row0 * F, R.edges * F * 8);
+                xl.send(R.peer_rank, E->orig_g[0] + R.row0, R.edges * 8); xl.recv(R.peer_rank, E->orig_g[1] + R.row0, R.edges * 8);
+            }
+            run_exchange_sync(E, xl);
+        }
+        {   // the product share and the opening of its truncation
+            Batch batch(E);
+            for (auto& R : E->orig_roles) {
+                if (!R.edges) continue;
+                cognn_keys kk = kof(R, op), tk = kof(R, top);
+                BE(cognn_rowscale_close_u64(E->ctx, E->orig_w[2] + R.row0 * F, E->orig_w[0] + R.row0 * F, peer_ptr(R, E->orig_w[0], E->orig_w[1], F),
+                                            E->orig_g[0] + R.row0, peer_ptr(R, E->orig_g[0], E->orig_g[1], 1), &kk, &tk, R.p, R.edges, F));
+            }
+        }
+        {
+            XList xl;
+            for (auto& R : E->orig_roles) {
+                if (!R.edges || R.peer_role >= 0) continue;
+                if (R.p == 1) xl.send(R.peer_rank, E->orig_w[2] + R.row0 * F, R.edges * F * 8);   // (the client closes with both, the server with its dealt share alone)
+                else xl.recv(R.peer_rank, E->orig_w[3] + R.row0 * F, R.edges * F * 8);
+            }
+            run_exchange_sync(E, xl);
+        }
+        {
+            Batch batch(E);
+            for (auto& R : E->orig_roles) {
+                if (!R.edges) continue;
+                cognn_keys tk = kof(R, top);
+                const u64* c0 = R.p == 0 ? E->orig_w[2] + R.row0 * F : nullptr;
+                const u64* c1 = R.p == 0 ? peer_ptr(R, E->orig_w[2], E->orig_w[3], F) : nullptr;
+                BE(cognn_trunc_close_u64(E->ctx, E->orig_edge + R.row0 * F, c0, c1, &tk, R.p, 0, R.edges * F));
+            }
+        }
+    }
+    // UpdatePreMergeComp + GatherComp: the scaled rows of every edge into a hosted destination row, and the client results for
+    // destination owners whose co-party lives on another rank - pre-summed over this rank's parties - on their way
+    if (E->orig_out_rows > 0) BE(cognn_gather_csr_u64(E->ctx, E->orig_out, nullptr, E->orig_edge, E->orig_out_rowptr, E->orig_out_col, E->orig_out_rows, F));
+    {
+        XList xl;
+        for (auto& b : E->orig_send) xl.send(b.rank, E->orig_out + b.off * F, b.rows * F * 8);
+        for (auto& b : E->orig_recv) xl.recv(b.rank, E->orig_inb + b.off * F, b.rows * F * 8);
+        run_exchange(E, xl);
+    }
+    if (E->aggRows > 0) BE(cognn_gather_csr_u64(E->ctx, E->orig_acc, E->orig_acc, E->orig_edge, E->orig_agg_rowptr, E->orig_agg_col, E->aggRows, F));
+    exchange_wait(E);
+    for (auto& b : E->orig_recv) {
+        u64* a = E->orig_acc + E->B_off[b.g] * (int64_t)F;
+        BE(cognn_add_u64(E->ctx, a, a, E->orig_inb + b.off * F, b.rows * F));
+    }
+    for (auto& s : E->sides) BE(cognn_memcpy_d2d(E->ctx, dst(s), seg(E->orig_acc, s), (size_t)s.n * F * 8));
+}
+
 void run_iteration_original(cognn_engine* E, int64_t it) {
     const int f = E->cfg.num_layers, ep = 2 * f;
     const int e = (int)(it % ep);
@@ -106,7 +332,8 @@ void run_iteration_original(cognn_engine* E, int64_t it) {
         Phase ph_mp(E, T_PH_MP);
         // forward: the aggregate IS ah_t of the layer (:452); backward: into the scratch buffer that is not the input
         auto out = [&](Side& s) { return fwd ? s.ah[layer] : (s.cur == s.buf[1] ? s.buf[0] : s.buf[1]); };
-        original_message_passing(E, it, F, fwd, [&](Side& s) { return s.cur; }, out);
+        if (E->world > 1) original_message_passing_ranks(E, it, F, fwd, [&](Side& s) { return s.cur; }, out);
+        else original_message_passing(E, it, F, fwd, [&](Side& s) { return s.cur; }, out);
         for (auto& s : E->sides) { s.cur = out(s); s.curF = F; }
     }
     Phase ph_ap(E, T_PH_APPLY);

@@ -111,13 +111,15 @@ def test_unsupported_experiments_are_refused(tmp_path):
     assert res.returncode == 2 and "GraphSC" in res.stderr
 
 
-def test_gcn_original_through_the_launcher(tmp_path):
-    """The unoptimised kernel (bin/gcn-original in the reference's scripts, --cognn-unopt-*): one process hosts both parties; two
-    epochs of 4 GAS iterations; the per-party logs carry one accuracy block per epoch and the oracle's numbers."""
+@pytest.mark.parametrize("gpus", [1, 2])
+def test_gcn_original_through_the_launcher(tmp_path, gpus):
+    """The unoptimised kernel (bin/gcn-original in the reference's scripts, --cognn-unopt-*): one process hosts both parties, or one
+    rank each (the reference's deployment); two epochs of 4 GAS iterations; the per-party logs carry one accuracy block per epoch
+    and the oracle's numbers."""
     import original_gcn
     from cognn_amd import worker
     data, logs = tmp_path / "data", tmp_path / "log"
-    cmd = LAUNCH + ["--executable", "gcn-original", "--dataset", "cora_small", "--parties", "2", "--gpus", "1", "--iterations", "8",
+    cmd = LAUNCH + ["--executable", "gcn-original", "--dataset", "cora_small", "--parties", "2", "--gpus", str(gpus), "--iterations", "8",
                     "--data-dir", str(data), "--log-dir", str(logs), "--synthetic", "--backend", "gloo", "--worker", CPU_WORKER]
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=tmp_path)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]

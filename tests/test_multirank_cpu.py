@@ -146,6 +146,17 @@ def test_original_gcn_single_process(tmp_path, k, extra):
     _check(dict(BASE, k=k, variant="original-gcn", iters=8, **extra), 1, tmp_path)
 
 
+@pytest.mark.parametrize("k,world,extra", [(2, 2, {}), (3, 3, {}), (4, 2, {}), (4, 4, {}), (4, 4, {"hostile": 1}), (6, 3, {"V": 61, "Eu": 200}),
+                                            (3, 3, {"V": 9, "Eu": 5}), (5, 5, {"V": 61, "Eu": 300, "hid": 5, "lab": 3, "inproc": True}),
+                                            (4, 2, {"packed_openings": True})])
+def test_original_gcn_across_ranks(tmp_path, k, world, extra):
+    """The unoptimised kernel with its parties on different ranks (the reference's deployment of it: k processes): the client and
+    the server of a Scatter instance exchange the openings of the two per-edge scales, the client's results for destination owners
+    whose co-party lives elsewhere travel pre-summed - same shares and weights as the oracle after every GAS iteration of two
+    epochs, also over the hostile transport and with sparse graphs (dummy self entries, parties without edges to each other)."""
+    _check(dict(BASE, k=k, variant="original-gcn", iters=8, **extra), world, tmp_path)
+
+
 @pytest.mark.parametrize("seed", [1, 2])
 @pytest.mark.parametrize("k,world,variant,iters,extra", [(4, 2, "optimize-gcn", 6, {}), (4, 4, "optimize-gcn", 6, {}), (4, 4, "optimize-gcn-inference", 2, {}),
                                                         (4, 2, "optimize-gcn", 6, {"exchanged_openings": True}), (6, 2, "optimize-gcn", 12, {"whole_epochs": True}),

@@ -67,6 +67,15 @@ def test_original_gcn_single_process_hip(tmp_path, k, extra):
     _check(dict(BASE, k=k, variant="original-gcn", iters=8, backend="hip", **extra), 1, tmp_path)
 
 
+@pytest.mark.parametrize("k,world,extra", [(2, 2, {}), (4, 2, {"V": 700, "Eu": 2500, "in": 33, "hid": 16, "lab": 7}), (3, 3, {"V": 9, "Eu": 5}),
+                                            (5, 5, {"V": 1433, "Eu": 5000, "in": 65, "hid": 16, "lab": 7, "inproc": True})])
+def test_original_gcn_across_ranks_hip(tmp_path, k, world, extra):
+    """The unoptimised kernel with its parties on different ranks (the reference's deployment of BASELINE config 1: one process per
+    party), HIP kernels: client / server roles of every Scatter instance exchange their openings - the oracle's shares and weights
+    after every GAS iteration of two epochs (odd row widths, dummy self entries, five parties as five engine threads)."""
+    _check(dict(BASE, k=k, variant="original-gcn", iters=8, backend="hip", **extra), world, tmp_path)
+
+
 @pytest.mark.parametrize("chunks,world", [(2, 2), (3, 4), (4, 2)])
 def test_chunked_exchange_pipeline_hip(tmp_path, chunks, world):
     # COGNN_OPT_EXCHANGE_CHUNKS on the HIP kernels: the chunk window of the element-wise launches (batched and single), the

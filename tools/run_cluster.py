@@ -12,8 +12,7 @@ names, settings, directory layout and log naming, so tools/plot/*.py keep workin
 (tmp_run_cluster.py:116-118, :146).  Where the reference starts one process per party inside a network namespace
 (:224-241), this launcher either hosts all parties on one GPU (`--gpus 1`, default: bin/<executable> once per party log)
 or starts one bin/<executable> -c 1 process per GPU (`--gpus N`, parties in contiguous blocks, shares over RCCL).
-The --cognn-unopt-* experiments run bin/gcn-original (the unoptimised kernel; a single process hosts all its parties, so --gpus
-is ignored for them); the FL / plaintext / GraphSC baselines are other programs of the reference and are refused with a message.
+The --cognn-unopt-* experiments run bin/gcn-original (the unoptimised kernel) the same way; the FL / plaintext / GraphSC baselines are other programs of the reference and are refused with a message.
 A single custom run keeps the explicit form:
 
     python tools/run_cluster.py --executable gcn-optimize --dataset pubmed --parties 4 --gpus 4 --iterations 12 \\
@@ -211,8 +210,6 @@ def run_experiment(name, a):
                 log_dir = os.path.join(root, "log", executable, dataset, sub) + ("" if pre else "/noPreprocess")
                 setting = "%s/%s/%s" % (executable, dataset, sub)                        # tmp_run_cluster.py:124, :220
                 gpus = max(d for d in range(1, a.gpus + 1) if n % d == 0)      # ranks must host equally many parties
-                if executable == "gcn-original":
-                    gpus = 1                                               # the unoptimised kernel runs as one process
                 rc = rc or run_one(executable, dataset, n, iterations, setting, data_dir, log_dir, gpus=gpus, no_preprocess=not pre,
                                    worker=a.worker, backend=a.backend, timeout=a.timeout)
     return rc
