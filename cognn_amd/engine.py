@@ -8,7 +8,7 @@ import numpy as np
 from . import capi
 from .engine_api import EngineConfig
 
-VARIANTS = {"optimize-gcn": 0, "optimize-gcn-inference": 1, "original-gcn": 2}     # original-gcn: single process only (cognn_engine.h)
+VARIANTS = {"optimize-gcn": 0, "optimize-gcn-inference": 1, "original-gcn": 2}     # original-gcn across ranks: party placement (cognn_engine.h)
 
 
 class GnnParam:

@@ -7,7 +7,7 @@ namespace cognn_eng {
 
 
 // ---------------------------------------------------------------------------------------------
-// original-gcn (algo_kernels/vertex_centric/original-gcn/gcn.h; BASELINE config 1) - single process
+// original-gcn (algo_kernels/vertex_centric/original-gcn/gcn.h; BASELINE config 1) - all parties in one process
 // ---------------------------------------------------------------------------------------------
 // Index of the per-edge Scatter: the instance (client P, destination party g) lists P's edges into g ordered by destination vid,
 // then source vid (updateSrcVertexPos[g] / updateDstVertexPos[g], ss_...h:467-504) - for g == P with one dummy self entry for every
@@ -202,7 +202,7 @@ void build_original_ranks(cognn_engine* E) {
                 if (!any) continue;
                 cognn_engine::OrigBlock b;
                 b.g = g; b.rank = r; b.rows = nrows(g); b.off = off;
-                off += b.rows;
+                off += b.rows + (b.rows & 1);                        // (16-byte aligned blocks for the add)
                 E->orig_recv.push_back(b);
             }
         }

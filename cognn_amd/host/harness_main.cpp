@@ -157,7 +157,7 @@ int main(int argc, char* argv[]) {
     }
     if (tileIndex >= threadCount) { std::cerr << "Tile index out of range." << std::endl; return -1; }
     const bool inference = prog.find("inference") != std::string::npos || getenv("COGNN_INFERENCE_VARIANT");
-    // bin/gcn-original = the unoptimised kernel (algo_kernels/vertex_centric/original-gcn, tools/tmp_run_cluster.py:285-286); single process
+    // bin/gcn-original = the unoptimised kernel (algo_kernels/vertex_centric/original-gcn, tools/tmp_run_cluster.py:285-286)
     const bool original = !inference && (prog.find("gcn-original") != std::string::npos || getenv("COGNN_ORIGINAL_VARIANT"));
 
     GnnParam gp;

@@ -24,8 +24,9 @@ typedef struct cognn_engine cognn_engine;
 enum { COGNN_VARIANT_OPTIMIZE_GCN = 0, COGNN_VARIANT_OPTIMIZE_GCN_INFERENCE = 1,
        /* algo_kernels/vertex_centric/original-gcn/gcn.h (bin: gcn-original, BASELINE config 1): aggregate-then-transform, 4 GAS
         * iterations per epoch, messages of width {input_dim, hidden_dim, -, hidden_dim}, every message scaled on its edge by the two
-        * degree normalisers (ScatterComp :211-251), forward product after the aggregation.  Single process only (world = 1: every
-        * party's two share-holders are hosted together); the offline call is a no-op (product shares are dealt when used). */
+        * degree normalisers (ScatterComp :211-251), forward product after the aggregation.  One process (every party's two
+        * share-holders hosted together: one fused launch per destination party) or, in the party placement, one rank per block of
+        * parties (the roles of every Scatter instance exchange their openings); the offline call is a no-op (product shares are dealt when used). */
        COGNN_VARIANT_ORIGINAL_GCN = 2 };
 
 /* GNNParam (include/task/task.h:78-170) + harness flags (include/harness.h:123) */

@@ -44,6 +44,8 @@ static int fail(const char* fmt, ...) {
     return 1;
 }
 #define REQ(c, msg) do { if (!(c)) return fail("%s", msg); } while (0)
+// the alignment contract of the HIP entry points (kernels_elementwise.hip: al()), so that the host logic meets it on this backend too
+#define AL(p) ((((uintptr_t)(const void*)(p)) & 15u) == 0)
 
 static inline cognn_opkeys K(const cognn_keys* k) {
     cognn_opkeys r;
@@ -127,6 +129,7 @@ int cognn_lane_begin(cognn_ctx*, int32_t) { return 0; }      // ... and in progr
 int cognn_lane_select(cognn_ctx*, int32_t) { return 0; }
 int cognn_lane_end(cognn_ctx*) { return 0; }
 int cognn_prng_fill_u64(cognn_ctx*, uint64_t* out, uint64_t key, int64_t n) {
+    REQ(AL(out), "cognn_prng_fill_u64: misaligned tensor (the HIP kernels move 16-byte element pairs)");
     CG_PAR
     for (int64_t i = 0; i < n; ++i) out[i] = cognn_prng(key, (u64)i);
     return 0;
@@ -141,7 +144,8 @@ int cognn_unpack48_u64(cognn_ctx*, uint64_t* dst, const void* packed, int64_t n)
     for (int64_t i = 0; i < n; ++i) dst[i] = ((u64)mid[i] << 16) | ((u64)top[i] << 48);
     return 0;
 }
-int cognn_gemm_mask_fill_u64(cognn_ctx*, uint64_t* out, uint64_t key, int64_t n) {   // a product's A mask: limb-form values (cognn_spec.h)
+int cognn_gemm_mask_fill_u64(cognn_ctx*, uint64_t* out, uint64_t key, int64_t n) {
+    REQ(AL(out), "cognn_gemm_mask_fill_u64: misaligned tensor (the HIP kernels move 16-byte element pairs)");   // a product's A mask: limb-form values (cognn_spec.h)
     CG_PAR
     for (int64_t i = 0; i < n; ++i) out[i] = cognn_gemm_mask(key, (u64)i);
     return 0;
@@ -188,6 +192,7 @@ int cognn_ring_gemm_u64(cognn_ctx*, uint64_t* C, const uint64_t* A, const uint64
     return 0;
 }
 int cognn_mask_open_u64(cognn_ctx*, uint64_t* E, const uint64_t* X, uint64_t key, int64_t rows, int64_t cols, int tr) {
+    REQ(AL(E) && AL(X), "cognn_mask_open_u64: misaligned tensor (the HIP kernels move 16-byte element pairs)");
     const bool limb = (tr & COGNN_MASK_OPEN_LIMB) != 0;     // the A mask of a product: limb form
     tr &= ~COGNN_MASK_OPEN_LIMB;
     auto mask = [&](u64 idx) { return limb ? cognn_gemm_mask(key, idx) : cognn_prng(key, idx); };
@@ -200,6 +205,7 @@ int cognn_mask_open_u64(cognn_ctx*, uint64_t* E, const uint64_t* X, uint64_t key
     return 0;
 }
 int cognn_add_u64(cognn_ctx*, uint64_t* o, const uint64_t* a, const uint64_t* b, int64_t n) {
+    REQ(AL(o) && AL(a) && AL(b), "cognn_add_u64: misaligned tensor (the HIP kernels move 16-byte element pairs)");
     CHUNK(n)
     CG_PAR
     for (int64_t i = lo_; i < hi_; ++i) o[i] = a[i] + b[i];
@@ -216,6 +222,7 @@ int cognn_fanout_u64(cognn_ctx*, uint64_t* const* out, int32_t count, const uint
     return 0;
 }
 int cognn_sub_u64(cognn_ctx*, uint64_t* o, const uint64_t* a, const uint64_t* b, int64_t n) {
+    REQ(AL(o) && AL(a) && AL(b), "cognn_sub_u64: misaligned tensor (the HIP kernels move 16-byte element pairs)");
     CHUNK(n)
     CG_PAR
     for (int64_t i = lo_; i < hi_; ++i) o[i] = a[i] - b[i];
@@ -315,6 +322,7 @@ int cognn_beaver_gemm_close_group_u64(cognn_ctx* c, const cognn_gemm_job* jobs, 
 }
 int cognn_trunc_open_add_u64(cognn_ctx*, uint64_t* c, const uint64_t* x, const uint64_t* c1, const cognn_keys* gkeys,
                              const cognn_keys* tkeys, int p, int64_t n) {
+    REQ(AL(c) && AL(x) && AL(c1), "cognn_trunc_open_add_u64: misaligned tensor (the HIP kernels move 16-byte element pairs)");
     CHUNK(n)
     const cognn_opkeys tk = K(tkeys);
     for (int64_t i = lo_; i < hi_; ++i)
@@ -322,6 +330,7 @@ int cognn_trunc_open_add_u64(cognn_ctx*, uint64_t* c, const uint64_t* x, const u
     return 0;
 }
 int cognn_trunc_open_u64(cognn_ctx*, uint64_t* c, const uint64_t* x, uint64_t mul, const cognn_keys* keys, int p, int64_t n) {
+    REQ(AL(c) && AL(x), "cognn_trunc_open_u64: misaligned tensor (the HIP kernels move 16-byte element pairs)");
     CHUNK(n)
     const cognn_opkeys k = K(keys);
     CG_PAR
@@ -330,6 +339,7 @@ int cognn_trunc_open_u64(cognn_ctx*, uint64_t* c, const uint64_t* x, uint64_t mu
 }
 int cognn_trunc_close_u64(cognn_ctx*, uint64_t* out, const uint64_t* c0, const uint64_t* c1, const cognn_keys* keys, int p,
                           int mode, int64_t n) {
+    REQ(AL(out) && AL(c0) && AL(c1), "cognn_trunc_close_u64: misaligned tensor (the HIP kernels move 16-byte element pairs)");
     CHUNK(n)
     REQ(p == 1 || (c0 && c1), "trunc_close: p=0 needs both opened values");
     const cognn_opkeys k = K(keys);
@@ -343,6 +353,7 @@ int cognn_trunc_close_u64(cognn_ctx*, uint64_t* out, const uint64_t* c0, const u
 }
 int cognn_trunc_close_open_u64(cognn_ctx* c, uint64_t* out, uint64_t* E, const uint64_t* c0, const uint64_t* c1, const cognn_keys* keys,
                                int p, uint64_t key_open, int64_t n) {
+    REQ(AL(out) && AL(E) && AL(c0) && AL(c1), "cognn_trunc_close_open_u64: misaligned tensor (the HIP kernels move 16-byte element pairs)");
     CHUNK(n)
     const int rc = cognn_trunc_close_u64(c, out, c0, c1, keys, p, 0, n);
     if (rc) return rc;
@@ -353,6 +364,7 @@ int cognn_trunc_close_open_u64(cognn_ctx* c, uint64_t* out, uint64_t* E, const u
 // both parties' closes side by side, then the opening from their sum - what the two-round form would have exchanged
 int cognn_trunc_close_pub_u64(cognn_ctx* c, uint64_t* out, uint64_t* E, const uint64_t* c0, const uint64_t* c1, const cognn_keys* keys,
                               int p, uint64_t key_open0, uint64_t key_open1, int reveal, int64_t n) {
+    REQ(AL(out) && AL(E) && AL(c0) && AL(c1), "cognn_trunc_close_pub_u64: misaligned tensor (the HIP kernels move 16-byte element pairs)");
     CHUNK(n)
     REQ(E && c0 && c1, "trunc_close_pub: both opened values are needed");
     std::vector<u64> y0((size_t)n), y1((size_t)n);
@@ -390,6 +402,7 @@ int cognn_dealer_trunc_pub_u64(cognn_ctx*, uint64_t* t, uint64_t* rp0, uint64_t*
 }
 int cognn_rowscale_open_u64(cognn_ctx*, uint64_t* E, uint64_t* G, const uint64_t* V, const uint64_t* s, const cognn_keys* keys,
                             int p, int64_t rows, int64_t F) {
+    REQ(AL(E) && AL(G) && AL(V) && AL(s), "cognn_rowscale_open_u64: misaligned tensor (the HIP kernels move 16-byte element pairs)");
     if (E) for (int64_t i = 0; i < rows * F; ++i) E[i] = V[i] - cognn_prng(keys->k[p == 0 ? COGNN_SL_A0 : COGNN_SL_A1], (u64)i);
     CG_PAR
     for (int64_t r = 0; r < rows; ++r) G[r] = s[r] - cognn_prng(keys->k[p == 0 ? COGNN_SL_B0 : COGNN_SL_B1], (u64)r);
@@ -397,6 +410,7 @@ int cognn_rowscale_open_u64(cognn_ctx*, uint64_t* E, uint64_t* G, const uint64_t
 }
 int cognn_rowscale_close_u64(cognn_ctx*, uint64_t* c, const uint64_t* E, const uint64_t* E1, const uint64_t* G, const uint64_t* G1,
                              const cognn_keys* keys, const cognn_keys* tkeys, int p, int64_t rows, int64_t F) {
+    REQ(AL(c) && AL(E) && AL(E1), "cognn_rowscale_close_u64: misaligned tensor (the HIP kernels move 16-byte element pairs)");
     CHUNK(rows * F)
     const cognn_opkeys k = K(keys), tk = K(tkeys);
     CG_PAR
@@ -408,6 +422,7 @@ int cognn_rowscale_close_u64(cognn_ctx*, uint64_t* c, const uint64_t* E, const u
     return 0;
 }
 int cognn_relu_open_u64(cognn_ctx*, uint64_t* E, uint64_t* G, const uint64_t* z, const cognn_keys* keys, int p, int64_t n) {
+    REQ(AL(E) && AL(G) && AL(z), "cognn_relu_open_u64: misaligned tensor (the HIP kernels move 16-byte element pairs)");
     CHUNK(n)
     CG_PAR
     for (int64_t i = lo_; i < hi_; ++i) {
@@ -420,6 +435,7 @@ int cognn_relu_open_u64(cognn_ctx*, uint64_t* E, uint64_t* G, const uint64_t* z,
 }
 int cognn_relu_mul_u64(cognn_ctx*, uint64_t* w, const uint64_t* E, const uint64_t* E1, const uint64_t* G, const uint64_t* G1,
                        const cognn_keys* keys, int p, int64_t n) {
+    REQ(AL(w) && AL(E) && AL(G) && AL(E1) && AL(G1), "cognn_relu_mul_u64: misaligned tensor (the HIP kernels move 16-byte element pairs)");
     CHUNK(n)
     const cognn_opkeys k = K(keys);
     CG_PAR
@@ -433,6 +449,7 @@ int cognn_relu_mul_u64(cognn_ctx*, uint64_t* w, const uint64_t* E, const uint64_
     return 0;
 }
 int cognn_relu_close_u64(cognn_ctx*, uint64_t* h, uint8_t* mask, const uint64_t* z, const uint64_t* w0, const uint64_t* w1, int64_t n) {
+    REQ(AL(h) && AL(z) && AL(w0) && AL(w1), "cognn_relu_close_u64: misaligned tensor (the HIP kernels move 16-byte element pairs)");
     CHUNK(n)
     CG_PAR
     for (int64_t i = lo_; i < hi_; ++i) {
@@ -444,6 +461,7 @@ int cognn_relu_close_u64(cognn_ctx*, uint64_t* h, uint8_t* mask, const uint64_t*
 }
 int cognn_relu_close_open_u64(cognn_ctx* c, uint64_t* h, uint64_t* E, uint8_t* mask, const uint64_t* z, const uint64_t* w0, const uint64_t* w1,
                               uint64_t key_open, int64_t n) {
+    REQ(AL(h) && AL(E) && AL(z) && AL(w0) && AL(w1), "cognn_relu_close_open_u64: misaligned tensor (the HIP kernels move 16-byte element pairs)");
     CHUNK(n)
     cognn_relu_close_u64(c, h, mask, z, w0, w1, n);
     CG_PAR
@@ -451,6 +469,7 @@ int cognn_relu_close_open_u64(cognn_ctx* c, uint64_t* h, uint64_t* E, uint8_t* m
     return 0;
 }
 int cognn_mask_select_u64(cognn_ctx*, uint64_t* out, const uint64_t* in, const uint8_t* mask, int64_t n) {
+    REQ(AL(out) && AL(in), "cognn_mask_select_u64: misaligned tensor (the HIP kernels move 16-byte element pairs)");
     CHUNK(n)
     CG_PAR
     for (int64_t i = lo_; i < hi_; ++i) out[i] = mask[i] ? in[i] : 0;

@@ -218,7 +218,8 @@ def test_launcher_runs_the_cpp_binary_on_the_gpu(tmp_path):
 @pytest.mark.gpu
 def test_launcher_runs_gcn_original_on_the_gpu(tmp_path):
     """bin/gcn-original (the reference's --cognn-unopt-* executable): the engine's original-gcn variant, 4 GAS iterations per epoch,
-    both parties' logs with the oracle's loss after each of two epochs; -c 1 (one rank per GPU) is refused for this kernel."""
+    both parties' logs with the oracle's loss after each of two epochs (one process hosts both parties here; one rank per party:
+    tests/test_multirank_gpu.py::test_original_gcn_across_ranks_hip)."""
     import original_gcn
     from cognn_amd import worker
     data, logs = tmp_path / "data", tmp_path / "log"
@@ -239,8 +240,3 @@ def test_launcher_runs_gcn_original_on_the_gpu(tmp_path):
         loss = [float(x) for x in re.findall(r"cross-entropy-loss = ([0-9.]+)", text)]
         want = [m["loss"] for m in o.metrics if m["party"] == party]
         assert len(loss) == 2 and np.allclose(loss, want, atol=1e-5), (loss, want)
-    files = [str(data / ("cora_small" + e)) for e in (".edge.preprocessed", ".vertex.preprocessed", ".part.preprocessed")]
-    r = subprocess.run([os.path.join(ROOT, "bin", "gcn-original"), "-t", "2", "-g", "2", "-i", "0", "-m", "4", "-s", "c1", "-r", "1", "-c", "1"] + files +
-                       [str(tmp_path / "out"), str(data / "cora_small_config.txt")], capture_output=True, text=True, timeout=120, cwd=tmp_path,
-                      env=dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"))
-    assert r.returncode != 0 and "single process" in r.stderr

@@ -148,7 +148,7 @@ def test_original_gcn_single_process(tmp_path, k, extra):
 
 @pytest.mark.parametrize("k,world,extra", [(2, 2, {}), (3, 3, {}), (4, 2, {}), (4, 4, {}), (4, 4, {"hostile": 1}), (6, 3, {"V": 61, "Eu": 200}),
                                             (3, 3, {"V": 9, "Eu": 5}), (5, 5, {"V": 61, "Eu": 300, "hid": 5, "lab": 3, "inproc": True}),
-                                            (4, 2, {"packed_openings": True})])
+                                            (4, 2, {"packed_openings": True}), (4, 2, {"V": 71, "Eu": 260, "in": 33, "hid": 5, "lab": 7})])
 def test_original_gcn_across_ranks(tmp_path, k, world, extra):
     """The unoptimised kernel with its parties on different ranks (the reference's deployment of it: k processes): the client and
     the server of a Scatter instance exchange the openings of the two per-edge scales, the client's results for destination owners
