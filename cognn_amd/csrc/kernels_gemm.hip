@@ -1382,11 +1382,15 @@ void beaver_gemm_tn_ws_kernel(u64* Z, const u64* __restrict__ E0, const u64* __r
 // ------------------------------------------------------------------------------------------
 // NT = ceil(N / 16) column tiles per wave (one B image of NT x 8 KiB per K step), WAVES row tiles per workgroup: <1, 4> for
 // N <= 16, <NT, 8> for 16 < N <= 64 (128 x 64 output block, as many accumulator registers as beaver_gemm_d16n_kernel).
-template <int NT, int WAVES, bool TWO, bool PREA = false>   // TWO: an operand may arrive as two shares (E1 / F1 given); false saves the second stream's registers
+// DEAL (the dealer's product share of such a triple, offline phase): Z += (A_0 + A_1)^T . (B_0 + B_1) with every operand generated in
+// registers - the two halves of the A fragment are the limb-form masks of streams keyA / keyA1 (their PRNG bytes ARE the limbs), both
+// segments of the B image hold B_0 + B_1 (streams keyB / keyB1); nothing is loaded.  Z holds -C_0 on entry.
+template <int NT, int WAVES, bool TWO, bool PREA = false, bool DEAL = false>   // TWO: an operand may arrive as two shares (E1 / F1 given); false saves the second stream's registers
 __device__ __forceinline__ void tn_d16_body(u64* Z, const u64* __restrict__ E0, const u64* __restrict__ E1, const u64* __restrict__ F,
                                             const u64* __restrict__ F1, u64 keyA, u64 keyB, int p, int M, int N, int K, int nst, int ksteps, int mtiles,
                                             int a_storage, int bx, int by, unsigned char* sB, const u64x2* __restrict__ Epl = nullptr,
-                                            const u64x2* __restrict__ Apl = nullptr) {
+                                            const u64x2* __restrict__ Apl = nullptr, u64 keyA1 = 0, u64 keyB1 = 0) {
+    static_assert(!DEAL || (!TWO && !PREA), "the dealer form generates its operands");
     // PREA (a constant left operand whose mask is dealt once - the feature tensor of the layer-0 weight gradient): both halves of the A
     // fragment are read from fragment-ordered images (presplit_tn_kernel) - no loads along m, no mask generation, no limb split
     constexpr int kThreadsTn = WAVES * 64;
@@ -1423,6 +1427,7 @@ __device__ __forceinline__ void tn_d16_body(u64* Z, const u64* __restrict__ E0, 
         for (int s = 0; s < 8; ++s) acc[t][s] = v4i{0, 0, 0, 0};
     u64 a0[8], a1[(TWO || PREA) ? 8 : 1], f0[TPT][2], f1[TWO ? TPT : 1][2];
     auto load_a = [&](int st) {
+        if (DEAL) return;
         if (PREA) {                                          // a0: the E half, a1: the mask half, four coalesced 16-byte pieces each
             const size_t off = (((size_t)tile * nst + st) * 4 << 6) + lane;
 #pragma unroll
@@ -1440,6 +1445,7 @@ __device__ __forceinline__ void tn_d16_body(u64* Z, const u64* __restrict__ E0, 
         }
     };
     auto load_b = [&](int st) {
+        if (DEAL) return;
 #pragma unroll
         for (int q = 0; q < TPT; ++q)
 #pragma unroll
@@ -1458,6 +1464,11 @@ __device__ __forceinline__ void tn_d16_body(u64* Z, const u64* __restrict__ E0, 
             for (int j = 0; j < 2; ++j) {
                 const int k = st * 32 + bk[q] + j;
                 const u64 keep = (bn[q] < N && k < K) ? ~0ull : 0ull;
+                if (DEAL) {
+                    const u64 x = (u64)k * (u64)N + (u64)bn[q];
+                    v[j] = v[2 + j] = (cognn_prng(keyB, x) + cognn_prng(keyB1, x)) & keep;
+                    continue;
+                }
                 const u64 f = (TWO ? f0[q][j] + f1[q][j] : f0[q][j]) & keep;
                 v[j] = ((cognn_prng(keyB, (u64)k * (u64)N + (u64)bn[q]) & keep) + (p == 1 ? f : 0ull));
                 v[2 + j] = f;
@@ -1483,7 +1494,7 @@ __device__ __forceinline__ void tn_d16_body(u64* Z, const u64* __restrict__ E0, 
         u64 v[8], w[8];
         if (active) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { v[e] = (TWO && !PREA) ? a0[e] + a1[e] : a0[e]; if (PREA) w[e] = a1[e]; }
+            for (int e = 0; e < 8; ++e) { v[e] = DEAL ? 0ull : (TWO && !PREA) ? a0[e] + a1[e] : a0[e]; if (PREA) w[e] = a1[e]; }
             if (st + 1 < st1) load_a(st + 1);               // the next step's opened shares are in flight during this step's arithmetic
         }
         if (st + 1 < st1) {
@@ -1502,11 +1513,14 @@ __device__ __forceinline__ void tn_d16_body(u64* Z, const u64* __restrict__ E0, 
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const u64 keep = (mok && k0 + e < K) ? ~0ull : 0ull;
-                    v[e] &= keep;
+                    if (DEAL) v[e] = cognn_prng(keyA1, x) & keep;
+                    else v[e] &= keep;
                     w[e] = cognn_prng(keyA, x) & keep;
                     x += xs;
                 }
-                split4(v, pe0); split4(v + 4, pe1); split4_limb(w, pm0); split4_limb(w + 4, pm1);
+                if (DEAL) { split4_limb(v, pe0); split4_limb(v + 4, pe1); }
+                else { split4(v, pe0); split4(v + 4, pe1); }
+                split4_limb(w, pm0); split4_limb(w + 4, pm1);
             }
             v4i af[8];
 #pragma unroll
@@ -1556,14 +1570,14 @@ void beaver_gemm_tn_d16_kernel(u64* Z, const u64* __restrict__ E0, const u64* __
 struct GemmTnJob {
     u64* Z; const u64* E0; const u64* E1; const u64* F; const u64* F1;
     const u64x2* Epl; const u64x2* Apl;                     // PREA: both halves of the A fragments as images (cognn_gemm_presplit_tn_u64)
-    u64 keyA, keyB;
+    u64 keyA, keyB, keyA1, keyB1;                           // (keyA1 / keyB1: the second streams of the dealer form)
     int p, K, nst, ksteps, splits, a_storage, wg_end;
 };
 struct GemmTnGroup {
     GemmTnJob j[kGroupMax];
     int count, M, N, mtiles, gx;
 };
-template <int NT, int WAVES, bool TWO, bool PREA = false>
+template <int NT, int WAVES, bool TWO, bool PREA = false, bool DEAL = false>
 __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(2, (NT == 1 && !TWO) ? 3 : 2)))
 void beaver_gemm_tn_group_kernel(GemmTnGroup g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char sB[];
@@ -1571,8 +1585,8 @@ void beaver_gemm_tn_group_kernel(GemmTnGroup g) {
     while (job < g.count - 1 && (int)blockIdx.x >= g.j[job].wg_end) ++job;
     const GemmTnJob& J = g.j[job];
     const int w = (int)blockIdx.x - (job ? g.j[job - 1].wg_end : 0);
-    tn_d16_body<NT, WAVES, TWO, PREA>(J.Z, J.E0, J.E1, J.F, J.F1, J.keyA, J.keyB, J.p, g.M, g.N, J.K, J.nst, J.ksteps, g.mtiles, J.a_storage, w % g.gx, w / g.gx, sB,
-                                      J.Epl, J.Apl);
+    tn_d16_body<NT, WAVES, TWO, PREA, DEAL>(J.Z, J.E0, J.E1, J.F, J.F1, J.keyA, J.keyB, J.p, g.M, g.N, J.K, J.nst, J.ksteps, g.mtiles, J.a_storage, w % g.gx, w / g.gx, sB,
+                                            J.Epl, J.Apl, J.keyA1, J.keyB1);
 }
 // the images PREA reads: [row tile of M][K step][16-byte piece j][lane] with lane (r = m - 16 tile, b) holding k = 32 st + 8 b + e,
 // e = 0..7 (the k order of tn_d16_body's A fragment); src: the operand stored [K x M] (summed with src1 if given) - or, src == NULL,
@@ -2284,6 +2298,10 @@ extern "C" int cognn_dealer_gemm_c1_tn_group_u64(cognn_ctx* ctx, const cognn_dea
     FillJobs f;
     memset(&f, 0, sizeof(f));
     long long nmax = 0;
+    // jobs of a shape the register-direct TN kernel serves run in its dealer form - every operand generated in registers, the jobs of
+    // one (M, N) in one launch (only their C_1 = -C_0 is filled first); the others fill their operands and run one product each
+    static const bool no_deal = getenv("COGNN_NO_DEALER_TN_DEAL") != nullptr;
+    std::vector<char> dealt((size_t)count, 0);
     for (int32_t j = 0; j < count; ++j) {
         const cognn_dealer_tn_job& J = jobs[j];
         CG_REQUIRE(J.M >= 0 && J.N >= 0 && J.K >= 0 && J.M < (1ll << 31) && J.N < (1ll << 31) && J.K < (1ll << 31) && (J.transA == 1 || J.transA == 2),
@@ -2294,21 +2312,66 @@ extern "C" int cognn_dealer_gemm_c1_tn_group_u64(cognn_ctx* ctx, const cognn_dea
             f.out[f.count] = out; f.k0[f.count] = k0; f.k1[f.count] = k1; f.rows[f.count] = rows; f.cols[f.count] = cols; f.mode[f.count] = mode;
             nmax = std::max(nmax, rows * cols); ++f.count;
         };
-        add((u64*)J.scratchA, J.keys.k[COGNN_SL_A0], J.keys.k[COGNN_SL_A1], J.M, J.K, (J.transA & 3) | 4 | 8);
-        add((u64*)J.scratchB, J.keys.k[COGNN_SL_B0], J.keys.k[COGNN_SL_B1], J.K, J.N, 4);
+        dealt[(size_t)j] = (!no_deal && cognn_beaver_gemm_tn_groupable(J.M, J.N, J.K, 0)) ? 1 : 0;
+        if (!dealt[(size_t)j]) {
+            add((u64*)J.scratchA, J.keys.k[COGNN_SL_A0], J.keys.k[COGNN_SL_A1], J.M, J.K, (J.transA & 3) | 4 | 8);
+            add((u64*)J.scratchB, J.keys.k[COGNN_SL_B0], J.keys.k[COGNN_SL_B1], J.K, J.N, 4);
+        }
         add((u64*)J.C1, J.keys.k[COGNN_SL_C0], 0, J.M, J.N, 16);
     }
     if (f.count == 0) return 0;
     hipLaunchKernelGGL(prng_fill_jobs_kernel, dim3((unsigned)std::min<long long>((nmax + 255) / 256, 4096), (unsigned)f.count), dim3(256), 0, ctx->stream, f);
     CG_LAUNCH_CHECK();
+    for (int32_t j0 = 0; j0 < count; ++j0) {
+        if (dealt[(size_t)j0] != 1) continue;
+        const long long M = jobs[j0].M, N = jobs[j0].N;
+        const int NT = (int)((N + 15) / 16), waves = NT == 1 ? 4 : 8;
+        const int mtiles = (int)((M + 15) / 16), gx = (mtiles + waves - 1) / waves;
+        GemmTnGroup g;
+        memset(&g, 0, sizeof(g));
+        g.M = (int)M; g.N = (int)N; g.mtiles = mtiles; g.gx = gx;
+        int live = 0;
+        for (int32_t j = j0; j < count && live < kGroupMax; ++j) if (dealt[(size_t)j] == 1 && jobs[j].M == M && jobs[j].N == N) ++live;
+        const int budget = NT == 1 ? 768 : 256;              // resident workgroups (launch_tn_d16), shared out evenly over the jobs
+        int wg_end = 0;
+        for (int32_t j = j0; j < count && g.count < kGroupMax; ++j) {
+            const cognn_dealer_tn_job& J = jobs[j];
+            if (dealt[(size_t)j] != 1 || J.M != M || J.N != N) continue;
+            dealt[(size_t)j] = 2;
+            GemmTnJob& d = g.j[g.count++];
+            d.Z = (u64*)J.C1;
+            d.keyA = J.keys.k[COGNN_SL_A0]; d.keyA1 = J.keys.k[COGNN_SL_A1]; d.keyB = J.keys.k[COGNN_SL_B0]; d.keyB1 = J.keys.k[COGNN_SL_B1];
+            d.p = 0; d.K = (int)J.K; d.nst = (int)((J.K + 31) / 32); d.a_storage = J.transA == 2 ? 1 : 0;   // (the fill's addressing: transA = 1 reads the stream across)
+            int splits = std::max(1, std::min(d.nst, (budget / std::max(live, 1) + gx - 1) / gx));
+            d.ksteps = (d.nst + splits - 1) / splits;
+            d.splits = (d.nst + d.ksteps - 1) / d.ksteps;
+            wg_end += gx * d.splits;
+            d.wg_end = wg_end;
+        }
+        const size_t lds = 2 * (size_t)NT * kD16Stage;
+#define CG_TNDEAL_LAUNCH(NT_, W_)                                                                                                                 \
+        do {                                                                                                                                      \
+            if (int rc_lds_ = cg_ensure_dynamic_lds((const void*)beaver_gemm_tn_group_kernel<NT_, W_, false, false, true>, (int)lds)) return rc_lds_; \
+            hipLaunchKernelGGL((beaver_gemm_tn_group_kernel<NT_, W_, false, false, true>), dim3((unsigned)wg_end), dim3(W_ * 64), lds, ctx->stream, g);  \
+        } while (0)
+        if (NT == 1) CG_TNDEAL_LAUNCH(1, 4);
+        else if (NT == 2) CG_TNDEAL_LAUNCH(2, 8);
+        else if (NT == 3) CG_TNDEAL_LAUNCH(3, 8);
+        else CG_TNDEAL_LAUNCH(4, 8);
+#undef CG_TNDEAL_LAUNCH
+        CG_LAUNCH_CHECK();
+    }
+    int rest = 0;
+    for (int32_t j = 0; j < count; ++j) if (!dealt[(size_t)j] && jobs[j].M * jobs[j].N != 0) ++rest;
+    if (!rest) return 0;
     // the products are independent (own buffers): small ones - a few microseconds of work behind a long K - run side by side on the
     // context's launch lanes instead of one after the other
-    const int lanes = (count > 1 && !ctx->lanes_active && !ctx->capturing) ? std::min<int>(4, count) : 0;
+    const int lanes = (rest > 1 && !ctx->lanes_active && !ctx->capturing) ? std::min<int>(4, rest) : 0;
     if (lanes) { if (int rc = cognn_lane_begin(ctx, lanes)) return rc; }
     int rc = 0, next = 0;
     for (int32_t j = 0; j < count && !rc; ++j) {
         const cognn_dealer_tn_job& J = jobs[j];
-        if (J.M * J.N == 0) continue;
+        if (J.M * J.N == 0 || dealt[(size_t)j]) continue;
         if (lanes) { rc = cognn_lane_select(ctx, next); next = (next + 1) % lanes; }
         if (!rc) rc = gemm_dispatch(ctx, (u64*)J.C1, (const u64*)J.scratchA, nullptr, (const u64*)J.scratchB, J.M, J.N, J.K, J.transA, 1);
     }

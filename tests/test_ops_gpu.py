@@ -840,10 +840,14 @@ def test_dealer_product_shares_as_one_grouped_launch(ctx, N, K, Ms):
             assert np.array_equal(host(one), want[q]), q
 
 
-@pytest.mark.parametrize("shapes", [[(128, 16, 4929, 2), (128, 16, 4930, 2), (16, 3, 4929, 1)], [(64, 7, 1354, 1)], [(33, 5, 300, 2), (5, 1, 1, 1), (8, 8, 0, 2)]])
+@pytest.mark.parametrize("shapes", [[(128, 16, 4929, 2), (128, 16, 4930, 2), (16, 3, 4929, 1)], [(64, 7, 1354, 1)], [(33, 5, 300, 2), (5, 1, 1, 1), (8, 8, 0, 2)],
+                                    [(500, 16, 4930, 2), (16, 3, 4930, 1), (500, 16, 4929, 2), (16, 3, 4929, 1), (500, 16, 255, 2), (500, 16, 256, 1)],
+                                    [(128, 64, 9000, 2), (64, 16, 9000, 1), (128, 64, 8191, 2), (40, 33, 700, 1), (40, 48, 700, 2), (2, 2, 70000, 1)],
+                                    [(24, 16, 3000 + 7 * q, 1 + q % 2) for q in range(16)]])
 def test_dealer_product_shares_with_a_transposed_operand(ctx, shapes):
     """cognn_dealer_gemm_c1_tn_group_u64: the weight-gradient triples (A used transposed: transA 1 = logical mask index, 2 = the mask
-    in storage order) - all fills in one launch, C_1 = -C_0 + (A_0 + A_1)^T-form product - against numpy and the per-triple call."""
+    in storage order) - C_1 = -C_0 + (A_0 + A_1)^T-form product; the jobs of one (M, N) the register-direct kernel serves in ONE launch
+    of its dealer form (every operand generated in registers), the others (K < 256) after a fill - against numpy and the per-triple call."""
     from cognn_amd import capi
     jobs = (capi.DealerTnJob * len(shapes))()
     keep, want = [], []
