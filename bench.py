@@ -508,10 +508,12 @@ def main():
             torch.cuda.synchronize()
 
     n_warm = max(args.warmup, 2) if recorded else args.warmup   # (recorded epochs: one eager, one while recording)
+    if not recorded:
+        eng.enable_timing(True)               # (the warm-up creates the timing events the timed region reuses: creating one costs as much as a small kernel)
     for _ in range(n_warm):
         eng.run(0, iters)
     if not recorded:
-        eng.enable_timing(True)               # (per-kernel HIP-event timers would break up the recorded epoch)
+        eng.enable_timing(True)               # restart the timers (per-kernel HIP-event timers would break up a recorded epoch)
     x0 = xch.stats() if xch else None
     barrier()
     t0 = time.perf_counter()

@@ -74,6 +74,8 @@ int cognn_ctx_destroy(cognn_ctx* ctx) {
     if (!ctx) return 0;
     if (cg_salt_owner.load() == ctx) (void)cognn_set_epoch_salt(ctx, 0);
     (void)cognn_timer_reset(ctx);
+    for (auto ev : ctx->event_pool) (void)hipEventDestroy(ev);
+    ctx->event_pool.clear();
     if (ctx->lanes_active) ctx->stream = ctx->main_stream;
     for (auto st : ctx->lanes) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
     for (auto ev : ctx->lane_done) (void)hipEventDestroy(ev);
@@ -180,11 +182,16 @@ int cognn_memset0(cognn_ctx* ctx, void* dst, size_t bytes) {
     if (bytes) CG_HIP(hipMemsetAsync(dst, 0, bytes, ctx->stream));
     return 0;
 }
+static int timer_event(cognn_ctx* ctx, hipEvent_t* ev) {
+    if (!ctx->event_pool.empty()) { *ev = ctx->event_pool.back(); ctx->event_pool.pop_back(); return 0; }
+    CG_HIP(hipEventCreate(ev));
+    return 0;
+}
 int cognn_timer_begin(cognn_ctx* ctx, int kind) {
     { const int rc_flush_ = cg_flush(ctx); if (rc_flush_) return rc_flush_; }
     CG_REQUIRE(ctx && kind >= 0 && kind < 10, "cognn_timer_begin: bad arguments");
     hipEvent_t ev;
-    CG_HIP(hipEventCreate(&ev));
+    if (int rc = timer_event(ctx, &ev)) return rc;
     CG_HIP(hipEventRecord(ev, ctx->stream));
     ctx->open_begin[kind].push_back(ev);
     return 0;
@@ -193,7 +200,7 @@ int cognn_timer_end(cognn_ctx* ctx, int kind) {
     { const int rc_flush_ = cg_flush(ctx); if (rc_flush_) return rc_flush_; }
     CG_REQUIRE(ctx && kind >= 0 && kind < 10 && !ctx->open_begin[kind].empty(), "cognn_timer_end: no open timer");
     hipEvent_t ev;
-    CG_HIP(hipEventCreate(&ev));
+    if (int rc = timer_event(ctx, &ev)) return rc;
     CG_HIP(hipEventRecord(ev, ctx->stream));
     cognn_timer_pair pr{ctx->open_begin[kind].back(), ev};
     ctx->open_begin[kind].pop_back();
@@ -216,9 +223,9 @@ int cognn_timer_read(cognn_ctx* ctx, int kind, int64_t* launches, double* total_
 int cognn_timer_reset(cognn_ctx* ctx) {
     CG_REQUIRE(ctx, "cognn_timer_reset: null ctx");
     for (size_t k = 0; k < sizeof(ctx->timers) / sizeof(ctx->timers[0]); ++k) {
-        for (auto& pr : ctx->timers[k]) { (void)hipEventDestroy(pr.b); (void)hipEventDestroy(pr.e); }
+        for (auto& pr : ctx->timers[k]) { ctx->event_pool.push_back(pr.b); ctx->event_pool.push_back(pr.e); }
         ctx->timers[k].clear();
-        for (auto& ev : ctx->open_begin[k]) (void)hipEventDestroy(ev);
+        for (auto& ev : ctx->open_begin[k]) ctx->event_pool.push_back(ev);
         ctx->open_begin[k].clear();
     }
     return 0;

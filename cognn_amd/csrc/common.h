@@ -22,6 +22,7 @@ struct cognn_ctx {
     bool own_stream;
     std::vector<cognn_timer_pair> timers[10];  // per kind
     std::vector<hipEvent_t> open_begin[10];
+    std::vector<hipEvent_t> event_pool;        // timing events handed back by cognn_timer_reset: creating one costs more than a small kernel
     int batch_depth = 0;
     cognn_pending_batch pending;
     // launch lanes (cognn_lane_begin): auxiliary streams, created on first use
