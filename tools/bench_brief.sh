@@ -9,7 +9,7 @@ for w in "$@"; do
   python - gpurun_out/$TAG/$w.json <<'PY'
 import json, sys
 d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
-print(d["config"]["workload"] if "workload" in d["config"] else sys.argv[1], "online %.4f ms  offline %s  incl %s" % (
-    d["ms_per_step"], d.get("offline_ms"), d.get("epoch_time_incl_offline_s") and 1e3 * d["epoch_time_incl_offline_s"]))
+print(d["config"]["name"], "online %.4f ms (%.4f without kernel timers)  offline %s  incl %s" % (
+    d["ms_per_step"], d["ms_per_step_without_kernel_timers"], d.get("offline_ms"), d.get("epoch_time_incl_offline_s") and 1e3 * d["epoch_time_incl_offline_s"]))
 PY
 done
