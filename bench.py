@@ -707,10 +707,12 @@ def main():
                 dt2 = time.perf_counter() - t0
             base += 2 + args.steps
             eng.offline(base * ep_len, base * ep_len + iters)      # (warm: the dealer kernels have run once)
+            eng.offline_discard(base * ep_len, base * ep_len + iters)
             barrier()
-            t1 = time.perf_counter()                       # the dealer phase of further steps alone (their shares are never consumed)
-            for e in range(1, 1 + args.steps):
+            t1 = time.perf_counter()                       # the dealer phase of further steps alone: their shares are handed back unconsumed
+            for e in range(1, 1 + args.steps):                # (host bookkeeping only), so every step deals into the buffers of the one before
                 eng.offline((base + e) * ep_len, (base + e) * ep_len + iters)
+                eng.offline_discard((base + e) * ep_len, (base + e) * ep_len + iters)
             barrier()
             t_off_total = time.perf_counter() - t1
             if world > 1:

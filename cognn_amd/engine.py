@@ -121,6 +121,12 @@ class Engine:
     def offline(self, it0, it1):
         _check(self.lib.cognn_engine_offline(self.h, it0, it1))
 
+    def offline_discard(self, it0, it1):
+        """Returns the unconsumed product shares of iterations [it0, it1) to the buffer pool; how many there were."""
+        n = ctypes.c_int64()
+        _check(self.lib.cognn_engine_offline_discard(self.h, it0, it1, ctypes.byref(n)))
+        return n.value
+
     def offline_save(self, directory):
         _check(self.lib.cognn_engine_offline_save(self.h, str(directory).encode()))
 

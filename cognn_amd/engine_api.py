@@ -38,6 +38,7 @@ _SIGNATURES = {
     "cognn_engine_start": (ctypes.c_int, [_P]),
     "cognn_engine_offline": (ctypes.c_int, [_P, _L, _L]),
     "cognn_engine_run": (ctypes.c_int, [_P, _L, _L]),
+    "cognn_engine_offline_discard": (ctypes.c_int, [_P, _L, _L, ctypes.POINTER(_L)]),
     "cognn_engine_offline_save": (ctypes.c_int, [_P, ctypes.c_char_p]),
     "cognn_engine_offline_load": (ctypes.c_int, [_P, ctypes.c_char_p, _L, _L, ctypes.POINTER(_L)]),
     "cognn_engine_get_shares": (ctypes.c_int, [_P, _I, _I, _P, ctypes.POINTER(_L), ctypes.POINTER(_L)]),

@@ -117,6 +117,21 @@ int cognn_engine_offline_save(cognn_engine* E, const char* dir) {
     });
 }
 
+int cognn_engine_offline_discard(cognn_engine* E, int64_t it0, int64_t it1, int64_t* discarded) {
+    return guard([&] {
+        if (!E) throw EngineError("cognn_engine_offline_discard: null engine");
+        int64_t n = 0;
+        for (auto& s : E->sides)
+            for (auto f = s.c1.begin(); f != s.c1.end();) {
+                if (f->first.first < it0 || f->first.first >= it1) { ++f; continue; }
+                E->c1_pool[f->second.elems].push_back(f->second.ptr);   // (one stream: a later deal into the buffer is ordered after this one)
+                f = s.c1.erase(f);
+                ++n;
+            }
+        if (discarded) *discarded = n;
+    });
+}
+
 int cognn_engine_offline_load(cognn_engine* E, const char* dir, int64_t it0, int64_t it1, int64_t* loaded) {
     return guard([&] {
         if (!E || !dir || !E->started) throw EngineError("cognn_engine_offline_load: bad arguments or engine not started");

@@ -151,6 +151,9 @@ int cognn_engine_set_option(cognn_engine* e, int32_t option, int64_t value);
  * the run (parties, ranks, dimensions, graph size, rows of the owner); load reads the files whose header matches the
  * product of that (owner, iteration) exactly and returns their number in *loaded - anything else (stale cache of another
  * dataset / partition / shape) is ignored and dealt on demand. */
+/* hands the product shares dealt for iterations [begin,end) that no iteration has consumed back to the engine's buffer pool (a run that
+ * was cut short, a measurement of the dealer phase alone); discarded (may be NULL): how many */
+int cognn_engine_offline_discard(cognn_engine* e, int64_t iter_begin, int64_t iter_end, int64_t* discarded);
 int cognn_engine_offline_save(cognn_engine* e, const char* dir);
 int cognn_engine_offline_load(cognn_engine* e, const char* dir, int64_t iter_begin, int64_t iter_end, int64_t* loaded);
 /* GAS iterations [begin,end) (ss_...h:239-248); asynchronous on the engine's stream */

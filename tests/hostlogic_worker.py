@@ -80,6 +80,17 @@ def main():
         res[str(keep)] = {"same": bool(np.array_equal(a, b)), "grew": m1[0] - m0[0]}
         e5.close()
     out["replay"] = res
+    # 3b. product shares dealt and handed back unconsumed: the next deal reuses their buffers, the run that follows deals on demand
+    e7 = make(3, 60, 150, 12, 6, 4)
+    e7.offline(0, 6); m0 = e7.memory()
+    n0 = e7.offline_discard(0, 6)
+    e7.offline(6, 12); m1 = e7.memory()
+    n1 = e7.offline_discard(0, 6)                      # (nothing left of those iterations)
+    e7.run(0, 6); got = e7.shares(1, 1).copy()
+    e8 = make(3, 60, 150, 12, 6, 4)
+    e8.run(0, 6)
+    out["discard"] = {"first": n0, "again": n1, "grew": m1[0] - m0[0], "same": bool(np.array_equal(got, e8.shares(1, 1)))}
+    e7.close(); e8.close()
     # 4. whole epochs in one call take the paths that only exist across GAS iterations (the deferred ReLU' selection, the backward
     #    PreScatter scale run ahead by the chain that truncates g): same shares and weights as one call per iteration, same memory
     #    from the second epoch on

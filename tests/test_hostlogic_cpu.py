@@ -30,6 +30,7 @@ def check(out):
     assert out["loaded_truncated"] == 14
     assert out["replay"]["True"] == {"same": True, "grew": 0}
     assert out["replay"]["False"]["same"] is True
+    assert out["discard"] == {"first": 15, "again": 0, "grew": 0, "same": True}
     assert out["epoch_calls_identical"] is True
     assert out["epoch_calls_memory"][1] == out["epoch_calls_memory"][2]
     ph = out["phases"]
