@@ -38,7 +38,7 @@ def main():
     workloads = sys.argv[3:] or sorted(os.listdir(src))
     import subprocess
     try:
-        head = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+        head = os.environ.get("COGNN_GIT_HEAD") or subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
     except OSError:
         head = ""
     # "build": what the passes were collected on - the tag of the gpurun directory and the commit checked out when the raw
