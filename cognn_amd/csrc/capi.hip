@@ -40,7 +40,25 @@ namespace {
 __global__ void salt_set_kernel(unsigned long long* a, unsigned long long* b, unsigned long long* c, unsigned long long v) {
     if (threadIdx.x == 0) { *a = v; *b = v; *c = v; }
 }
+__global__ __launch_bounds__(256) void zero_words_kernel(unsigned long long* p, size_t words) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < words; i += (size_t)gridDim.x * 256) p[i] = 0ull;
+}
+__global__ __launch_bounds__(256) void zero_bytes_kernel(unsigned char* p, size_t bytes) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < bytes; i += (size_t)gridDim.x * 256) p[i] = 0;
+}
 }  // namespace
+int cg_zero(cognn_ctx* ctx, void* p, size_t bytes) {
+    if (!bytes) return 0;
+    static const bool with_memset = getenv("COGNN_ZERO_WITH_MEMSET") != nullptr;   // (the runtime's memset: only for tools/repro_graph_memset_node.py)
+    if (with_memset) { CG_HIP(hipMemsetAsync(p, 0, bytes, ctx->stream)); return 0; }
+    const bool words = (((uintptr_t)p | bytes) & 7u) == 0;
+    const size_t n = words ? bytes / 8 : bytes;
+    const unsigned grid = (unsigned)std::min<size_t>((n + 255) / 256, 8192);
+    if (words) hipLaunchKernelGGL(zero_words_kernel, dim3(grid), dim3(256), 0, ctx->stream, (unsigned long long*)p, n);
+    else hipLaunchKernelGGL(zero_bytes_kernel, dim3(grid), dim3(256), 0, ctx->stream, (unsigned char*)p, n);
+    CG_LAUNCH_CHECK();
+    return 0;
+}
 
 extern "C" {
 
@@ -179,7 +197,7 @@ int cognn_memcpy_d2d(cognn_ctx* ctx, void* dst, const void* src, size_t bytes) {
 int cognn_memset0(cognn_ctx* ctx, void* dst, size_t bytes) {
     { const int rc_flush_ = cg_flush(ctx); if (rc_flush_) return rc_flush_; }
     CG_REQUIRE(ctx, "cognn_memset0: null ctx");
-    if (bytes) CG_HIP(hipMemsetAsync(dst, 0, bytes, ctx->stream));
+    if (int rc = cg_zero(ctx, dst, bytes)) return rc;
     return 0;
 }
 static int timer_event(cognn_ctx* ctx, hipEvent_t* ev) {
@@ -243,6 +261,7 @@ int cognn_set_epoch_salt(cognn_ctx* ctx, uint64_t salt) {
         cognn_ctx* none = nullptr;
         if (!cg_salt_owner.compare_exchange_strong(none, ctx) && none != ctx)
             return cognn_set_error("cognn_set_epoch_salt: another context holds a non-zero epoch salt (one recorded-epoch engine per process at a time)");
+        if (none == nullptr) CG_HIP(hipDeviceSynchronize());   // just acquired: what other contexts have in flight evaluates its streams under salt 0
     }
     hipLaunchKernelGGL(salt_set_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->salt_sym[0], ctx->salt_sym[1], ctx->salt_sym[2], (unsigned long long)salt);
     CG_LAUNCH_CHECK();

@@ -42,6 +42,10 @@ static inline int cg_salt_guard(cognn_ctx* ctx) {
     cognn_ctx* o = cg_salt_owner.load(std::memory_order_relaxed);
     return (o && o != ctx) ? cognn_set_error("another context's epoch salt is set on the device (a recorded epoch is in flight): refused") : 0;
 }
+// stream-ordered zeroing by a kernel of this library (capi.hip).  Not hipMemsetAsync: a memset NODE of a recorded launch sequence
+// replays wrongly on ROCm 7.2 once the process has used the legacy default stream in between - the zeroing is no longer ordered
+// before the node that follows it (tools/repro_graph_memset_node.py; memcpy and kernel nodes are not affected).
+int cg_zero(cognn_ctx* ctx, void* p, size_t bytes);
 // launches whatever is queued
 static inline int cg_flush_pending(cognn_ctx* ctx) {
     if (int rc = cg_salt_guard(ctx)) return rc;

@@ -949,8 +949,8 @@ int cognn_metrics_q16(cognn_ctx* ctx, const uint64_t* pfx, const int32_t* labels
                       int64_t rows, int64_t L, int64_t train_rows, int64_t val_rows, int64_t* counts6, double* loss) {
     { const int rc_flush_ = cg_flush(ctx); if (rc_flush_) return rc_flush_; }
     CG_REQUIRE(ctx && pfx && labels && counts6 && loss, "cognn_metrics_q16: bad arguments");
-    CG_HIP(hipMemsetAsync(counts6, 0, 6 * sizeof(int64_t), ctx->stream));
-    CG_HIP(hipMemsetAsync(loss, 0, sizeof(double), ctx->stream));
+    if (int rc = cg_zero(ctx, counts6, 6 * sizeof(int64_t))) return rc;
+    if (int rc = cg_zero(ctx, loss, sizeof(double))) return rc;
     if (rows <= 0) return 0;
     CG_REQUIRE(L > 0 && L <= 64, "cognn_metrics_q16: unsupported label count %lld (max 64)", (long long)L);
     int G = 1;

@@ -1740,7 +1740,7 @@ int fill(cognn_ctx* ctx, u64* out, u64 k0, u64 k1, int64_t rows, int64_t cols, i
 int gemm_dispatch(cognn_ctx* ctx, u64* C, const u64* A, const u64* A2, const u64* B, int64_t M, int64_t N, int64_t K, int transA, int accumulate) {
     if (M <= 0 || N <= 0) return 0;
     if (K <= 0) {
-        if (!accumulate) CG_HIP(hipMemsetAsync(C, 0, (size_t)M * N * 8, ctx->stream));
+        if (!accumulate) { if (int rc_z_ = cg_zero(ctx, C, (size_t)M * N * 8)) return rc_z_; }
         return 0;
     }
     const int64_t KP = (K + kKStep - 1) / kKStep * kKStep;
@@ -1765,7 +1765,7 @@ int gemm_dispatch(cognn_ctx* ctx, u64* C, const u64* A, const u64* A2, const u64
         }
     }
     if (transA && N <= kFusedBN && K >= 256 && M * N <= (1ll << 22)) {
-        if (!accumulate) CG_HIP(hipMemsetAsync(C, 0, (size_t)M * N * 8, ctx->stream));
+        if (!accumulate) { if (int rc_z_ = cg_zero(ctx, C, (size_t)M * N * 8)) return rc_z_; }
         return launch_tn(ctx, C, A, A2, B, M, N, K);
     }
     // generic path
@@ -1775,7 +1775,7 @@ int gemm_dispatch(cognn_ctx* ctx, u64* C, const u64* A, const u64* A2, const u64
         kchunk = 1024;
         splits = (int)((K + kchunk - 1) / kchunk);
     }
-    if (!accumulate) CG_HIP(hipMemsetAsync(C, 0, (size_t)M * N * 8, ctx->stream));
+    if (!accumulate) { if (int rc_z_ = cg_zero(ctx, C, (size_t)M * N * 8)) return rc_z_; }
     dim3 grid((unsigned)((N + 63) / 64), (unsigned)((M + 3) / 4), (unsigned)splits);
     CG_REQUIRE(grid.y <= 65535 && splits <= 65535, "ring_gemm: shape too large for generic path");
     if (transA) hipLaunchKernelGGL(ring_gemm_simple_kernel<true>, grid, dim3(256), 0, ctx->stream, C, A, A2, B, (int)M, (int)N, (int)K, kchunk, splits > 1);
@@ -1892,7 +1892,7 @@ int beaver_close_impl(cognn_ctx* ctx, uint64_t* Z, const uint64_t* E, const uint
                 ksteps = (nst32 + ksplits - 1) / ksplits;
                 ksplits = (nst32 + ksteps - 1) / ksteps;
             }
-            if (ksplits > 1) CG_HIP(hipMemsetAsync(Z, 0, (size_t)M * N * 8, ctx->stream));
+            if (ksplits > 1) { if (int rc_z_ = cg_zero(ctx, Z, (size_t)M * N * 8)) return rc_z_; }
             const dim3 grid((unsigned)((tiles + 3) / 4), (unsigned)ksplits);
 #define CG_D16_LAUNCH(...)                                                                                                   \
     hipLaunchKernelGGL((beaver_gemm_d16_kernel<__VA_ARGS__>), grid, dim3(256), 0, ctx->stream, (u64*)Z, (const u64*)E, (const u64*)E1, planes, keyA_, \
@@ -1976,7 +1976,7 @@ int beaver_close_impl(cognn_ctx* ctx, uint64_t* Z, const uint64_t* E, const uint
             ksteps = (nst + ksplits - 1) / ksplits;
             ksplits = (nst + ksteps - 1) / ksteps;
         }
-        if (ksplits > 1) CG_HIP(hipMemsetAsync(Z, 0, (size_t)M * N * 8, ctx->stream));
+        if (ksplits > 1) { if (int rc_z_ = cg_zero(ctx, Z, (size_t)M * N * 8)) return rc_z_; }
         if (ksplits > 1) {
             if (cn == 2) { if (kal) CG_WS_LAUNCH(0, false, true, 2, 0, true); else CG_WS_LAUNCH(0, false, false, 2, 0, true); }
             else { if (kal) CG_WS_LAUNCH(0, false, true, 1, 0, true); else CG_WS_LAUNCH(0, false, false, 1, 0, true); }

@@ -100,6 +100,47 @@ def test_recorded_epochs_bit_exact(k, V, Eu, in_dim, hid, lab):
     eng.close()
 
 
+def test_recorded_and_eager_engines_interleaved():
+    """Two engines in one process, one replaying recorded epochs (device-side epoch salt, private stream), one launching eagerly
+    (host-salted keys), alternating epoch by epoch for four epochs: each ends every epoch in its own oracle's shares and weights -
+    the recorded engine's salt is back to 0, and its ownership released, whenever its call returns.  A third engine that also
+    records runs after the first is closed (one recorded-epoch engine at a time holds the device salt)."""
+    import ctypes
+    import torch
+    from cognn_amd import capi
+    oa, ea = _setup(3, 120, 400, 33, 16, 7, seed=33, renew_feature_mask=True)
+    ob, eb = _setup(2, 70, 170, 20, 8, 4, seed=21, gseed=5)
+    ea.graph_epochs(True)
+    raw = capi.Context(0)                                     # a third user: the raw C ABI on the legacy default stream
+    t0 = torch.zeros(1 << 16, dtype=torch.int64, device="cuda"); t1 = torch.ones(1 << 16, dtype=torch.int64, device="cuda")
+    for ep in range(4):
+        for it in range(6 * ep, 6 * ep + 6):
+            oa.iteration(it); ob.iteration(it)
+        ea.run(6 * ep, 6 * ep + 6)                            # (no sync in between: B's launches queue behind A's on another stream)
+        eb.run(6 * ep, 6 * ep + 3)
+        eb.run(6 * ep + 3, 6 * ep + 6)
+        # default-stream work of other users between the replays, each followed by a wait: with the engine's zeroing recorded as
+        # hipMemsetAsync nodes this is what made replays wrong (tools/repro_graph_memset_node.py)
+        raw.call("cognn_add_u64", ctypes.c_void_p(t0.data_ptr()), ctypes.c_void_p(t0.data_ptr()), ctypes.c_void_p(t1.data_ptr()), 1 << 16)
+        raw.sync()
+        t0.add_(1); torch.cuda.synchronize()
+        _compare(oa, ea, 3, 6 * ep + 5)
+        _compare(ob, eb, 2, 6 * ep + 5)
+    assert int(t0[0].item()) == 8
+    raw.close()
+    ea.close()
+    oc, ec = _setup(2, 70, 170, 20, 8, 4, seed=5, gseed=2, renew_feature_mask=True)
+    ec.graph_epochs(True)
+    for ep in range(3):
+        for it in range(6 * ep, 6 * ep + 6):
+            oc.iteration(it); ob.iteration(24 + it)
+        ec.run(6 * ep, 6 * ep + 6)
+        eb.run(24 + 6 * ep, 24 + 6 * ep + 6)
+        _compare(oc, ec, 2, 6 * ep + 5)
+        _compare(ob, eb, 2, 24 + 6 * ep + 5)
+    eb.close(); ec.close()
+
+
 @pytest.mark.parametrize("k", [2, 3])
 def test_whole_epochs_in_one_call_bit_exact(k):
     """cognn_engine_run over whole epochs without reading anything in between: the paths that only exist across GAS iterations

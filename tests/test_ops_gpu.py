@@ -25,6 +25,36 @@ def keys_of(seed, owner, it, op):
     return capi.make_keys(seed, owner, it, op), (lambda slot: co.stream_key(seed, owner, it, op, slot))
 
 
+def test_device_epoch_salt_belongs_to_one_context(ctx):
+    """cognn_set_epoch_salt (the device-side salt of recorded epochs): while one context holds a non-zero salt every launch of
+    another context is refused - it would evaluate its dealer streams under a salt it did not set - and so is a second non-zero
+    salt; after the reset (which synchronises) both work again and read salt 0."""
+    from cognn_amd import capi
+    other = capi.Context(0)
+    try:
+        n, key = 4096, co.stream_key(7, 1, 2, 3, 4)
+        out = dev_empty(n)
+        ctx.call("cognn_set_epoch_salt", 5)
+        ctx.call("cognn_prng_fill_u64", ptr(out), key, n)
+        assert np.array_equal(host(out), co.prng(key + 5, n))
+        with pytest.raises(capi.CognnError, match="epoch salt"):
+            other.call("cognn_prng_fill_u64", ptr(out), key, n)
+        with pytest.raises(capi.CognnError, match="epoch salt"):
+            other.call("cognn_set_epoch_salt", 9)
+        ctx.call("cognn_set_epoch_salt", 0)
+        other.call("cognn_prng_fill_u64", ptr(out), key, n)
+        assert np.array_equal(host(out), co.prng(key, n))
+        other.call("cognn_set_epoch_salt", 9)                 # ... and now the other context may hold it
+        with pytest.raises(capi.CognnError, match="epoch salt"):
+            ctx.call("cognn_prng_fill_u64", ptr(out), key, n)
+        other.call("cognn_set_epoch_salt", 0)
+        ctx.call("cognn_prng_fill_u64", ptr(out), key, n)
+        assert np.array_equal(host(out), co.prng(key, n))
+    finally:
+        other.call("cognn_set_epoch_salt", 0)
+        other.close()
+
+
 def test_prng_and_share_split(ctx):
     n = 100003
     key = co.stream_key(7, 1, 2, 3, 4)
