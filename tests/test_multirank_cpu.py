@@ -157,6 +157,21 @@ def test_original_gcn_across_ranks(tmp_path, k, world, extra):
     _check(dict(BASE, k=k, variant="original-gcn", iters=8, **extra), world, tmp_path)
 
 
+@pytest.mark.parametrize("seed", range(4 * int(os.environ.get("COGNN_FUZZ_SCALE", "1"))))
+def test_original_gcn_across_ranks_random_configuration(tmp_path, seed):
+    """Random party / rank counts, graph sizes (down to fewer vertices than parties have neighbours: empty instances, dummy self
+    entries everywhere) and odd widths for the unoptimised kernel across ranks; every second one as threads of one process."""
+    rng = np.random.default_rng(7700 + seed)
+    world = int(rng.choice([2, 3, 4]))
+    k = world * int(rng.integers(1, 3))
+    V = int(rng.integers(k, 160))
+    cfg = dict(BASE, k=k, V=V, Eu=int(min(V * (V - 1) // 2, rng.integers(1, 3 * V + 1))), gseed=int(rng.integers(1, 1000)),
+               seed=int(rng.integers(1, 1 << 30)), hid=int(rng.choice([3, 8, 16])), lab=int(rng.choice([2, 5, 7])),
+               variant="original-gcn", iters=8, inproc=bool(seed % 2))
+    cfg["in"] = int(rng.choice([5, 16, 33]))
+    _check(cfg, world, tmp_path)
+
+
 @pytest.mark.parametrize("seed", [1, 2])
 @pytest.mark.parametrize("k,world,variant,iters,extra", [(4, 2, "optimize-gcn", 6, {}), (4, 4, "optimize-gcn", 6, {}), (4, 4, "optimize-gcn-inference", 2, {}),
                                                         (4, 2, "optimize-gcn", 6, {"exchanged_openings": True}), (6, 2, "optimize-gcn", 12, {"whole_epochs": True}),

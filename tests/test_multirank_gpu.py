@@ -103,6 +103,19 @@ def test_multirank_random_configuration_hip(tmp_path, seed):
     _check(cfg, world, tmp_path)
 
 
+@pytest.mark.parametrize("seed", range(2 * int(os.environ.get("COGNN_FUZZ_SCALE", "1"))))
+def test_original_gcn_across_ranks_random_configuration_hip(tmp_path, seed):
+    rng = np.random.default_rng(7800 + seed)
+    world = int(rng.choice([2, 3, 4]))
+    k = world * int(rng.integers(1, 3))
+    V = int(rng.integers(k, 600))
+    cfg = dict(BASE, k=k, V=V, Eu=int(min(V * (V - 1) // 2, rng.integers(1, 4 * V + 1))), gseed=int(rng.integers(1, 1000)),
+               seed=int(rng.integers(1, 1 << 30)), hid=int(rng.choice([3, 8, 16])), lab=int(rng.choice([2, 5, 7])),
+               variant="original-gcn", iters=8, backend="hip", inproc=bool(seed % 2))
+    cfg["in"] = int(rng.choice([5, 16, 33, 65]))
+    _check(cfg, world, tmp_path)
+
+
 # ---- the north-star layout on the HIP kernels: 8 parties, one per rank, world 8.  A GPU box admits at most 6 processes on its card,
 # so the eight ranks run as threads of one process over a mailbox transport (tests/inproc_worker.py): eight engines / contexts on
 # the one GPU, every owner / co-party pair across a rank boundary ----
