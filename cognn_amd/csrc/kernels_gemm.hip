@@ -982,8 +982,10 @@ void beaver_gemm_group_kernel(GemmGroup g, GemmEpi epi) {
     // (tile, ls) of the current step, advanced incrementally (ls = step inside this workgroup's K range, i.e. of its LDS image).  The
     // accumulators are cleared behind the stores of a tile's last step, in a block the compiler cannot fold away: cleared
     // `if (ls == 0)` it turned the clearing into 32 x NT selects in EVERY step.
-    // (Two operand register sets used alternately, the loop unrolled by two, saves the 16 copies per step - and costs registers: one
-    // column tile went from 126 to 136, four column tiles spilled: 1.04 -> 3.3 ms.  Not done.)
+    // (Two operand register sets used alternately, the loop body instantiated twice, saves the 16 copies per step and gives the loads a
+    // whole step to land - and costs registers: four column tiles spilled (1.04 -> 3.3 ms); one column tile alone (round 4, A/B on one
+    // box) went from 126 to 140 registers, i.e. from four waves per SIMD to three, and the hidden_dim = 16 pass from 2.17 to 2.20 ms.
+    // Not done.)
     int tile = wid, ls = 0;
     for (int it = 0; it < total; ++it) {
         const int st = st_lo + ls;
