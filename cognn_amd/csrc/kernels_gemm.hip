@@ -982,11 +982,14 @@ void beaver_gemm_group_kernel(GemmGroup g, GemmEpi epi) {
     // (tile, ls) of the current step, advanced incrementally (ls = step inside this workgroup's K range, i.e. of its LDS image).  The
     // accumulators are cleared behind the stores of a tile's last step, in a block the compiler cannot fold away: cleared
     // `if (ls == 0)` it turned the clearing into 32 x NT selects in EVERY step.
-    // (Two operand register sets used alternately, the loop body instantiated twice, saves the 16 copies per step and gives the loads a
-    // whole step to land - and costs registers: four column tiles spilled (1.04 -> 3.3 ms); one column tile alone (round 4, A/B on one
-    // box) went from 126 to 140 registers, i.e. from four waves per SIMD to three, and the hidden_dim = 16 pass from 2.17 to 2.20 ms.
-    // Not done.)
+    // (Two operand register sets used alternately, the loop body instantiated twice, saves the 16 copies per step - and costs registers:
+    // four column tiles spilled (1.04 -> 3.3 ms); one column tile alone went from 126 to 140 registers (round 4: from 108 to 134 after
+    // the MFMA nest was turned B limb outermost), i.e. from four waves per SIMD to three, and the hidden_dim = 16 pass from 2.17 to
+    // 2.20 ms in an A/B on one box.  Not done.  Nor an unconditional load of the next step (the last step loading itself again keeps the
+    // operand registers out of a branch: 16 copies -> 5, 126 -> 116 registers): the compiler then issues the loads at the END of the step
+    // and waits for them at the top of the next - the product phases of a hidden_dim = 16 pass went from 0.249 to 0.262 ms.)
     int tile = wid, ls = 0;
+    u64 xrow = (u64)(wid * 16 + r) * (u64)K + (u64)(2 * b);   // mask index of this lane's row at k = 2 b, advanced with the tile (no 64-bit multiply per step)
     for (int it = 0; it < total; ++it) {
         const int st = st_lo + ls;
         const int m = tile * 16 + r;
@@ -1003,7 +1006,7 @@ void beaver_gemm_group_kernel(GemmGroup g, GemmEpi epi) {
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
             if (PREA) break;
-            const u64 x = (u64)m * (u64)K + (u64)(st * 32 + 8 * jj + 2 * b);
+            const u64 x = xrow + (u64)(st * 32 + 8 * jj);
             if (DEALT) {                                     // dealt mask: a memory stream instead of the counter PRNG
                 const size_t xc = FULL ? (size_t)x : (size_t)min((u64)x, (u64)M * (u64)K - 2);
                 if (KEVEN) { const u64x2 t = *reinterpret_cast<const u64x2*>(Amask + xc); w[2 * jj] = t.x; w[2 * jj + 1] = t.y; }
@@ -1053,10 +1056,12 @@ void beaver_gemm_group_kernel(GemmGroup g, GemmEpi epi) {
                 for (int i = 0; i < 8; ++i) { acc[t][i][0] ^= af[i][0] ^ bf[i][1]; acc[t][i][1] ^= af[i][2] ^ bf[i][3]; acc[t][i][2] ^= af[i][1]; acc[t][i][3] ^= af[i][3] ^ bf[i][0] ^ bf[i][2]; }
                 continue;
             }
+            // B limb outermost: the first eight MFMAs need bf[0] only, so the LDS reads of bf[1..7] land behind them (A limb outermost
+            // needed all eight before the second MFMA); the eight accumulators of a B limb are distinct, integer adds commute
 #pragma unroll
-            for (int i = 0; i < 8; ++i)
+            for (int jj = 0; jj < 8; ++jj)
 #pragma unroll
-                for (int jj = 0; jj + i < 8; ++jj) acc[t][i + jj] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[i], bf[jj], acc[t][i + jj], 0, 0, 0);
+                for (int i = 0; i + jj < 8; ++i) acc[t][i + jj] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[i], bf[jj], acc[t][i + jj], 0, 0, 0);
         }
         if (ls == nst - 1 && !(DBG & 32)) {
         if (EPI) {
@@ -1110,6 +1115,7 @@ void beaver_gemm_group_kernel(GemmGroup g, GemmEpi epi) {
 #pragma unroll
             for (int s2 = 0; s2 < 8; ++s2) acc[t][s2] = v4i{0, 0, 0, 0};
         asm volatile("; accumulators cleared for the next row tile");
+        xrow += (u64)nw * 16ull * (u64)K;
         }
         tile = tile_n; ls = ls_n;
     }
@@ -1533,9 +1539,9 @@ __device__ __forceinline__ void tn_d16_body(u64* Z, const u64* __restrict__ E0, 
 #pragma unroll
                 for (int i = 0; i < 8; ++i) bf[i] = *reinterpret_cast<const v4i*>(img + t * kD16Stage + i * 1024 + lane * 16);
 #pragma unroll
-                for (int i = 0; i < 8; ++i)
+                for (int j = 0; j < 8; ++j)                  // (B limb outermost: see beaver_gemm_group_kernel)
 #pragma unroll
-                    for (int j = 0; j + i < 8; ++j) acc[t][i + j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[i], bf[j], acc[t][i + j], 0, 0, 0);
+                    for (int i = 0; i + j < 8; ++i) acc[t][i + j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[i], bf[j], acc[t][i + j], 0, 0, 0);
             }
         }
         __syncthreads();                                     // the other image is complete; this one may be overwritten
