@@ -18,6 +18,6 @@ for w in sys.argv[2:]:
         v = []
         for rep in (1, 2):
             d = json.loads(open("gpurun_out/%s_%s%d/%s.json" % (tag, arm, rep, w)).read().strip().splitlines()[-1])
-            v.append((d["kernels"]["beaver_gemm_close"]["avg_ms_per_phase"], d["kernels"]["beaver_gemm_close"]["frac_of_5000_TOPs"]))
+            v.append((round(d["kernels"]["beaver_gemm_close"]["avg_ms_per_phase"], 4), round(d["kernels"]["beaver_gemm_close"]["frac_of_5000_TOPs"], 4)))
         print(w, name, "product phases avg ms / frac of peak:", v)
 PY
