@@ -58,6 +58,12 @@ def make_mailbox_exchange(rank, boxes, device, wrap, stats):
                     data = boxes[(peer, rank)].get(timeout=300)
                     assert data.numel() == nbytes, (rank, peer, data.numel(), nbytes)
                     wrap(ptr, nbytes, device).copy_(data)
+                    if device.type == "cuda":
+                        # the snapshot was allocated on the SENDER's stream: without this the caching allocator hands its block back to
+                        # that stream's pool as soon as the reference below is dropped - while this rank's copy may still be queued behind
+                        # its own kernels (a round in which a rank only receives does not drain its stream first) - and the sender's
+                        # next snapshot overwrote it: one wrong weight share in ~7 % of the runs of a configuration a soak run found
+                        data.record_stream(torch.cuda.current_stream())
             if device.type == "cuda":
                 torch.cuda.current_stream().synchronize()
             return 0

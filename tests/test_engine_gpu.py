@@ -100,6 +100,23 @@ def test_recorded_epochs_bit_exact(k, V, Eu, in_dim, hid, lab):
     eng.close()
 
 
+@pytest.mark.parametrize("pair_fusion", [False, True])
+def test_products_dealt_on_use_on_launch_lanes(monkeypatch, pair_fusion):
+    """The per-side product path (COGNN_GEMM_PER_SIDE: what shapes the grouped launch does not serve take anyway) at a size where its
+    launch lanes are in use, with the product shares dealt where they are used (no offline call: the loop then stays on one stream,
+    its buffers come from the pool the consumers feed) - four epochs, every p = 1 side dealing into the buffers the epoch before
+    released, pairs co-located or not."""
+    monkeypatch.setenv("COGNN_GEMM_PER_SIDE", "1")
+    oracle, eng = _setup(4, 2400, 9000, 128, 64, 16, seed=5, gseed=9)
+    eng.pair_fusion(pair_fusion)
+    for it in range(24):
+        oracle.iteration(it)
+        eng.run(it, it + 1)
+        if it % 6 == 5:
+            _compare(oracle, eng, 4, it)
+    eng.close()
+
+
 def test_recorded_and_eager_engines_interleaved():
     """Two engines in one process, one replaying recorded epochs (device-side epoch salt, private stream), one launching eagerly
     (host-salted keys), alternating epoch by epoch for four epochs: each ends every epoch in its own oracle's shares and weights -

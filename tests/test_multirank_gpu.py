@@ -103,6 +103,16 @@ def test_multirank_random_configuration_hip(tmp_path, seed):
     _check(cfg, world, tmp_path)
 
 
+@pytest.mark.parametrize("variant,iters", [("optimize-gcn", 12), ("original-gcn", 8)])
+def test_two_parties_per_rank_products_per_side_hip(tmp_path, variant, iters):
+    """Two parties per rank, the per-side product path (COGNN_GEMM_PER_SIDE), no offline call, product-sized shapes: the two p = 1 sides
+    of a rank follow each other and deal their product shares where they are used, into buffers the sides before them released."""
+    cfg = dict(BASE, k=4, V=2400, Eu=9000, hid=64, lab=16, variant=variant, iters=iters, backend="hip", inproc=True, density=0.05,
+               env={"COGNN_GEMM_PER_SIDE": "1"})
+    cfg["in"] = 128
+    _check(cfg, 2, tmp_path)
+
+
 @pytest.mark.parametrize("seed", range(2 * int(os.environ.get("COGNN_FUZZ_SCALE", "1"))))
 def test_original_gcn_across_ranks_random_configuration_hip(tmp_path, seed):
     rng = np.random.default_rng(7800 + seed)
