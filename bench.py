@@ -442,6 +442,11 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the engine has no CPU fallback")
+    if world > 1:
+        # a rank that waits for a peer forever (a transport that never completes) would leave no trace: after this many seconds every
+        # rank dumps its Python stacks to stderr and exits non-zero (COGNN_BENCH_WATCHDOG_S; the N = 8 run takes about two minutes)
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ.get("COGNN_BENCH_WATCHDOG_S", "1500")), exit=True)
     # COGNN_BENCH_BACKEND=gloo: rehearsal of the N > 1 path on a box with fewer GPUs than ranks (ranks share the devices round
     # robin, messages are staged through host memory); the real multi-GPU run uses RCCL ("nccl")
     backend = os.environ.get("COGNN_BENCH_BACKEND", "nccl")
@@ -734,6 +739,9 @@ def main():
         out["cpu_baseline"] = None
     if rank == 0:
         print(json.dumps(out))
+    if world > 1:
+        import faulthandler
+        faulthandler.cancel_dump_traceback_later()
     if eng is not None:
         eng.close()
     if xch:
