@@ -177,6 +177,28 @@ def cpu_baseline(args, wl):
                       "in=%d hid=%d labels=%d, %.2f s" % (k, variant, lv2, le2, in_dim, hid, lab, dt)}
 
 
+def attach_transport(eng, torch, dist, cdist, backend, local_rank, per_round):
+    """The exchange of a multi-rank run: the native RCCL transport (ncclSend / ncclRecv groups issued from C++), or - when ANY rank could
+    not create it, agreed through the process group so that no rank is left behind - the torch.distributed callback transport on the same
+    devices (batch_isend_irecv on the engine's buffers: what round 2 used); with the gloo rehearsal backend the host-staged callbacks.
+    Returns (RcclExchange or None, description, error or None)."""
+    device = torch.device("cuda", local_rank)
+    if backend != "nccl":
+        eng.set_exchange(cdist.make_exchange_async(device, host_staged=True, per_round=per_round))
+        return None, "torch.distributed %s, host-staged (rehearsal transport)" % backend, None
+    xch, err = None, None
+    try:
+        xch = cdist.attach_rccl(eng, local_rank)
+    except Exception as ex:  # noqa: BLE001 - the fallback below still measures
+        err = str(ex)[-300:]
+    ok = torch.tensor([0 if err else 1], dtype=torch.int32, device=device)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if int(ok.item()) == 1:
+        return xch, "native RCCL p2p groups on a communication stream (csrc/exchange_rccl.hip)", None
+    eng.set_exchange(cdist.make_exchange_async(device, host_staged=False, per_round=per_round))
+    return None, "torch.distributed nccl p2p (FALLBACK: the native RCCL transport could not be created on some rank)", err or "failed on another rank"
+
+
 def cross_path_check(eng, Engine, k, src, dst, part, param, variant, iters, in_dim, lab, passes, recorded=False):
     """After the timed region (N = 1): the shares the bench's own sequence left behind - forward-only stores, retained offline
     products, the pass replayed warmup + steps times - must equal, bit for bit and for every party, those of a fresh engine
@@ -283,11 +305,7 @@ def placement_leg(torch, dist, Engine, args, placement, backend, rank, world, lo
     sides, max over ranks), with its own N-rank check.  Extra keys only."""
     from cognn_amd import dist as cdist
     eng = Engine(k, src, dst, part, param, seed=0xC06A11, variant=variant, rank=rank, world=world, device=local_rank, placement=placement)
-    xch = None
-    if backend == "nccl":
-        xch = cdist.attach_rccl(eng, local_rank)
-    else:
-        eng.set_exchange(cdist.make_exchange_async(torch.device("cuda", local_rank), host_staged=True, per_round=False))
+    xch, _, _ = attach_transport(eng, torch, dist, cdist, backend, local_rank, False)
     for P in eng.hosted:
         vids = eng.party_vids(P)
         rng = np.random.default_rng(0xC06A12 + P)
@@ -477,10 +495,7 @@ def main():
     xch = None
     if world > 1:
         from cognn_amd import dist as cdist
-        if backend == "nccl":                 # the native transport: ncclSend/ncclRecv groups issued from C++ (include/cognn_exchange.h)
-            xch = cdist.attach_rccl(eng, local_rank)
-        else:                                 # rehearsal transport (gloo, host-staged)
-            eng.set_exchange(cdist.make_exchange_async(torch.device("cuda", local_rank), host_staged=True, per_round=args.chunks > 1))
+        xch, transport_desc, transport_err = attach_transport(eng, torch, dist, cdist, backend, local_rank, args.chunks > 1)
         if args.chunks > 1:
             eng.exchange_chunks(args.chunks)
         if args.packed:
@@ -555,7 +570,7 @@ def main():
         cc, cr, ones = xch.ranks()
         ranks_seen = {"ranks": cc, "comm_rank": cr, "allreduce_of_ones": ones}
     elif world > 1:
-        t1 = torch.ones(1, dtype=torch.int64)
+        t1 = torch.ones(1, dtype=torch.int64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t1)
         ranks_seen = {"ranks": dist.get_world_size(), "comm_rank": dist.get_rank(), "allreduce_of_ones": int(t1.item())}
 
@@ -615,7 +630,7 @@ def main():
         "config": {"workload": "%d-party %s pass (GAS iterations 0-%d) on a synthetic %d-vertex/%d-edge global graph, "
                                "partition vid %% %d, input_dim=%d hidden_dim=%d num_labels=%d, %d part%s per GPU"
                                % (k, variant, iters - 1, V, 2 * Eu, k, in_dim, hid, lab, k // world, "y" if k // world == 1 else "ies"),
-                   "name": args.workload, "parties": k, "exchange": "in-device" if world == 1 else ("rccl-p2p" if backend == "nccl" else backend + "-host-staged"),
+                   "name": args.workload, "parties": k, "exchange": "in-device" if world == 1 else ("rccl-p2p" if xch else "torch-nccl-p2p (fallback)" if backend == "nccl" else backend + "-host-staged"),
                    "exchange_chunks": args.chunks if world > 1 else None, "packed_openings": bool(args.packed) if world > 1 else None,
                    "placement": (args.placement if world > 1 else "all parties and both share-holders of every vertex set on the one GPU")},
         "epoch_time_s": dt / args.steps,
@@ -660,7 +675,9 @@ def main():
                            "GBps_while_communicating": ((x1["bytes_sent"] - x0["bytes_sent"]) / 1e9) / max((x1["comm_ms"] - x0["comm_ms"]) / 1e3, 1e-12),
                            "transport": "native RCCL p2p groups on a communication stream (csrc/exchange_rccl.hip)"}
     if world > 1 and not xch:
-        out["exchange"] = dict(ranks_seen, transport="torch.distributed %s, host-staged (rehearsal transport)" % backend)
+        out["exchange"] = dict(ranks_seen, transport=transport_desc)
+        if transport_err:
+            out["exchange"]["native_transport_error"] = transport_err
     if not args.no_check and world == 1:
         try:
             out["check"] = cross_path_check(eng, Engine, k, src, dst, part, param, variant, iters, in_dim, lab, n_warm + 2 * args.steps, recorded=recorded)   # (warm-up, the timed steps, the same steps without kernel timers)
